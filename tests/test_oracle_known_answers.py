@@ -1,0 +1,118 @@
+"""Pins the CPU oracle against every known answer that exists for the path.
+
+The reference ships no tests and cannot be built here, so these are all the
+anchors there are:
+  * README.md:11-40: the 6-point worked example (8x6 matrix A and rhs b);
+  * survey-time output of the reference assembly for the field_1d.cpp:20-29
+    default input (resolution 12): 14 rows / 38 triplets and the float64 least-squares solution
+    (cond(AtA) = 165.7);
+  * closed-form row / triplet counts of configs C1..C3 (default Weights).
+"""
+import numpy as np
+import pytest
+
+
+README_A = np.array([
+    [1, 0, 0, 0, 0, 0],
+    [0, 0, 0, 0, 0, 1],
+    [-1, 1, 0, 0, 0, 0],
+    [0, 0, 0, 0, -1, 1],
+    [1, -2, 1, 0, 0, 0],
+    [0, 1, -2, 1, 0, 0],
+    [0, 0, 1, -2, 1, 0],
+    [0, 0, 0, 1, -2, 1]], dtype=np.float64)
+README_B = np.array([4, 2, 1, -1, 0, 0, 0, 0], dtype=np.float64)
+
+SURVEY_FIELD_1D_X = np.array([-0.1846154, -0.1006993, -0.0167832, 0.0671329, 0.1230769, 0.1510490,
+                              0.1510490, 0.1230769, 0.0671329, -0.0167832, -0.1006993, -0.1846154])
+
+
+def _dense(f, n):
+    rows, cols, vals, rhs = f.get()
+    A = np.zeros((len(rhs), n))
+    np.add.at(A, (rows, cols), vals.astype(np.float64))
+    return A, rhs.astype(np.float64)
+
+
+def test_readme_worked_example(oracle):
+    """README.md:11-40.  Value rows via add_value_constraint (f(0)=4, f(5)=2), the gradient at
+    x=0 via add_gradient_constraint (kNearestNeighbor: f(1)-f(0)=1), smoothness via
+    add_field_constraints(model_2=1).  The README's last gradient row f(5)-f(4)=-1 sits at x=5,
+    where cell_index (field_interpolation.cpp:116-117) rejects the point -- so that row is entered
+    with add_equation, exactly as SURVEY.md section 4 prescribes for this example."""
+    f = oracle.LatticeField([6])
+    assert f.add_value_constraint([0.0], 4.0, 1.0)
+    assert f.add_value_constraint([5.0], 2.0, 1.0)
+    assert f.add_gradient_constraint([0.0], [1.0], 1.0, oracle.GRAD_NEAREST)
+    assert not f.add_gradient_constraint([5.0], [-1.0], 1.0, oracle.GRAD_NEAREST)   # dropped at the border
+    f.add_equation(1.0, -1.0, [(4, -1.0), (5, 1.0)])
+    f.add_field_constraints(oracle.Weights(model_2=1.0))
+    A, b = _dense(f, 6)
+    # add_value_constraint also stores the zero-weight neighbour (x1 with weight 0 for pos 0.0);
+    # the dense matrix is what the README prints.
+    assert A.shape == (8, 6)
+    np.testing.assert_array_equal(A, README_A)
+    np.testing.assert_array_equal(b, README_B)
+    x = f.solve_exact()
+    x_ref = np.linalg.lstsq(README_A, README_B, rcond=None)[0]
+    np.testing.assert_allclose(x, x_ref, rtol=0, atol=2e-6)
+
+
+def _field_1d(oracle, resolution):
+    """src/field_1d.cpp:98-110 with the default input of :20-29."""
+    w = oracle.Weights()
+    f = oracle.LatticeField([resolution])
+    for pos, value, grad in [(0.2, 0.0, +1.0), (0.8, 0.0, -1.0)]:
+        pos_lattice = np.float32(pos) * np.float32(resolution - 1)
+        grad_lattice = np.float32(grad) / np.float32(resolution - 1)
+        f.add_value_constraint([pos_lattice], value, w.data_pos)
+        f.add_gradient_constraint([pos_lattice], [grad_lattice], w.data_gradient, w.gradient_kernel)
+    f.add_field_constraints(w)
+    return f
+
+
+def test_field_1d_default_matches_survey_probe(oracle):
+    f = _field_1d(oracle, 12)
+    assert f.num_rows == 14 and f.num_triplets == 38          # SURVEY.md 8(c) [probe]
+    x = f.solve_exact()
+    np.testing.assert_allclose(x, SURVEY_FIELD_1D_X, rtol=0, atol=1e-7)
+    AtA, _, _ = f.normal_equations()
+    assert abs(np.linalg.cond(AtA.toarray()) - 165.7) < 0.1   # cond(AtA)=165.7
+
+
+def test_config_c1_counts(oracle):
+    """1022 model rows / 3066 triplets + (2+2) data rows / 8 triplets."""
+    f = _field_1d(oracle, 1024)
+    assert f.num_rows == 1022 + 4
+    assert f.num_triplets == 3066 + 8
+
+
+@pytest.mark.parametrize("sizes,rows,trip", [
+    ([1024, 1024], 2093056, 6279168),       # C2 model part
+    ([64, 64, 64], 3 * 64 * 64 * 62, 3 * 3 * 64 * 64 * 62),
+])
+def test_model_row_counts_closed_form(oracle, sizes, rows, trip):
+    """model rows = D*N*(1-2/side), x3 triplets (default Weights)."""
+    f = oracle.LatticeField(sizes)
+    f.add_field_constraints(oracle.Weights())
+    assert f.num_rows == rows and f.num_triplets == trip
+
+
+def test_ata_interior_stencil_is_1_m4_6_m4_1(oracle):
+    """interior row of model_2=w in 1-D is w^2*[1 -4 6 -4 1]; the diagonal
+    runs 1,5,6,...,6,5,1 (section 7 hard part 5)."""
+    f = oracle.LatticeField([16])
+    f.add_field_constraints(oracle.Weights(model_2=0.5))
+    AtA, atb, diag = f.normal_equations()
+    M = AtA.toarray() / 0.25
+    np.testing.assert_allclose(M[8, 6:11], [1, -4, 6, -4, 1])
+    np.testing.assert_allclose(np.diag(M), [1, 5] + [6] * 12 + [5, 1])
+    assert not atb.any()
+
+
+def test_model_0_is_emitted_once_per_axis(oracle):
+    """field_interpolation.cpp:257-263 sits inside the per-axis loop: diag = D*model_0^2."""
+    f = oracle.LatticeField([5, 4, 3])
+    f.add_field_constraints(oracle.Weights(model_0=2.0, model_2=0.0))
+    _, _, diag = f.normal_equations()
+    np.testing.assert_allclose(diag, 3 * 4.0)
