@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- solved lattice points / second on MI355X (BASELINE.json metric).
+
+One "step" = one full pass of the hot path on a synthetic lattice problem whose inputs already sit in
+HBM: data-constraint assembly (fi_add_points + fi_assemble) + Jacobi-PCG to ||r|| <= tol*||Atb||
+(fi_solve_cg).  Workload (config.workload): BASELINE.json config 4 -- a 256^3 lattice, 1M scattered noisy
+value constraints, model_2 = 0.5 -- on one GPU; with --gpus N the lattice is 256 x 256 x (256*N) with
+N*1M points of the same density, one 256^3 slab per GPU (weak scaling), halo planes and dot products
+over RCCL.
+
+Prints ONE JSON line on rank 0 (see the task contract), including
+  "roofline"     achieved HBM GB/s of the AtA-apply kernel: algorithmic bytes / mean
+                 launch duration measured with HIP events inside the timed region (fi_stats.spmv_ms_avg);
+  "cpu_baseline" the C++ oracle (restatement of the reference's triplets -> AtA -> BiCGSTAB path, fp32,
+                 one thread) timed on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(side, tol):
+    """Oracle ("port") on a bounded sample: config 4 scaled to side^3 with the same point density."""
+    import numpy as np
+    from field_interpolation_amd import synth
+    from oracle import fi_oracle as fo
+    npts = int(round(1_000_000 * (side / 256.0) ** 3))
+    sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3)
+    t0 = time.perf_counter()
+    f = fo.LatticeField(sizes)
+    f.add_field_constraints(fo.Weights(model_2=w.model_2))
+    f.add_value_constraints(pos, val, w.data_pos)
+    t1 = time.perf_counter()
+    res = f.solve_with_guess(np.zeros(f.num_unknowns, np.float32), 0, tol)
+    t2 = time.perf_counter()
+    iters = res[1] if res else -1
+    return {"value": f.num_unknowns / (t2 - t0), "unit": "lattice points/s", "cores": 1, "kind": "port",
+            "sample": "config 4 at %d^3 (%d points, same density), assembly %.2f s + AtA/BiCGSTAB fp32 %.2f s, "
+                      "%d iterations" % (side, npts, t1 - t0, t2 - t1, iters)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--side", type=int, default=256)
+    ap.add_argument("--points", type=int, default=1_000_000, help="data points per 256^3-equivalent slab")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--tol", type=float, default=1e-5)
+    ap.add_argument("--cpu-side", type=int, default=112, help="lattice side of the CPU baseline sample (0: skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import field_interpolation_amd as fi
+    from field_interpolation_amd import _capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    side = args.side
+    depth = side * world
+    npts = args.points * world
+    sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3, depth=depth)
+
+    field = fi.LatticeField(sizes, dtype=args.dtype, rank=rank, nranks=world)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            import ctypes
+            buf = ctypes.create_string_buffer(128)
+            _capi.check(_capi.lib().fi_comm_unique_id(buf))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
+        dist.broadcast(uid, 0)
+        field.comm_init(bytes(uid.cpu().numpy().tobytes()))
+    lo, hi = field.slab
+    # each rank keeps the points within one cell of its slab (the library drops the rest anyway)
+    keep = (pos[:, 2] >= lo - 1.0) & (pos[:, 2] < hi + 1.0)
+    d_pos = torch.from_numpy(np.ascontiguousarray(pos[keep])).to(dev)
+    d_val = torch.from_numpy(np.ascontiguousarray(val[keep])).to(dev)
+    torch.cuda.synchronize()
+
+    field.add_field_constraints(w)
+
+    def step():
+        field.clear_points()
+        field.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, d_pos, None, None, values=d_val)
+        field.assemble()
+        out = field.solve_cg(None, 0, args.tol)
+        if out is None:
+            raise RuntimeError("CG breakdown")
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    spmv_ms, spmv_n, asm_ms, solve_ms = 0.0, 0, 0.0, 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, iters, rel = step()
+        st = field.stats()
+        spmv_ms += st["spmv_ms_avg"] * st["spmv_samples"]
+        spmv_n += st["spmv_samples"]
+        asm_ms += st["assemble_ms"]
+        solve_ms += st["solve_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = field.stats()
+    true_rel = field.true_residual()
+
+    n_global = side * side * depth
+    value = n_global * args.steps / elapsed
+    spmv_avg_ms = spmv_ms / max(spmv_n, 1)
+    achieved = st["spmv_bytes"] / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+    line = {
+        "metric": "solved lattice points/sec (assembly+CG to tol=%g)" % args.tol,
+        "value": value, "unit": "lattice points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5, "
+                               "Jacobi-PCG to rel. residual %g" % (side, side, depth, npts, args.tol),
+                   "parallelism": "slab%d" % world, "iterations": iters, "rel_residual": rel,
+                   "true_rel_residual": true_rel, "assemble_ms": asm_ms / args.steps,
+                   "solve_ms": solve_ms / args.steps, "occupied_cells": st["num_cells"],
+                   "data_rows": st["num_data_rows"]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "AtA apply (matrix-free stencil + cell blocks)", "launch_ms": spmv_avg_ms,
+                     "algorithmic_bytes": st["spmv_bytes"], "samples": spmv_n},
+    }
+    if rank == 0 and world == 1 and args.cpu_side > 0:
+        line["cpu_baseline"] = cpu_baseline(args.cpu_side, args.tol)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,452 @@
+// fi_assembly.hip -- data-constraint assembly on the GPU.
+//
+// Reference path replaced: add_points -> add_value_constraint / add_gradient_constraint
+// (field_interpolation.cpp:343-371, 57-107, 123-187) followed by as_sparse_matrix_float, make_square
+// and A^T*b (sparse_linear.cpp:59-70, 105-113, 120).  The reference appends one 12-byte triplet per
+// coefficient and later squares the whole matrix with a sparse*sparse product.  Here:
+//
+//   1. k_emit_rows      one thread per data point: the point's value row and D gradient rows are written
+//                       as "cell rows" -- (extended cell id, 2^D corner coefficients, rhs) -- with the
+//                       same fp32 arithmetic, in the same order, as the reference (multilerp :15-55).
+//                       All default kernels touch only the 2^D corners of the cell floor(pos).
+//   2. radix sort       rows by cell id (stable, so rows of a cell keep their input order; hipCUB).
+//   3. k_build_blocks   one thread per occupied cell: fp64 accumulation of the symmetric 2^D x 2^D block
+//                       sum a a^T and of sum a*rhs, stored entry-major (coalesced for the apply kernel).
+//   4. k_scatter_cells  A^T b and the data part of diag(A^T A) onto the lattice, 2^D parity colours so
+//                       that no two cells of one launch share a corner: deterministic, no atomics.
+//
+// HBM layout: rows are SoA (key[], coef[2^D][], rhs[]); blocks are SoA over cells (blk[e][cell]).
+
+#include <hipcub/hipcub.hpp>
+
+#include "fi_internal.h"
+
+namespace fi {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__host__ __device__ inline int packed_index(int i, int j, int nc)  // i <= j
+{
+	return i * nc - (i * (i - 1)) / 2 + (j - i);
+}
+
+struct EmitArgs {
+	Geom  g;
+	float vw, gw;
+	int   vk, gk;
+	int   has_nrm, has_pw, has_val;
+	uint32_t invalid_key;
+};
+
+// Extended local cell id of the cell with GLOBAL origin c[] (origins run from -1), or invalid when the
+// cell does not touch this rank's slab.
+template <int D>
+__device__ inline uint32_t cell_key(const Geom& g, const int* c, uint32_t invalid)
+{
+	uint32_t key = 0;
+	uint32_t mul = 1;
+	for (int d = 0; d < D; ++d) {
+		const int l = c[d] - g.coff[d];
+		if (l < 0 || l >= g.cn[d]) { return invalid; }
+		key += static_cast<uint32_t>(l) * mul;
+		mul *= static_cast<uint32_t>(g.cn[d]);
+	}
+	return key;
+}
+
+template <int D>
+__global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, const float* __restrict__ pos,
+                                                         const float* __restrict__ nrm,
+                                                         const float* __restrict__ pw,
+                                                         const float* __restrict__ val,
+                                                         uint32_t* __restrict__ key, float* __restrict__ coef,
+                                                         float* __restrict__ rhs)
+{
+	constexpr int NC = 1 << D;
+	const long i = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= n) { return; }
+	const Geom& g = a.g;
+
+	float p[D];
+	bool  finite = true;
+	for (int d = 0; d < D; ++d) {
+		p[d]   = pos[i * D + d];
+		finite = finite && isfinite(p[d]);
+	}
+	const float w     = a.has_pw ? pw[i] : 1.0f;
+	const float value = a.has_val ? val[i] : 0.0f;
+	const long  slot0 = i * (1 + D);
+
+	// cell of the point: floor(pos) per axis (multilerp :29-32, cell_index :115)
+	int   cell[D];
+	float t[D];
+	bool  cell_in_ext = finite;  // origin within [-1, size-1] on every axis
+	bool  cell_valid  = finite;  // 0 <= origin and origin + 1 < size (cell_index :116)
+	for (int d = 0; d < D; ++d) {
+		const float fl = floorf(p[d]);
+		if (!(fl >= -1.0f && fl <= static_cast<float>(g.gn[d] - 1))) {
+			cell_in_ext = false;
+			cell_valid  = false;
+			cell[d]     = 0;
+			t[d]        = 0.0f;
+			continue;
+		}
+		cell[d] = static_cast<int>(fl);
+		t[d]    = p[d] - static_cast<float>(cell[d]);
+		if (!(0 <= cell[d] && cell[d] + 1 < g.gn[d])) { cell_valid = false; }
+	}
+
+	// ---- value row ----------------------------------------------------------------------------
+	{
+		const float cw = w * a.vw;
+		uint32_t k = a.invalid_key;
+		float    c[NC];
+		float    b = 0.0f;
+		for (int q = 0; q < NC; ++q) { c[q] = 0.0f; }
+		if (a.vk == FI_VALUE_LINEAR_INTERPOLATION) {
+			// field_interpolation.cpp:57-80: corners outside the lattice are dropped, the kept weights
+			// are not renormalised; rhs = (sum of kept coefficient) * value.
+			if (cw != 0.0f && cell_in_ext) {
+				int   kept = 0;
+				float sum  = 0.0f;
+				for (int q = 0; q < NC; ++q) {
+					float lw = 1.0f;
+					bool  in = true;
+					for (int d = 0; d < D; ++d) {
+						const int up = (q >> d) & 1;
+						const int cc = cell[d] + up;
+						lw *= up ? t[d] : 1.0f - t[d];
+						in = in && (0 <= cc) && (cc < g.gn[d]);
+					}
+					if (in) {
+						const float s = lw * cw;
+						c[q] = s;
+						sum += s;
+						++kept;
+					}
+				}
+				if (kept > 0) {
+					k = cell_key<D>(g, cell, a.invalid_key);
+					b = sum * value;
+				}
+			}
+		} else {
+			// field_interpolation.cpp:82-107 through add_equation (sparse_linear.cpp:34-50): nearest
+			// lattice point by std::round; row [1]*cw, rhs (value - (pos-nearest).gradient)*cw.
+			if (cw != 0.0f && finite) {
+				bool  ok    = true;
+				float along = 0.0f;
+				int   corner = 0;
+				int   cc[D];
+				for (int d = 0; d < D; ++d) {
+					const float r = roundf(p[d]);
+					if (!(r >= 0.0f && r <= static_cast<float>(g.gn[d] - 1))) {
+						ok = false;
+						cc[d] = 0;
+						continue;
+					}
+					const int q = static_cast<int>(r);
+					along += (p[d] - static_cast<float>(q)) * nrm[i * D + d];
+					// the nearest point is a corner of the (extended) cell floor(pos)
+					int base = static_cast<int>(floorf(p[d]));
+					if (base < -1) { base = -1; }
+					if (base > q) { base = q; }
+					if (q - base > 1) { base = q - 1; }
+					cc[d] = base;
+					corner |= (q - base) << d;
+				}
+				if (ok) {
+					k = cell_key<D>(g, cc, a.invalid_key);
+					c[corner] = 1.0f * cw;
+					b = (value - along) * cw;
+				}
+			}
+		}
+		key[slot0] = k;
+		rhs[slot0] = b;
+		for (int q = 0; q < NC; ++q) { coef[slot0 * NC + q] = c[q]; }
+	}
+
+	// ---- gradient rows ------------------------------------------------------------------------
+	for (int d = 0; d < D; ++d) {
+		const long slot = slot0 + 1 + d;
+		uint32_t k = a.invalid_key;
+		float    c[NC];
+		float    b = 0.0f;
+		for (int q = 0; q < NC; ++q) { c[q] = 0.0f; }
+		if (a.has_nrm) {
+			const float cw = w * a.gw;
+			const float gd = nrm[i * D + d];
+			if (cw != 0.0f && cell_valid) {
+				if (a.gk == FI_GRADIENT_NEAREST_NEIGHBOR) {
+					// field_interpolation.cpp:134-149: [-1, +1]*cw on the cell edge along d.
+					c[0]      = -1.0f * cw;
+					c[1 << d] = +1.0f * cw;
+					b         = gd * cw;
+					k         = cell_key<D>(g, cell, a.invalid_key);
+				} else if (a.gk == FI_GRADIENT_CELL_EDGES) {
+					// field_interpolation.cpp:150-187: +-cw*2/2^D on all corners, rhs cw*g_d.
+					const float term = cw * 2.0f / static_cast<float>(NC);
+					for (int q = 0; q < NC; ++q) { c[q] = (((q >> d) & 1) ? +1.0f : -1.0f) * term; }
+					b = cw * gd;
+					k = cell_key<D>(g, cell, a.invalid_key);
+				}
+			}
+		}
+		key[slot] = k;
+		rhs[slot] = b;
+		for (int q = 0; q < NC; ++q) { coef[slot * NC + q] = c[q]; }
+	}
+}
+
+__global__ void k_iota(uint32_t* v, long n)
+{
+	const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n) { v[i] = static_cast<uint32_t>(i); }
+}
+
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uint32_t* __restrict__ start,
+                                                            const uint32_t* __restrict__ count,
+                                                            const uint32_t* __restrict__ sorted_row,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ rhs, T* __restrict__ blk,
+                                                            double* __restrict__ cell_rhs)
+{
+	constexpr int NC = 1 << D;
+	constexpr int NB = NC * (NC + 1) / 2;
+	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c >= ncell) { return; }
+	double B[NB];
+	double gvec[NC];
+	for (int e = 0; e < NB; ++e) { B[e] = 0.0; }
+	for (int q = 0; q < NC; ++q) { gvec[q] = 0.0; }
+	const uint32_t s = start[c], m = count[c];
+	for (uint32_t r = 0; r < m; ++r) {
+		const long row = sorted_row[s + r];
+		double     a[NC];
+		for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(coef[row * NC + q]); }
+		const double b = static_cast<double>(rhs[row]);
+		int e = 0;
+		for (int i = 0; i < NC; ++i) {
+			for (int j = i; j < NC; ++j) { B[e++] += a[i] * a[j]; }
+			gvec[i] += a[i] * b;
+		}
+	}
+	for (int e = 0; e < NB; ++e) { blk[static_cast<long>(e) * ncell + c] = static_cast<T>(B[e]); }
+	for (int q = 0; q < NC; ++q) { cell_rhs[static_cast<long>(q) * ncell + c] = gvec[q]; }
+}
+
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, const uint32_t* __restrict__ cell_id,
+                                                             const T* __restrict__ blk,
+                                                             const double* __restrict__ cell_rhs,
+                                                             T* __restrict__ atb, T* __restrict__ diag, int colour)
+{
+	constexpr int NC = 1 << D;
+	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c >= ncell) { return; }
+	uint32_t id = cell_id[c];
+	int      l[3] = {0, 0, 0};
+	int      col  = 0;
+	for (int d = 0; d < D; ++d) {
+		l[d] = static_cast<int>(id % static_cast<uint32_t>(g.cn[d]));
+		id /= static_cast<uint32_t>(g.cn[d]);
+		col |= (l[d] & 1) << d;
+	}
+	if (col != colour) { return; }
+	for (int q = 0; q < NC; ++q) {
+		int64_t idx = 0;
+		bool    ok  = true;
+		for (int d = 0; d < D; ++d) {
+			const int gq = l[d] + g.coff[d] + ((q >> d) & 1);  // global coordinate of the corner
+			const int li = gq - g.off[d];
+			ok = ok && (0 <= gq) && (gq < g.gn[d]) && (g.own_lo[d] <= li) && (li < g.own_hi[d]);
+			idx += static_cast<int64_t>(li) * g.stride[d];
+		}
+		if (ok) {
+			atb[idx] += static_cast<T>(cell_rhs[static_cast<long>(q) * ncell + c]);
+			diag[idx] += blk[static_cast<long>(packed_index(q, q, NC)) * ncell + c];
+		}
+	}
+}
+
+inline int blocks_for(long n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
+
+template <int D>
+void emit_rows_dim(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val, float vw,
+                   int vk, float gw, int gk)
+{
+	constexpr int NC = 1 << D;
+	auto* pb  = new Pending();
+	c->pending.push_back(pb);
+	pb->nrows = n * (1 + D);
+	pb->key.alloc(sizeof(uint32_t) * pb->nrows);
+	pb->coef.alloc(sizeof(float) * pb->nrows * NC);
+	pb->rhs.alloc(sizeof(float) * pb->nrows);
+	EmitArgs a;
+	a.g = c->g;
+	a.vw = vw;
+	a.gw = gw;
+	a.vk = vk;
+	a.gk = gk;
+	a.has_nrm = nrm != nullptr;
+	a.has_pw  = pw != nullptr;
+	a.has_val = val != nullptr;
+	a.invalid_key = static_cast<uint32_t>(static_cast<int64_t>(c->g.cn[0]) * c->g.cn[1] * c->g.cn[2]);
+	if (n > 0) {
+		hipLaunchKernelGGL(k_emit_rows<D>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, a, n, pos, nrm, pw, val,
+		                   pb->key.as<uint32_t>(), pb->coef.as<float>(), pb->rhs.as<float>());
+		FI_HIP_TRY(hipGetLastError());
+	}
+}
+
+template <int D, typename T>
+void assemble_dim(fi_ctx* c)
+{
+	constexpr int NC = 1 << D;
+	constexpr int NB = NC * (NC + 1) / 2;
+	hipStream_t st = c->stream;
+	const Geom& g  = c->g;
+	const uint32_t invalid = static_cast<uint32_t>(static_cast<int64_t>(g.cn[0]) * g.cn[1] * g.cn[2]);
+
+	// operator arrays over local storage
+	c->atb.alloc(sizeof(T) * g.nloc);
+	c->diag.alloc(sizeof(T) * g.nloc);
+	FI_HIP_TRY(hipMemsetAsync(c->atb.p, 0, sizeof(T) * g.nloc, st));
+	FI_HIP_TRY(hipMemsetAsync(c->diag.p, 0, sizeof(T) * g.nloc, st));
+
+	long total = 0;
+	for (auto* pb : c->pending) { total += pb->nrows; }
+	c->cells.ncell = 0;
+	c->cells.nb    = NB;
+	c->stats.num_data_rows = 0;
+	c->stats.num_cells     = 0;
+	if (total == 0) { return; }
+	FI_REQUIRE(total < (1L << 31), FI_ERR_UNSUPPORTED, "more than 2^31 data rows in one context");
+
+	// gather the batches into one row table (single batch: used in place)
+	DevBuf key_cat, coef_cat, rhs_cat;
+	const uint32_t* key  = nullptr;
+	const float*    coef = nullptr;
+	const float*    rhs  = nullptr;
+	if (c->pending.size() == 1) {
+		key  = c->pending[0]->key.as<uint32_t>();
+		coef = c->pending[0]->coef.as<float>();
+		rhs  = c->pending[0]->rhs.as<float>();
+	} else {
+		key_cat.alloc(sizeof(uint32_t) * total);
+		coef_cat.alloc(sizeof(float) * total * NC);
+		rhs_cat.alloc(sizeof(float) * total);
+		long at = 0;
+		for (auto* pb : c->pending) {
+			if (pb->nrows == 0) { continue; }
+			FI_HIP_TRY(hipMemcpyAsync(key_cat.as<uint32_t>() + at, pb->key.p, sizeof(uint32_t) * pb->nrows,
+			                          hipMemcpyDeviceToDevice, st));
+			FI_HIP_TRY(hipMemcpyAsync(coef_cat.as<float>() + at * NC, pb->coef.p, sizeof(float) * pb->nrows * NC,
+			                          hipMemcpyDeviceToDevice, st));
+			FI_HIP_TRY(hipMemcpyAsync(rhs_cat.as<float>() + at, pb->rhs.p, sizeof(float) * pb->nrows,
+			                          hipMemcpyDeviceToDevice, st));
+			at += pb->nrows;
+		}
+		key  = key_cat.as<uint32_t>();
+		coef = coef_cat.as<float>();
+		rhs  = rhs_cat.as<float>();
+	}
+
+	// sort rows by cell
+	DevBuf row_in, row_sorted, key_sorted, uniq, counts, starts, nruns, tmp;
+	row_in.alloc(sizeof(uint32_t) * total);
+	row_sorted.alloc(sizeof(uint32_t) * total);
+	key_sorted.alloc(sizeof(uint32_t) * total);
+	uniq.alloc(sizeof(uint32_t) * total);
+	counts.alloc(sizeof(uint32_t) * total);
+	starts.alloc(sizeof(uint32_t) * total);
+	nruns.alloc(sizeof(uint32_t) * 4);
+	hipLaunchKernelGGL(k_iota, dim3(blocks_for(total)), dim3(kThreads), 0, st, row_in.as<uint32_t>(), total);
+	int end_bit = 1;
+	while ((1ull << end_bit) <= invalid) { ++end_bit; }
+	size_t tb = 0;
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
+	                                              row_sorted.as<uint32_t>(), static_cast<int>(total), 0, end_bit, st));
+	tmp.alloc(tb);
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
+	                                              row_sorted.as<uint32_t>(), static_cast<int>(total), 0, end_bit, st));
+	// runs of equal keys = occupied cells (+ one run of invalid rows at the end)
+	size_t tb2 = 0;
+	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
+	                                                 counts.as<uint32_t>(), nruns.as<uint32_t>(),
+	                                                 static_cast<int>(total), st));
+	DevBuf tmp2;
+	tmp2.alloc(tb2);
+	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp2.p, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
+	                                                 counts.as<uint32_t>(), nruns.as<uint32_t>(),
+	                                                 static_cast<int>(total), st));
+	uint32_t h_runs = 0;
+	FI_HIP_TRY(hipMemcpyAsync(&h_runs, nruns.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipStreamSynchronize(st));
+	if (h_runs == 0) { return; }
+	uint32_t h_last_key = 0, h_last_count = 0;
+	FI_HIP_TRY(hipMemcpy(&h_last_key, uniq.as<uint32_t>() + (h_runs - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+	FI_HIP_TRY(hipMemcpy(&h_last_count, counts.as<uint32_t>() + (h_runs - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+	long ncell   = h_runs;
+	long invalid_rows = 0;
+	if (h_last_key == invalid) {
+		ncell -= 1;
+		invalid_rows = h_last_count;
+	}
+	c->stats.num_data_rows = total - invalid_rows;
+	c->stats.num_cells     = ncell;
+	if (ncell == 0) { return; }
+	size_t tb3 = 0;
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(),
+	                                            static_cast<int>(h_runs), st));
+	DevBuf tmp3;
+	tmp3.alloc(tb3);
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(),
+	                                            static_cast<int>(h_runs), st));
+
+	c->cells.ncell = ncell;
+	c->cells.cell_id.alloc(sizeof(uint32_t) * ncell);
+	c->cells.blk.alloc(sizeof(T) * NB * ncell);
+	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
+	DevBuf cell_rhs;
+	cell_rhs.alloc(sizeof(double) * NC * ncell);
+	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
+	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,
+	                   c->cells.blk.as<T>(), cell_rhs.as<double>());
+	FI_HIP_TRY(hipGetLastError());
+	for (int colour = 0; colour < NC; ++colour) {
+		hipLaunchKernelGGL((k_scatter_cells<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, g, ncell,
+		                   c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), cell_rhs.as<double>(),
+		                   c->atb.as<T>(), c->diag.as<T>(), colour);
+	}
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipStreamSynchronize(st));  // temporaries die here
+}
+
+}  // namespace
+
+void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val, float vw,
+                     int vk, float gw, int gk)
+{
+	switch (c->g.ndim) {
+	case 1: emit_rows_dim<1>(c, n, pos, nrm, pw, val, vw, vk, gw, gk); break;
+	case 2: emit_rows_dim<2>(c, n, pos, nrm, pw, val, vw, vk, gw, gk); break;
+	default: emit_rows_dim<3>(c, n, pos, nrm, pw, val, vw, vk, gw, gk); break;
+	}
+}
+
+void assemble(fi_ctx* c)
+{
+	const bool f64 = c->dtype == FI_F64;
+	switch (c->g.ndim) {
+	case 1: f64 ? assemble_dim<1, double>(c) : assemble_dim<1, float>(c); break;
+	case 2: f64 ? assemble_dim<2, double>(c) : assemble_dim<2, float>(c); break;
+	default: f64 ? assemble_dim<3, double>(c) : assemble_dim<3, float>(c); break;
+	}
+}
+
+}  // namespace fi

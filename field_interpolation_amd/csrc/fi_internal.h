@@ -1,0 +1,170 @@
+// fi_internal.h -- shared declarations of the HIP solver core (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/fi_hip.h"
+
+namespace fi {
+
+// ---- error plumbing: nothing throws or aborts across the C ABI ------------------------------------
+void set_error(const char* fmt, ...);
+
+struct Fail {
+	int code;
+};
+
+#define FI_HIP_TRY(expr)                                                                              \
+	do {                                                                                              \
+		hipError_t e_ = (expr);                                                                       \
+		if (e_ != hipSuccess) {                                                                       \
+			::fi::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));      \
+			throw ::fi::Fail{FI_ERR_HIP};                                                             \
+		}                                                                                             \
+	} while (0)
+
+#define FI_REQUIRE(cond, code, ...)                                                                   \
+	do {                                                                                              \
+		if (!(cond)) {                                                                                \
+			::fi::set_error(__VA_ARGS__);                                                             \
+			throw ::fi::Fail{code};                                                                   \
+		}                                                                                             \
+	} while (0)
+
+// ---- device buffer --------------------------------------------------------------------------------
+struct DevBuf {
+	void*  p     = nullptr;
+	size_t bytes = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	~DevBuf() { release(); }
+	void release()
+	{
+		if (p) { (void)hipFree(p); }
+		p     = nullptr;
+		bytes = 0;
+	}
+	void alloc(size_t nbytes)
+	{
+		if (nbytes <= bytes && p) { return; }
+		release();
+		if (nbytes == 0) { nbytes = 16; }
+		FI_HIP_TRY(hipMalloc(&p, nbytes));
+		bytes = nbytes;
+	}
+	template <typename T>
+	T* as() const { return static_cast<T*>(p); }
+};
+
+// ---- geometry: the (slab of the) lattice one context owns ------------------------------------------
+// The slowest axis L = ndim-1 is the decomposed one.  Local storage holds `halo` ghost planes on both
+// sides of the owned planes along L; every kernel takes global coordinates from `off`.
+struct Geom {
+	int     ndim;
+	int     n[3];       // local extent incl. ghost planes
+	int     gn[3];      // global extent
+	int     off[3];     // global coordinate of local index 0
+	int     own_lo[3];  // owned local range [lo, hi)
+	int     own_hi[3];
+	int64_t stride[3];  // local strides (x fastest)
+	int64_t nloc;       // local elements incl. ghosts
+	int64_t nown;       // owned elements
+	int64_t own_first;  // local linear index of the first owned element (ghosts come first along L)
+	// extended cell grid (cell origins -1 .. size-1): local extents and the global origin of cell 0
+	int     cn[3];
+	int     coff[3];
+};
+
+// Coefficients of the model rows exactly as the reference stores them in A: fp32(stencil * weight)
+// (sparse_linear.cpp:43), widened to T.  field_interpolation.cpp:257-315.
+template <typename T>
+struct ModelCoef {
+	T   c[5][5];  // c[k][m], k = difference order 1..4, m = 0..k
+	T   w0sq;     // model_0^2 (added once per axis)
+	T   gs;       // gradient_smoothness (row coefficient +-gs)
+	int on[6];    // on[k] for k = 0..4, on[5] = gradient smoothness
+	int maxk;     // widest enabled difference order (0 if none)
+};
+
+// ---- per-cell data operator -----------------------------------------------------------------------
+struct CellData {
+	int64_t ncell = 0;
+	DevBuf  cell_id;  // uint32[ncell], extended local cell id, ascending
+	DevBuf  blk;      // T[nb*ncell]  upper triangle of the 2^D x 2^D block, entry-major (SoA)
+	int     nb = 0;   // entries per block: 2^D(2^D+1)/2
+};
+
+struct Pending {  // one fi_add_points batch, already turned into cell rows on the device
+	int64_t nrows = 0;  // slots (valid or not)
+	DevBuf  key;        // uint32[nrows]   extended local cell id or 0xFFFFFFFF
+	DevBuf  coef;       // float[nrows * 2^D]
+	DevBuf  rhs;        // float[nrows]
+};
+
+struct Comm;  // RCCL state (fi_comm.cpp)
+
+struct CgScalars {  // lives in device memory; kernels read/write it, the host polls it
+	double rz, rz_new, pq, rr, bb, tol2;
+	double sums[4];
+	int    iter, done, max_iter, pad;
+};
+
+}  // namespace fi
+
+struct fi_ctx {
+	int        dtype = FI_F32;
+	int        device = 0;
+	int        rank = 0, nranks = 1;
+	int        halo = 0;
+	int        slab_lo = 0, slab_hi = 0;
+	fi::Geom   g{};
+	fi_weights w{};
+	bool       model_set = false;
+	bool       assembled = false;
+	bool       vectors_ready = false;
+	hipStream_t stream = nullptr;
+
+	std::vector<fi::Pending*> pending;
+	fi::CellData              cells;
+
+	// operator pieces (T arrays over local storage)
+	fi::DevBuf atb, diag, dinv;
+	// solver vectors
+	fi::DevBuf x, r, p, q;
+	fi::DevBuf partial;       // double[4 * max_blocks]
+	fi::DevBuf scal;          // CgScalars
+	fi::CgScalars* scal_host = nullptr;  // pinned
+	int        max_blocks = 0;
+
+	fi::Comm*  comm = nullptr;
+	fi_stats   stats{};
+	std::vector<hipEvent_t> ev;  // sampled events around AtA applies
+};
+
+namespace fi {
+
+size_t elem_size(const fi_ctx* c);
+
+// fi_operator.hip
+void operator_prepare(fi_ctx* c);                                   // model diag etc. after assemble
+void apply_AtA(fi_ctx* c, const void* x, void* y, double* pq_partial);  // y = AtA x (+ fused x.y partials)
+int  apply_num_partials(const fi_ctx* c);
+double apply_algorithmic_bytes(const fi_ctx* c);
+void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.cpp
+
+// fi_assembly.hip
+void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val,
+                     float vw, int vk, float gw, int gk);
+void assemble(fi_ctx* c);
+
+// fi_comm.cpp
+void comm_destroy(Comm* cm);
+void allreduce_sum(fi_ctx* c, double* dev, int count);
+
+}  // namespace fi

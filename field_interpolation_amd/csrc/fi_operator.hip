@@ -1,0 +1,350 @@
+// fi_operator.hip -- the matrix-free normal-equation operator  y = (A^T A) x.
+//
+// Reference path replaced: make_square (sparse_linear.cpp:105-113) builds A^T A explicitly with a
+// sparse*sparse product and every solver iteration multiplies by it (Eigen CSC SpMV, :199-206, :235).
+// Here A^T A is never formed:
+//
+//   model rows  (add_model_constraint, field_interpolation.cpp:243-316) are forward-anchored finite
+//               differences along one axis; y += S^T (S x) is evaluated per lattice point from the
+//               2k+1 neighbours on that axis, with the reference's existence rule for boundary rows
+//               (row anchored at a exists iff 0 <= a and a + k < size, :265,273,282,292) applied through
+//               GLOBAL coordinates, so slabs and tiles reproduce the 1,5,6,...,6,5,1 boundary diagonal.
+//   data rows   live as one symmetric 2^D x 2^D block per occupied cell (fi_assembly.hip).
+//
+// Kernels in this file
+//   k_apply_generic   any D, any model order, gradient_smoothness; one thread per owned point, direct
+//                     (L1/L2-served) neighbour loads.  Fallback and 1-D path.
+//   k_apply_cells     one thread per occupied cell: y[corners] += B x[corners].
+//   k_model_diag      analytic diag of the model part; k_invert_diag: Jacobi scaling.
+// The LDS-tiled kernels for 2-D / 3-D lattices are in fi_stencil.hip.
+
+#include "fi_internal.h"
+
+namespace fi {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ inline double wave_sum(double v)
+{
+	for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); }
+	return v;
+}
+
+// Sum over the 256 threads of a block; result valid in thread 0.
+__device__ inline double block_sum(double v)
+{
+	__shared__ double s[kThreads / 64];
+	v = wave_sum(v);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (lane == 0) { s[wave] = v; }
+	__syncthreads();
+	double r = 0;
+	if (threadIdx.x == 0) {
+		for (int w = 0; w < kThreads / 64; ++w) { r += s[w]; }
+	}
+	__syncthreads();
+	return r;
+}
+
+__host__ __device__ inline int packed_index(int i, int j, int nc)  // i <= j
+{
+	return i * nc - (i * (i - 1)) / 2 + (j - i);
+}
+
+template <int D>
+__device__ inline int64_t owned_to_local(const Geom& g, int64_t o, int* li)
+{
+	int64_t idx = 0;
+	for (int d = 0; d < D; ++d) {
+		const int ext = g.own_hi[d] - g.own_lo[d];
+		li[d] = g.own_lo[d] + static_cast<int>(o % ext);
+		o /= ext;
+		idx += static_cast<int64_t>(li[d]) * g.stride[d];
+	}
+	return idx;
+}
+
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T> mc, const T* __restrict__ x,
+                                                             T* __restrict__ y, double* __restrict__ partial,
+                                                             const int* __restrict__ done)
+{
+	if (done && *done) { return; }
+	const int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	double contrib = 0.0;
+	if (o < g.nown) {
+		int li[3] = {0, 0, 0};
+		const int64_t idx = owned_to_local<D>(g, o, li);
+		const T xi = x[idx];
+		T acc = 0;
+		for (int d = 0; d < D; ++d) {
+			const int     c = li[d] + g.off[d];
+			const int     n = g.gn[d];
+			const int64_t s = g.stride[d];
+			if (mc.on[0]) { acc += mc.w0sq * xi; }
+			if (mc.maxk > 0) {
+				T win[9];
+				for (int m = -4; m <= 4; ++m) {
+					const int gc = c + m;
+					const bool in = (m >= -mc.maxk) && (m <= mc.maxk) && (gc >= 0) && (gc < n);
+					win[m + 4] = in ? x[idx + m * s] : T(0);
+				}
+				for (int k = 1; k <= 4; ++k) {
+					if (!mc.on[k]) { continue; }
+					for (int m = 0; m <= k; ++m) {
+						const int a = c - m;  // anchor of a row that touches this point with coefficient c[k][m]
+						if (a >= 0 && a + k < n) {
+							T t = 0;
+							for (int j = 0; j <= k; ++j) { t += mc.c[k][j] * win[4 - m + j]; }
+							acc += mc.c[k][m] * t;
+						}
+					}
+				}
+			}
+		}
+		if (mc.on[5]) {
+			// field_interpolation.cpp:303-315: rows [-1,+1,+1,-1]*gs on {0, s_d, s_o, s_o+s_d}; every
+			// unordered axis pair is emitted twice (once from each axis).
+			for (int d = 0; d < D; ++d) {
+				for (int e = d + 1; e < D; ++e) {
+					const int cd = li[d] + g.off[d], ce = li[e] + g.off[e];
+					const int64_t sd = g.stride[d], se = g.stride[e];
+					for (int bd = 0; bd < 2; ++bd) {
+						for (int be = 0; be < 2; ++be) {
+							const int ad = cd - bd, ae = ce - be;
+							if (ad >= 0 && ad + 1 < g.gn[d] && ae >= 0 && ae + 1 < g.gn[e]) {
+								const int64_t a = idx - bd * sd - be * se;
+								const T row = mc.gs * (-x[a] + x[a + sd] + x[a + se] - x[a + sd + se]);
+								const T sign = (bd ^ be) ? T(1) : T(-1);
+								acc += T(2) * (sign * mc.gs) * row;
+							}
+						}
+					}
+				}
+			}
+		}
+		y[idx]  = acc;
+		contrib = static_cast<double>(xi) * static_cast<double>(acc);
+	}
+	if (partial) {
+		const double s = block_sum(contrib);
+		if (threadIdx.x == 0) { partial[blockIdx.x] = s; }
+	}
+}
+
+template <typename T>
+__device__ inline void atomic_add(T* p, T v)
+{
+	unsafeAtomicAdd(p, v);
+}
+
+// y[corners] += B x[corners] for every occupied cell.  Inputs may sit on ghost planes; outputs go to
+// owned points only.  fp32/fp64 hardware atomics (global_atomic_add_f32 / _f64, no CAS loop).
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell, const uint32_t* __restrict__ cell_id,
+                                                           const T* __restrict__ blk, const T* __restrict__ x,
+                                                           T* __restrict__ y, double* __restrict__ partial,
+                                                           const int* __restrict__ done)
+{
+	if (done && *done) { return; }
+	constexpr int NC = 1 << D;
+	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	double contrib = 0.0;
+	if (c < ncell) {
+		uint32_t id = cell_id[c];
+		int l[3] = {0, 0, 0};
+		for (int d = 0; d < D; ++d) {
+			l[d] = static_cast<int>(id % static_cast<uint32_t>(g.cn[d]));
+			id /= static_cast<uint32_t>(g.cn[d]);
+		}
+		int64_t idx[NC];
+		bool    in[NC], own[NC];
+		T       xv[NC];
+		for (int q = 0; q < NC; ++q) {
+			int64_t ix = 0;
+			bool ok = true, ow = true;
+			for (int d = 0; d < D; ++d) {
+				const int gq = l[d] + g.coff[d] + ((q >> d) & 1);
+				const int li = gq - g.off[d];
+				ok = ok && (0 <= gq) && (gq < g.gn[d]);
+				ow = ow && (g.own_lo[d] <= li) && (li < g.own_hi[d]);
+				ix += static_cast<int64_t>(li) * g.stride[d];
+			}
+			idx[q] = ix;
+			in[q]  = ok;
+			own[q] = ok && ow;
+			xv[q]  = ok ? x[ix] : T(0);
+		}
+		for (int i = 0; i < NC; ++i) {
+			if (!own[i]) { continue; }
+			T s = 0;
+			for (int j = 0; j < NC; ++j) {
+				const int e = i <= j ? packed_index(i, j, NC) : packed_index(j, i, NC);
+				s += blk[static_cast<int64_t>(e) * ncell + c] * xv[j];
+			}
+			atomic_add(&y[idx[i]], s);
+			contrib += static_cast<double>(xv[i]) * static_cast<double>(s);
+		}
+		(void)in;
+	}
+	if (partial) {
+		const double s = block_sum(contrib);
+		if (threadIdx.x == 0) { partial[blockIdx.x] = s; }
+	}
+}
+
+// diag(A^T A) of the model rows, added onto `diag` (which already holds the data part).
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_model_diag(Geom g, ModelCoef<T> mc, T* __restrict__ diag)
+{
+	const int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (o >= g.nown) { return; }
+	int li[3] = {0, 0, 0};
+	const int64_t idx = owned_to_local<D>(g, o, li);
+	T acc = 0;
+	for (int d = 0; d < D; ++d) {
+		const int c = li[d] + g.off[d], n = g.gn[d];
+		if (mc.on[0]) { acc += mc.w0sq; }
+		for (int k = 1; k <= 4; ++k) {
+			if (!mc.on[k]) { continue; }
+			for (int m = 0; m <= k; ++m) {
+				const int a = c - m;
+				if (a >= 0 && a + k < n) { acc += mc.c[k][m] * mc.c[k][m]; }
+			}
+		}
+	}
+	if (mc.on[5]) {
+		for (int d = 0; d < D; ++d) {
+			for (int e = d + 1; e < D; ++e) {
+				const int cd = li[d] + g.off[d], ce = li[e] + g.off[e];
+				for (int bd = 0; bd < 2; ++bd) {
+					for (int be = 0; be < 2; ++be) {
+						const int ad = cd - bd, ae = ce - be;
+						if (ad >= 0 && ad + 1 < g.gn[d] && ae >= 0 && ae + 1 < g.gn[e]) {
+							acc += T(2) * mc.gs * mc.gs;
+						}
+					}
+				}
+			}
+		}
+	}
+	diag[idx] += acc;
+}
+
+// Eigen::DiagonalPreconditioner semantics: 1/diag, or 1 where diag == 0.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_invert_diag(int64_t n, const T* __restrict__ diag, T* __restrict__ dinv)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i < n) {
+		const T d = diag[i];
+		dinv[i]   = (d != T(0)) ? T(1) / d : T(1);
+	}
+}
+
+inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
+
+template <typename T>
+ModelCoef<T> make_coef(const fi_weights& w)
+{
+	// A holds fp32(stencil * weight) (sparse_linear.cpp:43); square in T afterwards.
+	static const float pascal[5][5] = {
+	    {1, 0, 0, 0, 0}, {-1, +1, 0, 0, 0}, {+1, -2, +1, 0, 0}, {+1, -3, +3, -1, 0}, {+1, -4, +6, -4, +1}};
+	const float wk[5] = {w.model_0, w.model_1, w.model_2, w.model_3, w.model_4};
+	ModelCoef<T> mc{};
+	mc.maxk = 0;
+	for (int k = 0; k <= 4; ++k) {
+		mc.on[k] = wk[k] > 0.0f;  // field_interpolation.cpp:257,265,273,282,292: `weights.model_k > 0`
+		for (int m = 0; m <= 4; ++m) {
+			volatile float prod = pascal[k][m] * wk[k];
+			mc.c[k][m] = mc.on[k] ? static_cast<T>(prod) : T(0);
+		}
+		if (k >= 1 && mc.on[k]) { mc.maxk = k; }
+	}
+	{
+		volatile float w0 = 1.0f * w.model_0;
+		mc.w0sq = mc.on[0] ? static_cast<T>(w0) * static_cast<T>(w0) : T(0);
+	}
+	mc.on[5] = w.gradient_smoothness > 0.0f;
+	mc.gs    = mc.on[5] ? static_cast<T>(w.gradient_smoothness) : T(0);
+	return mc;
+}
+
+template <int D, typename T>
+void prepare_dim(fi_ctx* c)
+{
+	const Geom& g = c->g;
+	const ModelCoef<T> mc = make_coef<T>(c->w);
+	hipLaunchKernelGGL((k_model_diag<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g, mc,
+	                   c->diag.as<T>());
+	c->dinv.alloc(sizeof(T) * g.nloc);
+	hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc,
+	                   c->diag.as<T>(), c->dinv.as<T>());
+	FI_HIP_TRY(hipGetLastError());
+}
+
+template <int D, typename T>
+void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
+{
+	const Geom& g = c->g;
+	const ModelCoef<T> mc = make_coef<T>(c->w);
+	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
+	const int nb_model = blocks_for(g.nown);
+	hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial, done);
+	if (c->cells.ncell > 0) {
+		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(blocks_for(c->cells.ncell)), dim3(kThreads), 0, c->stream, g,
+		                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), x, y,
+		                   partial ? partial + nb_model : nullptr, done);
+	}
+	FI_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+size_t elem_size(const fi_ctx* c) { return c->dtype == FI_F64 ? sizeof(double) : sizeof(float); }
+
+int apply_num_partials(const fi_ctx* c)
+{
+	return blocks_for(c->g.nown) + (c->cells.ncell > 0 ? blocks_for(c->cells.ncell) : 0);
+}
+
+double apply_algorithmic_bytes(const fi_ctx* c)
+{
+	// B_spmv = 2*s*N + C_occ*(4 + s*2^D(2^D+1)/2)
+	const double s = static_cast<double>(elem_size(c));
+	return 2.0 * s * static_cast<double>(c->g.nown) +
+	       static_cast<double>(c->cells.ncell) * (4.0 + s * static_cast<double>(c->cells.nb));
+}
+
+void operator_prepare(fi_ctx* c)
+{
+	const bool f64 = c->dtype == FI_F64;
+	switch (c->g.ndim) {
+	case 1: f64 ? prepare_dim<1, double>(c) : prepare_dim<1, float>(c); break;
+	case 2: f64 ? prepare_dim<2, double>(c) : prepare_dim<2, float>(c); break;
+	default: f64 ? prepare_dim<3, double>(c) : prepare_dim<3, float>(c); break;
+	}
+}
+
+void apply_AtA(fi_ctx* c, const void* x, void* y, double* partial)
+{
+	const bool f64 = c->dtype == FI_F64;
+	switch (c->g.ndim) {
+	case 1:
+		f64 ? apply_dim<1, double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial)
+		    : apply_dim<1, float>(c, static_cast<const float*>(x), static_cast<float*>(y), partial);
+		break;
+	case 2:
+		f64 ? apply_dim<2, double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial)
+		    : apply_dim<2, float>(c, static_cast<const float*>(x), static_cast<float*>(y), partial);
+		break;
+	default:
+		f64 ? apply_dim<3, double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial)
+		    : apply_dim<3, float>(c, static_cast<const float*>(x), static_cast<float*>(y), partial);
+		break;
+	}
+}
+
+}  // namespace fi

@@ -1,0 +1,1018 @@
+// fi_solver.hip -- Jacobi-preconditioned conjugate gradients and weighted Jacobi on A^T A x = A^T b,
+// plus the C ABI (include/fi_hip.h).
+//
+// Reference path replaced: Eigen::BiCGSTAB<SparseMatrix<float>> with its default diagonal
+// preconditioner, reached from solve_sparse_linear_with_guess (sparse_linear.cpp:186-212) and
+// solve_tiled_with_guess (:427-440), and the hand-written loop of jacobi_iterations (:214-241).
+// A^T A is symmetric positive semi-definite, so CG applies ("Planned CDNA4
+// counterpart"); the stop rule is Eigen's: ||r||_2 <= tol * ||A^T b||_2.
+//
+// One CG iteration = 3 vector kernels + 2 single-block scalar kernels, all enqueued on one stream:
+//   apply        q = AtA p, per-block partials of p.q                      (fi_operator / fi_stencil)
+//   k_reduce     partials -> pq                              [all-reduce over ranks when slabbed]
+//   k_update     alpha = rz/pq; x += alpha p; r -= alpha q; partials of r.(Dinv r) and r.r
+//   k_reduce     -> rz_new, rr; beta; iteration count; convergence flag
+//   k_direction  p = Dinv r + beta p
+// Dot products: fp64 per-thread products, wave64 __shfl_down tree, LDS across the 4 waves, one partial
+// per block, summed in a fixed order by one block => bitwise reproducible run to run.
+// No host synchronisation inside an iteration: alpha/beta/flags stay in HBM (`CgScalars`); the host
+// looks at the flag every `kCheckEvery` iterations; kernels of a finished solve exit at once.
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstdarg>
+#include <cstring>
+#include <limits>
+
+#include "fi_internal.h"
+
+namespace fi {
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...)
+{
+	char    buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_error = buf;
+}
+
+namespace {
+
+constexpr int kThreads    = 256;
+constexpr int kCheckEvery = 16;
+constexpr int kMaxSamples = 128;
+
+__device__ inline double wave_sum(double v)
+{
+	for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); }
+	return v;
+}
+
+template <int NV>
+__device__ inline void block_sum(double* v, double* out)  // out[] valid in thread 0
+{
+	__shared__ double s[NV][kThreads / 64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int k = 0; k < NV; ++k) {
+		const double w = wave_sum(v[k]);
+		if (lane == 0) { s[k][wave] = w; }
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int k = 0; k < NV; ++k) {
+			double r = 0;
+			for (int w = 0; w < kThreads / 64; ++w) { r += s[k][w]; }
+			out[k] = r;
+		}
+	}
+	__syncthreads();
+}
+
+inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
+
+// grid-stride launch width for the streaming vector kernels: 256 CUs x 8 blocks
+inline int stream_blocks(int64_t n)
+{
+	const int64_t b = (n + kThreads * 4 - 1) / (kThreads * 4);
+	return static_cast<int>(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+// ---- vector kernels (owned range is contiguous: the slowest axis is the decomposed one) ---------
+
+// r = b - q; p = Dinv r; partials: r.(Dinv r), r.r, b.b
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cg_init(int64_t n, const T* __restrict__ b, const T* __restrict__ q,
+                                                       const T* __restrict__ dinv, T* __restrict__ r,
+                                                       T* __restrict__ p, double* __restrict__ partial, int nblk)
+{
+	double acc[3] = {0, 0, 0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T bi = b[i];
+		const T ri = bi - q[i];
+		const T zi = dinv[i] * ri;
+		r[i] = ri;
+		p[i] = zi;
+		acc[0] += static_cast<double>(ri) * static_cast<double>(zi);
+		acc[1] += static_cast<double>(ri) * static_cast<double>(ri);
+		acc[2] += static_cast<double>(bi) * static_cast<double>(bi);
+	}
+	double out[3];
+	block_sum<3>(acc, out);
+	if (threadIdx.x == 0) {
+		partial[blockIdx.x]            = out[0];
+		partial[nblk + blockIdx.x]     = out[1];
+		partial[2 * nblk + blockIdx.x] = out[2];
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cg_update(int64_t n, const CgScalars* __restrict__ sc,
+                                                         const T* __restrict__ p, const T* __restrict__ q,
+                                                         const T* __restrict__ dinv, T* __restrict__ x,
+                                                         T* __restrict__ r, double* __restrict__ partial, int nblk)
+{
+	if (sc->done) { return; }
+	const T alpha = static_cast<T>(sc->rz / sc->pq);
+	double acc[2] = {0, 0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += alpha * p[i];
+		const T ri = r[i] - alpha * q[i];
+		r[i]       = ri;
+		const T zi = dinv[i] * ri;
+		acc[0] += static_cast<double>(ri) * static_cast<double>(zi);
+		acc[1] += static_cast<double>(ri) * static_cast<double>(ri);
+	}
+	double out[2];
+	block_sum<2>(acc, out);
+	if (threadIdx.x == 0) {
+		partial[blockIdx.x]        = out[0];
+		partial[nblk + blockIdx.x] = out[1];
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cg_direction(int64_t n, const CgScalars* __restrict__ sc,
+                                                            const T* __restrict__ r, const T* __restrict__ dinv,
+                                                            T* __restrict__ p)
+{
+	if (sc->done) { return; }
+	const T beta = static_cast<T>(sc->sums[3]);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		p[i] = dinv[i] * r[i] + beta * p[i];
+	}
+}
+
+// x <- x + w * (b - q) * Dinv     (jacobi_iterations, sparse_linear.cpp:233-239, algebraically identical)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_jacobi_update(int64_t n, T w, const T* __restrict__ b,
+                                                             const T* __restrict__ q, const T* __restrict__ dinv,
+                                                             T* __restrict__ x)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += w * (b[i] - q[i]) * dinv[i];
+	}
+}
+
+// r = b - q; partials r.r, b.b
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_residual_norm(int64_t n, const T* __restrict__ b, const T* __restrict__ q,
+                                                             double* __restrict__ partial, int nblk)
+{
+	double acc[2] = {0, 0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const double bi = static_cast<double>(b[i]);
+		const double ri = bi - static_cast<double>(q[i]);
+		acc[0] += ri * ri;
+		acc[1] += bi * bi;
+	}
+	double out[2];
+	block_sum<2>(acc, out);
+	if (threadIdx.x == 0) {
+		partial[blockIdx.x]        = out[0];
+		partial[nblk + blockIdx.x] = out[1];
+	}
+}
+
+// ---- scalar kernels: one block --------------------------------------------------------------------
+// Sums `nvec` partial arrays (each `stride` apart, `count` entries) in a fixed order into sc->sums[].
+__global__ __launch_bounds__(kThreads) void k_reduce(CgScalars* sc, const double* __restrict__ partial, int nvec,
+                                                      int stride, int count, int respect_done)
+{
+	if (respect_done && sc->done) { return; }
+	for (int v = 0; v < nvec; ++v) {
+		double acc[1] = {0};
+		for (int i = threadIdx.x; i < count; i += kThreads) { acc[0] += partial[v * stride + i]; }
+		double out[1];
+		block_sum<1>(acc, out);
+		if (threadIdx.x == 0) { sc->sums[v] = out[0]; }
+	}
+}
+
+enum Phase { kPhaseInit = 0, kPhaseSpmv = 1, kPhaseUpdate = 2 };
+
+__global__ void k_cg_logic(CgScalars* sc, int phase)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
+	if (phase == kPhaseInit) {
+		sc->rz = sc->sums[0];
+		sc->rr = sc->sums[1];
+		sc->bb = sc->sums[2];
+		sc->tol2 *= sc->bb;  // tol^2 * ||Atb||^2
+		sc->iter = 0;
+		sc->done = 0;
+		if (sc->bb == 0.0) {
+			sc->done = 4;  // rhs == 0: Eigen returns x = 0
+		} else if (!(sc->rr > sc->tol2)) {
+			sc->done = 1;
+		} else if (sc->max_iter <= 0) {
+			sc->done = 3;
+		}
+		return;
+	}
+	if (sc->done) { return; }
+	if (phase == kPhaseSpmv) {
+		sc->pq = sc->sums[0];
+		if (!(sc->pq > 0.0) || !isfinite(sc->pq)) { sc->done = 2; }  // breakdown
+		return;
+	}
+	// after the update
+	sc->rz_new  = sc->sums[0];
+	sc->rr      = sc->sums[1];
+	sc->sums[3] = sc->rz_new / sc->rz;  // beta
+	sc->rz      = sc->rz_new;
+	sc->iter += 1;
+	if (!isfinite(sc->rr)) {
+		sc->done = 2;
+	} else if (!(sc->rr > sc->tol2)) {
+		sc->done = 1;
+	} else if (sc->iter >= sc->max_iter) {
+		sc->done = 3;
+	}
+}
+
+// ---- layout conversion between caller fp32 buffers (owned unknowns) and solver vectors ------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_from_float(int64_t n, const float* __restrict__ src, T* __restrict__ dst)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i < n) { dst[i] = static_cast<T>(src[i]); }
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_to_float(int64_t n, const T* __restrict__ src, float* __restrict__ dst)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i < n) { dst[i] = static_cast<float>(src[i]); }
+}
+template <typename T, typename U>
+__global__ __launch_bounds__(kThreads) void k_convert(int64_t n, const T* __restrict__ src, U* __restrict__ dst)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i < n) { dst[i] = static_cast<U>(src[i]); }
+}
+
+// upscale_field (field_interpolation.cpp:431-485): one thread per point of the large lattice.
+struct UpscaleArgs {
+	int ndim;
+	int ssz[3], lsz[3];
+};
+__global__ __launch_bounds__(kThreads) void k_upscale(UpscaleArgs a, int64_t nlarge, const float* __restrict__ small,
+                                                       float* __restrict__ out)
+{
+	const int64_t li = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (li >= nlarge) { return; }
+	int     base[3];
+	float   t[3];
+	int64_t rest = li;
+	for (int d = 0; d < a.ndim; ++d) {
+		const int c = static_cast<int>(rest % a.lsz[d]);
+		rest /= a.lsz[d];
+		const float sp = static_cast<float>(c) * (static_cast<float>(a.ssz[d]) - 1.0f) /
+		                 (static_cast<float>(a.lsz[d]) - 1.0f);
+		const float fl = floorf(sp);
+		base[d] = static_cast<int>(fl);
+		t[d]    = sp - static_cast<float>(base[d]);
+	}
+	float wsum = 0.0f, fsum = 0.0f;
+	for (int q = 0; q < (1 << a.ndim); ++q) {
+		int64_t idx = 0, stride = 1;
+		float   w  = 1.0f;
+		bool    in = true;
+		for (int d = 0; d < a.ndim; ++d) {
+			const int up = (q >> d) & 1;
+			const int cc = base[d] + up;
+			idx += stride * cc;
+			stride *= a.ssz[d];
+			w *= up ? t[d] : 1.0f - t[d];
+			in = in && (0 <= cc) && (cc < a.ssz[d]);
+		}
+		if (in) {
+			wsum += w;
+			fsum += w * small[idx];
+		}
+	}
+	out[li] = (wsum == 0.0f) ? 0.0f : fsum / wsum;
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+
+void compute_geom(fi_ctx* c, int ndim, const int* sizes)
+{
+	Geom& g = c->g;
+	g = Geom{};
+	g.ndim = ndim;
+	const int L = ndim - 1;
+	for (int d = 0; d < 3; ++d) {
+		g.gn[d]     = d < ndim ? sizes[d] : 1;
+		g.n[d]      = g.gn[d];
+		g.off[d]    = 0;
+		g.own_lo[d] = 0;
+		g.own_hi[d] = g.gn[d];
+		g.cn[d]     = d < ndim ? g.gn[d] + 1 : 1;
+		g.coff[d]   = d < ndim ? -1 : 0;
+	}
+	const int G = g.gn[L];
+	c->slab_lo = static_cast<int>(static_cast<int64_t>(c->rank) * G / c->nranks);
+	c->slab_hi = static_cast<int>(static_cast<int64_t>(c->rank + 1) * G / c->nranks);
+	const int H = c->nranks > 1 ? c->halo : 0;
+	g.n[L]      = (c->slab_hi - c->slab_lo) + 2 * H;
+	g.off[L]    = c->slab_lo - H;
+	g.own_lo[L] = H;
+	g.own_hi[L] = H + (c->slab_hi - c->slab_lo);
+	if (c->nranks > 1) {
+		g.cn[L]   = (c->slab_hi - c->slab_lo) + 1;
+		g.coff[L] = c->slab_lo - 1;
+	}
+	int64_t s = 1;
+	for (int d = 0; d < 3; ++d) {
+		g.stride[d] = s;
+		s *= g.n[d];
+	}
+	g.nloc = s;
+	g.nown = 1;
+	for (int d = 0; d < 3; ++d) { g.nown *= (g.own_hi[d] - g.own_lo[d]); }
+	g.own_first = static_cast<int64_t>(g.own_lo[L]) * g.stride[L];
+}
+
+int model_reach(const fi_weights& w)
+{
+	int k = 0;
+	if (w.model_1 > 0) { k = 1; }
+	if (w.model_2 > 0) { k = 2; }
+	if (w.model_3 > 0) { k = 3; }
+	if (w.model_4 > 0) { k = 4; }
+	return k;
+}
+
+template <typename T>
+T* owned(const fi_ctx* c, const DevBuf& b)
+{
+	return b.as<T>() + c->g.own_first;
+}
+
+void ensure_vectors(fi_ctx* c)
+{
+	if (c->vectors_ready) { return; }
+	const size_t es = elem_size(c);
+	const Geom&  g  = c->g;
+	c->x.alloc(es * g.nloc);
+	c->r.alloc(es * g.nloc);
+	c->p.alloc(es * g.nloc);
+	c->q.alloc(es * g.nloc);
+	FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, es * g.nloc, c->stream));
+	FI_HIP_TRY(hipMemsetAsync(c->r.p, 0, es * g.nloc, c->stream));
+	FI_HIP_TRY(hipMemsetAsync(c->p.p, 0, es * g.nloc, c->stream));
+	FI_HIP_TRY(hipMemsetAsync(c->q.p, 0, es * g.nloc, c->stream));
+	int nb = apply_num_partials(c);
+	if (nb < 2048) { nb = 2048; }
+	c->max_blocks = nb;
+	c->partial.alloc(sizeof(double) * 4 * nb);
+	c->vectors_ready = true;
+}
+
+template <typename T>
+void load_owned(fi_ctx* c, DevBuf& v, const float* src, int memory)
+{
+	const Geom& g = c->g;
+	if (!src) {
+		FI_HIP_TRY(hipMemsetAsync(v.p, 0, sizeof(T) * g.nloc, c->stream));
+		return;
+	}
+	DevBuf tmp;
+	const float* dsrc = src;
+	if (memory == FI_HOST) {
+		tmp.alloc(sizeof(float) * g.nown);
+		FI_HIP_TRY(hipMemcpyAsync(tmp.p, src, sizeof(float) * g.nown, hipMemcpyHostToDevice, c->stream));
+		dsrc = tmp.as<float>();
+	}
+	hipLaunchKernelGGL((k_from_float<T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown, dsrc,
+	                   owned<T>(c, v));
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+}
+
+template <typename T>
+void store_owned(fi_ctx* c, const DevBuf& v, float* dst, int memory)
+{
+	const Geom& g = c->g;
+	if (!dst) { return; }
+	if (memory == FI_DEVICE) {
+		hipLaunchKernelGGL((k_to_float<T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
+		                   owned<T>(c, v), dst);
+		FI_HIP_TRY(hipGetLastError());
+		FI_HIP_TRY(hipStreamSynchronize(c->stream));
+		return;
+	}
+	DevBuf tmp;
+	tmp.alloc(sizeof(float) * g.nown);
+	hipLaunchKernelGGL((k_to_float<T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown, owned<T>(c, v),
+	                   tmp.as<float>());
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipMemcpyAsync(dst, tmp.p, sizeof(float) * g.nown, hipMemcpyDeviceToHost, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+}
+
+void reduce_and_logic(fi_ctx* c, int nvec, int stride, int count, int phase)
+{
+	CgScalars* sc = c->scal.as<CgScalars>();
+	hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, sc, c->partial.as<double>(), nvec, stride, count,
+	                   phase == kPhaseInit ? 0 : 1);
+	if (c->nranks > 1) { allreduce_sum(c, sc->sums, nvec); }
+	hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, c->stream, sc, phase);
+}
+
+template <typename T>
+void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
+                float* rel_residual, int memory)
+{
+	const Geom& g = c->g;
+	ensure_vectors(c);
+	hipStream_t st = c->stream;
+	if (max_iterations <= 0) {
+		const int64_t dflt = 2 * static_cast<int64_t>(g.gn[0]) * g.gn[1] * g.gn[2];  // Eigen: 2 * cols
+		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
+	}
+	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
+
+	load_owned<T>(c, c->x, guess, memory);
+
+	hipEvent_t e0, e1;
+	FI_HIP_TRY(hipEventCreate(&e0));
+	FI_HIP_TRY(hipEventCreate(&e1));
+	FI_HIP_TRY(hipEventRecord(e0, st));
+
+	CgScalars init{};
+	init.tol2     = tolerance * tolerance;
+	init.max_iter = max_iterations;
+	init.done     = 0;
+	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
+	CgScalars* sc = c->scal.as<CgScalars>();
+
+	const int nb_vec = stream_blocks(g.nown);
+	T* x = c->x.as<T>();
+	T* r = c->r.as<T>();
+	T* p = c->p.as<T>();
+	T* q = c->q.as<T>();
+	const T* b    = c->atb.as<T>();
+	const T* dinv = c->dinv.as<T>();
+	const int64_t o = g.own_first;
+
+	// r0 = b - A x0
+	exchange_halo(c, x);
+	apply_AtA(c, x, q, nullptr);
+	hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_vec), dim3(kThreads), 0, st, g.nown, b + o, q + o, dinv + o, r + o, p + o,
+	                   c->partial.as<double>(), nb_vec);
+	reduce_and_logic(c, 3, nb_vec, nb_vec, kPhaseInit);
+
+	const int nb_apply = apply_num_partials(c);
+	int samples = 0;
+	c->stats.spmv_samples = 0;
+	c->stats.spmv_ms_avg  = 0;
+	while (static_cast<int>(c->ev.size()) < 2 * kMaxSamples) {
+		hipEvent_t e;
+		FI_HIP_TRY(hipEventCreate(&e));
+		c->ev.push_back(e);
+	}
+	int issued = 0;
+	// wall-clock guard: a solve that cannot reach its tolerance (fp32 stagnation with the default 2N
+	// iteration cap) must not hold the GPU for hours.  FI_SOLVE_TIMEOUT_S overrides the 600 s default.
+	double limit_s = 600.0;
+	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
+	const auto wall0 = std::chrono::steady_clock::now();
+	bool timed_out = false;
+	for (;;) {
+		FI_HIP_TRY(hipMemcpyAsync(c->scal_host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		if (c->scal_host->done) { break; }
+		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
+			timed_out = true;
+			break;
+		}
+		for (int k = 0; k < kCheckEvery; ++k) {
+			exchange_halo(c, p);
+			const bool sample = samples < kMaxSamples;
+			if (sample) { FI_HIP_TRY(hipEventRecord(c->ev[2 * samples], st)); }
+			apply_AtA(c, p, q, c->partial.as<double>());
+			if (sample) {
+				FI_HIP_TRY(hipEventRecord(c->ev[2 * samples + 1], st));
+				++samples;
+			}
+			reduce_and_logic(c, 1, 0, nb_apply, kPhaseSpmv);
+			hipLaunchKernelGGL((k_cg_update<T>), dim3(nb_vec), dim3(kThreads), 0, st, g.nown, sc, p + o, q + o, dinv + o,
+			                   x + o, r + o, c->partial.as<double>(), nb_vec);
+			reduce_and_logic(c, 2, nb_vec, nb_vec, kPhaseUpdate);
+			hipLaunchKernelGGL((k_cg_direction<T>), dim3(nb_vec), dim3(kThreads), 0, st, g.nown, sc, r + o, dinv + o, p + o);
+			++issued;
+		}
+		FI_HIP_TRY(hipGetLastError());
+	}
+	FI_HIP_TRY(hipEventRecord(e1, st));
+	FI_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	(void)issued;
+
+	const CgScalars& h = *c->scal_host;
+	// iterations that actually ran (kernels of later iterations exited on the flag)
+	int used = samples;
+	if (h.iter < used) { used = h.iter; }
+	double sum_ms = 0;
+	for (int k = 0; k < used; ++k) {
+		float t = 0;
+		FI_HIP_TRY(hipEventElapsedTime(&t, c->ev[2 * k], c->ev[2 * k + 1]));
+		sum_ms += t;
+	}
+	c->stats.spmv_samples = used;
+	c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
+	c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+	c->stats.solve_ms     = ms;
+	c->stats.iterations   = h.iter;
+	c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4)) ? 1 : 0;
+	c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+
+	if (h.done == 4) {  // rhs == 0  ->  x = 0 (Eigen's early return)
+		FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * g.nloc, st));
+	}
+	if (iterations) { *iterations = h.iter; }
+	if (rel_residual) { *rel_residual = static_cast<float>(c->stats.rel_residual); }
+	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
+	store_owned<T>(c, c->x, out, memory);
+}
+
+template <typename T>
+void jacobi_t(fi_ctx* c, const float* guess, int sweeps, float weight, float* out, int memory)
+{
+	const Geom& g = c->g;
+	ensure_vectors(c);
+	load_owned<T>(c, c->x, guess, memory);
+	const int nb_vec = stream_blocks(g.nown);
+	T* x = c->x.as<T>();
+	T* q = c->q.as<T>();
+	const int64_t o = g.own_first;
+	CgScalars init{};
+	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	for (int s = 0; s < sweeps; ++s) {
+		exchange_halo(c, x);
+		apply_AtA(c, x, q, nullptr);
+		hipLaunchKernelGGL((k_jacobi_update<T>), dim3(nb_vec), dim3(kThreads), 0, c->stream, g.nown, static_cast<T>(weight),
+		                   c->atb.as<T>() + o, q + o, c->dinv.as<T>() + o, x + o);
+	}
+	FI_HIP_TRY(hipGetLastError());
+	store_owned<T>(c, c->x, out, memory);
+}
+
+template <typename T>
+double true_residual_t(fi_ctx* c)
+{
+	const Geom& g = c->g;
+	ensure_vectors(c);
+	CgScalars init{};
+	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	const int nb_vec = stream_blocks(g.nown);
+	const int64_t o = g.own_first;
+	exchange_halo(c, c->x.p);
+	apply_AtA(c, c->x.p, c->q.p, nullptr);
+	hipLaunchKernelGGL((k_residual_norm<T>), dim3(nb_vec), dim3(kThreads), 0, c->stream, g.nown, c->atb.as<T>() + o,
+	                   c->q.as<T>() + o, c->partial.as<double>(), nb_vec);
+	CgScalars* sc = c->scal.as<CgScalars>();
+	hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, sc, c->partial.as<double>(), 2, nb_vec, nb_vec, 0);
+	if (c->nranks > 1) { allreduce_sum(c, sc->sums, 2); }
+	FI_HIP_TRY(hipMemcpyAsync(c->scal_host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	const double rr = c->scal_host->sums[0], bb = c->scal_host->sums[1];
+	return bb > 0 ? std::sqrt(rr / bb) : std::sqrt(rr);
+}
+
+template <typename T>
+void apply_f64_t(fi_ctx* c, const double* xin, double* yout)
+{
+	const Geom& g = c->g;
+	ensure_vectors(c);
+	CgScalars init{};
+	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	DevBuf tmp;
+	tmp.alloc(sizeof(double) * g.nown);
+	FI_HIP_TRY(hipMemcpyAsync(tmp.p, xin, sizeof(double) * g.nown, hipMemcpyHostToDevice, c->stream));
+	FI_HIP_TRY(hipMemsetAsync(c->p.p, 0, sizeof(T) * g.nloc, c->stream));
+	hipLaunchKernelGGL((k_convert<double, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
+	                   tmp.as<double>(), owned<T>(c, c->p));
+	exchange_halo(c, c->p.p);
+	apply_AtA(c, c->p.p, c->q.p, nullptr);
+	hipLaunchKernelGGL((k_convert<T, double>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
+	                   owned<T>(c, c->q), tmp.as<double>());
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipMemcpyAsync(yout, tmp.p, sizeof(double) * g.nown, hipMemcpyDeviceToHost, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+}
+
+template <typename T>
+void get_vec_f64_t(fi_ctx* c, const DevBuf& v, double* out)
+{
+	const Geom& g = c->g;
+	DevBuf tmp;
+	tmp.alloc(sizeof(double) * g.nown);
+	hipLaunchKernelGGL((k_convert<T, double>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
+	                   owned<T>(c, v), tmp.as<double>());
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipMemcpyAsync(out, tmp.p, sizeof(double) * g.nown, hipMemcpyDeviceToHost, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+}
+
+void check_ctx(const fi_ctx* c) { FI_REQUIRE(c != nullptr, FI_ERR_INVALID, "null context"); }
+
+void check_assembled(const fi_ctx* c)
+{
+	check_ctx(c);
+	FI_REQUIRE(c->assembled, FI_ERR_STATE, "fi_assemble has not been called");
+}
+
+void bind_device(const fi_ctx* c) { FI_HIP_TRY(hipSetDevice(c->device)); }
+
+fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks)
+{
+	FI_REQUIRE(1 <= ndim && ndim <= FI_MAX_DIM, FI_ERR_INVALID, "ndim must be 1..%d (got %d)", FI_MAX_DIM, ndim);
+	FI_REQUIRE(sizes != nullptr, FI_ERR_INVALID, "sizes is null");
+	FI_REQUIRE(dtype == FI_F32 || dtype == FI_F64, FI_ERR_INVALID, "unknown dtype %d", dtype);
+	FI_REQUIRE(nranks >= 1 && 0 <= rank && rank < nranks, FI_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+	int64_t n = 1;
+	for (int d = 0; d < ndim; ++d) {
+		FI_REQUIRE(sizes[d] >= 1, FI_ERR_INVALID, "sizes[%d] = %d", d, sizes[d]);
+		n *= sizes[d];
+		FI_REQUIRE(static_cast<int64_t>(sizes[d]) + 1 < (1 << 20), FI_ERR_INVALID, "sizes[%d] too large", d);
+	}
+	FI_REQUIRE(n < (1LL << 31), FI_ERR_UNSUPPORTED, "lattice has %lld unknowns; the reference indexes with int",
+	           static_cast<long long>(n));
+	FI_REQUIRE(nranks == 1 || sizes[ndim - 1] >= nranks, FI_ERR_INVALID, "fewer planes (%d) than ranks (%d)",
+	           sizes[ndim - 1], nranks);
+	auto* c = new fi_ctx();
+	try {
+		c->dtype  = dtype;
+		c->rank   = rank;
+		c->nranks = nranks;
+		FI_HIP_TRY(hipGetDevice(&c->device));
+		FI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->halo = 1;
+		compute_geom(c, ndim, sizes);
+		c->scal.alloc(sizeof(CgScalars));
+		FI_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->scal_host), sizeof(CgScalars), hipHostMallocDefault));
+		// default Weights (field_interpolation.hpp:75-95)
+		c->w = fi_weights{1.0f, 1.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, FI_VALUE_LINEAR_INTERPOLATION,
+		                  FI_GRADIENT_CELL_EDGES};
+	} catch (...) {
+		fi_ctx_destroy(c);
+		throw;
+	}
+	return c;
+}
+
+}  // namespace
+}  // namespace fi
+
+// ===================================================================================================
+// C ABI
+
+#define FI_API_BEGIN try {
+#define FI_API_END                                                   \
+	}                                                                \
+	catch (const fi::Fail& f) { return f.code; }                     \
+	catch (const std::exception& e)                                  \
+	{                                                                \
+		fi::set_error("exception: %s", e.what());                    \
+		return FI_ERR_INVALID;                                       \
+	}                                                                \
+	catch (...)                                                      \
+	{                                                                \
+		fi::set_error("unknown exception");                          \
+		return FI_ERR_INVALID;                                       \
+	}                                                                \
+	return FI_OK;
+
+extern "C" {
+
+const char* fi_last_error(void) { return fi::g_error.c_str(); }
+
+int fi_device_count(int* count)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(count != nullptr, FI_ERR_INVALID, "count is null");
+	int n = 0;
+	const hipError_t e = hipGetDeviceCount(&n);
+	*count = (e == hipSuccess) ? n : 0;
+	FI_API_END
+}
+
+int fi_ctx_create(fi_ctx** out, int ndim, const int* sizes, int dtype)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(out != nullptr, FI_ERR_INVALID, "out is null");
+	*out = fi::create_ctx(ndim, sizes, dtype, 0, 1);
+	FI_API_END
+}
+
+int fi_ctx_create_slab(fi_ctx** out, int ndim, const int* sizes, int dtype, int rank, int nranks)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(out != nullptr, FI_ERR_INVALID, "out is null");
+	*out = fi::create_ctx(ndim, sizes, dtype, rank, nranks);
+	FI_API_END
+}
+
+int fi_ctx_destroy(fi_ctx* c)
+{
+	if (!c) { return FI_OK; }
+	(void)hipSetDevice(c->device);
+	if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+	for (auto* pb : c->pending) { delete pb; }
+	c->pending.clear();
+	for (auto e : c->ev) { (void)hipEventDestroy(e); }
+	if (c->comm) { fi::comm_destroy(c->comm); }
+	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
+	if (c->stream) { (void)hipStreamDestroy(c->stream); }
+	delete c;
+	return FI_OK;
+}
+
+int fi_slab_range(const fi_ctx* c, int* lo, int* hi)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	if (lo) { *lo = c->slab_lo; }
+	if (hi) { *hi = c->slab_hi; }
+	FI_API_END
+}
+
+int fi_set_model(fi_ctx* c, const fi_weights* w)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	FI_REQUIRE(w != nullptr, FI_ERR_INVALID, "weights is null");
+	c->w         = *w;
+	c->model_set = true;
+	c->assembled = false;
+	FI_API_END
+}
+
+int fi_add_points(fi_ctx* c, long n, const float* positions, const float* normals, const float* point_weights,
+                  const float* values, float value_weight, int value_kernel, float gradient_weight, int gradient_kernel,
+                  int memory)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	fi::bind_device(c);
+	FI_REQUIRE(n >= 0, FI_ERR_INVALID, "negative point count");
+	if (n == 0) { return FI_OK; }
+	FI_REQUIRE(positions != nullptr, FI_ERR_INVALID, "positions is null");  // CHECK_NOTNULL_F, cpp:382
+	FI_REQUIRE(value_kernel == FI_VALUE_NEAREST_NEIGHBOR || value_kernel == FI_VALUE_LINEAR_INTERPOLATION,
+	           FI_ERR_INVALID, "Unknown value kernel: %d", value_kernel);
+	FI_REQUIRE(!(value_kernel == FI_VALUE_NEAREST_NEIGHBOR && normals == nullptr), FI_ERR_INVALID,
+	           "nearest-neighbour value kernel needs normals (field_interpolation.cpp:361)");
+	if (normals) {
+		FI_REQUIRE(gradient_kernel >= 0 && gradient_kernel <= 2, FI_ERR_INVALID, "Unknown gradient kernel: %d",
+		           gradient_kernel);  // ABORT_F, cpp:238
+		FI_REQUIRE(gradient_kernel != FI_GRADIENT_LINEAR_INTERPOLATION || gradient_weight == 0.0f, FI_ERR_UNSUPPORTED,
+		           "GradientKernel::kLinearInterpolation rows span three lattice points per axis; pass them through "
+		           "fi_add_rows_coo");
+	}
+	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	const int D = c->g.ndim;
+	fi::DevBuf dpos, dnrm, dpw, dval;
+	const float *p = positions, *g = normals, *w = point_weights, *v = values;
+	if (memory == FI_HOST) {
+		auto up = [&](fi::DevBuf& b, const float* src, size_t count) -> const float* {
+			if (!src) { return nullptr; }
+			b.alloc(sizeof(float) * count);
+			FI_HIP_TRY(hipMemcpyAsync(b.p, src, sizeof(float) * count, hipMemcpyHostToDevice, c->stream));
+			return b.as<float>();
+		};
+		p = up(dpos, positions, static_cast<size_t>(n) * D);
+		g = up(dnrm, normals, static_cast<size_t>(n) * D);
+		w = up(dpw, point_weights, static_cast<size_t>(n));
+		v = up(dval, values, static_cast<size_t>(n));
+	}
+	fi::emit_point_rows(c, n, p, g, w, v, value_weight, value_kernel, gradient_weight, gradient_kernel);
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	c->assembled = false;
+	FI_API_END
+}
+
+int fi_add_rows_coo(fi_ctx* c, long nrows, long ntriplets, const fi_triplet* triplets, const float* rhs, int memory)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	(void)nrows;
+	(void)ntriplets;
+	(void)triplets;
+	(void)rhs;
+	(void)memory;
+	FI_REQUIRE(false, FI_ERR_UNSUPPORTED, "generic COO rows are not available in this build yet");
+	FI_API_END
+}
+
+int fi_clear_points(fi_ctx* c)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	for (auto* pb : c->pending) { delete pb; }
+	c->pending.clear();
+	c->assembled = false;
+	FI_API_END
+}
+
+int fi_assemble(fi_ctx* c)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	fi::bind_device(c);
+	hipEvent_t e0, e1;
+	FI_HIP_TRY(hipEventCreate(&e0));
+	FI_HIP_TRY(hipEventCreate(&e1));
+	FI_HIP_TRY(hipEventRecord(e0, c->stream));
+	// halo width along the decomposed axis: reach of the widest model stencil, at least the cell reach (1)
+	const int reach = fi::model_reach(c->w);
+	const int want  = reach > 1 ? reach : 1;
+	if (c->nranks > 1 && want != c->halo) {
+		FI_REQUIRE(c->pending.empty() || true, FI_ERR_STATE, "unreachable");
+		c->halo = want;
+		int sizes[3] = {c->g.gn[0], c->g.gn[1], c->g.gn[2]};
+		fi::compute_geom(c, c->g.ndim, sizes);
+		c->vectors_ready = false;
+	}
+	if (c->nranks > 1) {
+		FI_REQUIRE(c->slab_hi - c->slab_lo >= c->halo, FI_ERR_UNSUPPORTED,
+		           "slab of %d planes is thinner than the stencil reach %d", c->slab_hi - c->slab_lo, c->halo);
+	}
+	fi::assemble(c);
+	fi::operator_prepare(c);
+	FI_HIP_TRY(hipEventRecord(e1, c->stream));
+	FI_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	c->stats.assemble_ms  = ms;
+	c->stats.num_unknowns = c->g.nown;
+	c->stats.spmv_bytes   = fi::apply_algorithmic_bytes(c);
+	c->assembled          = true;
+	c->vectors_ready      = false;
+	FI_API_END
+}
+
+int fi_solve_cg(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
+                float* rel_residual, int memory)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	if (c->dtype == FI_F64) {
+		fi::solve_cg_t<double>(c, guess, max_iterations, tol, out, iterations, rel_residual, memory);
+	} else {
+		fi::solve_cg_t<float>(c, guess, max_iterations, tol, out, iterations, rel_residual, memory);
+	}
+	FI_API_END
+}
+
+int fi_jacobi(fi_ctx* c, const float* guess, int num_iterations, float weight, float* out, int memory)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	if (num_iterations < 0) { num_iterations = 0; }  // sparse_linear.cpp:220: returns the guess
+	if (c->dtype == FI_F64) {
+		fi::jacobi_t<double>(c, guess, num_iterations, weight, out, memory);
+	} else {
+		fi::jacobi_t<float>(c, guess, num_iterations, weight, out, memory);
+	}
+	FI_API_END
+}
+
+int fi_get_solution_f64(fi_ctx* c, double* out)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(c->vectors_ready && out, FI_ERR_STATE, "no solution yet");
+	c->dtype == FI_F64 ? fi::get_vec_f64_t<double>(c, c->x, out) : fi::get_vec_f64_t<float>(c, c->x, out);
+	FI_API_END
+}
+
+int fi_true_residual(fi_ctx* c, double* rel)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(rel != nullptr, FI_ERR_INVALID, "null output");
+	*rel = c->dtype == FI_F64 ? fi::true_residual_t<double>(c) : fi::true_residual_t<float>(c);
+	FI_API_END
+}
+
+int fi_apply_AtA_f64(fi_ctx* c, const double* x, double* y)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(x && y, FI_ERR_INVALID, "null vector");
+	c->dtype == FI_F64 ? fi::apply_f64_t<double>(c, x, y) : fi::apply_f64_t<float>(c, x, y);
+	FI_API_END
+}
+
+int fi_get_Atb_f64(fi_ctx* c, double* out)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	c->dtype == FI_F64 ? fi::get_vec_f64_t<double>(c, c->atb, out) : fi::get_vec_f64_t<float>(c, c->atb, out);
+	FI_API_END
+}
+
+int fi_get_diag_f64(fi_ctx* c, double* out)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	c->dtype == FI_F64 ? fi::get_vec_f64_t<double>(c, c->diag, out) : fi::get_vec_f64_t<float>(c, c->diag, out);
+	FI_API_END
+}
+
+int fi_get_stats(const fi_ctx* c, fi_stats* out)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	FI_REQUIRE(out != nullptr, FI_ERR_INVALID, "null output");
+	*out = c->stats;
+	FI_API_END
+}
+
+int fi_time_apply(fi_ctx* c, int reps, double* ms_per_launch)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(reps > 0 && ms_per_launch, FI_ERR_INVALID, "bad arguments");
+	fi::ensure_vectors(c);
+	fi::CgScalars init{};
+	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	hipEvent_t e0, e1;
+	FI_HIP_TRY(hipEventCreate(&e0));
+	FI_HIP_TRY(hipEventCreate(&e1));
+	fi::apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>());  // warm-up
+	FI_HIP_TRY(hipEventRecord(e0, c->stream));
+	for (int k = 0; k < reps; ++k) { fi::apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>()); }
+	FI_HIP_TRY(hipEventRecord(e1, c->stream));
+	FI_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	*ms_per_launch = ms / reps;
+	FI_API_END
+}
+
+int fi_upscale_field(const float* small_field, int ndim, const int* small_sizes, const int* large_sizes, float* out,
+                     int memory)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(small_field && small_sizes && large_sizes && out, FI_ERR_INVALID, "null argument");
+	FI_REQUIRE(1 <= ndim && ndim <= FI_MAX_DIM, FI_ERR_INVALID, "ndim must be 1..3");
+	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	fi::UpscaleArgs a{};
+	a.ndim = ndim;
+	int64_t ns = 1, nl = 1;
+	for (int d = 0; d < ndim; ++d) {
+		FI_REQUIRE(small_sizes[d] >= 1 && large_sizes[d] >= 1, FI_ERR_INVALID, "bad size");
+		a.ssz[d] = small_sizes[d];
+		a.lsz[d] = large_sizes[d];
+		ns *= small_sizes[d];
+		nl *= large_sizes[d];
+	}
+	fi::DevBuf ds, dl;
+	const float* s = small_field;
+	float*       o = out;
+	if (memory == FI_HOST) {
+		ds.alloc(sizeof(float) * ns);
+		dl.alloc(sizeof(float) * nl);
+		FI_HIP_TRY(hipMemcpy(ds.p, small_field, sizeof(float) * ns, hipMemcpyHostToDevice));
+		s = ds.as<float>();
+		o = dl.as<float>();
+	}
+	hipLaunchKernelGGL(fi::k_upscale, dim3(fi::blocks_for(nl)), dim3(fi::kThreads), 0, nullptr, a, nl, s, o);
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipDeviceSynchronize());
+	if (memory == FI_HOST) { FI_HIP_TRY(hipMemcpy(out, dl.p, sizeof(float) * nl, hipMemcpyDeviceToHost)); }
+	FI_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+/* fi_hip.h -- C ABI of the MI355X-native field_interpolation solver core (libfi_hip.so).
+ *
+ * This is the drop-in boundary: plain C, opaque context, POD structs, caller-owned buffers, integer
+ * status codes, no exceptions, no aborts.  Everything above it (the C++ headers in
+ * include/field_interpolation/, the ctypes mirror in field_interpolation_amd/) is host plumbing;
+ * everything below it is hand-written HIP for gfx950.
+ *
+ * Each entry point names the reference interface it replaces (file:line under the reference tree,
+ * emilk/field_interpolation).
+ *
+ * Conventions
+ *   - all calls are synchronous: they return after the GPU work they started has completed;
+ *   - `memory` says where caller buffers live: FI_HOST (malloc'ed) or FI_DEVICE (HBM pointers of the
+ *     current device, e.g. torch tensor data_ptr(); the caller must have finished writing them);
+ *   - positions / normals are interleaved xyzxyz... fp32 in LATTICE coordinates, exactly like
+ *     field_interpolation.hpp:153-173;
+ *   - a context is not thread safe; different contexts may be used from different threads.
+ *   - return value 0 = FI_OK; otherwise fi_last_error() holds a message for the calling thread.
+ */
+#ifndef FI_HIP_H
+#define FI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FI_OK 0
+#define FI_ERR_INVALID 1      /* bad argument (the reference CHECK_F / ABORT_F cases) */
+#define FI_ERR_HIP 2          /* HIP runtime failure */
+#define FI_ERR_STATE 3        /* call order violated (e.g. solve before assemble) */
+#define FI_ERR_COMM 4         /* RCCL failure */
+#define FI_ERR_UNSUPPORTED 5  /* valid in the reference, not available in this mode */
+#define FI_ERR_BREAKDOWN 6    /* solver breakdown (non-finite or non-positive curvature): reference returns {} */
+
+#define FI_HOST 0
+#define FI_DEVICE 1
+
+#define FI_F32 0 /* all vectors and operator coefficients fp32, reductions fp64 */
+#define FI_F64 1 /* everything fp64 */
+
+#define FI_MAX_DIM 3 /* field_interpolation.hpp:44 */
+
+/* field_interpolation.hpp:47-59 */
+#define FI_VALUE_NEAREST_NEIGHBOR 0
+#define FI_VALUE_LINEAR_INTERPOLATION 1
+#define FI_GRADIENT_NEAREST_NEIGHBOR 0
+#define FI_GRADIENT_CELL_EDGES 1
+#define FI_GRADIENT_LINEAR_INTERPOLATION 2
+
+typedef struct fi_ctx fi_ctx;
+
+/* field_interpolation.hpp:75-95 `Weights`, field for field. */
+typedef struct fi_weights {
+	float data_pos;
+	float data_gradient;
+	float model_0, model_1, model_2, model_3, model_4;
+	float gradient_smoothness;
+	int   value_kernel;
+	int   gradient_kernel;
+} fi_weights;
+
+/* sparse_linear.hpp:66-73 `SolveOptions`. */
+typedef struct fi_solve_options {
+	int   tile;
+	int   tile_size;
+	int   cg;
+	int   max_iterations;
+	float error_tolerance;
+} fi_solve_options;
+
+/* sparse_linear.hpp:8-15 `Triplet` (12 bytes). */
+typedef struct fi_triplet {
+	int   row, col;
+	float value;
+} fi_triplet;
+
+/* Counters and timings of the last assemble / solve (the reference logs these through loguru:
+ * sparse_linear.cpp:122-125,208-209,438-439). */
+typedef struct fi_stats {
+	long   num_unknowns;       /* owned lattice points of this rank */
+	long   num_data_rows;      /* data rows accepted (value + gradient rows inside the lattice) */
+	long   num_cells;          /* distinct lattice cells holding data */
+	long   num_generic_rows;   /* rows held in generic (COO) form */
+	int    iterations;         /* CG iterations of the last solve */
+	int    converged;          /* 1: ||r|| <= tol*||Atb|| reached; 0: stopped by max_iterations */
+	double rel_residual;       /* recurrence ||r||/||Atb|| at exit */
+	double assemble_ms;        /* GPU time of the last fi_assemble */
+	double solve_ms;           /* GPU time of the last solve */
+	double spmv_ms_avg;        /* mean duration of the AtA-apply launches sampled with HIP events */
+	int    spmv_samples;
+	double spmv_bytes;         /* algorithmic bytes of one AtA apply */
+} fi_stats;
+
+const char* fi_last_error(void);
+/* Number of visible HIP devices (does not initialise a context). */
+int fi_device_count(int* count);
+
+/* ---- context --------------------------------------------------------------------------------
+ * Replaces `LatticeField{sizes}` (field_interpolation.hpp:97-111): x (sizes[0]) is the fastest axis.
+ * The context lives on the current HIP device. */
+int fi_ctx_create(fi_ctx** out, int ndim, const int* sizes, int dtype);
+
+/* Slab-decomposed context for one rank of `nranks` (one process per GPU): the slowest axis
+ * (sizes[ndim-1]) is split into contiguous slabs; `sizes` are the GLOBAL lattice sizes.  Every rank
+ * passes every data point (or at least those within one cell of its slab); each rank keeps the cells
+ * that touch its slab.  Follow with fi_comm_init before fi_assemble. */
+int fi_ctx_create_slab(fi_ctx** out, int ndim, const int* sizes, int dtype, int rank, int nranks);
+int fi_ctx_destroy(fi_ctx* ctx);
+
+/* Owned range [lo, hi) of the slowest axis for this rank. */
+int fi_slab_range(const fi_ctx* ctx, int* lo, int* hi);
+
+/* RCCL bootstrap (no reference counterpart: the reference is single-process).  Rank 0 calls
+ * fi_comm_unique_id, the 128 bytes are broadcast by the launcher (torch.distributed), every rank calls
+ * fi_comm_init.  Halo planes of the CG search direction and the dot products then travel over xGMI. */
+int fi_comm_unique_id(void* out128);
+int fi_comm_init(fi_ctx* ctx, const void* unique_id128);
+
+/* ---- assembly -------------------------------------------------------------------------------
+ * fi_set_model replaces add_field_constraints(field, weights) (field_interpolation.cpp:326-341):
+ * the model_0..model_4 and gradient_smoothness rows of add_model_constraint (:243-316) are never
+ * materialised; the operator applies them matrix-free.  Only the model_* and gradient_smoothness
+ * fields of `w` are read here. */
+int fi_set_model(fi_ctx* ctx, const fi_weights* w);
+
+/* Replaces add_points (field_interpolation.cpp:343-371) and, with n == 1, add_value_constraint (:57-80),
+ * add_value_constraint_nearest_neighbor (:82-107) and add_gradient_constraint (:123-240).
+ *   per point i:  w_i = point_weights ? point_weights[i] : 1
+ *     value row    with weight w_i*value_weight  and target values ? values[i] : 0
+ *     gradient rows with weight w_i*gradient_weight  when normals != NULL
+ * A zero weight skips the rows, points outside the lattice are ignored, exactly as the reference.
+ * FI_VALUE_NEAREST_NEIGHBOR requires normals (reference CHECK_NOTNULL_F, :361) -> FI_ERR_INVALID.
+ * May be called several times; rows accumulate until fi_assemble. */
+int fi_add_points(fi_ctx* ctx, long n, const float* positions, const float* normals, const float* point_weights,
+                  const float* values, float value_weight, int value_kernel, float gradient_weight,
+                  int gradient_kernel, int memory);
+
+/* Generic rows: replaces handing an arbitrary `LinearEquation` (sparse_linear.hpp:18-22) to the solvers,
+ * as src/bipolar_2d.cpp:177-302 and src/line_2d.cpp:49-104 do.  Duplicate (row, col) entries are summed
+ * (sparse_linear.hpp:43).  Row indices are local to this call (0..nrows-1). */
+int fi_add_rows_coo(fi_ctx* ctx, long nrows, long ntriplets, const fi_triplet* triplets, const float* rhs,
+                    int memory);
+
+/* Replaces as_sparse_matrix_float + make_square + A^T*b (sparse_linear.cpp:59-70,105-113,120): bins the
+ * data rows by lattice cell, accumulates the per-cell A^T A blocks, A^T b and diag(A^T A) on the GPU. */
+int fi_assemble(fi_ctx* ctx);
+
+/* Drops all data rows (model weights are kept). */
+int fi_clear_points(fi_ctx* ctx);
+
+/* ---- solve ----------------------------------------------------------------------------------
+ * Replaces solve_sparse_linear_with_guess (sparse_linear.cpp:186-212) and the CG phase of
+ * solve_tiled_with_guess (:427-440).  Jacobi-preconditioned conjugate gradients on A^T A x = A^T b
+ * (the reference runs Eigen::BiCGSTAB with the same diagonal preconditioner and the same stop rule
+ * ||r||_2 <= tol * ||A^T b||_2).  max_iterations <= 0: 2*N (Eigen default); tol <= 0: fp32 epsilon.
+ * guess == NULL means zeros.  `guess`/`out` hold the owned unknowns of this rank (fp32). */
+int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, float* out, int* iterations,
+                float* rel_residual, int memory);
+
+/* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */
+int fi_jacobi(fi_ctx* ctx, const float* guess, int num_iterations, float weight, float* out, int memory);
+
+/* fp64 copy of the last solution (FI_F64 contexts keep full precision; FI_F32 widens). Host buffer. */
+int fi_get_solution_f64(fi_ctx* ctx, double* out);
+
+/* True residual ||Atb - AtA x||_2 / ||Atb||_2 of the last solution, evaluated on the GPU. */
+int fi_true_residual(fi_ctx* ctx, double* rel_residual);
+
+/* ---- test / measurement hooks (host buffers, owned unknowns) ------------------------------------ */
+int fi_apply_AtA_f64(fi_ctx* ctx, const double* x, double* y); /* y = (A^T A) x */
+int fi_get_Atb_f64(fi_ctx* ctx, double* out);
+int fi_get_diag_f64(fi_ctx* ctx, double* out);
+int fi_get_stats(const fi_ctx* ctx, fi_stats* out);
+/* Launches the AtA apply `reps` times on the context's stream between two HIP events. */
+int fi_time_apply(fi_ctx* ctx, int reps, double* ms_per_launch);
+
+/* ---- helpers either side of the path ---------------------------------------------------------
+ * Replaces upscale_field (field_interpolation.cpp:431-485): multilinear resampling small -> large. */
+int fi_upscale_field(const float* small_field, int ndim, const int* small_sizes, const int* large_sizes,
+                     float* out, int memory);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FI_HIP_H */

@@ -905,6 +905,17 @@ int fio_add_value_constraint(void* h, const float* pos, float value, float w)
 {
 	return fio::value_row(static_cast<Field*>(h), pos, value, w) ? 1 : 0;
 }
+// harness convenience: add_value_constraint (cpp:57-80) for n points with per-point targets, in order.
+int fio_add_value_constraints(void* h, int n, const float* pos, const float* values, const float* pw, float weight)
+{
+	Field* f = static_cast<Field*>(h);
+	int accepted = 0;
+	for (int i = 0; i < n; ++i) {
+		const float w = pw ? pw[i] : 1.0f;
+		accepted += fio::value_row(f, pos + static_cast<size_t>(i) * f->ndim, values[i], w * weight) ? 1 : 0;
+	}
+	return accepted;
+}
 int fio_add_value_constraint_nearest_neighbor(void* h, const float* pos, const float* grad, float value, float w)
 {
 	return fio::value_row_nearest(static_cast<Field*>(h), pos, grad, value, w) ? 1 : 0;

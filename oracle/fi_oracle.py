@@ -76,6 +76,7 @@ def lib():
         L.fio_push_rhs.argtypes = [vp, C.c_float]
         L.fio_add_equation.argtypes = [vp, C.c_float, C.c_float, C.c_int, ip, fp]
         L.fio_add_value_constraint.argtypes = [vp, fp, C.c_float, C.c_float]
+        L.fio_add_value_constraints.argtypes = [vp, C.c_int, fp, fp, fp, C.c_float]
         L.fio_add_value_constraint_nearest_neighbor.argtypes = [vp, fp, fp, C.c_float, C.c_float]
         L.fio_add_gradient_constraint.argtypes = [vp, fp, fp, C.c_float, C.c_int]
         L.fio_add_field_constraints.argtypes = [vp, C.POINTER(Weights)]
@@ -164,6 +165,11 @@ class LatticeField:
     def add_value_constraint(self, pos, value, weight):
         p = _f32(np.atleast_1d(pos))
         return bool(lib().fio_add_value_constraint(self._h, _f(p), value, weight))
+
+    def add_value_constraints(self, positions, values, weight, point_weights=None):
+        """add_value_constraint for every point, in order; returns how many were accepted."""
+        pos, val, pw = _f32(positions), _f32(values), _f32(point_weights)
+        return lib().fio_add_value_constraints(self._h, val.size, _f(pos), _f(val), _f(pw), weight)
 
     def add_value_constraint_nearest_neighbor(self, pos, gradient, value, weight):
         p, g = _f32(np.atleast_1d(pos)), _f32(np.atleast_1d(gradient))

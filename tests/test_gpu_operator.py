@@ -1,0 +1,148 @@
+"""P1/P2 parity on the GPU (SURVEY.md 8(d) parity protocol): the HIP operator pieces -- AtA*x, A^T b,
+diag(AtA) -- against the explicit float64 normal equations the oracle builds from reference-equal
+triplets.  Tolerances: fp64 contexts 1e-12 (relative to the largest entry), fp32 contexts 2e-6."""
+import numpy as np
+import pytest
+
+from util import build_pair, random_points, rel_inf
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f64": 1e-12, "f32": 2e-6}
+
+
+@pytest.fixture(scope="module")
+def fi():
+    import field_interpolation_amd as fi
+    from field_interpolation_amd import _capi
+    assert _capi.device_count() >= 1, "no HIP device visible"
+    return fi
+
+
+def _check_operator(fo, fg, dtype, seed=0):
+    AtA, atb, diag = fo.normal_equations()
+    n = fo.num_unknowns
+    rng = np.random.default_rng(seed)
+    assert rel_inf(fg.Atb(), atb) <= TOL[dtype] if np.abs(atb).max() > 0 else not fg.Atb().any()
+    assert rel_inf(fg.diag(), diag) <= TOL[dtype]
+    absA = abs(AtA)
+    for k in range(2):
+        x = rng.normal(size=n) if k == 0 else np.linspace(-50, 50, n) + rng.normal(size=n)
+        y = fg.apply_AtA(x)
+        y_ref = AtA @ x
+        scale = (absA @ np.abs(x)).max()        # |A^T A| |x|: the natural rounding scale of the product
+        assert np.abs(y - y_ref).max() <= TOL[dtype] * scale
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("sizes", [[33], [17, 12], [9, 8, 7]])
+@pytest.mark.parametrize("vk,gk", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_default_model_all_cell_kernels(oracle, fi, dtype, sizes, vk, gk):
+    rng = np.random.default_rng(7 + len(sizes) + 10 * vk + gk)
+    pos, nrm, pw, val = random_points(rng, sizes, 120)
+    w = fi.Weights(data_pos=0.8, data_gradient=1.25, value_kernel=fi.ValueKernel(vk), gradient_kernel=fi.GradientKernel(gk))
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, pw, val, dtype=dtype)
+    st = fg.stats() if not fg._dirty else (fg.assemble() or fg.stats())
+    assert st["num_data_rows"] == fo.num_rows - _model_rows(oracle, sizes, w)
+    _check_operator(fo, fg, dtype)
+
+
+def _model_rows(oracle, sizes, w):
+    from util import oracle_weights
+    f = oracle.LatticeField(sizes)
+    f.add_field_constraints(oracle_weights(oracle, w))
+    return f.num_rows
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("sizes", [[40], [14, 11], [8, 7, 9]])
+@pytest.mark.parametrize("kw", [
+    dict(model_0=0.3, model_1=0.7, model_2=0.5, model_3=0.9, model_4=1.1),
+    dict(model_2=0.0, model_1=1.0),
+    dict(model_2=0.0, model_4=0.6),
+    dict(model_2=0.5, gradient_smoothness=0.4),
+    dict(model_2=0.0, model_3=0.3, gradient_smoothness=1.5, model_0=0.05),
+])
+def test_every_model_term(oracle, fi, dtype, sizes, kw):
+    rng = np.random.default_rng(3)
+    pos, nrm, pw, val = random_points(rng, sizes, 40, margin=0.3)
+    w = fi.Weights(**kw)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, pw, None, dtype=dtype)
+    _check_operator(fo, fg, dtype)
+
+
+def test_tiny_and_degenerate_lattices(oracle, fi):
+    """Lattices narrower than the stencils: rows that do not fit are not emitted (cpp:265-292)."""
+    for sizes in ([1], [2], [3], [4, 1], [2, 2], [1, 5, 2], [3, 2, 2]):
+        rng = np.random.default_rng(len(sizes))
+        pos, nrm, pw, val = random_points(rng, sizes, 30, margin=0.6)
+        w = fi.Weights(model_0=0.2, model_1=0.3, model_2=0.5, model_3=0.7, model_4=0.9, gradient_smoothness=0.2)
+        fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, pw, val, dtype="f64")
+        _check_operator(fo, fg, "f64")
+
+
+def test_no_points_and_all_points_outside(oracle, fi):
+    sizes = [10, 9]
+    w = fi.Weights()
+    fg = fi.LatticeField(sizes, dtype="f64")
+    fg.add_field_constraints(w)
+    assert not fg.Atb().any()
+    pos = np.array([[-5.0, 3.0], [100.0, 2.0], [3.0, -7.5], [np.nan, 1.0]], np.float32)
+    nrm = np.ones_like(pos)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos[:3], nrm[:3], None, None, dtype="f64")
+    assert fg.stats()["num_data_rows"] == 0 or fg.assemble() is None
+    _check_operator(fo, fg, "f64")
+    fg.add_points(1.0, 1, 1.0, 1, pos[3:], nrm[3:])     # NaN position: ignored, not a crash
+    fg.assemble()
+    assert fg.stats()["num_data_rows"] == 0
+
+
+def test_many_points_per_cell_and_multiple_batches(oracle, fi):
+    """Thousands of rows in one cell (segmented accumulation) and rows arriving in several calls."""
+    sizes = [6, 5, 4]
+    rng = np.random.default_rng(11)
+    pos = (np.array([2.0, 1.0, 1.0]) + rng.uniform(0, 1, (5000, 3))).astype(np.float32)
+    nrm = rng.normal(size=(5000, 3)).astype(np.float32)
+    w = fi.Weights()
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, None, None, dtype="f64")
+    pos2, nrm2, pw2, _ = random_points(rng, sizes, 64)
+    fo.add_points(0.5, 1, 2.0, 0, pos2, nrm2, pw2)
+    fg.add_points(0.5, 1, 2.0, 0, pos2, nrm2, pw2)
+    _check_operator(fo, fg, "f64")
+    assert fg.stats()["num_cells"] <= 5 * 4 * 3 + 64 * 1
+
+
+def test_single_constraint_calls_match_reference_returns(oracle, fi):
+    sizes = [4, 4]
+    fo = oracle.LatticeField(sizes)
+    fg = fi.LatticeField(sizes, dtype="f64")
+    for pos in ([-1.5, 1.0], [-0.5, 1.0], [3.0, 3.0], [3.5, 3.5], [4.0, 1.0], [1.25, 2.75]):
+        assert fo.add_value_constraint(pos, 1.5, 0.9) == fg.add_value_constraint(pos, 1.5, 0.9)
+    assert not fg.add_value_constraint([1.0, 1.0], 1.0, 0.0)
+    for k in (0, 1):
+        for pos in ([2.5, 2.5], [3.0, 2.5], [-0.1, 2.5]):
+            assert fo.add_gradient_constraint(pos, [1, -2], 0.7, k) == fg.add_gradient_constraint(pos, [1, -2], 0.7, k)
+    for pos in ([3.4, -0.4], [3.5, 0.0], [0.0, -0.5], [0.49, 2.51]):
+        assert (fo.add_value_constraint_nearest_neighbor(pos, [1, 1], 2.0, 1.1)
+                == fg.add_value_constraint_nearest_neighbor(pos, [1, 1], 2.0, 1.1))
+    with pytest.raises(ValueError):
+        fg.add_gradient_constraint([1.0, 1.0], [1, 0], 1.0, 7)        # reference: ABORT_F (cpp:238)
+    w = fi.Weights()
+    from util import oracle_weights
+    fo.add_field_constraints(oracle_weights(oracle, w))
+    fg.add_field_constraints(w)
+    _check_operator(fo, fg, "f64")
+
+
+def test_error_conventions(fi):
+    from field_interpolation_amd._capi import FiError
+    f = fi.LatticeField([8, 8])
+    with pytest.raises(FiError):       # CHECK_NOTNULL_F(normals), field_interpolation.cpp:361
+        f.add_points(1.0, fi.ValueKernel.kNearestNeighbor, 1.0, fi.GradientKernel.kCellEdges,
+                     np.zeros((3, 2), np.float32), None, None)
+    with pytest.raises(FiError):
+        f.add_points(1.0, 1, 1.0, 9, np.zeros((3, 2), np.float32), np.zeros((3, 2), np.float32), None)
+    with pytest.raises(FiError):
+        fi.LatticeField([4, 4, 4, 4])      # MAX_DIM = 3 (hpp:44)
+    with pytest.raises(ValueError):
+        fi.sdf_from_points([4, 4], fi.Weights(), None)      # CHECK_NOTNULL_F(positions), cpp:382
