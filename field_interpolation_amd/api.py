@@ -334,6 +334,9 @@ def solve_sparse_linear_exact(field, num_columns=None, tolerance=1e-12, max_iter
     factorisation fails, e.g. for a singular AtA)."""
     if field.dtype != "f64":
         raise ValueError("solve_sparse_linear_exact needs a dtype='f64' field")
+    if max_iterations <= 0:
+        # CG in floating point can need several times N steps on these kappa ~ side^4 systems
+        max_iterations = max(2000, 20 * field.num_unknowns)
     res = field.solve_cg(None, max_iterations, tolerance)
     if res is None:
         return None

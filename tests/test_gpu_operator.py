@@ -42,7 +42,8 @@ def test_default_model_all_cell_kernels(oracle, fi, dtype, sizes, vk, gk):
     pos, nrm, pw, val = random_points(rng, sizes, 120)
     w = fi.Weights(data_pos=0.8, data_gradient=1.25, value_kernel=fi.ValueKernel(vk), gradient_kernel=fi.GradientKernel(gk))
     fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, pw, val, dtype=dtype)
-    st = fg.stats() if not fg._dirty else (fg.assemble() or fg.stats())
+    fg.assemble()
+    st = fg.stats()
     assert st["num_data_rows"] == fo.num_rows - _model_rows(oracle, sizes, w)
     _check_operator(fo, fg, dtype)
 
@@ -90,7 +91,8 @@ def test_no_points_and_all_points_outside(oracle, fi):
     pos = np.array([[-5.0, 3.0], [100.0, 2.0], [3.0, -7.5], [np.nan, 1.0]], np.float32)
     nrm = np.ones_like(pos)
     fo, fg = build_pair(oracle, fi, sizes, w, pos[:3], nrm[:3], None, None, dtype="f64")
-    assert fg.stats()["num_data_rows"] == 0 or fg.assemble() is None
+    fg.assemble()
+    assert fg.stats()["num_data_rows"] == 0 and fg.stats()["num_cells"] == 0
     _check_operator(fo, fg, "f64")
     fg.add_points(1.0, 1, 1.0, 1, pos[3:], nrm[3:])     # NaN position: ignored, not a crash
     fg.assemble()
