@@ -156,7 +156,11 @@ void operator_prepare(fi_ctx* c);                                   // model dia
 void apply_AtA(fi_ctx* c, const void* x, void* y, double* pq_partial);  // y = AtA x (+ fused x.y partials)
 int  apply_num_partials(const fi_ctx* c);
 double apply_algorithmic_bytes(const fi_ctx* c);
-void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.cpp
+void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.hip
+
+// fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
+int  stencil_partials(const fi_ctx* c);
+bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
 
 // fi_assembly.hip
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val,

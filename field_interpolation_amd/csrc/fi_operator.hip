@@ -72,9 +72,9 @@ __global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T>
                                                              const int* __restrict__ done)
 {
 	if (done && *done) { return; }
-	const int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	double contrib = 0.0;
-	if (o < g.nown) {
+	for (int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; o < g.nown;
+	     o += static_cast<int64_t>(gridDim.x) * kThreads) {
 		int li[3] = {0, 0, 0};
 		const int64_t idx = owned_to_local<D>(g, o, li);
 		const T xi = x[idx];
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T>
 				}
 			}
 		}
-		y[idx]  = acc;
-		contrib = static_cast<double>(xi) * static_cast<double>(acc);
+		y[idx] = acc;
+		contrib += static_cast<double>(xi) * static_cast<double>(acc);
 	}
 	if (partial) {
 		const double s = block_sum(contrib);
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell,
 {
 	if (done && *done) { return; }
 	constexpr int NC = 1 << D;
-	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	double contrib = 0.0;
-	if (c < ncell) {
+	for (int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; c < ncell;
+	     c += static_cast<int64_t>(gridDim.x) * kThreads) {
 		uint32_t id = cell_id[c];
 		int l[3] = {0, 0, 0};
 		for (int d = 0; d < D; ++d) {
@@ -246,6 +246,14 @@ __global__ __launch_bounds__(kThreads) void k_invert_diag(int64_t n, const T* __
 
 inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
 
+// grid-stride launch width: enough blocks to fill 256 CUs x 8, few enough that the fixed-order sum of
+// the per-block dot-product partials stays a ~microsecond single-block kernel
+inline int capped_blocks(int64_t n)
+{
+	const int64_t b = (n + kThreads - 1) / kThreads;
+	return static_cast<int>(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
 template <typename T>
 ModelCoef<T> make_coef(const fi_weights& w)
 {
@@ -291,10 +299,16 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 	const Geom& g = c->g;
 	const ModelCoef<T> mc = make_coef<T>(c->w);
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
-	const int nb_model = blocks_for(g.nown);
-	hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial, done);
+	int nb_model = stencil_partials(c);
+	if (nb_model > 0) {
+		stencil_apply(c, x, y, partial);
+	} else {
+		nb_model = capped_blocks(g.nown);
+		hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial,
+		                   done);
+	}
 	if (c->cells.ncell > 0) {
-		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(blocks_for(c->cells.ncell)), dim3(kThreads), 0, c->stream, g,
+		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(capped_blocks(c->cells.ncell)), dim3(kThreads), 0, c->stream, g,
 		                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), x, y,
 		                   partial ? partial + nb_model : nullptr, done);
 	}
@@ -307,7 +321,9 @@ size_t elem_size(const fi_ctx* c) { return c->dtype == FI_F64 ? sizeof(double) :
 
 int apply_num_partials(const fi_ctx* c)
 {
-	return blocks_for(c->g.nown) + (c->cells.ncell > 0 ? blocks_for(c->cells.ncell) : 0);
+	int nb_model = stencil_partials(c);
+	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
+	return nb_model + (c->cells.ncell > 0 ? capped_blocks(c->cells.ncell) : 0);
 }
 
 double apply_algorithmic_bytes(const fi_ctx* c)

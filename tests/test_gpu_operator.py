@@ -148,3 +148,36 @@ def test_error_conventions(fi):
         fi.LatticeField([4, 4, 4, 4])      # MAX_DIM = 3 (hpp:44)
     with pytest.raises(ValueError):
         fi.sdf_from_points([4, 4], fi.Weights(), None)      # CHECK_NOTNULL_F(positions), cpp:382
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("sizes", [[16, 9, 7], [64, 16, 8], [72, 40, 37], [132, 20, 70], [4, 3, 2], [8, 1, 5]])
+@pytest.mark.parametrize("kw", [dict(), dict(model_2=0.0, model_1=0.8), dict(model_0=0.3, model_1=0.6, model_2=1.7)])
+def test_lds_marching_kernel_3d(oracle, fi, dtype, sizes, kw):
+    """The LDS-tiled z-marching kernel (fi_stencil.hip) is taken for 3-D lattices whose x extent is a
+    multiple of the 16-byte vector width; tiles, partial tiles, chunk seams and all six boundary faces."""
+    rng = np.random.default_rng(sum(sizes))
+    pos, nrm, pw, val = random_points(rng, sizes, 200, margin=0.7)
+    fo, fg = build_pair(oracle, fi, sizes, fi.Weights(**kw), pos, nrm, pw, val, dtype=dtype)
+    _check_operator(fo, fg, dtype)
+
+
+def test_marching_kernel_chunk_sizes(oracle, fi, monkeypatch):
+    """Every z-chunk length must give the same operator (seams between workgroups along z)."""
+    sizes = [32, 18, 41]
+    rng = np.random.default_rng(5)
+    pos, nrm, pw, val = random_points(rng, sizes, 100, margin=0.5)
+    x = rng.normal(size=int(np.prod(sizes)))
+    ref = None
+    for zc in ("1", "2", "3", "8", "41", "64"):
+        monkeypatch.setenv("FI_ZC", zc)
+        fo, fg = build_pair(oracle, fi, sizes, fi.Weights(model_1=0.3), pos, nrm, pw, val, dtype="f64")
+        y = fg.apply_AtA(x)
+        if ref is None:
+            AtA, _, _ = fo.normal_equations()
+            ref = AtA @ x
+        assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+    monkeypatch.delenv("FI_ZC")
+    monkeypatch.setenv("FI_NO_MARCH", "1")
+    fo, fg = build_pair(oracle, fi, sizes, fi.Weights(model_1=0.3), pos, nrm, pw, val, dtype="f64")
+    assert np.abs(fg.apply_AtA(x) - ref).max() <= 1e-12 * np.abs(ref).max()
