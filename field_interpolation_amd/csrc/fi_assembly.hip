@@ -11,11 +11,12 @@
 //                       All default kernels touch only the 2^D corners of the cell floor(pos).
 //   2. radix sort       rows by cell id (stable, so rows of a cell keep their input order; hipCUB).
 //   3. k_build_blocks   one thread per occupied cell: fp64 accumulation of the symmetric 2^D x 2^D block
-//                       sum a a^T and of sum a*rhs, stored entry-major (coalesced for the apply kernel).
+//                       sum a a^T (packed upper triangle, one cell after another) and of sum a*rhs.
 //   4. k_scatter_cells  A^T b and the data part of diag(A^T A) onto the lattice, 2^D parity colours so
 //                       that no two cells of one launch share a corner: deterministic, no atomics.
 //
-// HBM layout: rows are SoA (key[], coef[2^D][], rhs[]); blocks are SoA over cells (blk[e][cell]).
+// HBM layout: rows: key[], coef[row][2^D], rhs[]; blocks: blk[cell][2^D(2^D+1)/2] (144 B per 3-D cell in
+// fp32: the apply kernels read a block as 9 consecutive 16-byte loads).
 
 #include <hipcub/hipcub.hpp>
 
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 			gvec[i] += a[i] * b;
 		}
 	}
-	for (int e = 0; e < NB; ++e) { blk[static_cast<long>(e) * ncell + c] = static_cast<T>(B[e]); }
+	for (int e = 0; e < NB; ++e) { blk[c * NB + e] = static_cast<T>(B[e]); }
 	for (int q = 0; q < NC; ++q) { cell_rhs[static_cast<long>(q) * ncell + c] = gvec[q]; }
 }
 
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, 
 		}
 		if (ok) {
 			atb[idx] += static_cast<T>(cell_rhs[static_cast<long>(q) * ncell + c]);
-			diag[idx] += blk[static_cast<long>(packed_index(q, q, NC)) * ncell + c];
+			diag[idx] += blk[c * (NC * (NC + 1) / 2) + packed_index(q, q, NC)];
 		}
 	}
 }

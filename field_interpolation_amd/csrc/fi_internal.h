@@ -96,8 +96,32 @@ struct ModelCoef {
 struct CellData {
 	int64_t ncell = 0;
 	DevBuf  cell_id;  // uint32[ncell], extended local cell id, ascending
-	DevBuf  blk;      // T[nb*ncell]  upper triangle of the 2^D x 2^D block, entry-major (SoA)
+	DevBuf  blk;      // T[ncell][nb]  upper triangle of the symmetric 2^D x 2^D block, one cell after another
 	int     nb = 0;   // entries per block: 2^D(2^D+1)/2
+};
+
+// Tiling of the z-marching stencil kernel (fi_stencil.hip) and, per workgroup and z-layer, the list of
+// occupied cells whose corners touch the workgroup's tile (cells on a tile border are listed by every
+// workgroup they touch).
+struct MarchParams {
+	int     nx, ny;          // lattice extent in x and y
+	int     nzl;             // local planes (incl. ghost planes)
+	int     gz;              // global extent of z
+	int     zoff;            // global z of local plane 0
+	int     own_z0, own_z1;  // owned local planes [z0, z1)
+	int     tiles_x, tiles_y, chunks, zc;
+	int     nwg;
+	int     tx;              // tile extent in x (lattice points)
+	int64_t plane;           // nx * ny
+};
+
+struct MarchState {
+	bool        valid = false;  // the marching kernel applies to this context
+	bool        fused = false;  // cell blocks are applied inside the marching kernel
+	MarchParams P{};
+	DevBuf      lay_off;        // uint32[nwg*(zc+1)+1] record ranges per (workgroup, layer)
+	DevBuf      rec;            // uint2[nrec] {cell index, (tcx+1) | (tcy+1) << 16}
+	int64_t     nrec = 0;
 };
 
 struct Pending {  // one fi_add_points batch, already turned into cell rows on the device
@@ -132,6 +156,7 @@ struct fi_ctx {
 
 	std::vector<fi::Pending*> pending;
 	fi::CellData              cells;
+	fi::MarchState            march;
 
 	// operator pieces (T arrays over local storage)
 	fi::DevBuf atb, diag, dinv;
@@ -159,6 +184,7 @@ double apply_algorithmic_bytes(const fi_ctx* c);
 void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.hip
 
 // fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
+void stencil_prepare(fi_ctx* c);   // after assemble(): tiling + per-workgroup cell lists
 int  stencil_partials(const fi_ctx* c);
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
 

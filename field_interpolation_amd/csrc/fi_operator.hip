@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell,
 			T s = 0;
 			for (int j = 0; j < NC; ++j) {
 				const int e = i <= j ? packed_index(i, j, NC) : packed_index(j, i, NC);
-				s += blk[static_cast<int64_t>(e) * ncell + c] * xv[j];
+				s += blk[c * (NC * (NC + 1) / 2) + e] * xv[j];
 			}
 			atomic_add(&y[idx[i]], s);
 			contrib += static_cast<double>(xv[i]) * static_cast<double>(s);
@@ -302,6 +302,7 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 	int nb_model = stencil_partials(c);
 	if (nb_model > 0) {
 		stencil_apply(c, x, y, partial);
+		if (c->march.fused) { return; }  // cell blocks were applied inside the marching kernel
 	} else {
 		nb_model = capped_blocks(g.nown);
 		hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial,
@@ -323,6 +324,7 @@ int apply_num_partials(const fi_ctx* c)
 {
 	int nb_model = stencil_partials(c);
 	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
+	if (c->march.valid && c->march.fused) { return nb_model; }
 	return nb_model + (c->cells.ncell > 0 ? capped_blocks(c->cells.ncell) : 0);
 }
 

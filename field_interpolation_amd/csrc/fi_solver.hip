@@ -854,6 +854,7 @@ int fi_assemble(fi_ctx* c)
 		           "slab of %d planes is thinner than the stencil reach %d", c->slab_hi - c->slab_lo, c->halo);
 	}
 	fi::assemble(c);
+	fi::stencil_prepare(c);
 	fi::operator_prepare(c);
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));
 	FI_HIP_TRY(hipEventSynchronize(e1));

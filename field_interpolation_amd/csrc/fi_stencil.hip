@@ -7,8 +7,10 @@
 //     u_a = x_a - 2 x_{a+1} + x_{a+2}      (row anchored at a, exists iff 0 <= a and a+2 < size)
 //     y_c += u_{c-2} - 2 u_{c-1} + u_c     (rows that touch c)
 // with non-existing rows masked to zero through GLOBAL coordinates, which reproduces the reference's
-// boundary rows (diag 1,5,6,...,6,5,1) on any tile / slab.  Algorithmic traffic: read x once, write y
-// once = 2*sizeof(T) bytes per lattice point.
+// boundary rows (diag 1,5,6,...,6,5,1) on any tile / slab.  The data rows (value / gradient constraints,
+// field_interpolation.cpp:57-187) enter as one symmetric 8x8 block per occupied cell (fi_assembly.hip)
+// and are applied inside the same kernel.  Algorithmic traffic: read x once, write y once, read every
+// block once = 2*sizeof(T) B per lattice point + (8 + 36*sizeof(T)) B per occupied cell.
 //
 // Work decomposition (CDNA4): one workgroup = 256 threads = a TX x 16 tile of (x, y) marching over ZC
 // planes of z; a thread owns VX consecutive x (one 16-byte global load/store per plane: float4/double2).
@@ -17,10 +19,17 @@
 //   * x/y neighbours come from an LDS copy of the plane (tile + halo ring), 3-deep ring => one barrier per
 //     plane; own columns are 16-byte aligned in LDS (ds_read_b128 for the y rows);
 //   * boundary masks for x/y are per-thread constants hoisted out of the march; z masks are wave-uniform;
+//   * cell blocks of layer z (corners on planes z and z+1, both in the LDS ring): one thread per cell
+//     multiplies its block with the 8 corner values and stores the 8 products into 8 LDS planes indexed by
+//     corner -- for a fixed corner index two cells never hit the same lattice point, so there are no
+//     atomics and no ordering: bitwise reproducible.  After one extra barrier the owner of a lattice point
+//     adds the 4 "lower" products to its output and carries the 4 "upper" ones to the next plane in
+//     registers.  Layers without data (the common case for surface point clouds) skip all of it.
 //   * p.q partials: fp32 products per plane, fp64 per-thread accumulation, wave64 shuffle tree, one
 //     partial per workgroup;
 //   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. (same XCD, same L2) get adjacent tiles.
-// Data term (per-cell blocks): see k_apply_cells in fi_operator.hip (fused variant: section "cells").
+
+#include <hipcub/hipcub.hpp>
 
 #include "fi_internal.h"
 
@@ -46,22 +55,17 @@ struct VecOf<double> {
 	static constexpr int VX = 2;
 };
 
-struct MarchParams {
-	int     nx, ny;          // lattice extent in x and y
-	int     nzl;             // local planes (incl. ghost planes)
-	int     gz;              // global extent of z
-	int     zoff;            // global z of local plane 0
-	int     own_z0, own_z1;  // owned local planes [z0, z1)
-	int     tiles_x, tiles_y, chunks, zc;
-	int     nwg;
-	int64_t plane;  // nx * ny
-};
-
 template <typename T>
 struct MarchCoef {
 	T w0x3;  // 3 * model_0^2
 	T w1sq;  // model_1^2
 	T w2sq;  // model_2^2
+};
+
+struct CellLists {
+	const uint32_t* lay_off;  // [nwg*(zc+1)+1]
+	const uint2*    rec;      // {cell index, (tcx+1) | (tcy+1)<<16}
+	const void*     blk;      // T[ncell][36]
 };
 
 __device__ inline double wave_sum(double v)
@@ -70,9 +74,15 @@ __device__ inline double wave_sum(double v)
 	return v;
 }
 
-template <typename T, bool HAS1, bool HAS2>
-__global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, MarchCoef<T> C, const T* __restrict__ x,
-                                                             T* __restrict__ y, double* __restrict__ partial,
+__host__ __device__ constexpr int tri(int i, int j)  // packed upper-triangle index of an 8x8 block, i <= j
+{
+	return i * 8 - (i * (i - 1)) / 2 + (j - i);
+}
+
+template <typename T, bool HAS1, bool HAS2, bool CELLS>
+__global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
+                                                             const T* __restrict__ x, T* __restrict__ y,
+                                                             double* __restrict__ partial,
                                                              const int* __restrict__ done)
 {
 	using V = typename VecOf<T>::V;
@@ -84,8 +94,10 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 	constexpr int R    = HAS2 ? 2 : 1;
 	constexpr int NHALO = 2 * R * (TX + 2 * R) + 2 * R * kTY;
 	constexpr int NH    = (NHALO + kThreads - 1) / kThreads;
+	constexpr int NYB   = CELLS ? 8 : 1;
 
 	__shared__ __attribute__((aligned(16))) T xs[3][ROWS][W];
+	__shared__ __attribute__((aligned(16))) T yb[NYB][CELLS ? kTY : 1][CELLS ? TX : VX];
 	__shared__ double red[kThreads / 64];
 
 	if (done && *done) { return; }
@@ -190,15 +202,68 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 		}
 	};
 
+	// ---- cell blocks of one layer: products into the 8 corner planes -----------------------------------
+	const uint32_t* lay = CELLS ? L.lay_off + static_cast<int64_t>(wg) * (P.zc + 1) : nullptr;
+	auto cells_scatter = [&](uint32_t rs, uint32_t re, int buf_lo, int buf_hi) {
+		const T* blk = static_cast<const T*>(L.blk);
+		for (uint32_t r = rs + threadIdx.x; r < re; r += kThreads) {
+			const uint2 rc  = L.rec[r];
+			const int   tcx = static_cast<int>(rc.y & 0xFFFFu) - 1;
+			const int   tcy = static_cast<int>(rc.y >> 16) - 1;
+			T b[36];
+			const V* bp = reinterpret_cast<const V*>(blk + static_cast<int64_t>(rc.x) * 36);
+#pragma unroll
+			for (int k = 0; k < 36 / VX; ++k) {
+				const V    v  = bp[k];
+				const T*   pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+				for (int j = 0; j < VX; ++j) { b[k * VX + j] = pv[j]; }
+			}
+			T xv[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				const int bx = q & 1, by = (q >> 1) & 1, bz = q >> 2;
+				xv[q] = xs[bz ? buf_hi : buf_lo][kR + tcy + by][PADX + tcx + bx];
+			}
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				T s = T(0);
+#pragma unroll
+				for (int j = 0; j < 8; ++j) { s += b[i <= j ? tri(i, j) : tri(j, i)] * xv[j]; }
+				const int px = tcx + (i & 1), py = tcy + ((i >> 1) & 1);
+				if (px >= 0 && px < TX && py >= 0 && py < kTY) { yb[i][py][px] = s; }
+			}
+		}
+	};
+	// owner side: lower 4 planes -> this plane, upper 4 planes -> carry; planes are zeroed for the next layer
+	auto cells_gather = [&](T* lower, T* upper) {
+		const V zero = V{};
+#pragma unroll
+		for (int j = 0; j < VX; ++j) { lower[j] = T(0); upper[j] = T(0); }
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			V* slot = reinterpret_cast<V*>(&yb[q][ty][VX * tx]);
+			const V  v  = *slot;
+			const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+			for (int j = 0; j < VX; ++j) {
+				if (q < 4) { lower[j] += pv[j]; } else { upper[j] += pv[j]; }
+			}
+			*slot = zero;
+		}
+	};
+
 	// ---- prologue ---------------------------------------------------------------------------------
-	// registers at the top of step z: xm1 = x(z-1) [HAS1 only], xc = x(z), xp1 = x(z+1), xp2 = x(z+2),
-	// u1 = masked u(z-1), u2 = masked u(z-2), d1 = masked (x(z) - x(z-1)).
+	// registers at the top of step z: xc = x(z), xp1 = x(z+1), xp2 = x(z+2), xnext = x(z+3) (in flight),
+	// u1 = masked u(z-1), u2 = masked u(z-2), d1 = masked (x(z) - x(z-1)), carry = upper cell products.
 	V xc = load_own(z_begin), xp1 = load_own(z_begin + 1), xp2 = load_own(z_begin + 2);
 	V xnext = load_own(z_begin + 3);
 	T hcur[NH], hnext[NH];
 	load_halo(z_begin, hcur);
 	load_halo(z_begin + 1, hnext);
-	T u1[VX], u2[VX], d1[VX];
+	T u1[VX], u2[VX], d1[VX], carry[VX];
+#pragma unroll
+	for (int j = 0; j < VX; ++j) { carry[j] = T(0); }
 	{
 		const V xa = load_own(z_begin - 2), xb = load_own(z_begin - 1);
 		const T* pa = reinterpret_cast<const T*>(&xa);
@@ -214,6 +279,25 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 			u2[j] = mz2 * (pa[j] - T(2) * pb[j] + pc[j]);
 			u1[j] = mz1 * (pb[j] - T(2) * pc[j] + pd[j]);
 			d1[j] = md1 * (pc[j] - pb[j]);
+		}
+		if (CELLS) {
+			// layer z_begin-1: its upper corners sit on plane z_begin
+			const V zero = V{};
+#pragma unroll
+			for (int q = 0; q < 8; ++q) { *reinterpret_cast<V*>(&yb[q][ty][VX * tx]) = zero; }
+			const uint32_t rs = lay[0], re = lay[1];
+			if (re > rs) {
+				T hprev[NH];
+				load_halo(z_begin - 1, hprev);
+				write_plane((z_begin + 2) % 3, xb, hprev);  // plane z_begin-1
+				write_plane(z_begin % 3, xc, hcur);
+				__syncthreads();
+				cells_scatter(rs, re, (z_begin + 2) % 3, z_begin % 3);
+				__syncthreads();
+				T lower[VX];
+				cells_gather(lower, carry);
+				__syncthreads();  // plane z_begin-1's buffer is rewritten as plane z_begin+2 two steps on
+			}
 		}
 	}
 	write_plane(z_begin % 3, xc, hcur);
@@ -232,6 +316,13 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 		const T* pc  = reinterpret_cast<const T*>(&xc);
 		const T* pp1 = reinterpret_cast<const T*>(&xp1);
 		const T* pp2 = reinterpret_cast<const T*>(&xp2);
+
+		uint32_t rs = 0, re = 0;
+		if (CELLS) {
+			rs = lay[z - z_begin + 1];
+			re = lay[z - z_begin + 2];
+			if (re > rs) { cells_scatter(rs, re, z % 3, (z + 1) % 3); }
+		}
 
 		T acc2[VX], acc1[VX];
 #pragma unroll
@@ -308,12 +399,24 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 			}
 		}
 
+		// ---- data term: lower products of this layer + upper products carried from the layer below
+		T data[VX];
+#pragma unroll
+		for (int j = 0; j < VX; ++j) { data[j] = carry[j]; carry[j] = T(0); }
+		if (CELLS && re > rs) {
+			__syncthreads();
+			T lower[VX];
+			cells_gather(lower, carry);
+#pragma unroll
+			for (int j = 0; j < VX; ++j) { data[j] += lower[j]; }
+		}
+
 		V out;
 		T* po = reinterpret_cast<T*>(&out);
 		T  dsum = T(0);
 #pragma unroll
 		for (int j = 0; j < VX; ++j) {
-			T v = C.w0x3 * pc[j];
+			T v = C.w0x3 * pc[j] + data[j];
 			if (HAS2) { v += C.w2sq * acc2[j]; }
 			if (HAS1) { v += C.w1sq * acc1[j]; }
 			po[j] = v;
@@ -337,6 +440,55 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 	}
 }
 
+// ---- per-workgroup cell lists -------------------------------------------------------------------------
+// A cell with global origin (cx, cy, cz) touches the tile columns {cx/TX, and (cx+1)/TX when cx+1 is a
+// tile start}, likewise rows, and along z the chunk holding plane cz plus the next chunk when plane cz+1
+// starts it (layer 0 of that chunk).  mode 0: count per (workgroup, layer); mode 1: fill.
+__global__ __launch_bounds__(kThreads) void k_cell_lists(MarchParams P, Geom g, int64_t ncell,
+                                                          const uint32_t* __restrict__ cell_id,
+                                                          uint32_t* __restrict__ count,
+                                                          const uint32_t* __restrict__ off,
+                                                          uint32_t* __restrict__ cursor, uint2* __restrict__ rec,
+                                                          int mode)
+{
+	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c >= ncell) { return; }
+	uint32_t id = cell_id[c];
+	const int cx = static_cast<int>(id % static_cast<uint32_t>(g.cn[0])) + g.coff[0];
+	id /= static_cast<uint32_t>(g.cn[0]);
+	const int cy = static_cast<int>(id % static_cast<uint32_t>(g.cn[1])) + g.coff[1];
+	id /= static_cast<uint32_t>(g.cn[1]);
+	const int cz = static_cast<int>(id) + g.coff[2];      // global
+	const int zz = cz - P.zoff - P.own_z0;                // plane index relative to the first owned plane
+	const int nz_own = P.own_z1 - P.own_z0;
+
+	int tix[2], tcx[2], nx_ = 0;
+	if (cx >= 0 && cx / P.tx < P.tiles_x) { tix[nx_] = cx / P.tx; tcx[nx_] = cx % P.tx; ++nx_; }
+	if ((cx + 1) % P.tx == 0 && (cx + 1) / P.tx < P.tiles_x) { tix[nx_] = (cx + 1) / P.tx; tcx[nx_] = -1; ++nx_; }
+	int tiy[2], tcy[2], ny_ = 0;
+	if (cy >= 0 && cy / kTY < P.tiles_y) { tiy[ny_] = cy / kTY; tcy[ny_] = cy % kTY; ++ny_; }
+	if ((cy + 1) % kTY == 0 && (cy + 1) / kTY < P.tiles_y) { tiy[ny_] = (cy + 1) / kTY; tcy[ny_] = -1; ++ny_; }
+	int tk[2], tl[2], nz_ = 0;
+	if (zz >= 0 && zz < nz_own) { tk[nz_] = zz / P.zc; tl[nz_] = zz % P.zc + 1; ++nz_; }
+	if (zz + 1 >= 0 && zz + 1 < nz_own && (zz + 1) % P.zc == 0) { tk[nz_] = (zz + 1) / P.zc; tl[nz_] = 0; ++nz_; }
+
+	for (int a = 0; a < nz_; ++a) {
+		for (int b = 0; b < ny_; ++b) {
+			for (int d = 0; d < nx_; ++d) {
+				const int      wg     = (tk[a] * P.tiles_y + tiy[b]) * P.tiles_x + tix[d];
+				const uint32_t bucket = static_cast<uint32_t>(wg) * (P.zc + 1) + tl[a];
+				if (mode == 0) {
+					atomicAdd(&count[bucket], 1u);
+				} else {
+					const uint32_t pos = off[bucket] + atomicAdd(&cursor[bucket], 1u);
+					rec[pos] = make_uint2(static_cast<uint32_t>(c),
+					                      static_cast<uint32_t>(tcx[d] + 1) | (static_cast<uint32_t>(tcy[b] + 1) << 16));
+				}
+			}
+		}
+	}
+}
+
 int pick_chunk(int tiles_xy, int nz_own)
 {
 	if (const char* env = getenv("FI_ZC")) {
@@ -350,11 +502,12 @@ int pick_chunk(int tiles_xy, int nz_own)
 }
 
 template <typename T>
-bool march_setup(const fi_ctx* c, MarchParams* P, MarchCoef<T>* C)
+bool march_setup(const fi_ctx* c, MarchParams* P)
 {
 	const Geom& g = c->g;
 	constexpr int VX = VecOf<T>::VX;
 	constexpr int TX = kTXT * VX;
+	if (getenv("FI_NO_MARCH")) { return false; }
 	if (g.ndim != 3) { return false; }
 	if (g.gn[0] % VX != 0) { return false; }
 	const fi_weights& w = c->w;
@@ -367,6 +520,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, MarchCoef<T>* C)
 	P->zoff = g.off[2];
 	P->own_z0 = g.own_lo[2];
 	P->own_z1 = g.own_hi[2];
+	P->tx      = TX;
 	P->tiles_x = (P->nx + TX - 1) / TX;
 	P->tiles_y = (P->ny + kTY - 1) / kTY;
 	const int nz_own = P->own_z1 - P->own_z0;
@@ -374,58 +528,106 @@ bool march_setup(const fi_ctx* c, MarchParams* P, MarchCoef<T>* C)
 	P->chunks = (nz_own + P->zc - 1) / P->zc;
 	P->nwg    = P->tiles_x * P->tiles_y * P->chunks;
 	P->plane  = static_cast<int64_t>(P->nx) * P->ny;
-	const T w0 = w.model_0 > 0 ? static_cast<T>(w.model_0) : T(0);
-	const T w1 = w.model_1 > 0 ? static_cast<T>(w.model_1) : T(0);
-	const T w2 = w.model_2 > 0 ? static_cast<T>(w.model_2) : T(0);
-	C->w0x3 = T(3) * w0 * w0;
-	C->w1sq = w1 * w1;
-	C->w2sq = w2 * w2;
 	return true;
 }
 
 template <typename T>
-bool march_launch(fi_ctx* c, const T* x, T* y, double* partial, int* nwg_out)
+MarchCoef<T> march_coef(const fi_weights& w)
 {
-	MarchParams  P;
 	MarchCoef<T> C;
-	if (!march_setup<T>(c, &P, &C)) { return false; }
-	if (nwg_out) { *nwg_out = P.nwg; }
-	if (!x) { return true; }
+	const T w0 = w.model_0 > 0 ? static_cast<T>(w.model_0) : T(0);
+	const T w1 = w.model_1 > 0 ? static_cast<T>(w.model_1) : T(0);
+	const T w2 = w.model_2 > 0 ? static_cast<T>(w.model_2) : T(0);
+	C.w0x3 = T(3) * w0 * w0;
+	C.w1sq = w1 * w1;
+	C.w2sq = w2 * w2;
+	return C;
+}
+
+template <typename T, bool CELLS>
+void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial)
+{
+	const MarchParams& P = c->march.P;
+	const MarchCoef<T> C = march_coef<T>(c->w);
+	CellLists L{c->march.lay_off.as<uint32_t>(), c->march.rec.as<uint2>(), c->cells.blk.p};
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
 	const int  grid = ((P.nwg + 7) / 8) * 8;
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
 	if (h1 && h2) {
-		hipLaunchKernelGGL((k_apply_march3d<T, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, x, y,
-		                   partial, done);
+		hipLaunchKernelGGL((k_apply_march3d<T, true, true, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x,
+		                   y, partial, done);
 	} else if (h2) {
-		hipLaunchKernelGGL((k_apply_march3d<T, false, true>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, x, y,
-		                   partial, done);
+		hipLaunchKernelGGL((k_apply_march3d<T, false, true, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x,
+		                   y, partial, done);
 	} else {
-		hipLaunchKernelGGL((k_apply_march3d<T, true, false>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, x, y,
-		                   partial, done);
+		hipLaunchKernelGGL((k_apply_march3d<T, true, false, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x,
+		                   y, partial, done);
 	}
 	FI_HIP_TRY(hipGetLastError());
-	return true;
+}
+
+void build_cell_lists(fi_ctx* c)
+{
+	MarchState& m = c->march;
+	const MarchParams& P = m.P;
+	const int64_t ncell = c->cells.ncell;
+	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1);
+	hipStream_t st = c->stream;
+	DevBuf count, cursor, tmp;
+	count.alloc(sizeof(uint32_t) * (nbuckets + 1));
+	cursor.alloc(sizeof(uint32_t) * (nbuckets + 1));
+	m.lay_off.alloc(sizeof(uint32_t) * (nbuckets + 1));
+	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * (nbuckets + 1), st));
+	FI_HIP_TRY(hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * (nbuckets + 1), st));
+	const int nb = static_cast<int>((ncell + kThreads - 1) / kThreads);
+	hipLaunchKernelGGL(k_cell_lists, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, c->cells.cell_id.as<uint32_t>(),
+	                   count.as<uint32_t>(), nullptr, nullptr, nullptr, 0);
+	size_t tb = 0;
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, count.as<uint32_t>(), m.lay_off.as<uint32_t>(),
+	                                            static_cast<int>(nbuckets + 1), st));
+	tmp.alloc(tb);
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, count.as<uint32_t>(), m.lay_off.as<uint32_t>(),
+	                                            static_cast<int>(nbuckets + 1), st));
+	uint32_t total = 0;
+	FI_HIP_TRY(hipMemcpyAsync(&total, m.lay_off.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipStreamSynchronize(st));
+	m.nrec = total;
+	m.rec.alloc(sizeof(uint2) * (total ? total : 1));
+	hipLaunchKernelGGL(k_cell_lists, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, c->cells.cell_id.as<uint32_t>(),
+	                   nullptr, m.lay_off.as<uint32_t>(), cursor.as<uint32_t>(), m.rec.as<uint2>(), 1);
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipStreamSynchronize(st));
 }
 
 }  // namespace
 
-// Returns the number of p.q partials the stencil kernel writes, or 0 when the generic kernel must run.
-int stencil_partials(const fi_ctx* c)
+void stencil_prepare(fi_ctx* c)
 {
-	if (getenv("FI_NO_MARCH")) { return 0; }
-	int n = 0;
-	const bool ok = c->dtype == FI_F64 ? march_launch<double>(const_cast<fi_ctx*>(c), nullptr, nullptr, nullptr, &n)
-	                                   : march_launch<float>(const_cast<fi_ctx*>(c), nullptr, nullptr, nullptr, &n);
-	return ok ? n : 0;
+	MarchState& m = c->march;
+	m.valid = c->dtype == FI_F64 ? march_setup<double>(c, &m.P) : march_setup<float>(c, &m.P);
+	m.fused = false;
+	m.nrec  = 0;
+	if (!m.valid) { return; }
+	if (c->cells.ncell > 0 && !getenv("FI_NO_FUSE")) {
+		build_cell_lists(c);
+		m.fused = true;
+	}
 }
+
+// Number of p.q partials the stencil kernel writes, or 0 when the generic kernel must run.
+int stencil_partials(const fi_ctx* c) { return c->march.valid ? c->march.P.nwg : 0; }
 
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial)
 {
-	if (getenv("FI_NO_MARCH")) { return false; }
-	return c->dtype == FI_F64
-	           ? march_launch<double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial, nullptr)
-	           : march_launch<float>(c, static_cast<const float*>(x), static_cast<float*>(y), partial, nullptr);
+	if (!c->march.valid) { return false; }
+	if (c->dtype == FI_F64) {
+		c->march.fused ? march_launch_cells<double, true>(c, static_cast<const double*>(x), static_cast<double*>(y), partial)
+		               : march_launch_cells<double, false>(c, static_cast<const double*>(x), static_cast<double*>(y), partial);
+	} else {
+		c->march.fused ? march_launch_cells<float, true>(c, static_cast<const float*>(x), static_cast<float*>(y), partial)
+		               : march_launch_cells<float, false>(c, static_cast<const float*>(x), static_cast<float*>(y), partial);
+	}
+	return true;
 }
 
 }  // namespace fi
