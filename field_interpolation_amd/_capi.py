@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfi_hip.so")
+LIB_PATH = os.environ.get("FI_HIP_LIB", os.path.join(HERE, "libfi_hip.so"))   # override: experiments only
 
 FI_OK = 0
 FI_HOST, FI_DEVICE = 0, 1

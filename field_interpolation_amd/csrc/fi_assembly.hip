@@ -214,7 +214,8 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
                                                             const uint32_t* __restrict__ sorted_row,
                                                             const float* __restrict__ coef,
                                                             const float* __restrict__ rhs, T* __restrict__ blk,
-                                                            double* __restrict__ cell_rhs)
+                                                            double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
+                                                            T* __restrict__ row1)
 {
 	constexpr int NC = 1 << D;
 	constexpr int NB = NC * (NC + 1) / 2;
@@ -237,6 +238,11 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 		}
 	}
 	for (int e = 0; e < NB; ++e) { blk[c * NB + e] = static_cast<T>(B[e]); }
+	nrow[c] = m;
+	{
+		const long row = sorted_row[s];  // first row of the cell (the only one when m == 1)
+		for (int q = 0; q < NC; ++q) { row1[c * NC + q] = static_cast<T>(coef[row * NC + q]); }
+	}
 	for (int q = 0; q < NC; ++q) { cell_rhs[static_cast<long>(q) * ncell + c] = gvec[q]; }
 }
 
@@ -412,12 +418,14 @@ void assemble_dim(fi_ctx* c)
 	c->cells.ncell = ncell;
 	c->cells.cell_id.alloc(sizeof(uint32_t) * ncell);
 	c->cells.blk.alloc(sizeof(T) * NB * ncell);
+	c->cells.nrow.alloc(sizeof(uint32_t) * ncell);
+	c->cells.row1.alloc(sizeof(T) * NC * ncell);
 	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
 	DevBuf cell_rhs;
 	cell_rhs.alloc(sizeof(double) * NC * ncell);
 	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
 	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,
-	                   c->cells.blk.as<T>(), cell_rhs.as<double>());
+	                   c->cells.blk.as<T>(), cell_rhs.as<double>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>());
 	FI_HIP_TRY(hipGetLastError());
 	for (int colour = 0; colour < NC; ++colour) {
 		hipLaunchKernelGGL((k_scatter_cells<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, g, ncell,

@@ -97,6 +97,8 @@ struct CellData {
 	int64_t ncell = 0;
 	DevBuf  cell_id;  // uint32[ncell], extended local cell id, ascending
 	DevBuf  blk;      // T[ncell][nb]  upper triangle of the symmetric 2^D x 2^D block, one cell after another
+	DevBuf  nrow;     // uint32[ncell] number of data rows accumulated into the cell
+	DevBuf  row1;     // T[ncell][2^D] the row itself for cells holding exactly one row (block = row row^T)
 	int     nb = 0;   // entries per block: 2^D(2^D+1)/2
 };
 
@@ -112,6 +114,7 @@ struct MarchParams {
 	int     tiles_x, tiles_y, chunks, zc;
 	int     nwg;
 	int     tx;              // tile extent in x (lattice points)
+	int     dbg;             // timing experiments only (FI_DBG): 1 = no halo loads, 2 = no stores
 	int64_t plane;           // nx * ny
 };
 
@@ -119,9 +122,14 @@ struct MarchState {
 	bool        valid = false;  // the marching kernel applies to this context
 	bool        fused = false;  // cell blocks are applied inside the marching kernel
 	MarchParams P{};
-	DevBuf      lay_off;        // uint32[nwg*(zc+1)+1] record ranges per (workgroup, layer)
-	DevBuf      rec;            // uint2[nrec] {cell index, (tcx+1) | (tcy+1) << 16}
-	int64_t     nrec = 0;
+	// self-contained records per (workgroup, layer); two kinds: a single data row (rank-1 block,
+	// 2^D coefficients) or a full packed block (36 coefficients in 3-D)
+	DevBuf      lay_row, lay_blk;  // uint32[nwg*(zc+1)+1] record ranges
+	DevBuf      pos_row, pos_blk;  // uint32[n] (tcx+1) | (tcy+1) << 16, tile-relative cell origin
+	DevBuf      coef_row;          // T[n_row][8]
+	DevBuf      coef_blk;          // T[n_blk][36]
+	int64_t     n_row = 0, n_blk = 0;          // records (cells on tile borders are listed more than once)
+	int64_t     cells_row = 0, cells_blk = 0;  // distinct cells of each kind
 };
 
 struct Pending {  // one fi_add_points batch, already turned into cell rows on the device

@@ -330,10 +330,16 @@ int apply_num_partials(const fi_ctx* c)
 
 double apply_algorithmic_bytes(const fi_ctx* c)
 {
-	// B_spmv = 2*s*N + C_occ*(4 + s*2^D(2^D+1)/2)
+	// B_spmv = 2*s*N + C_occ*(4 + s*2^D(2^D+1)/2): read x once, write y once, read every
+	// occupied cell's record once.  The fused 3-D kernel keeps a cell that holds a single data row as that
+	// row (2^D coefficients) instead of the packed block, so its record is counted at its real, smaller size.
 	const double s = static_cast<double>(elem_size(c));
-	return 2.0 * s * static_cast<double>(c->g.nown) +
-	       static_cast<double>(c->cells.ncell) * (4.0 + s * static_cast<double>(c->cells.nb));
+	const double lattice = 2.0 * s * static_cast<double>(c->g.nown);
+	if (c->march.valid && c->march.fused) {
+		return lattice + static_cast<double>(c->march.cells_row) * (4.0 + s * 8.0) +
+		       static_cast<double>(c->march.cells_blk) * (4.0 + s * 36.0);
+	}
+	return lattice + static_cast<double>(c->cells.ncell) * (4.0 + s * static_cast<double>(c->cells.nb));
 }
 
 void operator_prepare(fi_ctx* c)

@@ -201,9 +201,8 @@ __global__ __launch_bounds__(kThreads) void k_reduce(CgScalars* sc, const double
 
 enum Phase { kPhaseInit = 0, kPhaseSpmv = 1, kPhaseUpdate = 2 };
 
-__global__ void k_cg_logic(CgScalars* sc, int phase)
+__device__ inline void cg_logic(CgScalars* sc, int phase)
 {
-	if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
 	if (phase == kPhaseInit) {
 		sc->rz = sc->sums[0];
 		sc->rr = sc->sums[1];
@@ -239,6 +238,26 @@ __global__ void k_cg_logic(CgScalars* sc, int phase)
 	} else if (sc->iter >= sc->max_iter) {
 		sc->done = 3;
 	}
+}
+
+__global__ void k_cg_logic(CgScalars* sc, int phase)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) { cg_logic(sc, phase); }
+}
+
+// single-rank form: fixed-order sum of the partials and the scalar recurrences in one launch
+__global__ __launch_bounds__(kThreads) void k_reduce_logic(CgScalars* sc, const double* __restrict__ partial, int nvec,
+                                                            int stride, int count, int phase)
+{
+	if (phase != kPhaseInit && sc->done) { return; }
+	for (int v = 0; v < nvec; ++v) {
+		double acc[1] = {0};
+		for (int i = threadIdx.x; i < count; i += kThreads) { acc[0] += partial[v * stride + i]; }
+		double out[1];
+		block_sum<1>(acc, out);
+		if (threadIdx.x == 0) { sc->sums[v] = out[0]; }
+	}
+	if (threadIdx.x == 0) { cg_logic(sc, phase); }
 }
 
 // ---- layout conversion between caller fp32 buffers (owned unknowns) and solver vectors ------------
@@ -425,9 +444,14 @@ void store_owned(fi_ctx* c, const DevBuf& v, float* dst, int memory)
 void reduce_and_logic(fi_ctx* c, int nvec, int stride, int count, int phase)
 {
 	CgScalars* sc = c->scal.as<CgScalars>();
+	if (c->nranks == 1) {
+		hipLaunchKernelGGL(k_reduce_logic, dim3(1), dim3(kThreads), 0, c->stream, sc, c->partial.as<double>(), nvec,
+		                   stride, count, phase);
+		return;
+	}
 	hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, sc, c->partial.as<double>(), nvec, stride, count,
 	                   phase == kPhaseInit ? 0 : 1);
-	if (c->nranks > 1) { allreduce_sum(c, sc->sums, nvec); }
+	allreduce_sum(c, sc->sums, nvec);
 	hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, c->stream, sc, phase);
 }
 

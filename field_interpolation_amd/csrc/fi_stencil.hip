@@ -19,12 +19,16 @@
 //   * x/y neighbours come from an LDS copy of the plane (tile + halo ring), 3-deep ring => one barrier per
 //     plane; own columns are 16-byte aligned in LDS (ds_read_b128 for the y rows);
 //   * boundary masks for x/y are per-thread constants hoisted out of the march; z masks are wave-uniform;
-//   * cell blocks of layer z (corners on planes z and z+1, both in the LDS ring): one thread per cell
-//     multiplies its block with the 8 corner values and stores the 8 products into 8 LDS planes indexed by
-//     corner -- for a fixed corner index two cells never hit the same lattice point, so there are no
-//     atomics and no ordering: bitwise reproducible.  After one extra barrier the owner of a lattice point
-//     adds the 4 "lower" products to its output and carries the 4 "upper" ones to the next plane in
-//     registers.  Layers without data (the common case for surface point clouds) skip all of it.
+//   * data cells of layer z (corners on planes z and z+1, both in the LDS ring): one thread per cell.  A
+//     cell holding a single data row a is kept as that row (y += a (a.x), 32 B in fp32); a cell holding
+//     more rows is kept as its packed symmetric block (144 B).  The thread stores its 8 corner products
+//     into 8 LDS planes indexed by corner -- for a fixed corner index two cells never hit the same lattice
+//     point, so no value is ever added by two writers: no float atomics, no ordering, bitwise reproducible.
+//     After one extra barrier the owner of a lattice point adds the 4 "lower" products to its output,
+//     carries the 4 "upper" ones to the next plane in registers and re-zeroes the slots it read.  Row
+//     records are prefetched three planes ahead.  Layers without data (the common case for surface point
+//     clouds) skip all of it.  The scatter/gather code is kept branch-free (clamped addresses, a dump slot
+//     for corners outside the tile): the kernel is instruction-issue sensitive.
 //   * p.q partials: fp32 products per plane, fp64 per-thread accumulation, wave64 shuffle tree, one
 //     partial per workgroup;
 //   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. (same XCD, same L2) get adjacent tiles.
@@ -38,8 +42,14 @@ namespace fi {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTY      = 16;
-constexpr int kTXT     = 16;  // threads along x
+#ifndef FI_TXT
+#define FI_TXT 16
+#endif
+#ifndef FI_CELL_WAVES
+#define FI_CELL_WAVES 3  // waves per SIMD the fused (data cell) variant is register-allocated for
+#endif
+constexpr int kTXT     = FI_TXT;             // threads along x
+constexpr int kTY      = kThreads / kTXT;   // tile rows (= threads along y)
 constexpr int kR       = 2;   // halo rows/cols kept in LDS
 
 template <typename T>
@@ -63,9 +73,12 @@ struct MarchCoef {
 };
 
 struct CellLists {
-	const uint32_t* lay_off;  // [nwg*(zc+1)+1]
-	const uint2*    rec;      // {cell index, (tcx+1) | (tcy+1)<<16}
-	const void*     blk;      // T[ncell][36]
+	const uint32_t* lay_row;   // [nwg*(zc+1)+1]
+	const uint32_t* lay_blk;   // [nwg*(zc+1)+1]
+	const uint32_t* pos_row;   // (tcx+1) | (tcy+1)<<16
+	const uint32_t* pos_blk;
+	const void*     coef_row;  // T[n_row][8]
+	const void*     coef_blk;  // T[n_blk][36]
 };
 
 __device__ inline double wave_sum(double v)
@@ -80,7 +93,7 @@ __host__ __device__ constexpr int tri(int i, int j)  // packed upper-triangle in
 }
 
 template <typename T, bool HAS1, bool HAS2, bool CELLS>
-__global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
+__global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done)
@@ -98,6 +111,8 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 
 	__shared__ __attribute__((aligned(16))) T xs[3][ROWS][W];
 	__shared__ __attribute__((aligned(16))) T yb[NYB][CELLS ? kTY : 1][CELLS ? TX : VX];
+	__shared__ T ydump[CELLS ? 64 : 1];  // write-only target of corner products that fall outside the tile
+	__shared__ uint32_t s_lay[2][CELLS ? 72 : 1];  // record ranges of this workgroup's layers (rows, blocks)
 	__shared__ double red[kThreads / 64];
 
 	if (done && *done) { return; }
@@ -127,7 +142,6 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 	// ---- per-thread constants: halo slots and x/y boundary masks --------------------------------
 	int  h_lds[NH];
 	int  h_glb[NH];
-	bool h_ok[NH];
 #pragma unroll
 	for (int s = 0; s < NH; ++s) {
 		const int h = threadIdx.x + s * kThreads;
@@ -143,11 +157,11 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 			hly = kR + r;
 			hlx = k < R ? (PADX - R + k) : (PADX + TX + (k - R));
 		}
-		const int hgx = x0 + hlx - PADX, hgy = y0 + hly - kR;
-		h_lds[s] = hly * W + hlx;
+		int hgx = x0 + hlx - PADX, hgy = y0 + hly - kR;
+		hgx = hgx < 0 ? 0 : (hgx >= P.nx ? P.nx - 1 : hgx);
+		hgy = hgy < 0 ? 0 : (hgy >= P.ny ? P.ny - 1 : hgy);
+		h_lds[s] = in ? hly * W + hlx : -1;
 		h_glb[s] = hgy * P.nx + hgx;
-		h_ok[s]  = in && (0 <= hgx) && (hgx < P.nx) && (0 <= hgy) && (hgy < P.ny);
-		if (!in) { h_lds[s] = -1; }
 	}
 
 	// model_2 rows along x anchored at gx-2 .. gx+VX-1; along y anchored at gy-2, gy-1, gy
@@ -175,24 +189,26 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 		c1y[1] = (gy + 1 < P.ny) ? T(-1) : T(0);             // row anchored at gy touches gy with -1
 	}
 
+	// Loads never branch: every address is clamped into the lattice.  A clamped (wrong) value is only ever
+	// multiplied by a zero mask / a zero block coefficient, so it just has to be finite.
+	const int lz_lo = P.zoff < 0 ? -P.zoff : 0;
+	const int lz_hi = (P.nzl < P.gz - P.zoff ? P.nzl : P.gz - P.zoff) - 1;
+	const int gxc = gx < P.nx ? gx : P.nx - VX;
+	const int gyc = gy < P.ny ? gy : P.ny - 1;
+	const T* xcol = x + static_cast<int64_t>(gyc) * P.nx + gxc;
+	auto clamp_plane = [&](int lz) { return lz < lz_lo ? lz_lo : (lz > lz_hi ? lz_hi : lz); };
 	auto load_own = [&](int lz) -> V {
-		V v;
-		T* pv = reinterpret_cast<T*>(&v);
-#pragma unroll
-		for (int j = 0; j < VX; ++j) { pv[j] = T(0); }
-		const int gzc = lz + P.zoff;
-		if (active && lz >= 0 && lz < P.nzl && gzc >= 0 && gzc < P.gz) {
-			v = *reinterpret_cast<const V*>(x + static_cast<int64_t>(lz) * P.plane + col);
-		}
-		return v;
+		return *reinterpret_cast<const V*>(xcol + static_cast<int64_t>(clamp_plane(lz)) * P.plane);
 	};
 	auto load_halo = [&](int lz, T* hv) {
-		const int  gzc = lz + P.zoff;
-		const bool pz  = lz >= 0 && lz < P.nzl && gzc >= 0 && gzc < P.gz;
+		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
+		if (P.dbg & 1) {
 #pragma unroll
-		for (int s = 0; s < NH; ++s) {
-			hv[s] = (pz && h_ok[s]) ? x[static_cast<int64_t>(lz) * P.plane + h_glb[s]] : T(0);
+			for (int s = 0; s < NH; ++s) { hv[s] = T(0); }
+			return;
 		}
+#pragma unroll
+		for (int s = 0; s < NH; ++s) { hv[s] = xp[h_glb[s]]; }
 	};
 	auto write_plane = [&](int buf, const V& own, const T* hv) {
 		*reinterpret_cast<V*>(&xs[buf][ly][lx]) = own;
@@ -202,16 +218,68 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 		}
 	};
 
-	// ---- cell blocks of one layer: products into the 8 corner planes -----------------------------------
-	const uint32_t* lay = CELLS ? L.lay_off + static_cast<int64_t>(wg) * (P.zc + 1) : nullptr;
-	auto cells_scatter = [&](uint32_t rs, uint32_t re, int buf_lo, int buf_hi) {
-		const T* blk = static_cast<const T*>(L.blk);
-		for (uint32_t r = rs + threadIdx.x; r < re; r += kThreads) {
-			const uint2 rc  = L.rec[r];
-			const int   tcx = static_cast<int>(rc.y & 0xFFFFu) - 1;
-			const int   tcy = static_cast<int>(rc.y >> 16) - 1;
+	// ---- data cells of one layer: corner products into the 8 corner planes ------------------------------
+	// the zc+2 range bounds of this workgroup are staged in LDS once, in the prologue (a scalar global load
+	// per plane would put its latency on every step of the march)
+	const uint32_t* layR = s_lay[0];
+	const uint32_t* layB = s_lay[1];
+	// store the 8 corner products of a cell; corners outside the tile go to the dump slot (no branches)
+	auto put8 = [&](int tcx, int tcy, const T* out) {
+		T* const dump = &ydump[threadIdx.x & 63];
+		const bool vx0 = tcx >= 0, vx1 = tcx + 1 < TX, vy0 = tcy >= 0, vy1 = tcy + 1 < kTY;
+		T* const base = &yb[0][0][0] + tcy * TX + tcx;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const bool ok = ((i & 1) ? vx1 : vx0) && ((i & 2) ? vy1 : vy0);
+			T* dst = base + i * (kTY * TX) + ((i >> 1) & 1) * TX + (i & 1);
+			dst = ok ? dst : dump;
+			*dst = out[i];
+		}
+	};
+	auto corners = [&](int tcx, int tcy, int buf_lo, int buf_hi, T* xv) {
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const int bx = q & 1, by = (q >> 1) & 1, bz = q >> 2;
+			xv[q] = xs[bz ? buf_hi : buf_lo][kR + tcy + by][PADX + tcx + bx];
+		}
+	};
+	auto row_apply = [&](uint32_t pos, const T* a, int buf_lo, int buf_hi) {
+		const int tcx = static_cast<int>(pos & 0xFFFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
+		T xv[8];
+		corners(tcx, tcy, buf_lo, buf_hi, xv);
+		T t = T(0);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) { t += a[q] * xv[q]; }
+		T out[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { out[i] = a[i] * t; }
+		put8(tcx, tcy, out);
+	};
+	auto load_row = [&](uint32_t r, uint32_t* pos, T* a) {
+		*pos = L.pos_row[r];
+		const V* ap = reinterpret_cast<const V*>(static_cast<const T*>(L.coef_row) + static_cast<int64_t>(r) * 8);
+#pragma unroll
+		for (int k = 0; k < 8 / VX; ++k) {
+			const V  v  = ap[k];
+			const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+			for (int j = 0; j < VX; ++j) { a[k * VX + j] = pv[j]; }
+		}
+	};
+	// rows beyond the prefetched first 256 of a layer, and all block records
+	auto cells_scatter = [&](uint32_t rsR, uint32_t reR, uint32_t rsB, uint32_t reB, int buf_lo, int buf_hi) {
+		for (uint32_t r = rsR + threadIdx.x; r < reR; r += kThreads) {
+			uint32_t pos;
+			T a[8];
+			load_row(r, &pos, a);
+			row_apply(pos, a, buf_lo, buf_hi);
+		}
+		const T* blk = static_cast<const T*>(L.coef_blk);
+		for (uint32_t r = rsB + threadIdx.x; r < reB; r += kThreads) {
+			const uint32_t pos = L.pos_blk[r];
+			const int tcx = static_cast<int>(pos & 0xFFFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
 			T b[36];
-			const V* bp = reinterpret_cast<const V*>(blk + static_cast<int64_t>(rc.x) * 36);
+			const V* bp = reinterpret_cast<const V*>(blk + static_cast<int64_t>(r) * 36);
 #pragma unroll
 			for (int k = 0; k < 36 / VX; ++k) {
 				const V    v  = bp[k];
@@ -219,23 +287,19 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 #pragma unroll
 				for (int j = 0; j < VX; ++j) { b[k * VX + j] = pv[j]; }
 			}
-			T xv[8];
-#pragma unroll
-			for (int q = 0; q < 8; ++q) {
-				const int bx = q & 1, by = (q >> 1) & 1, bz = q >> 2;
-				xv[q] = xs[bz ? buf_hi : buf_lo][kR + tcy + by][PADX + tcx + bx];
-			}
+			T xv[8], out[8];
+			corners(tcx, tcy, buf_lo, buf_hi, xv);
 #pragma unroll
 			for (int i = 0; i < 8; ++i) {
 				T s = T(0);
 #pragma unroll
 				for (int j = 0; j < 8; ++j) { s += b[i <= j ? tri(i, j) : tri(j, i)] * xv[j]; }
-				const int px = tcx + (i & 1), py = tcy + ((i >> 1) & 1);
-				if (px >= 0 && px < TX && py >= 0 && py < kTY) { yb[i][py][px] = s; }
+				out[i] = s;
 			}
+			put8(tcx, tcy, out);
 		}
 	};
-	// owner side: lower 4 planes -> this plane, upper 4 planes -> carry; planes are zeroed for the next layer
+	// owner side: lower 4 planes -> this plane, upper 4 planes -> carry; the slots are zeroed for the next layer
 	auto cells_gather = [&](T* lower, T* upper) {
 		const V zero = V{};
 #pragma unroll
@@ -254,74 +318,118 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 	};
 
 	// ---- prologue ---------------------------------------------------------------------------------
-	// registers at the top of step z: xc = x(z), xp1 = x(z+1), xp2 = x(z+2), xnext = x(z+3) (in flight),
-	// u1 = masked u(z-1), u2 = masked u(z-2), d1 = masked (x(z) - x(z-1)), carry = upper cell products.
-	V xc = load_own(z_begin), xp1 = load_own(z_begin + 1), xp2 = load_own(z_begin + 2);
-	V xnext = load_own(z_begin + 3);
-	T hcur[NH], hnext[NH];
-	load_halo(z_begin, hcur);
-	load_halo(z_begin + 1, hnext);
-	T u1[VX], u2[VX], d1[VX], carry[VX];
+	// Software pipeline, all ring indices relative to the step number s = z - z_begin:
+	//   own x values: plane s lives in register slot X[s % 6]; step s reads slots s, s+1, s+2 and issues the
+	//                 load of plane s+5 into the slot plane s-1 left (3 steps of lead);
+	//   halo values : plane s in H[s % 3]; step s stages plane s+1 and loads plane s+3 (2 steps of lead);
+	//   row records : layer s in PF[s % 3]; consumed at step s, refilled with layer s+3;
+	//   carried     : u1 = masked u(z-1), u2 = masked u(z-2), d1 = masked (x(z) - x(z-1)), carry = upper
+	//                 cell products of layer z-1.
+	// The loop body is instantiated six times so that no ring ever needs a register move (a move would
+	// wait for the load it copies and cut the lead to less than one step).
+	struct RowPF {
+		uint32_t pos;
+		T        a[8];
+		bool     ok;
+	};
+	V X0 = load_own(z_begin), X1 = load_own(z_begin + 1), X2 = load_own(z_begin + 2);
+	V X3 = load_own(z_begin + 3), X4 = load_own(z_begin + 4), X5 = V{};
+	T H0[NH], H1[NH], H2[NH];
+	load_halo(z_begin, H0);
+	load_halo(z_begin + 1, H1);
+	load_halo(z_begin + 2, H2);
+	if (CELLS) {  // issued after the plane loads so that the two latencies overlap
+		if (threadIdx.x < P.zc + 2) {
+			const int64_t o = static_cast<int64_t>(wg) * (P.zc + 1) + threadIdx.x;
+			s_lay[0][threadIdx.x] = L.lay_row[o];
+			s_lay[1][threadIdx.x] = L.lay_blk[o];
+		}
+		__syncthreads();
+	}
+	T U0[VX], U1[VX], U2[VX], D0[VX], D1[VX], carry[VX];  // U: u(z) ring of 3, D: d(z) ring of 2
 #pragma unroll
-	for (int j = 0; j < VX; ++j) { carry[j] = T(0); }
+	for (int j = 0; j < VX; ++j) { carry[j] = T(0); U0[j] = T(0); D0[j] = T(0); }
+	const int nsteps = z_end - z_begin;
+	RowPF PF0, PF1, PF2;
+	PF0.ok = PF1.ok = PF2.ok = false;
+	auto prefetch_rows = [&](int layer, RowPF& pf) {  // layer index l: cell plane z_begin - 1 + l
+		pf.ok = false;
+		if (CELLS && layer <= nsteps) {
+			const uint32_t r = layR[layer] + threadIdx.x;
+			pf.ok = r < layR[layer + 1];
+			if (pf.ok) { load_row(r, &pf.pos, pf.a); }
+		}
+	};
 	{
 		const V xa = load_own(z_begin - 2), xb = load_own(z_begin - 1);
 		const T* pa = reinterpret_cast<const T*>(&xa);
 		const T* pb = reinterpret_cast<const T*>(&xb);
-		const T* pc = reinterpret_cast<const T*>(&xc);
-		const T* pd = reinterpret_cast<const T*>(&xp1);
+		const T* pc = reinterpret_cast<const T*>(&X0);
+		const T* pd = reinterpret_cast<const T*>(&X1);
 		const int g2 = z_begin - 2 + P.zoff, g1 = z_begin - 1 + P.zoff;
 		const T mz2 = (g2 >= 0 && g2 + 2 < P.gz) ? T(1) : T(0);
 		const T mz1 = (g1 >= 0 && g1 + 2 < P.gz) ? T(1) : T(0);
 		const T md1 = (g1 >= 0 && g1 + 1 < P.gz) ? T(1) : T(0);
 #pragma unroll
 		for (int j = 0; j < VX; ++j) {
-			u2[j] = mz2 * (pa[j] - T(2) * pb[j] + pc[j]);
-			u1[j] = mz1 * (pb[j] - T(2) * pc[j] + pd[j]);
-			d1[j] = md1 * (pc[j] - pb[j]);
+			U1[j] = mz2 * (pa[j] - T(2) * pb[j] + pc[j]);  // u(z_begin-2)
+			U2[j] = mz1 * (pb[j] - T(2) * pc[j] + pd[j]);  // u(z_begin-1)
+			D1[j] = md1 * (pc[j] - pb[j]);                 // d(z_begin-1)
 		}
 		if (CELLS) {
-			// layer z_begin-1: its upper corners sit on plane z_begin
-			const V zero = V{};
+			// layer z_begin-1 (l = 0): its upper corners sit on plane z_begin
+			{
+				const V zero = V{};
 #pragma unroll
-			for (int q = 0; q < 8; ++q) { *reinterpret_cast<V*>(&yb[q][ty][VX * tx]) = zero; }
-			const uint32_t rs = lay[0], re = lay[1];
-			if (re > rs) {
+				for (int q = 0; q < 8; ++q) { *reinterpret_cast<V*>(&yb[q][ty][VX * tx]) = zero; }
+			}
+			prefetch_rows(1, PF0);
+			prefetch_rows(2, PF1);
+			prefetch_rows(3, PF2);
+			const uint32_t rsR = layR[0], reR = layR[1], rsB = layB[0], reB = layB[1];
+			if (reR > rsR || reB > rsB) {
 				T hprev[NH];
 				load_halo(z_begin - 1, hprev);
-				write_plane((z_begin + 2) % 3, xb, hprev);  // plane z_begin-1
-				write_plane(z_begin % 3, xc, hcur);
+				write_plane(2, xb, hprev);  // plane z_begin-1 borrows ring slot 2 (rewritten at step 1)
+				write_plane(0, X0, H0);
 				__syncthreads();
-				cells_scatter(rs, re, (z_begin + 2) % 3, z_begin % 3);
+				cells_scatter(rsR, reR, rsB, reB, 2, 0);
 				__syncthreads();
 				T lower[VX];
 				cells_gather(lower, carry);
-				__syncthreads();  // plane z_begin-1's buffer is rewritten as plane z_begin+2 two steps on
+				__syncthreads();
 			}
 		}
 	}
-	write_plane(z_begin % 3, xc, hcur);
+	write_plane(0, X0, H0);
 
 	double dot_acc = 0.0;
 
-	for (int z = z_begin; z < z_end; ++z) {
-		// stage plane z+1 into the LDS ring (needed by the cell blocks of layer z) and prefetch ahead
-		write_plane((z + 1) % 3, xp1, hnext);
-		load_halo(z + 2, hnext);
-		const V xfar = load_own(z + 4);
+	auto step = [&](int s, const V& xc, const V& xp1, const V& xp2, V& xload, const T* h_use, T* h_load, RowPF& pf,
+	                const T* uA, const T* uB, T* uC, const T* dA, T* dC) {
+		const int z = z_begin + s;
+		// stage plane z+1 into the LDS ring (needed by the cells of layer z) and prefetch ahead
+		write_plane((s + 1) % 3, xp1, h_use);
+		if (s + 3 <= nsteps) { load_halo(z + 3, h_load); }      // staged planes end at z_end, own planes at z_end+1
+		if (s + 5 <= nsteps + 1) { xload = load_own(z + 5); }
 		__syncthreads();
 
 		const int gzc = z + P.zoff;
-		const T (*pl)[W] = xs[z % 3];
+		const int b0 = s % 3, b1 = (s + 1) % 3;
+		const T (*pl)[W] = xs[b0];
 		const T* pc  = reinterpret_cast<const T*>(&xc);
 		const T* pp1 = reinterpret_cast<const T*>(&xp1);
 		const T* pp2 = reinterpret_cast<const T*>(&xp2);
 
-		uint32_t rs = 0, re = 0;
+		bool has_cells = false;
 		if (CELLS) {
-			rs = lay[z - z_begin + 1];
-			re = lay[z - z_begin + 2];
-			if (re > rs) { cells_scatter(rs, re, z % 3, (z + 1) % 3); }
+			const uint32_t rsR = layR[s + 1], reR = layR[s + 2], rsB = layB[s + 1], reB = layB[s + 2];
+			has_cells = (reR > rsR) || (reB > rsB);
+			if (has_cells) {
+				if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1); }
+				cells_scatter(rsR + kThreads < reR ? rsR + kThreads : reR, reR, rsB, reB, b0, b1);
+			}
+			prefetch_rows(s + 4, pf);  // layer of step s+3
 		}
 
 		T acc2[VX], acc1[VX];
@@ -383,9 +491,8 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 #pragma unroll
 				for (int j = 0; j < VX; ++j) {
 					const T u0 = mz * (pc[j] - T(2) * pp1[j] + pp2[j]);
-					acc2[j] += u2[j] - T(2) * u1[j] + u0;
-					u2[j] = u1[j];
-					u1[j] = u0;
+					acc2[j] += uA[j] - T(2) * uB[j] + u0;
+					uC[j] = u0;
 				}
 			}
 			if (HAS1) {
@@ -393,8 +500,8 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 #pragma unroll
 				for (int j = 0; j < VX; ++j) {
 					const T d0 = mz * (pp1[j] - pc[j]);
-					acc1[j] += d1[j] - d0;
-					d1[j] = d0;
+					acc1[j] += dA[j] - d0;
+					dC[j] = d0;
 				}
 			}
 		}
@@ -403,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 		T data[VX];
 #pragma unroll
 		for (int j = 0; j < VX; ++j) { data[j] = carry[j]; carry[j] = T(0); }
-		if (CELLS && re > rs) {
+		if (CELLS && has_cells) {
 			__syncthreads();
 			T lower[VX];
 			cells_gather(lower, carry);
@@ -423,13 +530,23 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 			dsum += pc[j] * v;
 		}
 		if (active) {
-			*reinterpret_cast<V*>(y + static_cast<int64_t>(z) * P.plane + col) = out;
+			if (!(P.dbg & 2)) { *reinterpret_cast<V*>(y + static_cast<int64_t>(z) * P.plane + col) = out; }
 			dot_acc += static_cast<double>(dsum);
 		}
-		xc    = xp1;
-		xp1   = xp2;
-		xp2   = xnext;
-		xnext = xfar;
+	};
+
+	for (int s0 = 0; s0 < nsteps; s0 += 6) {
+		step(s0, X0, X1, X2, X5, H1, H0, PF0, U1, U2, U0, D1, D0);
+		if (s0 + 1 >= nsteps) { break; }
+		step(s0 + 1, X1, X2, X3, X0, H2, H1, PF1, U2, U0, U1, D0, D1);
+		if (s0 + 2 >= nsteps) { break; }
+		step(s0 + 2, X2, X3, X4, X1, H0, H2, PF2, U0, U1, U2, D1, D0);
+		if (s0 + 3 >= nsteps) { break; }
+		step(s0 + 3, X3, X4, X5, X2, H1, H0, PF0, U1, U2, U0, D0, D1);
+		if (s0 + 4 >= nsteps) { break; }
+		step(s0 + 4, X4, X5, X0, X3, H2, H1, PF1, U2, U0, U1, D1, D0);
+		if (s0 + 5 >= nsteps) { break; }
+		step(s0 + 5, X5, X0, X1, X4, H0, H2, PF2, U0, U1, U2, D0, D1);
 	}
 
 	if (partial) {
@@ -443,13 +560,19 @@ __global__ __launch_bounds__(kThreads) void k_apply_march3d(MarchParams P, March
 // ---- per-workgroup cell lists -------------------------------------------------------------------------
 // A cell with global origin (cx, cy, cz) touches the tile columns {cx/TX, and (cx+1)/TX when cx+1 is a
 // tile start}, likewise rows, and along z the chunk holding plane cz plus the next chunk when plane cz+1
-// starts it (layer 0 of that chunk).  mode 0: count per (workgroup, layer); mode 1: fill.
-__global__ __launch_bounds__(kThreads) void k_cell_lists(MarchParams P, Geom g, int64_t ncell,
+// starts it (layer 0 of that chunk).  mode 0: count per (kind, workgroup, layer); mode 1: fill the
+// self-contained records (order inside a list is irrelevant: its cells never share an output slot).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cell_lists(MarchParams P, Geom g, int64_t ncell, int64_t nbuckets,
                                                           const uint32_t* __restrict__ cell_id,
+                                                          const uint32_t* __restrict__ nrow,
+                                                          const T* __restrict__ row1, const T* __restrict__ blk,
                                                           uint32_t* __restrict__ count,
-                                                          const uint32_t* __restrict__ off,
-                                                          uint32_t* __restrict__ cursor, uint2* __restrict__ rec,
-                                                          int mode)
+                                                          const uint32_t* __restrict__ off_row,
+                                                          const uint32_t* __restrict__ off_blk,
+                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ pos_row,
+                                                          uint32_t* __restrict__ pos_blk, T* __restrict__ coef_row,
+                                                          T* __restrict__ coef_blk, int mode)
 {
 	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	if (c >= ncell) { return; }
@@ -461,6 +584,8 @@ __global__ __launch_bounds__(kThreads) void k_cell_lists(MarchParams P, Geom g, 
 	const int cz = static_cast<int>(id) + g.coff[2];      // global
 	const int zz = cz - P.zoff - P.own_z0;                // plane index relative to the first owned plane
 	const int nz_own = P.own_z1 - P.own_z0;
+	const int kind = nrow[c] == 1u ? 0 : 1;               // 0: single row, 1: block
+	if (mode == 0) { atomicAdd(&count[2 * (nbuckets + 1) + kind], 1u); }  // distinct cells of each kind
 
 	int tix[2], tcx[2], nx_ = 0;
 	if (cx >= 0 && cx / P.tx < P.tiles_x) { tix[nx_] = cx / P.tx; tcx[nx_] = cx % P.tx; ++nx_; }
@@ -475,14 +600,22 @@ __global__ __launch_bounds__(kThreads) void k_cell_lists(MarchParams P, Geom g, 
 	for (int a = 0; a < nz_; ++a) {
 		for (int b = 0; b < ny_; ++b) {
 			for (int d = 0; d < nx_; ++d) {
-				const int      wg     = (tk[a] * P.tiles_y + tiy[b]) * P.tiles_x + tix[d];
-				const uint32_t bucket = static_cast<uint32_t>(wg) * (P.zc + 1) + tl[a];
+				const int     wg     = (tk[a] * P.tiles_y + tiy[b]) * P.tiles_x + tix[d];
+				const int64_t bucket = static_cast<int64_t>(wg) * (P.zc + 1) + tl[a];
+				const int64_t slot   = kind * (nbuckets + 1) + bucket;
 				if (mode == 0) {
-					atomicAdd(&count[bucket], 1u);
+					atomicAdd(&count[slot], 1u);
 				} else {
-					const uint32_t pos = off[bucket] + atomicAdd(&cursor[bucket], 1u);
-					rec[pos] = make_uint2(static_cast<uint32_t>(c),
-					                      static_cast<uint32_t>(tcx[d] + 1) | (static_cast<uint32_t>(tcy[b] + 1) << 16));
+					const uint32_t packed = static_cast<uint32_t>(tcx[d] + 1) | (static_cast<uint32_t>(tcy[b] + 1) << 16);
+					if (kind == 0) {
+						const uint32_t pos = off_row[bucket] + atomicAdd(&cursor[slot], 1u);
+						pos_row[pos] = packed;
+						for (int q = 0; q < 8; ++q) { coef_row[static_cast<int64_t>(pos) * 8 + q] = row1[c * 8 + q]; }
+					} else {
+						const uint32_t pos = off_blk[bucket] + atomicAdd(&cursor[slot], 1u);
+						pos_blk[pos] = packed;
+						for (int q = 0; q < 36; ++q) { coef_blk[static_cast<int64_t>(pos) * 36 + q] = blk[c * 36 + q]; }
+					}
 				}
 			}
 		}
@@ -493,7 +626,7 @@ int pick_chunk(int tiles_xy, int nz_own)
 {
 	if (const char* env = getenv("FI_ZC")) {
 		const int v = atoi(env);
-		if (v > 0) { return v; }
+		if (v > 0) { return v > 64 ? 64 : v; }  // s_lay holds at most 64 + 2 range bounds
 	}
 	// aim for >= 2048 workgroups (8 per CU), planes per chunk between 8 and 64
 	int zc = 64;
@@ -528,6 +661,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P)
 	P->chunks = (nz_own + P->zc - 1) / P->zc;
 	P->nwg    = P->tiles_x * P->tiles_y * P->chunks;
 	P->plane  = static_cast<int64_t>(P->nx) * P->ny;
+	P->dbg    = getenv("FI_DBG") ? atoi(getenv("FI_DBG")) : 0;
 	return true;
 }
 
@@ -549,7 +683,9 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial)
 {
 	const MarchParams& P = c->march.P;
 	const MarchCoef<T> C = march_coef<T>(c->w);
-	CellLists L{c->march.lay_off.as<uint32_t>(), c->march.rec.as<uint2>(), c->cells.blk.p};
+	const MarchState& m = c->march;
+	CellLists L{m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(),
+	            m.coef_row.p, m.coef_blk.p};
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
 	const int  grid = ((P.nwg + 7) / 8) * 8;
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
@@ -566,6 +702,7 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial)
 	FI_HIP_TRY(hipGetLastError());
 }
 
+template <typename T>
 void build_cell_lists(fi_ctx* c)
 {
 	MarchState& m = c->march;
@@ -574,27 +711,44 @@ void build_cell_lists(fi_ctx* c)
 	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1);
 	hipStream_t st = c->stream;
 	DevBuf count, cursor, tmp;
-	count.alloc(sizeof(uint32_t) * (nbuckets + 1));
-	cursor.alloc(sizeof(uint32_t) * (nbuckets + 1));
-	m.lay_off.alloc(sizeof(uint32_t) * (nbuckets + 1));
-	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * (nbuckets + 1), st));
-	FI_HIP_TRY(hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * (nbuckets + 1), st));
+	count.alloc(sizeof(uint32_t) * (2 * (nbuckets + 1) + 2));
+	cursor.alloc(sizeof(uint32_t) * 2 * (nbuckets + 1));
+	m.lay_row.alloc(sizeof(uint32_t) * (nbuckets + 1));
+	m.lay_blk.alloc(sizeof(uint32_t) * (nbuckets + 1));
+	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * (2 * (nbuckets + 1) + 2), st));
+	FI_HIP_TRY(hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * 2 * (nbuckets + 1), st));
 	const int nb = static_cast<int>((ncell + kThreads - 1) / kThreads);
-	hipLaunchKernelGGL(k_cell_lists, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, c->cells.cell_id.as<uint32_t>(),
-	                   count.as<uint32_t>(), nullptr, nullptr, nullptr, 0);
+	hipLaunchKernelGGL((k_cell_lists<T>), dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
+	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
+	                   c->cells.blk.as<T>(), count.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr, nullptr,
+	                   static_cast<T*>(nullptr), static_cast<T*>(nullptr), 0);
 	size_t tb = 0;
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, count.as<uint32_t>(), m.lay_off.as<uint32_t>(),
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
 	                                            static_cast<int>(nbuckets + 1), st));
 	tmp.alloc(tb);
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, count.as<uint32_t>(), m.lay_off.as<uint32_t>(),
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
 	                                            static_cast<int>(nbuckets + 1), st));
-	uint32_t total = 0;
-	FI_HIP_TRY(hipMemcpyAsync(&total, m.lay_off.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, count.as<uint32_t>() + (nbuckets + 1),
+	                                            m.lay_blk.as<uint32_t>(), static_cast<int>(nbuckets + 1), st));
+	uint32_t totals[2] = {0, 0};
+	FI_HIP_TRY(hipMemcpyAsync(&totals[0], m.lay_row.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipMemcpyAsync(&totals[1], m.lay_blk.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	uint32_t uniq[2] = {0, 0};
+	FI_HIP_TRY(hipMemcpyAsync(uniq, count.as<uint32_t>() + 2 * (nbuckets + 1), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
-	m.nrec = total;
-	m.rec.alloc(sizeof(uint2) * (total ? total : 1));
-	hipLaunchKernelGGL(k_cell_lists, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, c->cells.cell_id.as<uint32_t>(),
-	                   nullptr, m.lay_off.as<uint32_t>(), cursor.as<uint32_t>(), m.rec.as<uint2>(), 1);
+	m.n_row = totals[0];
+	m.n_blk = totals[1];
+	m.cells_row = uniq[0];
+	m.cells_blk = uniq[1];
+	m.pos_row.alloc(sizeof(uint32_t) * (m.n_row + 1));
+	m.pos_blk.alloc(sizeof(uint32_t) * (m.n_blk + 1));
+	m.coef_row.alloc(sizeof(T) * 8 * (m.n_row + 1));
+	m.coef_blk.alloc(sizeof(T) * 36 * (m.n_blk + 1));
+	hipLaunchKernelGGL((k_cell_lists<T>), dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
+	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
+	                   c->cells.blk.as<T>(), nullptr, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
+	                   cursor.as<uint32_t>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(),
+	                   m.coef_blk.as<T>(), 1);
 	FI_HIP_TRY(hipGetLastError());
 	FI_HIP_TRY(hipStreamSynchronize(st));
 }
@@ -606,10 +760,10 @@ void stencil_prepare(fi_ctx* c)
 	MarchState& m = c->march;
 	m.valid = c->dtype == FI_F64 ? march_setup<double>(c, &m.P) : march_setup<float>(c, &m.P);
 	m.fused = false;
-	m.nrec  = 0;
+	m.n_row = m.n_blk = 0;
 	if (!m.valid) { return; }
 	if (c->cells.ncell > 0 && !getenv("FI_NO_FUSE")) {
-		build_cell_lists(c);
+		c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
 		m.fused = true;
 	}
 }
