@@ -19,6 +19,8 @@ SYMBOLS = [
     "fi_add_rows_coo", "fi_assemble", "fi_clear_points", "fi_solve_cg", "fi_jacobi",
     "fi_get_solution_f64", "fi_true_residual", "fi_apply_AtA_f64", "fi_get_Atb_f64", "fi_get_diag_f64",
     "fi_get_stats", "fi_time_apply", "fi_upscale_field",
+    "fi_group_create", "fi_group_destroy", "fi_group_size", "fi_group_rank", "fi_group_assemble",
+    "fi_group_solve_cg", "fi_group_apply_AtA_f64", "fi_group_true_residual", "fi_group_get_solution_f64",
 ]
 
 
@@ -86,6 +88,16 @@ def lib():
     L.fi_get_stats.argtypes = [vp, C.POINTER(FiStats)]
     L.fi_time_apply.argtypes = [vp, C.c_int, dp]
     L.fi_upscale_field.argtypes = [fp, C.c_int, ip, ip, fp, C.c_int]
+    L.fi_group_create.argtypes = [C.POINTER(vp), C.c_int, ip, C.c_int, C.c_int]
+    L.fi_group_destroy.argtypes = [vp]
+    L.fi_group_size.argtypes = [vp]
+    L.fi_group_rank.restype = vp
+    L.fi_group_rank.argtypes = [vp, C.c_int]
+    L.fi_group_assemble.argtypes = [vp]
+    L.fi_group_solve_cg.argtypes = [vp, fp, C.c_int, C.c_float, fp, ip, C.POINTER(C.c_float)]
+    L.fi_group_apply_AtA_f64.argtypes = [vp, dp, dp]
+    L.fi_group_true_residual.argtypes = [vp, dp]
+    L.fi_group_get_solution_f64.argtypes = [vp, dp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError if the .so lacks a declared symbol
     _LIB = L

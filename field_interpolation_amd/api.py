@@ -87,7 +87,7 @@ class LatticeField:
     dtype: "f32" (vectors fp32, reductions fp64) or "f64".  rank/nranks select a slab of the slowest
     axis (one process per GPU)."""
 
-    def __init__(self, sizes, dtype="f32", rank=0, nranks=1):
+    def __init__(self, sizes, dtype="f32", rank=0, nranks=1, _borrowed=None):
         self.sizes = [int(s) for s in sizes]
         self.dtype = dtype
         self.rank, self.nranks = rank, nranks
@@ -97,9 +97,12 @@ class LatticeField:
             self.strides.append(s)
             s *= n
         self._h = C.c_void_p()
+        self._borrowed = _borrowed is not None
         sz = (C.c_int * len(self.sizes))(*self.sizes)
         code = {"f32": FI_F32, "f64": FI_F64}[dtype]
-        if nranks == 1:
+        if _borrowed is not None:       # a member of a LatticeGroup: the group owns the context
+            self._h = C.c_void_p(_borrowed)
+        elif nranks == 1:
             check(_capi.lib().fi_ctx_create(C.byref(self._h), len(self.sizes), sz, code))
         else:
             check(_capi.lib().fi_ctx_create_slab(C.byref(self._h), len(self.sizes), sz, code, rank, nranks))
@@ -111,9 +114,9 @@ class LatticeField:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h and _capi._LIB is not None:
+        if h and _capi._LIB is not None and not getattr(self, "_borrowed", False):
             _capi._LIB.fi_ctx_destroy(h)
-            self._h = None
+        self._h = None
 
     def num_dim(self):
         return len(self.sizes)
@@ -284,6 +287,77 @@ class LatticeField:
         ms = C.c_double(0)
         check(_capi.lib().fi_time_apply(self._h, reps, C.byref(ms)))
         return ms.value
+
+
+class LatticeGroup:
+    """All slabs of a decomposition in one process on one GPU (loop-back test facility, fi_hip.h
+    "loop-back group"): same kernels and slab rules as the one-process-per-GPU RCCL path."""
+
+    def __init__(self, sizes, nranks, dtype="f32"):
+        self.sizes = [int(s) for s in sizes]
+        self.dtype = dtype
+        self._g = C.c_void_p()
+        sz = (C.c_int * len(self.sizes))(*self.sizes)
+        check(_capi.lib().fi_group_create(C.byref(self._g), len(self.sizes), sz, {"f32": FI_F32, "f64": FI_F64}[dtype],
+                                          nranks))
+        self.members = [LatticeField(self.sizes, dtype=dtype, rank=r, nranks=nranks,
+                                     _borrowed=_capi.lib().fi_group_rank(self._g, r)) for r in range(nranks)]
+
+    def __del__(self):
+        g = getattr(self, "_g", None)
+        if g and _capi._LIB is not None:
+            for m in getattr(self, "members", []):
+                m._h = None
+            _capi._LIB.fi_group_destroy(g)
+            self._g = None
+
+    @property
+    def num_unknowns(self):
+        return int(np.prod(self.sizes))
+
+    def add_field_constraints(self, weights):
+        for m in self.members:
+            m.add_field_constraints(weights)
+
+    def add_points(self, *a, **kw):
+        for m in self.members:          # every rank sees every point and keeps the cells touching its slab
+            m.add_points(*a, **kw)
+
+    def assemble(self):
+        check(_capi.lib().fi_group_assemble(self._g))
+        for m in self.members:
+            m._dirty = False
+
+    def apply_AtA(self, x):
+        xx = np.ascontiguousarray(x, np.float64)
+        y = np.empty(self.num_unknowns, np.float64)
+        dp = C.POINTER(C.c_double)
+        check(_capi.lib().fi_group_apply_AtA_f64(self._g, xx.ctypes.data_as(dp), y.ctypes.data_as(dp)))
+        return y
+
+    def Atb(self):
+        return np.concatenate([m.Atb() for m in self.members])
+
+    def diag(self):
+        return np.concatenate([m.diag() for m in self.members])
+
+    def solve_cg(self, guess=None, max_iterations=0, error_tolerance=0.0):
+        g = None if guess is None else np.ascontiguousarray(guess, np.float32)
+        out = np.empty(self.num_unknowns, np.float32)
+        it, rel = C.c_int(0), C.c_float(0)
+        check(_capi.lib().fi_group_solve_cg(self._g, None if g is None else C.c_void_p(g.ctypes.data), int(max_iterations),
+                                            float(error_tolerance), C.c_void_p(out.ctypes.data), C.byref(it), C.byref(rel)))
+        return out, it.value, rel.value
+
+    def solution_f64(self):
+        out = np.empty(self.num_unknowns, np.float64)
+        check(_capi.lib().fi_group_get_solution_f64(self._g, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def true_residual(self):
+        r = C.c_double(0)
+        check(_capi.lib().fi_group_true_residual(self._g, C.byref(r)))
+        return r.value
 
 
 # ---- free functions with the reference's names ---------------------------------------------------

@@ -176,6 +176,8 @@ struct fi_ctx {
 	int        max_blocks = 0;
 
 	fi::Comm*  comm = nullptr;
+	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
+	bool       owns_stream = true;
 	fi_stats   stats{};
 	std::vector<hipEvent_t> ev;  // sampled events around AtA applies
 };

@@ -441,34 +441,97 @@ void store_owned(fi_ctx* c, const DevBuf& v, float* dst, int memory)
 	FI_HIP_TRY(hipStreamSynchronize(c->stream));
 }
 
-void reduce_and_logic(fi_ctx* c, int nvec, int stride, int count, int phase)
+// ---- rank sets ---------------------------------------------------------------------------------------
+// The solver drivers run over a set of slab contexts in lockstep.  In production the set has ONE member
+// (this process's slab; neighbours are reached through RCCL, fi_comm.hip).  A loop-back group
+// (fi_group_create) puts ALL slabs of a decomposition into one process on one device and one stream: halo
+// planes move with device-to-device copies and the dot products are summed by a tiny kernel.  It exists so
+// that the slab geometry, halo widths, global-coordinate boundary masks and cell ownership rules can be
+// tested on a single GPU against the undivided solve; it runs the same kernels as the RCCL path.
+using RankSet = std::vector<fi_ctx*>;
+
+__global__ void k_group_sum(CgScalars* const* sc, int nranks, int nvec)
 {
-	CgScalars* sc = c->scal.as<CgScalars>();
-	if (c->nranks == 1) {
-		hipLaunchKernelGGL(k_reduce_logic, dim3(1), dim3(kThreads), 0, c->stream, sc, c->partial.as<double>(), nvec,
-		                   stride, count, phase);
-		return;
+	if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
+	for (int v = 0; v < nvec; ++v) {
+		double s = 0;
+		for (int r = 0; r < nranks; ++r) { s += sc[r]->sums[v]; }  // fixed order
+		for (int r = 0; r < nranks; ++r) { sc[r]->sums[v] = s; }
 	}
-	hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, sc, c->partial.as<double>(), nvec, stride, count,
-	                   phase == kPhaseInit ? 0 : 1);
-	allreduce_sum(c, sc->sums, nvec);
-	hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, c->stream, sc, phase);
 }
 
-template <typename T>
-void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
-                float* rel_residual, int memory)
+void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec)
 {
-	const Geom& g = c->g;
-	ensure_vectors(c);
-	hipStream_t st = c->stream;
+	if (R.size() == 1) {
+		exchange_halo(R[0], (R[0]->*vec).p);
+		return;
+	}
+	for (size_t i = 0; i + 1 < R.size(); ++i) {
+		fi_ctx* lo = R[i];
+		fi_ctx* hi = R[i + 1];
+		const Geom& gl = lo->g;
+		const Geom& gh = hi->g;
+		const int    L     = gl.ndim - 1;
+		const int    H     = lo->halo;
+		const size_t es    = elem_size(lo);
+		const size_t plane = static_cast<size_t>(gl.stride[L]);
+		const size_t bytes = es * plane * H;
+		char* lo_base = static_cast<char*>((lo->*vec).p);
+		char* hi_base = static_cast<char*>((hi->*vec).p);
+		// lo's last H owned planes -> hi's lower ghost planes
+		FI_HIP_TRY(hipMemcpyAsync(hi_base, lo_base + es * plane * (gl.own_hi[L] - H), bytes, hipMemcpyDeviceToDevice,
+		                          lo->stream));
+		// hi's first H owned planes -> lo's upper ghost planes
+		FI_HIP_TRY(hipMemcpyAsync(lo_base + es * plane * gl.own_hi[L], hi_base + es * plane * gh.own_lo[L], bytes,
+		                          hipMemcpyDeviceToDevice, lo->stream));
+	}
+}
+
+// partial sums -> sums[] on every rank, summed over ranks, then the scalar recurrences of `phase`
+// (phase < 0: no recurrences).  `count_of(c)` partials per vector, vectors `stride_of(c)` apart.
+template <typename CountFn, typename StrideFn>
+void reduce_phase(RankSet& R, int nvec, CountFn count_of, StrideFn stride_of, int phase)
+{
+	if (R.size() == 1 && R[0]->nranks == 1 && phase >= 0) {
+		fi_ctx* c = R[0];
+		hipLaunchKernelGGL(k_reduce_logic, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(),
+		                   c->partial.as<double>(), nvec, stride_of(c), count_of(c), phase);
+		return;
+	}
+	for (fi_ctx* c : R) {
+		hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(),
+		                   c->partial.as<double>(), nvec, stride_of(c), count_of(c), (phase == kPhaseInit || phase < 0) ? 0 : 1);
+	}
+	if (R.size() > 1) {
+		fi_ctx* c0 = R[0];
+		hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, c0->stream, c0->group_scal.as<CgScalars*>(),
+		                   static_cast<int>(R.size()), nvec);
+	} else if (R[0]->nranks > 1) {
+		allreduce_sum(R[0], R[0]->scal.as<CgScalars>()->sums, nvec);
+	}
+	if (phase >= 0) {
+		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), phase); }
+	}
+}
+
+void reset_scalars(RankSet& R, const CgScalars& init)
+{
+	for (fi_ctx* c : R) {
+		FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	}
+}
+
+// Jacobi-PCG over a rank set; x of every member holds the guess on entry and the solution on return.
+template <typename T>
+void cg_run(RankSet& R, int max_iterations, float tol)
+{
+	fi_ctx* c0 = R[0];
+	hipStream_t st = c0->stream;
 	if (max_iterations <= 0) {
-		const int64_t dflt = 2 * static_cast<int64_t>(g.gn[0]) * g.gn[1] * g.gn[2];  // Eigen: 2 * cols
+		const int64_t dflt = 2 * static_cast<int64_t>(c0->g.gn[0]) * c0->g.gn[1] * c0->g.gn[2];  // Eigen: 2 * cols
 		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
 	}
 	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
-
-	load_owned<T>(c, c->x, guess, memory);
 
 	hipEvent_t e0, e1;
 	FI_HIP_TRY(hipEventCreate(&e0));
@@ -478,65 +541,66 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	CgScalars init{};
 	init.tol2     = tolerance * tolerance;
 	init.max_iter = max_iterations;
-	init.done     = 0;
-	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
-	CgScalars* sc = c->scal.as<CgScalars>();
+	reset_scalars(R, init);
 
-	const int nb_vec = stream_blocks(g.nown);
-	T* x = c->x.as<T>();
-	T* r = c->r.as<T>();
-	T* p = c->p.as<T>();
-	T* q = c->q.as<T>();
-	const T* b    = c->atb.as<T>();
-	const T* dinv = c->dinv.as<T>();
-	const int64_t o = g.own_first;
+	auto nbv       = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	auto nb_apply  = [](fi_ctx* c) { return apply_num_partials(c); };
+	auto zero      = [](fi_ctx*) { return 0; };
 
 	// r0 = b - A x0
-	exchange_halo(c, x);
-	apply_AtA(c, x, q, nullptr);
-	hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_vec), dim3(kThreads), 0, st, g.nown, b + o, q + o, dinv + o, r + o, p + o,
-	                   c->partial.as<double>(), nb_vec);
-	reduce_and_logic(c, 3, nb_vec, nb_vec, kPhaseInit);
+	halo_exchange(R, &fi_ctx::x);
+	for (fi_ctx* c : R) { apply_AtA(c, c->x.p, c->q.p, nullptr); }
+	for (fi_ctx* c : R) {
+		const int64_t o = c->g.own_first;
+		hipLaunchKernelGGL((k_cg_init<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->atb.as<T>() + o,
+		                   c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, c->p.as<T>() + o,
+		                   c->partial.as<double>(), nbv(c));
+	}
+	reduce_phase(R, 3, nbv, nbv, kPhaseInit);
 
-	const int nb_apply = apply_num_partials(c);
 	int samples = 0;
-	c->stats.spmv_samples = 0;
-	c->stats.spmv_ms_avg  = 0;
-	while (static_cast<int>(c->ev.size()) < 2 * kMaxSamples) {
+	while (static_cast<int>(c0->ev.size()) < 2 * kMaxSamples) {
 		hipEvent_t e;
 		FI_HIP_TRY(hipEventCreate(&e));
-		c->ev.push_back(e);
+		c0->ev.push_back(e);
 	}
-	int issued = 0;
 	// wall-clock guard: a solve that cannot reach its tolerance (fp32 stagnation with the default 2N
 	// iteration cap) must not hold the GPU for hours.  FI_SOLVE_TIMEOUT_S overrides the 600 s default.
 	double limit_s = 600.0;
 	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
 	const auto wall0 = std::chrono::steady_clock::now();
 	bool timed_out = false;
+	CgScalars* sc0 = c0->scal.as<CgScalars>();
 	for (;;) {
-		FI_HIP_TRY(hipMemcpyAsync(c->scal_host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
-		if (c->scal_host->done) { break; }
+		if (c0->scal_host->done) { break; }
 		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
 			timed_out = true;
 			break;
 		}
 		for (int k = 0; k < kCheckEvery; ++k) {
-			exchange_halo(c, p);
+			halo_exchange(R, &fi_ctx::p);
 			const bool sample = samples < kMaxSamples;
-			if (sample) { FI_HIP_TRY(hipEventRecord(c->ev[2 * samples], st)); }
-			apply_AtA(c, p, q, c->partial.as<double>());
+			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
+			for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>()); }
 			if (sample) {
-				FI_HIP_TRY(hipEventRecord(c->ev[2 * samples + 1], st));
+				FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples + 1], st));
 				++samples;
 			}
-			reduce_and_logic(c, 1, 0, nb_apply, kPhaseSpmv);
-			hipLaunchKernelGGL((k_cg_update<T>), dim3(nb_vec), dim3(kThreads), 0, st, g.nown, sc, p + o, q + o, dinv + o,
-			                   x + o, r + o, c->partial.as<double>(), nb_vec);
-			reduce_and_logic(c, 2, nb_vec, nb_vec, kPhaseUpdate);
-			hipLaunchKernelGGL((k_cg_direction<T>), dim3(nb_vec), dim3(kThreads), 0, st, g.nown, sc, r + o, dinv + o, p + o);
-			++issued;
+			reduce_phase(R, 1, nb_apply, zero, kPhaseSpmv);
+			for (fi_ctx* c : R) {
+				const int64_t o = c->g.own_first;
+				hipLaunchKernelGGL((k_cg_update<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+				                   c->scal.as<CgScalars>(), c->p.as<T>() + o, c->q.as<T>() + o, c->dinv.as<T>() + o,
+				                   c->x.as<T>() + o, c->r.as<T>() + o, c->partial.as<double>(), nbv(c));
+			}
+			reduce_phase(R, 2, nbv, nbv, kPhaseUpdate);
+			for (fi_ctx* c : R) {
+				const int64_t o = c->g.own_first;
+				hipLaunchKernelGGL((k_cg_direction<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+				                   c->scal.as<CgScalars>(), c->r.as<T>() + o, c->dinv.as<T>() + o, c->p.as<T>() + o);
+			}
 		}
 		FI_HIP_TRY(hipGetLastError());
 	}
@@ -546,99 +610,143 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
 	(void)hipEventDestroy(e0);
 	(void)hipEventDestroy(e1);
-	(void)issued;
 
-	const CgScalars& h = *c->scal_host;
-	// iterations that actually ran (kernels of later iterations exited on the flag)
-	int used = samples;
+	const CgScalars h = *c0->scal_host;
+	int used = samples;  // iterations that actually ran (kernels of later iterations exited on the flag)
 	if (h.iter < used) { used = h.iter; }
 	double sum_ms = 0;
 	for (int k = 0; k < used; ++k) {
 		float t = 0;
-		FI_HIP_TRY(hipEventElapsedTime(&t, c->ev[2 * k], c->ev[2 * k + 1]));
+		FI_HIP_TRY(hipEventElapsedTime(&t, c0->ev[2 * k], c0->ev[2 * k + 1]));
 		sum_ms += t;
 	}
-	c->stats.spmv_samples = used;
-	c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
-	c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
-	c->stats.solve_ms     = ms;
-	c->stats.iterations   = h.iter;
-	c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4)) ? 1 : 0;
-	c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
-
-	if (h.done == 4) {  // rhs == 0  ->  x = 0 (Eigen's early return)
-		FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * g.nloc, st));
+	for (fi_ctx* c : R) {
+		c->stats.spmv_samples = used;
+		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
+		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		c->stats.solve_ms     = ms;
+		c->stats.iterations   = h.iter;
+		c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4)) ? 1 : 0;
+		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+		if (h.done == 4) {  // rhs == 0  ->  x = 0 (Eigen's early return)
+			FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream));
+		}
 	}
-	if (iterations) { *iterations = h.iter; }
-	if (rel_residual) { *rel_residual = static_cast<float>(c->stats.rel_residual); }
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
+}
+
+template <typename T>
+void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
+                float* rel_residual, int memory)
+{
+	ensure_vectors(c);
+	load_owned<T>(c, c->x, guess, memory);
+	RankSet R{c};
+	struct Report {
+		fi_ctx* c; int* it; float* rel;
+		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
+	} report{c, iterations, rel_residual};
+	cg_run<T>(R, max_iterations, tol);
 	store_owned<T>(c, c->x, out, memory);
+}
+
+template <typename T>
+void jacobi_run(RankSet& R, int sweeps, float weight)
+{
+	CgScalars init{};
+	reset_scalars(R, init);
+	for (int s = 0; s < sweeps; ++s) {
+		halo_exchange(R, &fi_ctx::x);
+		for (fi_ctx* c : R) { apply_AtA(c, c->x.p, c->q.p, nullptr); }
+		for (fi_ctx* c : R) {
+			const int64_t o = c->g.own_first;
+			hipLaunchKernelGGL((k_jacobi_update<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   static_cast<T>(weight), c->atb.as<T>() + o, c->q.as<T>() + o, c->dinv.as<T>() + o,
+			                   c->x.as<T>() + o);
+		}
+	}
+	FI_HIP_TRY(hipGetLastError());
 }
 
 template <typename T>
 void jacobi_t(fi_ctx* c, const float* guess, int sweeps, float weight, float* out, int memory)
 {
-	const Geom& g = c->g;
 	ensure_vectors(c);
 	load_owned<T>(c, c->x, guess, memory);
-	const int nb_vec = stream_blocks(g.nown);
-	T* x = c->x.as<T>();
-	T* q = c->q.as<T>();
-	const int64_t o = g.own_first;
-	CgScalars init{};
-	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-	for (int s = 0; s < sweeps; ++s) {
-		exchange_halo(c, x);
-		apply_AtA(c, x, q, nullptr);
-		hipLaunchKernelGGL((k_jacobi_update<T>), dim3(nb_vec), dim3(kThreads), 0, c->stream, g.nown, static_cast<T>(weight),
-		                   c->atb.as<T>() + o, q + o, c->dinv.as<T>() + o, x + o);
-	}
-	FI_HIP_TRY(hipGetLastError());
+	RankSet R{c};
+	jacobi_run<T>(R, sweeps, weight);
 	store_owned<T>(c, c->x, out, memory);
+}
+
+// ||Atb - AtA x|| / ||Atb|| of the current x, evaluated on the device
+template <typename T>
+double true_residual_run(RankSet& R)
+{
+	CgScalars init{};
+	reset_scalars(R, init);
+	halo_exchange(R, &fi_ctx::x);
+	for (fi_ctx* c : R) { apply_AtA(c, c->x.p, c->q.p, nullptr); }
+	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	for (fi_ctx* c : R) {
+		const int64_t o = c->g.own_first;
+		hipLaunchKernelGGL((k_residual_norm<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->atb.as<T>() + o,
+		                   c->q.as<T>() + o, c->partial.as<double>(), nbv(c));
+	}
+	reduce_phase(R, 2, nbv, nbv, -1);
+	fi_ctx* c0 = R[0];
+	FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, c0->scal.p, sizeof(CgScalars), hipMemcpyDeviceToHost, c0->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c0->stream));
+	const double rr = c0->scal_host->sums[0], bb = c0->scal_host->sums[1];
+	return bb > 0 ? std::sqrt(rr / bb) : std::sqrt(rr);
 }
 
 template <typename T>
 double true_residual_t(fi_ctx* c)
 {
-	const Geom& g = c->g;
 	ensure_vectors(c);
+	RankSet R{c};
+	return true_residual_run<T>(R);
+}
+
+// y = AtA x with fp64 host vectors holding, rank after rank, the owned unknowns of every member
+template <typename T>
+void apply_f64_run(RankSet& R, const double* xin, double* yout)
+{
 	CgScalars init{};
-	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-	const int nb_vec = stream_blocks(g.nown);
-	const int64_t o = g.own_first;
-	exchange_halo(c, c->x.p);
-	apply_AtA(c, c->x.p, c->q.p, nullptr);
-	hipLaunchKernelGGL((k_residual_norm<T>), dim3(nb_vec), dim3(kThreads), 0, c->stream, g.nown, c->atb.as<T>() + o,
-	                   c->q.as<T>() + o, c->partial.as<double>(), nb_vec);
-	CgScalars* sc = c->scal.as<CgScalars>();
-	hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, sc, c->partial.as<double>(), 2, nb_vec, nb_vec, 0);
-	if (c->nranks > 1) { allreduce_sum(c, sc->sums, 2); }
-	FI_HIP_TRY(hipMemcpyAsync(c->scal_host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, c->stream));
-	FI_HIP_TRY(hipStreamSynchronize(c->stream));
-	const double rr = c->scal_host->sums[0], bb = c->scal_host->sums[1];
-	return bb > 0 ? std::sqrt(rr / bb) : std::sqrt(rr);
+	reset_scalars(R, init);
+	std::vector<DevBuf> tmp(R.size());
+	int64_t at = 0;
+	for (size_t i = 0; i < R.size(); ++i) {
+		fi_ctx* c = R[i];
+		const Geom& g = c->g;
+		tmp[i].alloc(sizeof(double) * g.nown);
+		FI_HIP_TRY(hipMemcpyAsync(tmp[i].p, xin + at, sizeof(double) * g.nown, hipMemcpyHostToDevice, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->p.p, 0, sizeof(T) * g.nloc, c->stream));
+		hipLaunchKernelGGL((k_convert<double, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
+		                   tmp[i].as<double>(), owned<T>(c, c->p));
+		at += g.nown;
+	}
+	halo_exchange(R, &fi_ctx::p);
+	for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, nullptr); }
+	at = 0;
+	for (size_t i = 0; i < R.size(); ++i) {
+		fi_ctx* c = R[i];
+		const Geom& g = c->g;
+		hipLaunchKernelGGL((k_convert<T, double>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
+		                   owned<T>(c, c->q), tmp[i].as<double>());
+		FI_HIP_TRY(hipMemcpyAsync(yout + at, tmp[i].p, sizeof(double) * g.nown, hipMemcpyDeviceToHost, c->stream));
+		at += g.nown;
+	}
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipStreamSynchronize(R[0]->stream));
 }
 
 template <typename T>
 void apply_f64_t(fi_ctx* c, const double* xin, double* yout)
 {
-	const Geom& g = c->g;
 	ensure_vectors(c);
-	CgScalars init{};
-	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-	DevBuf tmp;
-	tmp.alloc(sizeof(double) * g.nown);
-	FI_HIP_TRY(hipMemcpyAsync(tmp.p, xin, sizeof(double) * g.nown, hipMemcpyHostToDevice, c->stream));
-	FI_HIP_TRY(hipMemsetAsync(c->p.p, 0, sizeof(T) * g.nloc, c->stream));
-	hipLaunchKernelGGL((k_convert<double, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
-	                   tmp.as<double>(), owned<T>(c, c->p));
-	exchange_halo(c, c->p.p);
-	apply_AtA(c, c->p.p, c->q.p, nullptr);
-	hipLaunchKernelGGL((k_convert<T, double>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
-	                   owned<T>(c, c->q), tmp.as<double>());
-	FI_HIP_TRY(hipGetLastError());
-	FI_HIP_TRY(hipMemcpyAsync(yout, tmp.p, sizeof(double) * g.nown, hipMemcpyDeviceToHost, c->stream));
-	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	RankSet R{c};
+	apply_f64_run<T>(R, xin, yout);
 }
 
 template <typename T>
@@ -763,7 +871,7 @@ int fi_ctx_destroy(fi_ctx* c)
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
 	if (c->comm) { fi::comm_destroy(c->comm); }
 	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
-	if (c->stream) { (void)hipStreamDestroy(c->stream); }
+	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }
 	delete c;
 	return FI_OK;
 }
@@ -1037,6 +1145,142 @@ int fi_upscale_field(const float* small_field, int ndim, const int* small_sizes,
 	FI_HIP_TRY(hipGetLastError());
 	FI_HIP_TRY(hipDeviceSynchronize());
 	if (memory == FI_HOST) { FI_HIP_TRY(hipMemcpy(out, dl.p, sizeof(float) * nl, hipMemcpyDeviceToHost)); }
+	FI_API_END
+}
+
+
+// ---- loop-back group: all slabs of a decomposition in one process, on one device ------------------
+struct fi_group {
+	std::vector<fi_ctx*> members;
+	int dtype = FI_F32;
+};
+
+int fi_group_create(fi_group** out, int ndim, const int* sizes, int dtype, int nranks)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(out != nullptr, FI_ERR_INVALID, "out is null");
+	FI_REQUIRE(nranks >= 2, FI_ERR_INVALID, "a group needs at least two slabs");
+	auto* g = new fi_group();
+	g->dtype = dtype;
+	try {
+		for (int r = 0; r < nranks; ++r) { g->members.push_back(fi::create_ctx(ndim, sizes, dtype, r, nranks)); }
+		fi_ctx* c0 = g->members[0];
+		std::vector<fi::CgScalars*> ptrs;
+		for (fi_ctx* c : g->members) {
+			ptrs.push_back(c->scal.as<fi::CgScalars>());
+			if (c != c0) {  // one stream for the whole group: program order is the synchronisation
+				(void)hipStreamDestroy(c->stream);
+				c->stream      = c0->stream;
+				c->owns_stream = false;
+			}
+		}
+		c0->group_scal.alloc(sizeof(fi::CgScalars*) * ptrs.size());
+		FI_HIP_TRY(hipMemcpy(c0->group_scal.p, ptrs.data(), sizeof(fi::CgScalars*) * ptrs.size(), hipMemcpyHostToDevice));
+	} catch (...) {
+		for (fi_ctx* c : g->members) { fi_ctx_destroy(c); }
+		delete g;
+		throw;
+	}
+	*out = g;
+	FI_API_END
+}
+
+int fi_group_destroy(fi_group* g)
+{
+	if (!g) { return FI_OK; }
+	for (size_t i = g->members.size(); i-- > 0;) { fi_ctx_destroy(g->members[i]); }  // member 0 owns the stream
+	delete g;
+	return FI_OK;
+}
+
+int fi_group_size(const fi_group* g) { return g ? static_cast<int>(g->members.size()) : 0; }
+
+fi_ctx* fi_group_rank(fi_group* g, int rank)
+{
+	if (!g || rank < 0 || rank >= static_cast<int>(g->members.size())) { return nullptr; }
+	return g->members[rank];
+}
+
+int fi_group_assemble(fi_group* g)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(g != nullptr, FI_ERR_INVALID, "null group");
+	for (fi_ctx* c : g->members) {
+		const int rc = fi_assemble(c);
+		if (rc != FI_OK) { return rc; }
+	}
+	FI_API_END
+}
+
+static void group_ready(fi_group* g)
+{
+	FI_REQUIRE(g != nullptr, FI_ERR_INVALID, "null group");
+	for (fi_ctx* c : g->members) {
+		fi::check_assembled(c);
+		fi::ensure_vectors(c);
+	}
+	FI_HIP_TRY(hipSetDevice(g->members[0]->device));
+}
+
+int fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float tol, float* out, int* iterations,
+                      float* rel_residual)
+{
+	FI_API_BEGIN
+	group_ready(g);
+	int64_t at = 0;
+	for (fi_ctx* c : g->members) {
+		if (g->dtype == FI_F64) {
+			fi::load_owned<double>(c, c->x, guess ? guess + at : nullptr, FI_HOST);
+		} else {
+			fi::load_owned<float>(c, c->x, guess ? guess + at : nullptr, FI_HOST);
+		}
+		at += c->g.nown;
+	}
+	fi_ctx* c0 = g->members[0];
+	struct Report {
+		fi_ctx* c; int* it; float* rel;
+		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
+	} report{c0, iterations, rel_residual};
+	g->dtype == FI_F64 ? fi::cg_run<double>(g->members, max_iterations, tol) : fi::cg_run<float>(g->members, max_iterations, tol);
+	at = 0;
+	for (fi_ctx* c : g->members) {
+		if (g->dtype == FI_F64) {
+			fi::store_owned<double>(c, c->x, out ? out + at : nullptr, FI_HOST);
+		} else {
+			fi::store_owned<float>(c, c->x, out ? out + at : nullptr, FI_HOST);
+		}
+		at += c->g.nown;
+	}
+	FI_API_END
+}
+
+int fi_group_apply_AtA_f64(fi_group* g, const double* x, double* y)
+{
+	FI_API_BEGIN
+	group_ready(g);
+	FI_REQUIRE(x && y, FI_ERR_INVALID, "null vector");
+	g->dtype == FI_F64 ? fi::apply_f64_run<double>(g->members, x, y) : fi::apply_f64_run<float>(g->members, x, y);
+	FI_API_END
+}
+
+int fi_group_true_residual(fi_group* g, double* rel)
+{
+	FI_API_BEGIN
+	group_ready(g);
+	FI_REQUIRE(rel != nullptr, FI_ERR_INVALID, "null output");
+	*rel = g->dtype == FI_F64 ? fi::true_residual_run<double>(g->members) : fi::true_residual_run<float>(g->members);
+	FI_API_END
+}
+
+int fi_group_get_solution_f64(fi_group* g, double* out)
+{
+	FI_API_BEGIN
+	group_ready(g);
+	int64_t at = 0;
+	for (fi_ctx* c : g->members) {
+		g->dtype == FI_F64 ? fi::get_vec_f64_t<double>(c, c->x, out + at) : fi::get_vec_f64_t<float>(c, c->x, out + at);
+		at += c->g.nown;
+	}
 	FI_API_END
 }
 

@@ -174,6 +174,24 @@ int fi_get_stats(const fi_ctx* ctx, fi_stats* out);
 /* Launches the AtA apply `reps` times on the context's stream between two HIP events. */
 int fi_time_apply(fi_ctx* ctx, int reps, double* ms_per_launch);
 
+/* ---- loop-back group (test facility) ---------------------------------------------------------------
+ * All `nranks` slabs of a decomposition in ONE process on the current device: the same kernels, slab
+ * geometry, halo widths and ownership rules as the RCCL path, with halo planes moved by device-to-device
+ * copies and dot products summed by a kernel.  Lets a single GPU check the decomposed solve against the
+ * undivided one.  Per-rank assembly goes through fi_group_rank(g, r) and the fi_set_model / fi_add_points
+ * calls above; vectors passed to the group calls are host buffers holding the WHOLE lattice. */
+typedef struct fi_group fi_group;
+int     fi_group_create(fi_group** out, int ndim, const int* sizes, int dtype, int nranks);
+int     fi_group_destroy(fi_group* g);
+int     fi_group_size(const fi_group* g);
+fi_ctx* fi_group_rank(fi_group* g, int rank);
+int     fi_group_assemble(fi_group* g);
+int     fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float tol, float* out, int* iterations,
+                          float* rel_residual);
+int     fi_group_apply_AtA_f64(fi_group* g, const double* x, double* y);
+int     fi_group_true_residual(fi_group* g, double* rel_residual);
+int     fi_group_get_solution_f64(fi_group* g, double* out);
+
 /* ---- helpers either side of the path ---------------------------------------------------------
  * Replaces upscale_field (field_interpolation.cpp:431-485): multilinear resampling small -> large. */
 int fi_upscale_field(const float* small_field, int ndim, const int* small_sizes, const int* large_sizes,
