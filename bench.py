@@ -63,7 +63,8 @@ def main():
     import torch
 
     import field_interpolation_amd as fi
-    from field_interpolation_amd import _capi, synth
+    from field_interpolation_amd import dist as fdist
+    from field_interpolation_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,17 +86,10 @@ def main():
 
     field = fi.LatticeField(sizes, dtype=args.dtype, rank=rank, nranks=world)
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            import ctypes
-            buf = ctypes.create_string_buffer(128)
-            _capi.check(_capi.lib().fi_comm_unique_id(buf))
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
-        dist.broadcast(uid, 0)
-        field.comm_init(bytes(uid.cpu().numpy().tobytes()))
+        fdist.init_comm(field, dev)          # RCCL unique id from rank 0, broadcast by torch.distributed
     lo, hi = field.slab
-    # each rank keeps the points within one cell of its slab (the library drops the rest anyway)
-    keep = (pos[:, 2] >= lo - 1.0) & (pos[:, 2] < hi + 1.0)
+    # each rank uploads the points whose cells touch its slab (the library drops the rest anyway)
+    keep = fdist.points_of_slab(pos, 3, lo, hi)
     d_pos = torch.from_numpy(np.ascontiguousarray(pos[keep])).to(dev)
     d_val = torch.from_numpy(np.ascontiguousarray(val[keep])).to(dev)
     torch.cuda.synchronize()

@@ -876,6 +876,24 @@ int fi_ctx_destroy(fi_ctx* c)
 	return FI_OK;
 }
 
+int fi_slab_partition(int planes, int rank, int nranks, int* lo, int* hi)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(nranks >= 1 && 0 <= rank && rank < nranks && planes >= 0, FI_ERR_INVALID, "bad slab request");
+	if (lo) { *lo = static_cast<int>(static_cast<int64_t>(rank) * planes / nranks); }
+	if (hi) { *hi = static_cast<int>(static_cast<int64_t>(rank + 1) * planes / nranks); }
+	FI_API_END
+}
+
+int fi_halo_width(const fi_weights* w, int* width)
+{
+	FI_API_BEGIN
+	FI_REQUIRE(w && width, FI_ERR_INVALID, "null argument");
+	const int reach = fi::model_reach(*w);
+	*width = reach > 1 ? reach : 1;
+	FI_API_END
+}
+
 int fi_slab_range(const fi_ctx* c, int* lo, int* hi)
 {
 	FI_API_BEGIN

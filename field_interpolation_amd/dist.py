@@ -1,0 +1,54 @@
+"""Host-side pieces of the slab decomposition (one process per GPU, torch.distributed launcher).
+
+The reference is single-process; these helpers exist because the lattice is split
+into contiguous slabs of its slowest axis, one per rank:
+  slab_range      which planes a rank owns            (same arithmetic as fi_slab_partition in libfi_hip)
+  halo_width      ghost planes per side               (same rule as fi_halo_width)
+  points_of_slab  data points a rank has to see       (cells touching its slab: origin plane in [lo-1, hi-1])
+  init_comm       RCCL bootstrap: rank 0 makes the unique id, torch.distributed broadcasts it
+Nothing here touches the GPU except init_comm.
+"""
+import numpy as np
+
+
+def slab_range(planes, rank, nranks):
+    """Planes [lo, hi) of the slowest axis owned by `rank` (floor(rank*planes/nranks) rule)."""
+    if not (nranks >= 1 and 0 <= rank < nranks and planes >= 0):
+        raise ValueError("bad slab request")
+    return (rank * planes) // nranks, ((rank + 1) * planes) // nranks
+
+
+def halo_width(weights):
+    """Ghost planes per side: reach of the widest enabled model stencil (AtA of a k-th difference reaches
+    +-k), at least 1 for the cell blocks / gradient_smoothness."""
+    reach = 0
+    for k, w in enumerate((weights.model_1, weights.model_2, weights.model_3, weights.model_4), start=1):
+        if w > 0:
+            reach = k
+    return max(reach, 1)
+
+
+def points_of_slab(positions, ndim, lo, hi):
+    """Boolean mask of the points whose cell (origin floor(pos) along the slowest axis) touches planes
+    [lo, hi): origin in [lo-1, hi-1].  One extra cell of margin keeps nearest-neighbour rows too."""
+    z = np.asarray(positions, np.float32).reshape(-1, ndim)[:, ndim - 1]
+    return (z >= lo - 2.0) & (z < hi + 1.0)
+
+
+def init_comm(field, device=None):
+    """Create the RCCL communicator of a slab LatticeField: the 128-byte unique id made by rank 0 travels
+    through torch.distributed (any backend), then every rank calls fi_comm_init."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from . import _capi
+    if field.nranks == 1:
+        return
+    buf = ctypes.create_string_buffer(128)
+    if dist.get_rank() == 0:
+        _capi.check(_capi.lib().fi_comm_unique_id(buf))
+    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    if device is not None and dist.get_backend() == "nccl":
+        t = t.to(device)
+    dist.broadcast(t, 0)
+    field.comm_init(bytes(t.cpu().numpy().tobytes()))

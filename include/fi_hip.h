@@ -109,6 +109,11 @@ int fi_ctx_destroy(fi_ctx* ctx);
 
 /* Owned range [lo, hi) of the slowest axis for this rank. */
 int fi_slab_range(const fi_ctx* ctx, int* lo, int* hi);
+/* The partition rule itself (pure host arithmetic, no GPU): planes [lo, hi) of `planes` for `rank`. */
+int fi_slab_partition(int planes, int rank, int nranks, int* lo, int* hi);
+/* Ghost planes a slab keeps on each side: the reach of the widest enabled model stencil (model_k -> k),
+ * at least 1 (cell blocks and gradient_smoothness reach one plane). */
+int fi_halo_width(const fi_weights* w, int* width);
 
 /* RCCL bootstrap (no reference counterpart: the reference is single-process).  Rank 0 calls
  * fi_comm_unique_id, the 128 bytes are broadcast by the launcher (torch.distributed), every rank calls
