@@ -92,6 +92,7 @@ def main():
     keep = fdist.points_of_slab(pos, 3, lo, hi)
     d_pos = torch.from_numpy(np.ascontiguousarray(pos[keep])).to(dev)
     d_val = torch.from_numpy(np.ascontiguousarray(val[keep])).to(dev)
+    d_out = torch.empty(field.num_owned, dtype=torch.float32, device=dev)   # the solution stays in HBM
     torch.cuda.synchronize()
 
     field.add_field_constraints(w)
@@ -100,7 +101,7 @@ def main():
         field.clear_points()
         field.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, d_pos, None, None, values=d_val)
         field.assemble()
-        out = field.solve_cg(None, 0, args.tol)
+        out = field.solve_cg(None, 0, args.tol, out=d_out)
         if out is None:
             raise RuntimeError("CG breakdown")
         return out

@@ -44,7 +44,8 @@ class FiStats(C.Structure):
     _fields_ = [("num_unknowns", C.c_long), ("num_data_rows", C.c_long), ("num_cells", C.c_long),
                 ("num_generic_rows", C.c_long), ("iterations", C.c_int), ("converged", C.c_int),
                 ("rel_residual", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
-                ("spmv_ms_avg", C.c_double), ("spmv_samples", C.c_int), ("spmv_bytes", C.c_double)]
+                ("spmv_ms_avg", C.c_double), ("spmv_samples", C.c_int), ("spmv_bytes", C.c_double),
+                ("restarts", C.c_int), ("verified_residual", C.c_double)]
 
 
 class FiError(RuntimeError):
@@ -81,6 +82,7 @@ def lib():
     L.fi_assemble.argtypes = [vp]
     L.fi_clear_points.argtypes = [vp]
     L.fi_solve_cg.argtypes = [vp, fp, C.c_int, C.c_float, fp, ip, C.POINTER(C.c_float), C.c_int]
+    L.fi_set_option.argtypes = [vp, C.c_int, C.c_double]
     L.fi_jacobi.argtypes = [vp, fp, C.c_int, C.c_float, fp, C.c_int]
     L.fi_get_solution_f64.argtypes = [vp, dp]
     L.fi_true_residual.argtypes = [vp, dp]

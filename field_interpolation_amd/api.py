@@ -238,6 +238,11 @@ class LatticeField:
             raise
         return out, it.value, rel.value
 
+    def set_verify_residual(self, on):
+        """FI_OPT_VERIFY_RESIDUAL: True (default) checks b - A x at convergence and restarts CG if fp32 drift
+        left it above the tolerance; False stops on the recurrence residual alone, like the reference."""
+        check(_capi.lib().fi_set_option(self._h, 1, 1.0 if on else 0.0))
+
     def jacobi(self, guess, num_iterations, weight):
         self._ready()
         g, kg, _kg = _buf(guess)

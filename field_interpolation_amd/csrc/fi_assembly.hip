@@ -287,7 +287,13 @@ void emit_rows_dim(fi_ctx* c, long n, const float* pos, const float* nrm, const 
                    int vk, float gw, int gk)
 {
 	constexpr int NC = 1 << D;
-	auto* pb  = new Pending();
+	Pending* pb = nullptr;
+	if (!c->pending_pool.empty()) {
+		pb = c->pending_pool.back();
+		c->pending_pool.pop_back();
+	} else {
+		pb = new Pending();
+	}
 	c->pending.push_back(pb);
 	pb->nrows = n * (1 + D);
 	pb->key.alloc(sizeof(uint32_t) * pb->nrows);
@@ -335,7 +341,7 @@ void assemble_dim(fi_ctx* c)
 	FI_REQUIRE(total < (1L << 31), FI_ERR_UNSUPPORTED, "more than 2^31 data rows in one context");
 
 	// gather the batches into one row table (single batch: used in place)
-	DevBuf key_cat, coef_cat, rhs_cat;
+	DevBuf &key_cat = c->scratch[0], &coef_cat = c->scratch[1], &rhs_cat = c->scratch[2];
 	const uint32_t* key  = nullptr;
 	const float*    coef = nullptr;
 	const float*    rhs  = nullptr;
@@ -364,7 +370,8 @@ void assemble_dim(fi_ctx* c)
 	}
 
 	// sort rows by cell
-	DevBuf row_in, row_sorted, key_sorted, uniq, counts, starts, nruns, tmp;
+	DevBuf &row_in = c->scratch[3], &row_sorted = c->scratch[4], &key_sorted = c->scratch[5], &uniq = c->scratch[6],
+	       &counts = c->scratch[7], &starts = c->scratch[8], &nruns = c->scratch[9], &tmp = c->scratch[10];
 	row_in.alloc(sizeof(uint32_t) * total);
 	row_sorted.alloc(sizeof(uint32_t) * total);
 	key_sorted.alloc(sizeof(uint32_t) * total);
@@ -386,7 +393,7 @@ void assemble_dim(fi_ctx* c)
 	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
 	                                                 counts.as<uint32_t>(), nruns.as<uint32_t>(),
 	                                                 static_cast<int>(total), st));
-	DevBuf tmp2;
+	DevBuf& tmp2 = c->scratch[11];
 	tmp2.alloc(tb2);
 	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp2.p, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
 	                                                 counts.as<uint32_t>(), nruns.as<uint32_t>(),
@@ -410,7 +417,7 @@ void assemble_dim(fi_ctx* c)
 	size_t tb3 = 0;
 	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(),
 	                                            static_cast<int>(h_runs), st));
-	DevBuf tmp3;
+	DevBuf& tmp3 = c->scratch[12];
 	tmp3.alloc(tb3);
 	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(),
 	                                            static_cast<int>(h_runs), st));
@@ -421,7 +428,7 @@ void assemble_dim(fi_ctx* c)
 	c->cells.nrow.alloc(sizeof(uint32_t) * ncell);
 	c->cells.row1.alloc(sizeof(T) * NC * ncell);
 	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
-	DevBuf cell_rhs;
+	DevBuf& cell_rhs = c->scratch[13];
 	cell_rhs.alloc(sizeof(double) * NC * ncell);
 	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
 	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,

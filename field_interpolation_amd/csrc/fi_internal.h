@@ -142,9 +142,9 @@ struct Pending {  // one fi_add_points batch, already turned into cell rows on t
 struct Comm;  // RCCL state (fi_comm.cpp)
 
 struct CgScalars {  // lives in device memory; kernels read/write it, the host polls it
-	double rz, rz_new, pq, rr, bb, tol2;
+	double rz, rz_new, pq, rr, bb, tol2, alpha, beta, true_rr;
 	double sums[4];
-	int    iter, done, max_iter, pad;
+	int    iter, done, max_iter, restarts;
 };
 
 }  // namespace fi
@@ -163,6 +163,7 @@ struct fi_ctx {
 	hipStream_t stream = nullptr;
 
 	std::vector<fi::Pending*> pending;
+	std::vector<fi::Pending*> pending_pool;  // buffers of cleared batches, reused by the next fi_add_points
 	fi::CellData              cells;
 	fi::MarchState            march;
 
@@ -175,9 +176,13 @@ struct fi_ctx {
 	fi::CgScalars* scal_host = nullptr;  // pinned
 	int        max_blocks = 0;
 
+	// assembly temporaries, kept between fi_assemble calls (hipMalloc/hipFree are slow and synchronising)
+	fi::DevBuf scratch[24];
+
 	fi::Comm*  comm = nullptr;
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
 	bool       owns_stream = true;
+	int        verify_residual = 1;  // check b - A x when the recurrence converges, restart CG if it misses
 	fi_stats   stats{};
 	std::vector<hipEvent_t> ev;  // sampled events around AtA applies
 };

@@ -112,23 +112,53 @@ __global__ __launch_bounds__(kThreads) void k_cg_init(int64_t n, const T* __rest
 	}
 }
 
+// 16-byte vector view of T for the streaming kernels
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_cg_update(int64_t n, const CgScalars* __restrict__ sc,
-                                                         const T* __restrict__ p, const T* __restrict__ q,
-                                                         const T* __restrict__ dinv, T* __restrict__ x,
-                                                         T* __restrict__ r, double* __restrict__ partial, int nblk)
+struct Vec16;
+template <>
+struct Vec16<float> {
+	using V = float4;
+	static constexpr int N = 4;
+};
+template <>
+struct Vec16<double> {
+	using V = double2;
+	static constexpr int N = 2;
+};
+
+// CG step, first half: r -= alpha q; partials of r.(Dinv r) and r.r          (reads r, q, Dinv; writes r)
+// VEC: pointers 16-byte aligned and n a multiple of the vector width -> one 16-byte access per array.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_cg_resid(int64_t n, const CgScalars* __restrict__ sc,
+                                                        const T* __restrict__ q, const T* __restrict__ dinv,
+                                                        T* __restrict__ r, double* __restrict__ partial, int nblk)
 {
 	if (sc->done) { return; }
-	const T alpha = static_cast<T>(sc->rz / sc->pq);
+	using V = typename Vec16<T>::V;
+	constexpr int N = VEC ? Vec16<T>::N : 1;
+	const T alpha = static_cast<T>(sc->alpha);
 	double acc[2] = {0, 0};
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	const int64_t nv = n / N;
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		x[i] += alpha * p[i];
-		const T ri = r[i] - alpha * q[i];
-		r[i]       = ri;
-		const T zi = dinv[i] * ri;
-		acc[0] += static_cast<double>(ri) * static_cast<double>(zi);
-		acc[1] += static_cast<double>(ri) * static_cast<double>(ri);
+		T rv[N], qv[N], dv[N];
+		if (VEC) {
+			*reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i];
+			*reinterpret_cast<V*>(qv) = reinterpret_cast<const V*>(q)[i];
+			*reinterpret_cast<V*>(dv) = reinterpret_cast<const V*>(dinv)[i];
+		} else {
+			rv[0] = r[i]; qv[0] = q[i]; dv[0] = dinv[i];
+		}
+		T s0 = T(0), s1 = T(0);
+#pragma unroll
+		for (int j = 0; j < N; ++j) {
+			rv[j] -= alpha * qv[j];
+			s0 += rv[j] * (dv[j] * rv[j]);
+			s1 += rv[j] * rv[j];
+		}
+		if (VEC) { reinterpret_cast<V*>(r)[i] = *reinterpret_cast<V*>(rv); } else { r[i] = rv[0]; }
+		acc[0] += static_cast<double>(s0);
+		acc[1] += static_cast<double>(s1);
 	}
 	double out[2];
 	block_sum<2>(acc, out);
@@ -138,16 +168,45 @@ __global__ __launch_bounds__(kThreads) void k_cg_update(int64_t n, const CgScala
 	}
 }
 
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_cg_direction(int64_t n, const CgScalars* __restrict__ sc,
-                                                            const T* __restrict__ r, const T* __restrict__ dinv,
-                                                            T* __restrict__ p)
+// CG step, second half: x += alpha p (p still the direction the step was taken along), then
+// p = Dinv r + beta p                                                      (reads x, p, r, Dinv; writes x, p)
+// `iteration` is the 1-based number of the CG step these launches belong to: the x update is applied
+// exactly once, by the step that actually ran (sc->iter == iteration), also when that step converged.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_cg_xp(int64_t n, const CgScalars* __restrict__ sc, int iteration,
+                                                     const T* __restrict__ r, const T* __restrict__ dinv,
+                                                     T* __restrict__ x, T* __restrict__ p)
 {
-	if (sc->done) { return; }
-	const T beta = static_cast<T>(sc->sums[3]);
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	if (sc->iter != iteration || sc->done == 2) { return; }
+	using V = typename Vec16<T>::V;
+	constexpr int N = VEC ? Vec16<T>::N : 1;
+	const T    alpha = static_cast<T>(sc->alpha);
+	const T    beta  = static_cast<T>(sc->beta);
+	const bool go_on = sc->done == 0;
+	const int64_t nv = n / N;
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		p[i] = dinv[i] * r[i] + beta * p[i];
+		T xv[N], pv[N], rv[N], dv[N];
+		if (VEC) {
+			*reinterpret_cast<V*>(xv) = reinterpret_cast<const V*>(x)[i];
+			*reinterpret_cast<V*>(pv) = reinterpret_cast<const V*>(p)[i];
+		} else {
+			xv[0] = x[i]; pv[0] = p[i];
+		}
+#pragma unroll
+		for (int j = 0; j < N; ++j) { xv[j] += alpha * pv[j]; }
+		if (VEC) { reinterpret_cast<V*>(x)[i] = *reinterpret_cast<V*>(xv); } else { x[i] = xv[0]; }
+		if (go_on) {
+			if (VEC) {
+				*reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i];
+				*reinterpret_cast<V*>(dv) = reinterpret_cast<const V*>(dinv)[i];
+			} else {
+				rv[0] = r[i]; dv[0] = dinv[i];
+			}
+#pragma unroll
+			for (int j = 0; j < N; ++j) { pv[j] = dv[j] * rv[j] + beta * pv[j]; }
+			if (VEC) { reinterpret_cast<V*>(p)[i] = *reinterpret_cast<V*>(pv); } else { p[i] = pv[0]; }
+		}
 	}
 }
 
@@ -199,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(CgScalars* sc, const double
 	}
 }
 
-enum Phase { kPhaseInit = 0, kPhaseSpmv = 1, kPhaseUpdate = 2 };
+enum Phase { kPhaseInit = 0, kPhaseSpmv = 1, kPhaseUpdate = 2, kPhaseRestart = 3 };
 
 __device__ inline void cg_logic(CgScalars* sc, int phase)
 {
@@ -219,17 +278,35 @@ __device__ inline void cg_logic(CgScalars* sc, int phase)
 		}
 		return;
 	}
-	if (sc->done) { return; }
+	if (sc->done && phase != kPhaseRestart) { return; }
 	if (phase == kPhaseSpmv) {
-		sc->pq = sc->sums[0];
+		sc->pq    = sc->sums[0];
+		sc->alpha = sc->rz / sc->pq;
 		if (!(sc->pq > 0.0) || !isfinite(sc->pq)) { sc->done = 2; }  // breakdown
 		return;
 	}
-	// after the update
-	sc->rz_new  = sc->sums[0];
-	sc->rr      = sc->sums[1];
-	sc->sums[3] = sc->rz_new / sc->rz;  // beta
-	sc->rz      = sc->rz_new;
+	if (phase == kPhaseRestart) {
+		// r has been replaced by the true residual b - A x, p by Dinv r: accept if it meets the tolerance,
+		// otherwise CG restarts from here (bb, tol2, iter and max_iter stay)
+		sc->rz = sc->sums[0];
+		sc->rr = sc->sums[1];
+		sc->restarts += 1;
+		sc->true_rr = sc->rr;
+		sc->done = 0;
+		if (!isfinite(sc->rr)) {
+			sc->done = 2;
+		} else if (!(sc->rr > sc->tol2)) {
+			sc->done = 5;  // converged, and verified against b - A x
+		} else if (sc->iter >= sc->max_iter) {
+			sc->done = 3;
+		}
+		return;
+	}
+	// after the residual update
+	sc->rz_new = sc->sums[0];
+	sc->rr     = sc->sums[1];
+	sc->beta   = sc->rz_new / sc->rz;
+	sc->rz     = sc->rz_new;
 	sc->iter += 1;
 	if (!isfinite(sc->rr)) {
 		sc->done = 2;
@@ -238,6 +315,11 @@ __device__ inline void cg_logic(CgScalars* sc, int phase)
 	} else if (sc->iter >= sc->max_iter) {
 		sc->done = 3;
 	}
+}
+
+__global__ void k_set_done(CgScalars* sc, int value)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) { sc->done = value; }
 }
 
 __global__ void k_cg_logic(CgScalars* sc, int phase)
@@ -249,7 +331,7 @@ __global__ void k_cg_logic(CgScalars* sc, int phase)
 __global__ __launch_bounds__(kThreads) void k_reduce_logic(CgScalars* sc, const double* __restrict__ partial, int nvec,
                                                             int stride, int count, int phase)
 {
-	if (phase != kPhaseInit && sc->done) { return; }
+	if (phase != kPhaseInit && phase != kPhaseRestart && sc->done) { return; }
 	for (int v = 0; v < nvec; ++v) {
 		double acc[1] = {0};
 		for (int i = threadIdx.x; i < count; i += kThreads) { acc[0] += partial[v * stride + i]; }
@@ -500,7 +582,8 @@ void reduce_phase(RankSet& R, int nvec, CountFn count_of, StrideFn stride_of, in
 	}
 	for (fi_ctx* c : R) {
 		hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(),
-		                   c->partial.as<double>(), nvec, stride_of(c), count_of(c), (phase == kPhaseInit || phase < 0) ? 0 : 1);
+		                   c->partial.as<double>(), nvec, stride_of(c), count_of(c),
+		                   (phase == kPhaseInit || phase == kPhaseRestart || phase < 0) ? 0 : 1);
 	}
 	if (R.size() > 1) {
 		fi_ctx* c0 = R[0];
@@ -571,15 +654,42 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	const auto wall0 = std::chrono::steady_clock::now();
 	bool timed_out = false;
 	CgScalars* sc0 = c0->scal.as<CgScalars>();
+	auto vec_ok = [](fi_ctx* c) {
+		constexpr int N = Vec16<T>::N;
+		return (c->g.own_first % N == 0) && (c->g.nown % N == 0);
+	};
+	int issued = 0;         // CG steps enqueued so far (the device runs step k only while it is not done)
+	int restarts_left = c0->verify_residual ? 3 : 0;
 	for (;;) {
 		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
-		if (c0->scal_host->done) { break; }
+		if (c0->scal_host->done) {
+			// The recurrence residual met the tolerance.  In fp32 it drifts away from b - A x over hundreds of
+			// steps, so the true residual is evaluated once; if it misses the tolerance CG restarts from it
+			// (residual replacement).  Steps enqueued past the stop did nothing: resynchronise the numbering.
+			if (c0->scal_host->done != 1 || restarts_left <= 0) { break; }
+			--restarts_left;
+			issued = c0->scal_host->iter;
+			for (fi_ctx* c : R) {  // the apply kernels exit at once while the flag is up
+				hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), 0);
+			}
+			halo_exchange(R, &fi_ctx::x);
+			for (fi_ctx* c : R) { apply_AtA(c, c->x.p, c->q.p, nullptr); }
+			for (fi_ctx* c : R) {
+				const int64_t o = c->g.own_first;
+				hipLaunchKernelGGL((k_cg_init<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->atb.as<T>() + o,
+				                   c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, c->p.as<T>() + o,
+				                   c->partial.as<double>(), nbv(c));
+			}
+			reduce_phase(R, 2, nbv, nbv, kPhaseRestart);
+			continue;
+		}
 		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
 			timed_out = true;
 			break;
 		}
 		for (int k = 0; k < kCheckEvery; ++k) {
+			++issued;
 			halo_exchange(R, &fi_ctx::p);
 			const bool sample = samples < kMaxSamples;
 			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
@@ -591,15 +701,28 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 			reduce_phase(R, 1, nb_apply, zero, kPhaseSpmv);
 			for (fi_ctx* c : R) {
 				const int64_t o = c->g.own_first;
-				hipLaunchKernelGGL((k_cg_update<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
-				                   c->scal.as<CgScalars>(), c->p.as<T>() + o, c->q.as<T>() + o, c->dinv.as<T>() + o,
-				                   c->x.as<T>() + o, c->r.as<T>() + o, c->partial.as<double>(), nbv(c));
+				if (vec_ok(c)) {
+					hipLaunchKernelGGL((k_cg_resid<T, true>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+					                   c->scal.as<CgScalars>(), c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o,
+					                   c->partial.as<double>(), nbv(c));
+				} else {
+					hipLaunchKernelGGL((k_cg_resid<T, false>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+					                   c->scal.as<CgScalars>(), c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o,
+					                   c->partial.as<double>(), nbv(c));
+				}
 			}
 			reduce_phase(R, 2, nbv, nbv, kPhaseUpdate);
 			for (fi_ctx* c : R) {
 				const int64_t o = c->g.own_first;
-				hipLaunchKernelGGL((k_cg_direction<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
-				                   c->scal.as<CgScalars>(), c->r.as<T>() + o, c->dinv.as<T>() + o, c->p.as<T>() + o);
+				if (vec_ok(c)) {
+					hipLaunchKernelGGL((k_cg_xp<T, true>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+					                   c->scal.as<CgScalars>(), issued, c->r.as<T>() + o, c->dinv.as<T>() + o,
+					                   c->x.as<T>() + o, c->p.as<T>() + o);
+				} else {
+					hipLaunchKernelGGL((k_cg_xp<T, false>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+					                   c->scal.as<CgScalars>(), issued, c->r.as<T>() + o, c->dinv.as<T>() + o,
+					                   c->x.as<T>() + o, c->p.as<T>() + o);
+				}
 			}
 		}
 		FI_HIP_TRY(hipGetLastError());
@@ -626,8 +749,10 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
-		c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4)) ? 1 : 0;
+		c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4 || h.done == 5)) ? 1 : 0;
 		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+		c->stats.restarts     = h.restarts;
+		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
 		if (h.done == 4) {  // rhs == 0  ->  x = 0 (Eigen's early return)
 			FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream));
 		}
@@ -867,7 +992,9 @@ int fi_ctx_destroy(fi_ctx* c)
 	(void)hipSetDevice(c->device);
 	if (c->stream) { (void)hipStreamSynchronize(c->stream); }
 	for (auto* pb : c->pending) { delete pb; }
+	for (auto* pb : c->pending_pool) { delete pb; }
 	c->pending.clear();
+	c->pending_pool.clear();
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
 	if (c->comm) { fi::comm_destroy(c->comm); }
 	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
@@ -974,7 +1101,7 @@ int fi_clear_points(fi_ctx* c)
 {
 	FI_API_BEGIN
 	fi::check_ctx(c);
-	for (auto* pb : c->pending) { delete pb; }
+	for (auto* pb : c->pending) { c->pending_pool.push_back(pb); }  // keep the HBM buffers for the next batch
 	c->pending.clear();
 	c->assembled = false;
 	FI_API_END
@@ -1032,6 +1159,15 @@ int fi_solve_cg(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	} else {
 		fi::solve_cg_t<float>(c, guess, max_iterations, tol, out, iterations, rel_residual, memory);
 	}
+	FI_API_END
+}
+
+int fi_set_option(fi_ctx* c, int option, double value)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	FI_REQUIRE(option == FI_OPT_VERIFY_RESIDUAL, FI_ERR_INVALID, "unknown option %d", option);
+	c->verify_residual = value != 0.0;
 	FI_API_END
 }
 

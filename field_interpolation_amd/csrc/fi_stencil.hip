@@ -560,22 +560,33 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 // ---- per-workgroup cell lists -------------------------------------------------------------------------
 // A cell with global origin (cx, cy, cz) touches the tile columns {cx/TX, and (cx+1)/TX when cx+1 is a
 // tile start}, likewise rows, and along z the chunk holding plane cz plus the next chunk when plane cz+1
-// starts it (layer 0 of that chunk).  mode 0: count per (kind, workgroup, layer); mode 1: fill the
-// self-contained records (order inside a list is irrelevant: its cells never share an output slot).
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_cell_lists(MarchParams P, Geom g, int64_t ncell, int64_t nbuckets,
-                                                          const uint32_t* __restrict__ cell_id,
-                                                          const uint32_t* __restrict__ nrow,
-                                                          const T* __restrict__ row1, const T* __restrict__ blk,
-                                                          uint32_t* __restrict__ count,
-                                                          const uint32_t* __restrict__ off_row,
-                                                          const uint32_t* __restrict__ off_blk,
-                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ pos_row,
-                                                          uint32_t* __restrict__ pos_blk, T* __restrict__ coef_row,
-                                                          T* __restrict__ coef_blk, int mode)
+// starts it (layer 0 of that chunk): up to 8 (workgroup, layer) lists.  Built without ordering hazards:
+//   k_cell_members  every cell writes its memberships into 8 fixed slots: key = kind*nbuckets + bucket
+//                   (kind 0: single-row cell, 1: block cell), the tile-relative origin, and bumps the
+//                   bucket's count;
+//   radix sort      slots by key (stable: the lists come out in cell order, run to run identical);
+//   exclusive scan  of the counts = list bounds;
+//   k_cell_records  one thread per sorted slot copies the row / packed block into the self-contained record.
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g, int64_t ncell, int64_t nbuckets,
+                                                            const uint32_t* __restrict__ cell_id,
+                                                            const uint32_t* __restrict__ nrow,
+                                                            uint32_t* __restrict__ key, uint32_t* __restrict__ pos,
+                                                            uint32_t* __restrict__ count)
 {
 	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-	if (c >= ncell) { return; }
+	const bool live = c < ncell;
+	const int  kind = (live && nrow[c] == 1u) ? 0 : 1;    // 0: single-row cell, 1: block cell
+	{
+		// distinct cells of each kind: one atomic per wave (a single hot address serialises in L2)
+		const unsigned long long rows = __ballot(live && kind == 0), blks = __ballot(live && kind == 1);
+		if ((threadIdx.x & 63) == 0) {
+			if (rows) { atomicAdd(&count[2 * (nbuckets + 1) + 0], static_cast<uint32_t>(__popcll(rows))); }
+			if (blks) { atomicAdd(&count[2 * (nbuckets + 1) + 1], static_cast<uint32_t>(__popcll(blks))); }
+		}
+	}
+	if (!live) { return; }
 	uint32_t id = cell_id[c];
 	const int cx = static_cast<int>(id % static_cast<uint32_t>(g.cn[0])) + g.coff[0];
 	id /= static_cast<uint32_t>(g.cn[0]);
@@ -584,42 +595,67 @@ __global__ __launch_bounds__(kThreads) void k_cell_lists(MarchParams P, Geom g, 
 	const int cz = static_cast<int>(id) + g.coff[2];      // global
 	const int zz = cz - P.zoff - P.own_z0;                // plane index relative to the first owned plane
 	const int nz_own = P.own_z1 - P.own_z0;
-	const int kind = nrow[c] == 1u ? 0 : 1;               // 0: single row, 1: block
-	if (mode == 0) { atomicAdd(&count[2 * (nbuckets + 1) + kind], 1u); }  // distinct cells of each kind
 
-	int tix[2], tcx[2], nx_ = 0;
-	if (cx >= 0 && cx / P.tx < P.tiles_x) { tix[nx_] = cx / P.tx; tcx[nx_] = cx % P.tx; ++nx_; }
-	if ((cx + 1) % P.tx == 0 && (cx + 1) / P.tx < P.tiles_x) { tix[nx_] = (cx + 1) / P.tx; tcx[nx_] = -1; ++nx_; }
-	int tiy[2], tcy[2], ny_ = 0;
-	if (cy >= 0 && cy / kTY < P.tiles_y) { tiy[ny_] = cy / kTY; tcy[ny_] = cy % kTY; ++ny_; }
-	if ((cy + 1) % kTY == 0 && (cy + 1) / kTY < P.tiles_y) { tiy[ny_] = (cy + 1) / kTY; tcy[ny_] = -1; ++ny_; }
-	int tk[2], tl[2], nz_ = 0;
-	if (zz >= 0 && zz < nz_own) { tk[nz_] = zz / P.zc; tl[nz_] = zz % P.zc + 1; ++nz_; }
-	if (zz + 1 >= 0 && zz + 1 < nz_own && (zz + 1) % P.zc == 0) { tk[nz_] = (zz + 1) / P.zc; tl[nz_] = 0; ++nz_; }
-
-	for (int a = 0; a < nz_; ++a) {
-		for (int b = 0; b < ny_; ++b) {
-			for (int d = 0; d < nx_; ++d) {
-				const int     wg     = (tk[a] * P.tiles_y + tiy[b]) * P.tiles_x + tix[d];
-				const int64_t bucket = static_cast<int64_t>(wg) * (P.zc + 1) + tl[a];
-				const int64_t slot   = kind * (nbuckets + 1) + bucket;
-				if (mode == 0) {
-					atomicAdd(&count[slot], 1u);
-				} else {
-					const uint32_t packed = static_cast<uint32_t>(tcx[d] + 1) | (static_cast<uint32_t>(tcy[b] + 1) << 16);
-					if (kind == 0) {
-						const uint32_t pos = off_row[bucket] + atomicAdd(&cursor[slot], 1u);
-						pos_row[pos] = packed;
-						for (int q = 0; q < 8; ++q) { coef_row[static_cast<int64_t>(pos) * 8 + q] = row1[c * 8 + q]; }
-					} else {
-						const uint32_t pos = off_blk[bucket] + atomicAdd(&cursor[slot], 1u);
-						pos_blk[pos] = packed;
-						for (int q = 0; q < 36; ++q) { coef_blk[static_cast<int64_t>(pos) * 36 + q] = blk[c * 36 + q]; }
-					}
-				}
-			}
+	// candidate a = 0: the tile/chunk holding the origin; a = 1: the next one, which sees the cell at -1
+	const bool x_ok[2] = {cx >= 0 && cx / P.tx < P.tiles_x, (cx + 1) % P.tx == 0 && (cx + 1) / P.tx < P.tiles_x};
+	const int  x_ti[2] = {cx >= 0 ? cx / P.tx : 0, (cx + 1) / P.tx};
+	const int  x_tc[2] = {cx >= 0 ? cx % P.tx : 0, -1};
+	const bool y_ok[2] = {cy >= 0 && cy / kTY < P.tiles_y, (cy + 1) % kTY == 0 && (cy + 1) / kTY < P.tiles_y};
+	const int  y_ti[2] = {cy >= 0 ? cy / kTY : 0, (cy + 1) / kTY};
+	const int  y_tc[2] = {cy >= 0 ? cy % kTY : 0, -1};
+	const bool z_ok[2] = {zz >= 0 && zz < nz_own, zz + 1 >= 0 && zz + 1 < nz_own && (zz + 1) % P.zc == 0};
+	const int  z_tk[2] = {zz >= 0 ? zz / P.zc : 0, (zz + 1) / P.zc};
+	const int  z_tl[2] = {zz >= 0 ? zz % P.zc + 1 : 0, 0};
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		const int a = m >> 2, b = (m >> 1) & 1, d = m & 1;
+		uint32_t k = kNoKey, pp = 0;
+		if (z_ok[a] && y_ok[b] && x_ok[d]) {
+			const int     wg     = (z_tk[a] * P.tiles_y + y_ti[b]) * P.tiles_x + x_ti[d];
+			const int64_t bucket = static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a];
+			k  = static_cast<uint32_t>(kind * nbuckets + bucket);
+			pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(y_tc[b] + 1) << 16);
+			atomicAdd(&count[kind * (nbuckets + 1) + bucket], 1u);
 		}
+		key[c * 8 + m] = k;
+		pos[c * 8 + m] = pp;
 	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_t n_all,
+                                                            const uint32_t* __restrict__ slot_sorted,
+                                                            const uint32_t* __restrict__ pos,
+                                                            const T* __restrict__ row1, const T* __restrict__ blk,
+                                                            uint32_t* __restrict__ pos_row, uint32_t* __restrict__ pos_blk,
+                                                            T* __restrict__ coef_row, T* __restrict__ coef_blk)
+{
+	using V = typename VecOf<T>::V;
+	constexpr int VX = VecOf<T>::VX;
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= n_all) { return; }
+	const uint32_t slot = slot_sorted[i];
+	const int64_t  c    = slot >> 3;
+	if (i < n_row) {  // keys of kind 0 sort first
+		pos_row[i] = pos[slot];
+		const V* src = reinterpret_cast<const V*>(row1 + c * 8);
+		V*       dst = reinterpret_cast<V*>(coef_row + i * 8);
+#pragma unroll
+		for (int k = 0; k < 8 / VX; ++k) { dst[k] = src[k]; }
+	} else {
+		const int64_t j = i - n_row;
+		pos_blk[j] = pos[slot];
+		const V* src = reinterpret_cast<const V*>(blk + c * 36);
+		V*       dst = reinterpret_cast<V*>(coef_blk + j * 36);
+#pragma unroll
+		for (int k = 0; k < 36 / VX; ++k) { dst[k] = src[k]; }
+	}
+}
+
+__global__ void k_iota32(uint32_t* v, int64_t n)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n) { v[i] = static_cast<uint32_t>(i); }
 }
 
 int pick_chunk(int tiles_xy, int nz_own)
@@ -709,31 +745,44 @@ void build_cell_lists(fi_ctx* c)
 	const MarchParams& P = m.P;
 	const int64_t ncell = c->cells.ncell;
 	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1);
+	const int64_t nslots = ncell * 8;
+	FI_REQUIRE(nslots < (1LL << 31) && 2 * nbuckets < (1LL << 31), FI_ERR_UNSUPPORTED, "too many data cells for one context");
 	hipStream_t st = c->stream;
-	DevBuf count, cursor, tmp;
+	DevBuf &count = c->scratch[14], &key = c->scratch[15], &pos = c->scratch[16], &slot_in = c->scratch[17],
+	       &key_sorted = c->scratch[18], &slot_sorted = c->scratch[19], &tmp = c->scratch[20];
 	count.alloc(sizeof(uint32_t) * (2 * (nbuckets + 1) + 2));
-	cursor.alloc(sizeof(uint32_t) * 2 * (nbuckets + 1));
+	key.alloc(sizeof(uint32_t) * nslots);
+	pos.alloc(sizeof(uint32_t) * nslots);
+	slot_in.alloc(sizeof(uint32_t) * nslots);
+	key_sorted.alloc(sizeof(uint32_t) * nslots);
+	slot_sorted.alloc(sizeof(uint32_t) * nslots);
 	m.lay_row.alloc(sizeof(uint32_t) * (nbuckets + 1));
 	m.lay_blk.alloc(sizeof(uint32_t) * (nbuckets + 1));
 	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * (2 * (nbuckets + 1) + 2), st));
-	FI_HIP_TRY(hipMemsetAsync(cursor.p, 0, sizeof(uint32_t) * 2 * (nbuckets + 1), st));
 	const int nb = static_cast<int>((ncell + kThreads - 1) / kThreads);
-	hipLaunchKernelGGL((k_cell_lists<T>), dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
-	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
-	                   c->cells.blk.as<T>(), count.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr, nullptr,
-	                   static_cast<T*>(nullptr), static_cast<T*>(nullptr), 0);
-	size_t tb = 0;
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
+	hipLaunchKernelGGL(k_cell_members, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
+	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), key.as<uint32_t>(),
+	                   pos.as<uint32_t>(), count.as<uint32_t>());
+	hipLaunchKernelGGL(k_iota32, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+	                   slot_in.as<uint32_t>(), nslots);
+	// unused slots carry key 0xFFFFFFFF and sort to the end: all 32 key bits take part
+	size_t tb = 0, tb2 = 0;
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
+	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
+	                                              static_cast<int>(nslots), 0, 32, st));
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
 	                                            static_cast<int>(nbuckets + 1), st));
-	tmp.alloc(tb);
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
+	tmp.alloc(tb > tb2 ? tb : tb2);
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
+	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
+	                                              static_cast<int>(nslots), 0, 32, st));
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
 	                                            static_cast<int>(nbuckets + 1), st));
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, count.as<uint32_t>() + (nbuckets + 1),
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, count.as<uint32_t>() + (nbuckets + 1),
 	                                            m.lay_blk.as<uint32_t>(), static_cast<int>(nbuckets + 1), st));
-	uint32_t totals[2] = {0, 0};
+	uint32_t totals[2] = {0, 0}, uniq[2] = {0, 0};
 	FI_HIP_TRY(hipMemcpyAsync(&totals[0], m.lay_row.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipMemcpyAsync(&totals[1], m.lay_blk.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	uint32_t uniq[2] = {0, 0};
 	FI_HIP_TRY(hipMemcpyAsync(uniq, count.as<uint32_t>() + 2 * (nbuckets + 1), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
 	m.n_row = totals[0];
@@ -744,13 +793,14 @@ void build_cell_lists(fi_ctx* c)
 	m.pos_blk.alloc(sizeof(uint32_t) * (m.n_blk + 1));
 	m.coef_row.alloc(sizeof(T) * 8 * (m.n_row + 1));
 	m.coef_blk.alloc(sizeof(T) * 36 * (m.n_blk + 1));
-	hipLaunchKernelGGL((k_cell_lists<T>), dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
-	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
-	                   c->cells.blk.as<T>(), nullptr, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
-	                   cursor.as<uint32_t>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(),
-	                   m.coef_blk.as<T>(), 1);
+	const int64_t n_all = m.n_row + m.n_blk;
+	if (n_all > 0) {
+		hipLaunchKernelGGL((k_cell_records<T>), dim3(static_cast<int>((n_all + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+		                   st, m.n_row, n_all, slot_sorted.as<uint32_t>(), pos.as<uint32_t>(), c->cells.row1.as<T>(),
+		                   c->cells.blk.as<T>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(),
+		                   m.coef_blk.as<T>());
+	}
 	FI_HIP_TRY(hipGetLastError());
-	FI_HIP_TRY(hipStreamSynchronize(st));
 }
 
 }  // namespace

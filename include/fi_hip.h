@@ -89,6 +89,8 @@ typedef struct fi_stats {
 	double spmv_ms_avg;        /* mean duration of the AtA-apply launches sampled with HIP events */
 	int    spmv_samples;
 	double spmv_bytes;         /* algorithmic bytes of one AtA apply */
+	int    restarts;           /* residual replacements: b - A x was evaluated this many times at convergence */
+	double verified_residual;  /* ||b - A x||/||b|| at the last such evaluation (-1: none) */
 } fi_stats;
 
 const char* fi_last_error(void);
@@ -161,6 +163,12 @@ int fi_clear_points(fi_ctx* ctx);
  * guess == NULL means zeros.  `guess`/`out` hold the owned unknowns of this rank (fp32). */
 int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, float* out, int* iterations,
                 float* rel_residual, int memory);
+
+/* Solver options.  FI_OPT_VERIFY_RESIDUAL (default 1): when the recurrence residual meets the tolerance,
+ * evaluate b - A x; if it misses the tolerance (fp32 drift) restart CG from it, at most 3 times.  0 gives
+ * the reference's stop rule on the recurrence residual alone. */
+#define FI_OPT_VERIFY_RESIDUAL 1
+int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */
 int fi_jacobi(fi_ctx* ctx, const float* guess, int num_iterations, float weight, float* out, int memory);
