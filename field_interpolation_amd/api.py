@@ -195,6 +195,16 @@ class LatticeField:
                                         float(gradient_weight), int(gradient_kernel), mem))
         self._dirty = True
 
+    def add_rows_coo(self, rows, cols, values, rhs):
+        """Arbitrary rows of a `LinearEquation` (sparse_linear.hpp:18-22): triplets (row, col, value) with rows
+        numbered from 0 within this call, and one rhs per row.  Duplicate (row, col) entries are summed."""
+        trip = np.empty(len(values), dtype=[("row", np.int32), ("col", np.int32), ("value", np.float32)])
+        trip["row"], trip["col"], trip["value"] = rows, cols, values
+        b = np.ascontiguousarray(rhs, np.float32)
+        check(_capi.lib().fi_add_rows_coo(self._h, b.size, trip.size, C.c_void_p(trip.ctypes.data),
+                                          C.c_void_p(b.ctypes.data), FI_HOST))
+        self._dirty = True
+
     def clear_points(self):
         check(_capi.lib().fi_clear_points(self._h))
         self._dirty = True

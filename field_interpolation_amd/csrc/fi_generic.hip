@@ -1,0 +1,455 @@
+// fi_generic.hip -- arbitrary sparse rows (the generic `LinearEquation` path) on the GPU.
+//
+// Reference path replaced: callers that hand a hand-built `LinearEquation` (sparse_linear.hpp:18-22) to the
+// solvers -- src/bipolar_2d.cpp:177-302 (torus wrap, mip pyramid), src/line_2d.cpp:49-104 (interleaved xy
+// unknowns) -- and the one lattice kernel whose rows are not cell-local:
+// GradientKernel::kLinearInterpolation (field_interpolation.cpp:188-236: every row spans 3 lattice points
+// along its axis).  The reference turns the triplets into an Eigen CSC matrix (duplicates summed,
+// sparse_linear.hpp:43) and squares it (make_square, sparse_linear.cpp:105-113).  Here A^T A is never formed:
+//
+//   assemble   radix sort of the triplets by (row, col), duplicates summed in input order (stable sort;
+//              fp32 like as_sparse_matrix_float), CSR of A; a second sort by (col, row) gives CSC for the
+//              transposed product, so that  y = A^T (A x)  needs no atomics and is bitwise reproducible.
+//              A^T b and diag(A^T A) are accumulated per column in fp64.
+//   apply      k_generic_Ax   one thread per row     t = A x
+//              k_generic_Aty  one thread per column  y[col] += sum_i A[i,col] t[i]   (+ x.y partials)
+// Rows are short (<= 16 entries on lattice problems), so thread-per-row is adequate; traffic per apply:
+// 2 * nnz * (4 + sizeof(T)) bytes + gathers.  Single-GPU contexts only (columns are global unknowns).
+
+#include <hipcub/hipcub.hpp>
+
+#include "fi_internal.h"
+
+namespace fi {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
+inline int capped_blocks(int64_t n)
+{
+	const int64_t b = (n + kThreads - 1) / kThreads;
+	return static_cast<int>(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+__device__ inline double wave_sum(double v)
+{
+	for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); }
+	return v;
+}
+__device__ inline double block_sum(double v)
+{
+	__shared__ double s[kThreads / 64];
+	v = wave_sum(v);
+	if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = v; }
+	__syncthreads();
+	double r = 0;
+	if (threadIdx.x == 0) {
+		for (int w = 0; w < kThreads / 64; ++w) { r += s[w]; }
+	}
+	__syncthreads();
+	return r;
+}
+
+// AoS fi_triplet (12 bytes, sparse_linear.hpp:8-15) -> sort key (row_offset + row) << 32 | col, value
+__global__ __launch_bounds__(kThreads) void k_split_triplets(int64_t n, const fi_triplet* __restrict__ t,
+                                                              uint32_t row_offset, uint64_t* __restrict__ key,
+                                                              float* __restrict__ val, int64_t nrows, int64_t ncols,
+                                                              int* __restrict__ bad)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= n) { return; }
+	const fi_triplet e = t[i];
+	if (e.row < 0 || e.row >= nrows || e.col < 0 || e.col >= ncols) {  // reference CHECK_*_F, sparse_linear.cpp:80-83
+		*bad = 1;
+		key[i] = 0;
+		val[i] = 0.0f;
+		return;
+	}
+	key[i] = (static_cast<uint64_t>(row_offset + static_cast<uint32_t>(e.row)) << 32) | static_cast<uint32_t>(e.col);
+	val[i] = e.value;
+}
+
+// GradientKernel::kLinearInterpolation (field_interpolation.cpp:188-236): multilerp(pos - 0.5, extra_bound 1);
+// per axis d one row with -w at idx and +w at idx + stride_d for every kept sample, rhs (sum w) * g_d.
+// A point whose samples are all dropped contributes empty rows (the reference adds none: same A^T A, A^T b).
+template <int D>
+__global__ __launch_bounds__(kThreads) void k_emit_gradient_linear(Geom g, long n, const float* __restrict__ pos,
+                                                                    const float* __restrict__ nrm,
+                                                                    const float* __restrict__ pw, float gw,
+                                                                    uint32_t row_offset, uint64_t* __restrict__ key,
+                                                                    float* __restrict__ val, float* __restrict__ rhs)
+{
+	constexpr int NC = 1 << D;
+	const long i = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= n) { return; }
+	const float w  = pw ? pw[i] : 1.0f;
+	const float cw = w * gw;
+	int   base[D];
+	float t[D];
+	bool  finite = true;
+	for (int d = 0; d < D; ++d) {
+		const float p  = pos[i * D + d] - 0.5f;
+		finite = finite && isfinite(p);
+		const float fl = floorf(p);
+		const bool  in = fl >= -1.0f && fl <= static_cast<float>(g.gn[d]);
+		base[d] = in ? static_cast<int>(fl) : -4;  // far outside: every sample is dropped
+		t[d]    = p - static_cast<float>(base[d]);
+	}
+	int     idx[NC];
+	float   lw[NC];
+	int     kept = 0;
+	for (int q = 0; q < NC; ++q) {
+		int64_t ix = 0;
+		float   ww = 1.0f;
+		bool    in = finite && cw != 0.0f;
+		for (int d = 0; d < D; ++d) {
+			const int up = (q >> d) & 1;
+			const int cc = base[d] + up;
+			ix += g.stride[d] * cc;
+			ww *= up ? t[d] : 1.0f - t[d];
+			in = in && (0 <= cc) && (cc + 1 < g.gn[d]);  // extra_bound = 1
+		}
+		if (in) {
+			idx[kept] = static_cast<int>(ix);
+			lw[kept]  = ww;
+			++kept;
+		}
+	}
+	for (int d = 0; d < D; ++d) {
+		const uint32_t row = row_offset + static_cast<uint32_t>(i * D + d);
+		const long     o   = (i * D + d) * (2 * NC);
+		float sum = 0.0f;
+		for (int k = 0; k < NC; ++k) {
+			float    c   = 0.0f;
+			uint32_t c0 = 0, c1 = 0;
+			if (k < kept) {
+				c  = lw[k] * cw;
+				c0 = static_cast<uint32_t>(idx[k]);
+				c1 = static_cast<uint32_t>(idx[k] + static_cast<int>(g.stride[d]));
+				sum += c;
+			}
+			key[o + 2 * k]     = (static_cast<uint64_t>(row) << 32) | c0;
+			val[o + 2 * k]     = -c;
+			key[o + 2 * k + 1] = (static_cast<uint64_t>(row) << 32) | c1;
+			val[o + 2 * k + 1] = c;
+		}
+		rhs[static_cast<long>(row)] = sum * nrm[i * D + d];
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_widen(int64_t n, const float* __restrict__ in, T* __restrict__ out)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i < n) { out[i] = static_cast<T>(in[i]); }
+}
+
+__global__ __launch_bounds__(kThreads) void k_unpack_csr(int64_t nnz, const uint64_t* __restrict__ key,
+                                                          uint32_t* __restrict__ col, uint32_t* __restrict__ row_count)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= nnz) { return; }
+	col[i] = static_cast<uint32_t>(key[i] & 0xFFFFFFFFull);
+	atomicAdd(&row_count[key[i] >> 32], 1u);
+}
+
+__global__ __launch_bounds__(kThreads) void k_transpose_keys(int64_t nnz, const uint64_t* __restrict__ key,
+                                                              uint64_t* __restrict__ tkey)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= nnz) { return; }
+	tkey[i] = (key[i] << 32) | (key[i] >> 32);
+}
+
+__global__ __launch_bounds__(kThreads) void k_unpack_csc(int64_t nnz, const uint64_t* __restrict__ tkey,
+                                                          uint32_t* __restrict__ row, uint32_t* __restrict__ colkey)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= nnz) { return; }
+	row[i]    = static_cast<uint32_t>(tkey[i] & 0xFFFFFFFFull);
+	colkey[i] = static_cast<uint32_t>(tkey[i] >> 32);
+}
+
+// A^T b and diag(A^T A), one thread per column that holds entries, fp64 accumulation, added to the lattice arrays
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_generic_rhs_diag(int64_t ncols, const uint32_t* __restrict__ cols,
+                                                                const uint32_t* __restrict__ ptr,
+                                                                const uint32_t* __restrict__ row,
+                                                                const T* __restrict__ val,
+                                                                const float* __restrict__ rhs, T* __restrict__ atb,
+                                                                T* __restrict__ diag)
+{
+	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c >= ncols) { return; }
+	double b = 0, d = 0;
+	for (uint32_t k = ptr[c]; k < ptr[c + 1]; ++k) {
+		const double a = static_cast<double>(val[k]);
+		b += a * static_cast<double>(rhs[row[k]]);
+		d += a * a;
+	}
+	atb[cols[c]] += static_cast<T>(b);
+	diag[cols[c]] += static_cast<T>(d);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_generic_Ax(int64_t nrows, const uint32_t* __restrict__ ptr,
+                                                          const uint32_t* __restrict__ col,
+                                                          const T* __restrict__ val, const T* __restrict__ x,
+                                                          T* __restrict__ t, const int* __restrict__ done)
+{
+	if (done && *done) { return; }
+	for (int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; r < nrows;
+	     r += static_cast<int64_t>(gridDim.x) * kThreads) {
+		T s = 0;
+		for (uint32_t k = ptr[r]; k < ptr[r + 1]; ++k) { s += val[k] * x[col[k]]; }
+		t[r] = s;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_generic_Aty(int64_t ncols, const uint32_t* __restrict__ cols,
+                                                           const uint32_t* __restrict__ ptr,
+                                                           const uint32_t* __restrict__ row,
+                                                           const T* __restrict__ val, const T* __restrict__ t,
+                                                           const T* __restrict__ x, T* __restrict__ y,
+                                                           double* __restrict__ partial, const int* __restrict__ done)
+{
+	if (done && *done) { return; }
+	double contrib = 0;
+	for (int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; c < ncols;
+	     c += static_cast<int64_t>(gridDim.x) * kThreads) {
+		T s = 0;
+		for (uint32_t k = ptr[c]; k < ptr[c + 1]; ++k) { s += val[k] * t[row[k]]; }
+		const uint32_t j = cols[c];
+		y[j] += s;
+		contrib += static_cast<double>(x[j]) * static_cast<double>(s);
+	}
+	if (partial) {
+		const double s = block_sum(contrib);
+		if (threadIdx.x == 0) { partial[blockIdx.x] = s; }
+	}
+}
+
+void grow(DevBuf& b, size_t used_bytes, size_t need_bytes, hipStream_t st)
+{
+	if (need_bytes <= b.bytes) { return; }
+	size_t cap = b.bytes ? b.bytes : 4096;
+	while (cap < need_bytes) { cap *= 2; }
+	DevBuf n;
+	n.alloc(cap);
+	if (used_bytes) { FI_HIP_TRY(hipMemcpyAsync(n.p, b.p, used_bytes, hipMemcpyDeviceToDevice, st)); }
+	FI_HIP_TRY(hipStreamSynchronize(st));
+	std::swap(b.p, n.p);
+	std::swap(b.bytes, n.bytes);
+}
+
+}  // namespace
+
+void generic_reserve(fi_ctx* c, int64_t more_trip, int64_t more_rows)
+{
+	GenericRows& G = c->generic;
+	grow(G.key, sizeof(uint64_t) * G.ntrip, sizeof(uint64_t) * (G.ntrip + more_trip), c->stream);
+	grow(G.val, sizeof(float) * G.ntrip, sizeof(float) * (G.ntrip + more_trip), c->stream);
+	grow(G.rhs, sizeof(float) * G.nrows, sizeof(float) * (G.nrows + more_rows), c->stream);
+}
+
+void generic_add_coo(fi_ctx* c, int64_t nrows, int64_t ntrip, const fi_triplet* trip, const float* rhs, int memory)
+{
+	GenericRows& G = c->generic;
+	FI_REQUIRE(G.nrows + nrows < (1LL << 31) && G.ntrip + ntrip < (1LL << 31), FI_ERR_UNSUPPORTED, "too many generic rows");
+	generic_reserve(c, ntrip, nrows);
+	hipStream_t st = c->stream;
+	DevBuf dtrip, dbad;
+	const fi_triplet* src = trip;
+	if (memory == FI_HOST && ntrip > 0) {
+		dtrip.alloc(sizeof(fi_triplet) * ntrip);
+		FI_HIP_TRY(hipMemcpyAsync(dtrip.p, trip, sizeof(fi_triplet) * ntrip, hipMemcpyHostToDevice, st));
+		src = dtrip.as<fi_triplet>();
+	}
+	dbad.alloc(sizeof(int));
+	FI_HIP_TRY(hipMemsetAsync(dbad.p, 0, sizeof(int), st));
+	if (ntrip > 0) {
+		hipLaunchKernelGGL(k_split_triplets, dim3(blocks_for(ntrip)), dim3(kThreads), 0, st, ntrip, src,
+		                   static_cast<uint32_t>(G.nrows), G.key.as<uint64_t>() + G.ntrip, G.val.as<float>() + G.ntrip,
+		                   nrows, c->g.nown, dbad.as<int>());
+	}
+	if (nrows > 0) {
+		FI_HIP_TRY(hipMemcpyAsync(G.rhs.as<float>() + G.nrows, rhs, sizeof(float) * nrows,
+		                          memory == FI_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+	}
+	int bad = 0;
+	FI_HIP_TRY(hipMemcpyAsync(&bad, dbad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipStreamSynchronize(st));
+	FI_REQUIRE(bad == 0, FI_ERR_INVALID, "triplet index out of range (rows %lld, columns %lld)",
+	           static_cast<long long>(nrows), static_cast<long long>(c->g.nown));
+	G.ntrip += ntrip;
+	G.nrows += nrows;
+}
+
+void generic_add_gradient_linear(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, float gw)
+{
+	GenericRows& G = c->generic;
+	const int    D  = c->g.ndim;
+	const int64_t rows = static_cast<int64_t>(n) * D, trips = rows * 2 * (1 << D);
+	FI_REQUIRE(G.nrows + rows < (1LL << 31) && G.ntrip + trips < (1LL << 31), FI_ERR_UNSUPPORTED, "too many generic rows");
+	generic_reserve(c, trips, rows);
+	uint64_t* key = G.key.as<uint64_t>() + G.ntrip;
+	float*    val = G.val.as<float>() + G.ntrip;
+	const uint32_t off = static_cast<uint32_t>(G.nrows);
+	switch (D) {
+	case 1:
+		hipLaunchKernelGGL(k_emit_gradient_linear<1>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, n, pos, nrm,
+		                   pw, gw, off, key, val, G.rhs.as<float>());
+		break;
+	case 2:
+		hipLaunchKernelGGL(k_emit_gradient_linear<2>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, n, pos, nrm,
+		                   pw, gw, off, key, val, G.rhs.as<float>());
+		break;
+	default:
+		hipLaunchKernelGGL(k_emit_gradient_linear<3>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, n, pos, nrm,
+		                   pw, gw, off, key, val, G.rhs.as<float>());
+		break;
+	}
+	FI_HIP_TRY(hipGetLastError());
+	G.ntrip += trips;
+	G.nrows += rows;
+}
+
+void generic_clear(fi_ctx* c)
+{
+	c->generic.ntrip = 0;
+	c->generic.nrows = 0;
+	c->generic.nnz   = 0;
+	c->generic.ncols = 0;
+}
+
+template <typename T>
+static void generic_assemble_t(fi_ctx* c)
+{
+	GenericRows& G = c->generic;
+	G.nnz = G.ncols = 0;
+	c->stats.num_generic_rows = G.nrows;
+	if (G.ntrip == 0) { return; }
+	hipStream_t st = c->stream;
+	const int n = static_cast<int>(G.ntrip);
+	DevBuf ksort, vsort, ukey, tmp, nruns, tkey, tkey_s, val_s, colkey, colcount;
+	ksort.alloc(sizeof(uint64_t) * n);
+	vsort.alloc(sizeof(float) * n);
+	ukey.alloc(sizeof(uint64_t) * n);
+	G.csr_val.alloc(sizeof(T) * n);
+	nruns.alloc(sizeof(int) * 2);
+	size_t tb = 0;
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, G.key.as<uint64_t>(), ksort.as<uint64_t>(), G.val.as<float>(),
+	                                              vsort.as<float>(), n, 0, 64, st));
+	tmp.alloc(tb);
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, G.key.as<uint64_t>(), ksort.as<uint64_t>(), G.val.as<float>(),
+	                                              vsort.as<float>(), n, 0, 64, st));
+	// duplicates: summed in input order (stable sort) -- sparse_linear.hpp:43, Eigen setFromTriplets -- in the
+	// context's precision: fp32 like as_sparse_matrix_float (:59-70), fp64 like as_sparse_matrix_double (:72-93)
+	DevBuf vT;
+	vT.alloc(sizeof(T) * n);
+	hipLaunchKernelGGL((k_widen<T>), dim3(blocks_for(n)), dim3(kThreads), 0, st, static_cast<int64_t>(n), vsort.as<float>(),
+	                   vT.as<T>());
+	size_t tb2 = 0;
+	FI_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, ksort.as<uint64_t>(), ukey.as<uint64_t>(), vT.as<T>(),
+	                                             G.csr_val.as<T>(), nruns.as<int>(), hipcub::Sum(), n, st));
+	DevBuf tmp2;
+	tmp2.alloc(tb2);
+	FI_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(tmp2.p, tb2, ksort.as<uint64_t>(), ukey.as<uint64_t>(), vT.as<T>(),
+	                                             G.csr_val.as<T>(), nruns.as<int>(), hipcub::Sum(), n, st));
+	int nnz = 0;
+	FI_HIP_TRY(hipMemcpyAsync(&nnz, nruns.p, sizeof(int), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipStreamSynchronize(st));
+	G.nnz = nnz;
+	// CSR
+	G.csr_col.alloc(sizeof(uint32_t) * nnz);
+	G.csr_ptr.alloc(sizeof(uint32_t) * (G.nrows + 2));
+	DevBuf rowcount;
+	rowcount.alloc(sizeof(uint32_t) * (G.nrows + 2));
+	FI_HIP_TRY(hipMemsetAsync(rowcount.p, 0, sizeof(uint32_t) * (G.nrows + 2), st));
+	hipLaunchKernelGGL(k_unpack_csr, dim3(blocks_for(nnz)), dim3(kThreads), 0, st, nnz, ukey.as<uint64_t>(),
+	                   G.csr_col.as<uint32_t>(), rowcount.as<uint32_t>());
+	size_t tb3 = 0;
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, rowcount.as<uint32_t>(), G.csr_ptr.as<uint32_t>(),
+	                                            static_cast<int>(G.nrows + 1), st));
+	DevBuf tmp3;
+	tmp3.alloc(tb3);
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb3, rowcount.as<uint32_t>(), G.csr_ptr.as<uint32_t>(),
+	                                            static_cast<int>(G.nrows + 1), st));
+	// CSC: sort the unique entries by (col, row)
+	tkey.alloc(sizeof(uint64_t) * nnz);
+	tkey_s.alloc(sizeof(uint64_t) * nnz);
+	G.csc_val.alloc(sizeof(T) * nnz);
+	hipLaunchKernelGGL(k_transpose_keys, dim3(blocks_for(nnz)), dim3(kThreads), 0, st, nnz, ukey.as<uint64_t>(),
+	                   tkey.as<uint64_t>());
+	size_t tb4 = 0;
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, tkey.as<uint64_t>(), tkey_s.as<uint64_t>(),
+	                                              G.csr_val.as<T>(), G.csc_val.as<T>(), nnz, 0, 64, st));
+	DevBuf tmp4;
+	tmp4.alloc(tb4);
+	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp4.p, tb4, tkey.as<uint64_t>(), tkey_s.as<uint64_t>(),
+	                                              G.csr_val.as<T>(), G.csc_val.as<T>(), nnz, 0, 64, st));
+	G.csc_row.alloc(sizeof(uint32_t) * nnz);
+	colkey.alloc(sizeof(uint32_t) * nnz);
+	hipLaunchKernelGGL(k_unpack_csc, dim3(blocks_for(nnz)), dim3(kThreads), 0, st, nnz, tkey_s.as<uint64_t>(),
+	                   G.csc_row.as<uint32_t>(), colkey.as<uint32_t>());
+	G.csc_cols.alloc(sizeof(uint32_t) * nnz);
+	colcount.alloc(sizeof(uint32_t) * (nnz + 1));
+	size_t tb5 = 0;
+	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb5, colkey.as<uint32_t>(), G.csc_cols.as<uint32_t>(),
+	                                                 colcount.as<uint32_t>(), nruns.as<int>(), nnz, st));
+	DevBuf tmp5;
+	tmp5.alloc(tb5);
+	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp5.p, tb5, colkey.as<uint32_t>(), G.csc_cols.as<uint32_t>(),
+	                                                 colcount.as<uint32_t>(), nruns.as<int>(), nnz, st));
+	int ncols = 0;
+	FI_HIP_TRY(hipMemcpyAsync(&ncols, nruns.p, sizeof(int), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipStreamSynchronize(st));
+	G.ncols = ncols;
+	G.csc_ptr.alloc(sizeof(uint32_t) * (ncols + 2));
+	FI_HIP_TRY(hipMemsetAsync(colcount.as<uint32_t>() + ncols, 0, sizeof(uint32_t), st));
+	size_t tb6 = 0;
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb6, colcount.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), ncols + 1, st));
+	DevBuf tmp6;
+	tmp6.alloc(tb6);
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp6.p, tb6, colcount.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), ncols + 1, st));
+	G.t.alloc(elem_size(c) * (G.nrows + 1));
+	hipLaunchKernelGGL((k_generic_rhs_diag<T>), dim3(blocks_for(ncols)), dim3(kThreads), 0, st, ncols,
+	                   G.csc_cols.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), G.csc_row.as<uint32_t>(), G.csc_val.as<T>(),
+	                   G.rhs.as<float>(), c->atb.as<T>(), c->diag.as<T>());
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipStreamSynchronize(st));
+}
+
+void generic_assemble(fi_ctx* c)
+{
+	FI_REQUIRE(c->nranks == 1 || c->generic.ntrip == 0, FI_ERR_UNSUPPORTED,
+	           "generic rows (fi_add_rows_coo, GradientKernel::kLinearInterpolation) need an undivided lattice");
+	c->dtype == FI_F64 ? generic_assemble_t<double>(c) : generic_assemble_t<float>(c);
+}
+
+int generic_num_partials(const fi_ctx* c) { return c->generic.nnz > 0 ? capped_blocks(c->generic.ncols) : 0; }
+
+template <typename T>
+static void generic_apply_t(fi_ctx* c, const T* x, T* y, double* partial)
+{
+	GenericRows& G = c->generic;
+	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
+	hipLaunchKernelGGL((k_generic_Ax<T>), dim3(capped_blocks(G.nrows)), dim3(kThreads), 0, c->stream, G.nrows,
+	                   G.csr_ptr.as<uint32_t>(), G.csr_col.as<uint32_t>(), G.csr_val.as<T>(), x, G.t.as<T>(), done);
+	hipLaunchKernelGGL((k_generic_Aty<T>), dim3(capped_blocks(G.ncols)), dim3(kThreads), 0, c->stream, G.ncols,
+	                   G.csc_cols.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), G.csc_row.as<uint32_t>(), G.csc_val.as<T>(),
+	                   G.t.as<T>(), x, y, partial, done);
+	FI_HIP_TRY(hipGetLastError());
+}
+
+void generic_apply(fi_ctx* c, const void* x, void* y, double* partial)
+{
+	if (c->generic.nnz == 0) { return; }
+	c->dtype == FI_F64 ? generic_apply_t<double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial)
+	                   : generic_apply_t<float>(c, static_cast<const float*>(x), static_cast<float*>(y), partial);
+}
+
+}  // namespace fi

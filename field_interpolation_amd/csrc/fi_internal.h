@@ -132,6 +132,18 @@ struct MarchState {
 	int64_t     cells_row = 0, cells_blk = 0;  // distinct cells of each kind
 };
 
+// Arbitrary sparse rows (fi_add_rows_coo and GradientKernel::kLinearInterpolation): fi_generic.hip
+struct GenericRows {
+	int64_t ntrip = 0, nrows = 0;  // accumulated input
+	DevBuf  key;                   // uint64[ntrip]  (row << 32) | col
+	DevBuf  val;                   // float[ntrip]
+	DevBuf  rhs;                   // float[nrows]
+	int64_t nnz = 0, ncols = 0;    // assembled: distinct (row, col) entries, columns that hold entries
+	DevBuf  csr_ptr, csr_col, csr_val;            // A by rows
+	DevBuf  csc_cols, csc_ptr, csc_row, csc_val;  // A by columns (transposed product without atomics)
+	DevBuf  t;                                    // T[nrows]  t = A x
+};
+
 struct Pending {  // one fi_add_points batch, already turned into cell rows on the device
 	int64_t nrows = 0;  // slots (valid or not)
 	DevBuf  key;        // uint32[nrows]   extended local cell id or 0xFFFFFFFF
@@ -166,6 +178,7 @@ struct fi_ctx {
 	std::vector<fi::Pending*> pending_pool;  // buffers of cleared batches, reused by the next fi_add_points
 	fi::CellData              cells;
 	fi::MarchState            march;
+	fi::GenericRows           generic;
 
 	// operator pieces (T arrays over local storage)
 	fi::DevBuf atb, diag, dinv;
@@ -202,6 +215,14 @@ void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.
 void stencil_prepare(fi_ctx* c);   // after assemble(): tiling + per-workgroup cell lists
 int  stencil_partials(const fi_ctx* c);
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
+
+// fi_generic.hip
+void generic_add_coo(fi_ctx* c, int64_t nrows, int64_t ntrip, const fi_triplet* trip, const float* rhs, int memory);
+void generic_add_gradient_linear(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, float gw);
+void generic_clear(fi_ctx* c);
+void generic_assemble(fi_ctx* c);                      // after assemble(): adds A^T b and diag, builds CSR/CSC
+int  generic_num_partials(const fi_ctx* c);
+void generic_apply(fi_ctx* c, const void* x, void* y, double* partial);  // y += A^T (A x)
 
 // fi_assembly.hip
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val,

@@ -300,19 +300,21 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 	const ModelCoef<T> mc = make_coef<T>(c->w);
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
 	int nb_model = stencil_partials(c);
+	int nb_cells = 0;
 	if (nb_model > 0) {
 		stencil_apply(c, x, y, partial);
-		if (c->march.fused) { return; }  // cell blocks were applied inside the marching kernel
 	} else {
 		nb_model = capped_blocks(g.nown);
 		hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial,
 		                   done);
 	}
-	if (c->cells.ncell > 0) {
-		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(capped_blocks(c->cells.ncell)), dim3(kThreads), 0, c->stream, g,
+	if (c->cells.ncell > 0 && !(c->march.valid && c->march.fused)) {
+		nb_cells = capped_blocks(c->cells.ncell);
+		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(nb_cells), dim3(kThreads), 0, c->stream, g,
 		                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), x, y,
 		                   partial ? partial + nb_model : nullptr, done);
 	}
+	generic_apply(c, x, y, partial ? partial + nb_model + nb_cells : nullptr);
 	FI_HIP_TRY(hipGetLastError());
 }
 
@@ -324,8 +326,9 @@ int apply_num_partials(const fi_ctx* c)
 {
 	int nb_model = stencil_partials(c);
 	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
-	if (c->march.valid && c->march.fused) { return nb_model; }
-	return nb_model + (c->cells.ncell > 0 ? capped_blocks(c->cells.ncell) : 0);
+	int n = nb_model + generic_num_partials(c);
+	if (!(c->march.valid && c->march.fused) && c->cells.ncell > 0) { n += capped_blocks(c->cells.ncell); }
+	return n;
 }
 
 double apply_algorithmic_bytes(const fi_ctx* c)
@@ -334,7 +337,8 @@ double apply_algorithmic_bytes(const fi_ctx* c)
 	// occupied cell's record once.  The fused 3-D kernel keeps a cell that holds a single data row as that
 	// row (2^D coefficients) instead of the packed block, so its record is counted at its real, smaller size.
 	const double s = static_cast<double>(elem_size(c));
-	const double lattice = 2.0 * s * static_cast<double>(c->g.nown);
+	const double lattice = 2.0 * s * static_cast<double>(c->g.nown) +
+	                       2.0 * static_cast<double>(c->generic.nnz) * (4.0 + s);    // generic rows: CSR + CSC pass
 	if (c->march.valid && c->march.fused) {
 		return lattice + static_cast<double>(c->march.cells_row) * (4.0 + s * 8.0) +
 		       static_cast<double>(c->march.cells_blk) * (4.0 + s * 36.0);

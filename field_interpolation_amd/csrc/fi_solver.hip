@@ -1058,9 +1058,8 @@ int fi_add_points(fi_ctx* c, long n, const float* positions, const float* normal
 	if (normals) {
 		FI_REQUIRE(gradient_kernel >= 0 && gradient_kernel <= 2, FI_ERR_INVALID, "Unknown gradient kernel: %d",
 		           gradient_kernel);  // ABORT_F, cpp:238
-		FI_REQUIRE(gradient_kernel != FI_GRADIENT_LINEAR_INTERPOLATION || gradient_weight == 0.0f, FI_ERR_UNSUPPORTED,
-		           "GradientKernel::kLinearInterpolation rows span three lattice points per axis; pass them through "
-		           "fi_add_rows_coo");
+		FI_REQUIRE(gradient_kernel != FI_GRADIENT_LINEAR_INTERPOLATION || gradient_weight == 0.0f || c->nranks == 1,
+		           FI_ERR_UNSUPPORTED, "GradientKernel::kLinearInterpolation needs an undivided lattice");
 	}
 	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
 	const int D = c->g.ndim;
@@ -1078,7 +1077,12 @@ int fi_add_points(fi_ctx* c, long n, const float* positions, const float* normal
 		w = up(dpw, point_weights, static_cast<size_t>(n));
 		v = up(dval, values, static_cast<size_t>(n));
 	}
-	fi::emit_point_rows(c, n, p, g, w, v, value_weight, value_kernel, gradient_weight, gradient_kernel);
+	const bool lin = g && gradient_kernel == FI_GRADIENT_LINEAR_INTERPOLATION;
+	// cell-local rows (value rows; gradient rows of the nearest-neighbour / cell-edge kernels) ...
+	fi::emit_point_rows(c, n, p, g, w, v, value_weight, value_kernel, lin ? 0.0f : gradient_weight,
+	                    lin ? FI_GRADIENT_CELL_EDGES : gradient_kernel);
+	// ... and the 3-point-wide rows of GradientKernel::kLinearInterpolation as generic sparse rows
+	if (lin && gradient_weight != 0.0f) { fi::generic_add_gradient_linear(c, n, p, g, w, gradient_weight); }
 	FI_HIP_TRY(hipStreamSynchronize(c->stream));
 	c->assembled = false;
 	FI_API_END
@@ -1088,12 +1092,13 @@ int fi_add_rows_coo(fi_ctx* c, long nrows, long ntriplets, const fi_triplet* tri
 {
 	FI_API_BEGIN
 	fi::check_ctx(c);
-	(void)nrows;
-	(void)ntriplets;
-	(void)triplets;
-	(void)rhs;
-	(void)memory;
-	FI_REQUIRE(false, FI_ERR_UNSUPPORTED, "generic COO rows are not available in this build yet");
+	fi::bind_device(c);
+	FI_REQUIRE(nrows >= 0 && ntriplets >= 0, FI_ERR_INVALID, "negative count");
+	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	FI_REQUIRE(c->nranks == 1, FI_ERR_UNSUPPORTED, "generic rows need an undivided lattice");
+	FI_REQUIRE((ntriplets == 0 || triplets) && (nrows == 0 || rhs), FI_ERR_INVALID, "null buffer");
+	fi::generic_add_coo(c, nrows, ntriplets, triplets, rhs, memory);
+	c->assembled = false;
 	FI_API_END
 }
 
@@ -1103,6 +1108,7 @@ int fi_clear_points(fi_ctx* c)
 	fi::check_ctx(c);
 	for (auto* pb : c->pending) { c->pending_pool.push_back(pb); }  // keep the HBM buffers for the next batch
 	c->pending.clear();
+	fi::generic_clear(c);
 	c->assembled = false;
 	FI_API_END
 }
@@ -1131,6 +1137,7 @@ int fi_assemble(fi_ctx* c)
 		           "slab of %d planes is thinner than the stencil reach %d", c->slab_hi - c->slab_lo, c->halo);
 	}
 	fi::assemble(c);
+	fi::generic_assemble(c);
 	fi::stencil_prepare(c);
 	fi::operator_prepare(c);
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));

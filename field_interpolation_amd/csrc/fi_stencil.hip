@@ -530,7 +530,18 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 			dsum += pc[j] * v;
 		}
 		if (active) {
-			if (!(P.dbg & 2)) { *reinterpret_cast<V*>(y + static_cast<int64_t>(z) * P.plane + col) = out; }
+			if (!(P.dbg & 2)) {
+				V* dst = reinterpret_cast<V*>(y + static_cast<int64_t>(z) * P.plane + col);
+				if (P.dbg & 4) {
+					typedef T NV __attribute__((ext_vector_type(VX)));
+					NV nv;
+#pragma unroll
+					for (int j = 0; j < VX; ++j) { nv[j] = po[j]; }
+					__builtin_nontemporal_store(nv, reinterpret_cast<NV*>(dst));
+				} else {
+					*dst = out;
+				}
+			}
 			dot_acc += static_cast<double>(dsum);
 		}
 	};
