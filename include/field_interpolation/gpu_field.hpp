@@ -1,0 +1,60 @@
+// gpu_field.hpp -- the matrix-free fast path for lattice problems (not in the reference).
+//
+// GpuLatticeField is the GPU twin of LatticeField: same call sequence (add_field_constraints, add_points /
+// add_value_constraint / add_gradient_constraint, then a solver), but no row is ever written to host memory:
+// everything goes straight to libfi_hip (include/fi_hip.h).
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "field_interpolation.hpp"
+
+struct fi_ctx;
+
+namespace field_interpolation {
+
+class GpuLatticeField
+{
+public:
+	// double_precision: keep all lattice vectors in fp64 (for tolerances below ~1e-5).
+	explicit GpuLatticeField(const std::vector<int>& sizes, bool double_precision = false);
+	~GpuLatticeField();
+	GpuLatticeField(const GpuLatticeField&) = delete;
+	GpuLatticeField& operator=(const GpuLatticeField&) = delete;
+
+	const std::vector<int>& sizes() const { return sizes_; }
+	size_t num_unknowns() const;
+
+	void add_field_constraints(const Weights& weights);
+	bool add_value_constraint(const float pos[], float value, float weight);
+	bool add_value_constraint_nearest_neighbor(const float pos[], const float gradient[], float value, float weight);
+	bool add_gradient_constraint(const float pos[], const float gradient[], float weight, GradientKernel kernel);
+	void add_points(float value_weight, ValueKernel value_kernel, float gradient_weight, GradientKernel gradient_kernel,
+	                int num_points, const float positions[], const float* normals, const float* point_weights);
+
+	// solve_sparse_linear_with_guess / solve_tiled_with_guess / jacobi_iterations of the reference.
+	// An empty result means failure (wrong guess length, solver breakdown), as in the reference.
+	std::vector<float> solve_with_guess(const std::vector<float>& guess, int max_iterations, float error_tolerance);
+	std::vector<float> solve_tiled_with_guess(const std::vector<float>& guess, const SolveOptions& options);
+	std::vector<float> jacobi_iterations(const std::vector<float>& guess, int num_iterations, float weight);
+
+	int    last_iterations() const { return iterations_; }
+	float  last_error() const { return error_; }
+	size_t num_data_rows() const;   // rows accepted from points (what eq.rhs.size() would have grown by)
+
+private:
+	bool assemble();
+	fi_ctx*          ctx_ = nullptr;
+	std::vector<int> sizes_;
+	bool             dirty_ = true;
+	int              iterations_ = 0;
+	float            error_ = 0;
+};
+
+// sdf_from_points without the triplet list.
+std::unique_ptr<GpuLatticeField> gpu_sdf_from_points(const std::vector<int>& sizes, const Weights& weights,
+                                                     int num_points, const float positions[], const float* normals,
+                                                     const float* point_weights);
+
+} // namespace field_interpolation
