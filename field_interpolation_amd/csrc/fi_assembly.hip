@@ -215,7 +215,8 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
                                                             const float* __restrict__ coef,
                                                             const float* __restrict__ rhs, T* __restrict__ blk,
                                                             double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
-                                                            T* __restrict__ row1)
+                                                            T* __restrict__ row1, T* __restrict__ mrow,
+                                                            uint32_t* __restrict__ nfac)
 {
 	constexpr int NC = 1 << D;
 	constexpr int NB = NC * (NC + 1) / 2;
@@ -244,6 +245,58 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 		for (int q = 0; q < NC; ++q) { row1[c * NC + q] = static_cast<T>(coef[row * NC + q]); }
 	}
 	for (int q = 0; q < NC; ++q) { cell_rhs[static_cast<long>(q) * ncell + c] = gvec[q]; }
+
+	// Factor rows for the fused 3-D kernel: the cell's block as a sum of <= 2^D outer products a a^T.
+	//   m <= 2^D rows : the data rows themselves (nothing to compute);
+	//   m >  2^D rows : fp32 contexts: the rows of U from B = U^T U (Cholesky of the fp64 block; B is positive
+	//                   semi-definite, a vanishing pivot means a vanishing row/column of the remaining Schur
+	//                   complement and simply drops out); fp64 contexts: the packed block (marker k = 255).
+	if (mrow) {
+		uint32_t k = 0;
+		if (m <= static_cast<uint32_t>(NC)) {
+			for (uint32_t r = 0; r < m; ++r) {
+				const long row = sorted_row[s + r];
+				for (int q = 0; q < NC; ++q) { mrow[(c * NC + r) * NC + q] = static_cast<T>(coef[row * NC + q]); }
+			}
+			k = m;
+		} else if (sizeof(T) == 8) {
+			// fp64 contexts keep the packed block itself: a Cholesky factor of a nearly singular block is only
+			// good to ~1e-9 (half the digits), which fp32 never sees but fp64 parity (1e-12) does
+			for (int e = 0; e < NB; ++e) { mrow[c * NC * NC + e] = static_cast<T>(B[e]); }
+			k = 0xFFu;
+		} else {
+			double dmax = 0;
+			for (int i = 0; i < NC; ++i) { dmax = fmax(dmax, B[packed_index(i, i, NC)]); }
+			const double tiny = 1e-14 * dmax;
+#pragma unroll
+			for (int i = 0; i < NC; ++i) {
+				// row i of U, in place: U[i][j] = (B[i][j] - sum_{t<i} U[t][i] U[t][j]) / U[i][i]
+				double piv = B[packed_index(i, i, NC)];
+#pragma unroll
+				for (int t = 0; t < i; ++t) { piv -= B[packed_index(t, i, NC)] * B[packed_index(t, i, NC)]; }
+				const bool   live = piv > tiny;
+				const double inv  = live ? 1.0 / sqrt(piv) : 0.0;
+				B[packed_index(i, i, NC)] = live ? sqrt(piv) : 0.0;
+#pragma unroll
+				for (int j = i + 1; j < NC; ++j) {
+					double v = B[packed_index(i, j, NC)];
+#pragma unroll
+					for (int t = 0; t < i; ++t) { v -= B[packed_index(t, i, NC)] * B[packed_index(t, j, NC)]; }
+					B[packed_index(i, j, NC)] = v * inv;
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < NC; ++i) {
+				if (B[packed_index(i, i, NC)] != 0.0) {
+					for (int q = 0; q < NC; ++q) {
+						mrow[(c * NC + k) * NC + q] = q < i ? T(0) : static_cast<T>(B[packed_index(i, q, NC)]);
+					}
+					++k;
+				}
+			}
+		}
+		nfac[c] = k;
+	}
 }
 
 template <int D, typename T>
@@ -427,12 +480,18 @@ void assemble_dim(fi_ctx* c)
 	c->cells.blk.alloc(sizeof(T) * NB * ncell);
 	c->cells.nrow.alloc(sizeof(uint32_t) * ncell);
 	c->cells.row1.alloc(sizeof(T) * NC * ncell);
+	if (D == 3) {  // factor rows feed the fused 3-D kernel only
+		c->cells.mrow.alloc(sizeof(T) * NC * NC * ncell);
+		c->cells.nfac.alloc(sizeof(uint32_t) * ncell);
+	}
 	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
 	DevBuf& cell_rhs = c->scratch[13];
 	cell_rhs.alloc(sizeof(double) * NC * ncell);
 	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
 	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,
-	                   c->cells.blk.as<T>(), cell_rhs.as<double>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>());
+	                   c->cells.blk.as<T>(), cell_rhs.as<double>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
+	                   D == 3 ? c->cells.mrow.as<T>() : static_cast<T*>(nullptr),
+	                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr));
 	FI_HIP_TRY(hipGetLastError());
 	for (int colour = 0; colour < NC; ++colour) {
 		hipLaunchKernelGGL((k_scatter_cells<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, g, ncell,

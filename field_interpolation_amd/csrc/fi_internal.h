@@ -99,6 +99,8 @@ struct CellData {
 	DevBuf  blk;      // T[ncell][nb]  upper triangle of the symmetric 2^D x 2^D block, one cell after another
 	DevBuf  nrow;     // uint32[ncell] number of data rows accumulated into the cell
 	DevBuf  row1;     // T[ncell][2^D] the row itself for cells holding exactly one row (block = row row^T)
+	DevBuf  mrow;     // T[ncell][2^D][2^D] (3-D only) up to 2^D factor rows a_k with block = sum a_k a_k^T
+	DevBuf  nfac;     // uint32[ncell] number of factor rows
 	int     nb = 0;   // entries per block: 2^D(2^D+1)/2
 };
 
@@ -122,12 +124,12 @@ struct MarchState {
 	bool        valid = false;  // the marching kernel applies to this context
 	bool        fused = false;  // cell blocks are applied inside the marching kernel
 	MarchParams P{};
-	// self-contained records per (workgroup, layer); two kinds: a single data row (rank-1 block,
-	// 2^D coefficients) or a full packed block (36 coefficients in 3-D)
+	// self-contained records per (workgroup, layer); two kinds: a cell holding a single data row (8
+	// coefficients) or a cell holding several: up to 8 factor rows in a 64-coefficient slot
 	DevBuf      lay_row, lay_blk;  // uint32[nwg*(zc+1)+1] record ranges
-	DevBuf      pos_row, pos_blk;  // uint32[n] (tcx+1) | (tcy+1) << 16, tile-relative cell origin
+	DevBuf      pos_row, pos_blk;  // uint32[n] (tcx+1) | k << 8 | (tcy+1) << 16: tile-relative origin, k rows
 	DevBuf      coef_row;          // T[n_row][8]
-	DevBuf      coef_blk;          // T[n_blk][36]
+	DevBuf      coef_blk;          // T[n_blk][8][8]
 	int64_t     n_row = 0, n_blk = 0;          // records (cells on tile borders are listed more than once)
 	int64_t     cells_row = 0, cells_blk = 0;  // distinct cells of each kind
 };

@@ -341,7 +341,7 @@ double apply_algorithmic_bytes(const fi_ctx* c)
 	                       2.0 * static_cast<double>(c->generic.nnz) * (4.0 + s);    // generic rows: CSR + CSC pass
 	if (c->march.valid && c->march.fused) {
 		return lattice + static_cast<double>(c->march.cells_row) * (4.0 + s * 8.0) +
-		       static_cast<double>(c->march.cells_blk) * (4.0 + s * 36.0);
+		       static_cast<double>(c->march.cells_blk) * (4.0 + s * 36.0);  // a multi-row cell at its packed-block size
 	}
 	return lattice + static_cast<double>(c->cells.ncell) * (4.0 + s * static_cast<double>(c->cells.nb));
 }

@@ -78,7 +78,7 @@ struct CellLists {
 	const uint32_t* pos_row;   // (tcx+1) | (tcy+1)<<16
 	const uint32_t* pos_blk;
 	const void*     coef_row;  // T[n_row][8]
-	const void*     coef_blk;  // T[n_blk][36]
+	const void*     coef_blk;  // T[n_blk][8][8]: up to 8 factor rows per multi-row cell
 };
 
 __device__ inline double wave_sum(double v)
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 		}
 	};
 	auto row_apply = [&](uint32_t pos, const T* a, int buf_lo, int buf_hi) {
-		const int tcx = static_cast<int>(pos & 0xFFFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
+		const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
 		T xv[8];
 		corners(tcx, tcy, buf_lo, buf_hi, xv);
 		T t = T(0);
@@ -274,27 +274,47 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 			load_row(r, &pos, a);
 			row_apply(pos, a, buf_lo, buf_hi);
 		}
-		const T* blk = static_cast<const T*>(L.coef_blk);
+		const T* multi = static_cast<const T*>(L.coef_blk);
 		for (uint32_t r = rsB + threadIdx.x; r < reB; r += kThreads) {
 			const uint32_t pos = L.pos_blk[r];
-			const int tcx = static_cast<int>(pos & 0xFFFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
-			T b[36];
-			const V* bp = reinterpret_cast<const V*>(blk + static_cast<int64_t>(r) * 36);
-#pragma unroll
-			for (int k = 0; k < 36 / VX; ++k) {
-				const V    v  = bp[k];
-				const T*   pv = reinterpret_cast<const T*>(&v);
-#pragma unroll
-				for (int j = 0; j < VX; ++j) { b[k * VX + j] = pv[j]; }
-			}
+			const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
+			const int nrows = static_cast<int>((pos >> 8) & 0xFFu);
 			T xv[8], out[8];
 			corners(tcx, tcy, buf_lo, buf_hi, xv);
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				T s = T(0);
+			for (int i = 0; i < 8; ++i) { out[i] = T(0); }
+			const V* ap = reinterpret_cast<const V*>(multi + static_cast<int64_t>(r) * 64);
+			if (sizeof(T) == 8 && nrows == 0xFF) {  // fp64: the packed symmetric block, out = B x
+				T b[36];
 #pragma unroll
-				for (int j = 0; j < 8; ++j) { s += b[i <= j ? tri(i, j) : tri(j, i)] * xv[j]; }
-				out[i] = s;
+				for (int k = 0; k < 36 / VX; ++k) {
+					const V  w  = ap[k];
+					const T* pw = reinterpret_cast<const T*>(&w);
+#pragma unroll
+					for (int j = 0; j < VX; ++j) { b[k * VX + j] = pw[j]; }
+				}
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+#pragma unroll
+					for (int j = 0; j < 8; ++j) { out[i] += b[i <= j ? tri(i, j) : tri(j, i)] * xv[j]; }
+				}
+				put8(tcx, tcy, out);
+				continue;
+			}
+			for (int k = 0; k < nrows; ++k) {  // the cell's factor rows, one after another: out += a (a.x)
+				T a[8];
+#pragma unroll
+				for (int v = 0; v < 8 / VX; ++v) {
+					const V  w  = ap[k * (8 / VX) + v];
+					const T* pw = reinterpret_cast<const T*>(&w);
+#pragma unroll
+					for (int j = 0; j < VX; ++j) { a[v * VX + j] = pw[j]; }
+				}
+				T t = T(0);
+#pragma unroll
+				for (int q = 0; q < 8; ++q) { t += a[q] * xv[q]; }
+#pragma unroll
+				for (int i = 0; i < 8; ++i) { out[i] += a[i] * t; }
 			}
 			put8(tcx, tcy, out);
 		}
@@ -637,7 +657,8 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_t n_all,
                                                             const uint32_t* __restrict__ slot_sorted,
                                                             const uint32_t* __restrict__ pos,
-                                                            const T* __restrict__ row1, const T* __restrict__ blk,
+                                                            const T* __restrict__ row1, const T* __restrict__ mrow,
+                                                            const uint32_t* __restrict__ nfac,
                                                             uint32_t* __restrict__ pos_row, uint32_t* __restrict__ pos_blk,
                                                             T* __restrict__ coef_row, T* __restrict__ coef_blk)
 {
@@ -654,12 +675,13 @@ __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_
 #pragma unroll
 		for (int k = 0; k < 8 / VX; ++k) { dst[k] = src[k]; }
 	} else {
-		const int64_t j = i - n_row;
-		pos_blk[j] = pos[slot];
-		const V* src = reinterpret_cast<const V*>(blk + c * 36);
-		V*       dst = reinterpret_cast<V*>(coef_blk + j * 36);
-#pragma unroll
-		for (int k = 0; k < 36 / VX; ++k) { dst[k] = src[k]; }
+		const int64_t  j = i - n_row;
+		const uint32_t k = nfac[c];
+		pos_blk[j] = pos[slot] | (k << 8);
+		const V* src = reinterpret_cast<const V*>(mrow + c * 64);
+		V*       dst = reinterpret_cast<V*>(coef_blk + j * 64);
+		const uint32_t nvec = (k == 0xFFu ? 36u : k * 8u) / VX;  // 255: the packed block (fp64 contexts)
+		for (uint32_t r = 0; r < nvec; ++r) { dst[r] = src[r]; }
 	}
 }
 
@@ -803,13 +825,13 @@ void build_cell_lists(fi_ctx* c)
 	m.pos_row.alloc(sizeof(uint32_t) * (m.n_row + 1));
 	m.pos_blk.alloc(sizeof(uint32_t) * (m.n_blk + 1));
 	m.coef_row.alloc(sizeof(T) * 8 * (m.n_row + 1));
-	m.coef_blk.alloc(sizeof(T) * 36 * (m.n_blk + 1));
+	m.coef_blk.alloc(sizeof(T) * 64 * (m.n_blk + 1));
 	const int64_t n_all = m.n_row + m.n_blk;
 	if (n_all > 0) {
 		hipLaunchKernelGGL((k_cell_records<T>), dim3(static_cast<int>((n_all + kThreads - 1) / kThreads)), dim3(kThreads), 0,
 		                   st, m.n_row, n_all, slot_sorted.as<uint32_t>(), pos.as<uint32_t>(), c->cells.row1.as<T>(),
-		                   c->cells.blk.as<T>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(),
-		                   m.coef_blk.as<T>());
+		                   c->cells.mrow.as<T>(), c->cells.nfac.as<uint32_t>(), m.pos_row.as<uint32_t>(),
+		                   m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(), m.coef_blk.as<T>());
 	}
 	FI_HIP_TRY(hipGetLastError());
 }

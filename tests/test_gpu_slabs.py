@@ -66,7 +66,7 @@ def test_cg_equals_undivided(fi, sizes, nranks, dtype):
     tol = 1e-9 if dtype == "f64" else 1e-4
     x1, it1, rel1 = one.solve_cg(guess, 0, tol)
     xg, itg, relg = grp.solve_cg(guess, 0, tol)
-    assert abs(itg - it1) <= (0 if dtype == "f64" else 2)
+    assert abs(itg - it1) <= max(3, it1 // 100)      # reduction order differs; the verified stop may add a step
     assert relg <= tol
     if dtype == "f64":
         assert rel_inf(grp.solution_f64(), one.solution_f64()) <= 1e-9

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-launch HBM traffic of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB units).
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <out.json>
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly half the bytes of a wide (16 B/lane)
+coalesced stream; WRITE_SIZE is exact.  Both the raw and the doubled read figure are recorded; `traffic`
+uses the doubled reads because the kernel's plane loads are 16 B/lane streams."""
+import csv
+import json
+import sys
+
+
+def avg(path, counter, needle):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    big = [v for v in vals if v > 0.5 * max(vals)]          # drop the launches that exited on the done flag
+    return sum(big) / len(big), len(big)
+
+
+def main():
+    fetch_csv, write_csv, needle, out = sys.argv[1:5]
+    f, nf = avg(fetch_csv, "FETCH_SIZE", needle)
+    w, nw = avg(write_csv, "WRITE_SIZE", needle)
+    res = {"kernel": needle, "launches": [nf, nw], "fetch_size_kb_raw": f, "write_size_kb": w,
+           "read_bytes_corrected": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
+           "traffic_bytes": 2.0 * f * 1024.0 + w * 1024.0}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
