@@ -63,13 +63,16 @@ def test_cg_equals_undivided(fi, sizes, nranks, dtype):
     w = fi.Weights(model_1=0.1)
     one, grp = _pair(fi, sizes, nranks, w, pos, nrm, None, None, dtype)
     guess = rng.normal(size=int(np.prod(sizes))).astype(np.float32)
+    # the same recurrence, step for step: 25 iterations from the same guess give the same iterate
+    x1, it1, _ = one.solve_cg(guess, 25, 1e-30)
+    xg, itg, _ = grp.solve_cg(guess, 25, 1e-30)
+    assert it1 == itg == 25
+    assert rel_inf(grp.solution_f64(), one.solution_f64()) <= (1e-9 if dtype == "f64" else 2e-4)
+    # and to convergence: both meet the tolerance (verified against b - A x), the solutions agree
     tol = 1e-9 if dtype == "f64" else 1e-4
     x1, it1, rel1 = one.solve_cg(guess, 0, tol)
     xg, itg, relg = grp.solve_cg(guess, 0, tol)
-    assert abs(itg - it1) <= max(3, it1 // 100)      # reduction order differs; the verified stop may add a step
-    assert relg <= tol
-    if dtype == "f64":
-        assert rel_inf(grp.solution_f64(), one.solution_f64()) <= 1e-9
-        assert grp.true_residual() <= tol * 1.01 and one.true_residual() <= tol * 1.01
-    else:
-        assert rel_inf(xg, x1) <= 5e-3
+    assert abs(itg - it1) <= max(3, it1 // 50)       # reduction order differs; the verified stop may add steps
+    assert relg <= tol and rel1 <= tol
+    assert grp.true_residual() <= tol * 1.01 and one.true_residual() <= tol * 1.01
+    assert rel_inf(grp.solution_f64(), one.solution_f64()) <= (1e-5 if dtype == "f64" else 2e-2)
