@@ -45,7 +45,8 @@ class FiStats(C.Structure):
                 ("num_generic_rows", C.c_long), ("iterations", C.c_int), ("converged", C.c_int),
                 ("rel_residual", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
                 ("spmv_ms_avg", C.c_double), ("spmv_samples", C.c_int), ("spmv_bytes", C.c_double),
-                ("restarts", C.c_int), ("verified_residual", C.c_double)]
+                ("restarts", C.c_int), ("verified_residual", C.c_double),
+                ("num_levels", C.c_int), ("coarse_iterations", C.c_int)]
 
 
 class FiError(RuntimeError):

@@ -253,6 +253,14 @@ class LatticeField:
         left it above the tolerance; False stops on the recurrence residual alone, like the reference."""
         check(_capi.lib().fi_set_option(self._h, 1, 1.0 if on else 0.0))
 
+    def set_levels(self, levels, coarse_tolerance=None):
+        """FI_OPT_LEVELS: build `levels` coarser replicas at the next assemble; solve_cg(guess=None) then starts
+        from a coarse-to-fine cascade (src/sdf_field.cpp:272-288 generalised, on the device)."""
+        check(_capi.lib().fi_set_option(self._h, 2, float(levels)))
+        if coarse_tolerance is not None:
+            check(_capi.lib().fi_set_option(self._h, 3, float(coarse_tolerance)))
+        self._dirty = True
+
     def jacobi(self, guess, num_iterations, weight):
         self._ready()
         g, kg, _kg = _buf(guess)

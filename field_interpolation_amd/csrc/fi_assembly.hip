@@ -39,6 +39,7 @@ struct EmitArgs {
 	int   vk, gk;
 	int   has_nrm, has_pw, has_val;
 	uint32_t invalid_key;
+	float pos_scale, nrm_scale;  // 1 on the caller's lattice; 1/2^l and 2^l on coarser levels
 };
 
 // Extended local cell id of the cell with GLOBAL origin c[] (origins run from -1), or invalid when the
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 	float p[D];
 	bool  finite = true;
 	for (int d = 0; d < D; ++d) {
-		p[d]   = pos[i * D + d];
+		p[d]   = pos[i * D + d] * a.pos_scale;
 		finite = finite && isfinite(p[d]);
 	}
 	const float w     = a.has_pw ? pw[i] : 1.0f;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 						continue;
 					}
 					const int q = static_cast<int>(r);
-					along += (p[d] - static_cast<float>(q)) * nrm[i * D + d];
+					along += (p[d] - static_cast<float>(q)) * (nrm[i * D + d] * a.nrm_scale);
 					// the nearest point is a corner of the (extended) cell floor(pos)
 					int base = static_cast<int>(floorf(p[d]));
 					if (base < -1) { base = -1; }
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 		for (int q = 0; q < NC; ++q) { c[q] = 0.0f; }
 		if (a.has_nrm) {
 			const float cw = w * a.gw;
-			const float gd = nrm[i * D + d];
+			const float gd = nrm[i * D + d] * a.nrm_scale;
 			if (cw != 0.0f && cell_valid) {
 				if (a.gk == FI_GRADIENT_NEAREST_NEIGHBOR) {
 					// field_interpolation.cpp:134-149: [-1, +1]*cw on the cell edge along d.
@@ -337,7 +338,7 @@ inline int blocks_for(long n) { return static_cast<int>((n + kThreads - 1) / kTh
 
 template <int D>
 void emit_rows_dim(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val, float vw,
-                   int vk, float gw, int gk)
+                   int vk, float gw, int gk, float pos_scale, float nrm_scale)
 {
 	constexpr int NC = 1 << D;
 	Pending* pb = nullptr;
@@ -361,6 +362,8 @@ void emit_rows_dim(fi_ctx* c, long n, const float* pos, const float* nrm, const 
 	a.has_nrm = nrm != nullptr;
 	a.has_pw  = pw != nullptr;
 	a.has_val = val != nullptr;
+	a.pos_scale = pos_scale;
+	a.nrm_scale = nrm_scale;
 	a.invalid_key = static_cast<uint32_t>(static_cast<int64_t>(c->g.cn[0]) * c->g.cn[1] * c->g.cn[2]);
 	if (n > 0) {
 		hipLaunchKernelGGL(k_emit_rows<D>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, a, n, pos, nrm, pw, val,
@@ -505,12 +508,12 @@ void assemble_dim(fi_ctx* c)
 }  // namespace
 
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val, float vw,
-                     int vk, float gw, int gk)
+                     int vk, float gw, int gk, float pos_scale, float nrm_scale)
 {
 	switch (c->g.ndim) {
-	case 1: emit_rows_dim<1>(c, n, pos, nrm, pw, val, vw, vk, gw, gk); break;
-	case 2: emit_rows_dim<2>(c, n, pos, nrm, pw, val, vw, vk, gw, gk); break;
-	default: emit_rows_dim<3>(c, n, pos, nrm, pw, val, vw, vk, gw, gk); break;
+	case 1: emit_rows_dim<1>(c, n, pos, nrm, pw, val, vw, vk, gw, gk, pos_scale, nrm_scale); break;
+	case 2: emit_rows_dim<2>(c, n, pos, nrm, pw, val, vw, vk, gw, gk, pos_scale, nrm_scale); break;
+	default: emit_rows_dim<3>(c, n, pos, nrm, pw, val, vw, vk, gw, gk, pos_scale, nrm_scale); break;
 	}
 }
 

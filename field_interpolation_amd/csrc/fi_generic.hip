@@ -78,6 +78,7 @@ template <int D>
 __global__ __launch_bounds__(kThreads) void k_emit_gradient_linear(Geom g, long n, const float* __restrict__ pos,
                                                                     const float* __restrict__ nrm,
                                                                     const float* __restrict__ pw, float gw,
+                                                                    float pos_scale, float nrm_scale,
                                                                     uint32_t row_offset, uint64_t* __restrict__ key,
                                                                     float* __restrict__ val, float* __restrict__ rhs)
 {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_gradient_linear(Geom g, long 
 	float t[D];
 	bool  finite = true;
 	for (int d = 0; d < D; ++d) {
-		const float p  = pos[i * D + d] - 0.5f;
+		const float p  = pos[i * D + d] * pos_scale - 0.5f;
 		finite = finite && isfinite(p);
 		const float fl = floorf(p);
 		const bool  in = fl >= -1.0f && fl <= static_cast<float>(g.gn[d]);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_gradient_linear(Geom g, long 
 			key[o + 2 * k + 1] = (static_cast<uint64_t>(row) << 32) | c1;
 			val[o + 2 * k + 1] = c;
 		}
-		rhs[static_cast<long>(row)] = sum * nrm[i * D + d];
+		rhs[static_cast<long>(row)] = sum * (nrm[i * D + d] * nrm_scale);
 	}
 }
 
@@ -288,7 +289,8 @@ void generic_add_coo(fi_ctx* c, int64_t nrows, int64_t ntrip, const fi_triplet* 
 	G.nrows += nrows;
 }
 
-void generic_add_gradient_linear(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, float gw)
+void generic_add_gradient_linear(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, float gw,
+                                 float pos_scale, float nrm_scale)
 {
 	GenericRows& G = c->generic;
 	const int    D  = c->g.ndim;
@@ -301,15 +303,15 @@ void generic_add_gradient_linear(fi_ctx* c, long n, const float* pos, const floa
 	switch (D) {
 	case 1:
 		hipLaunchKernelGGL(k_emit_gradient_linear<1>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, n, pos, nrm,
-		                   pw, gw, off, key, val, G.rhs.as<float>());
+		                   pw, gw, pos_scale, nrm_scale, off, key, val, G.rhs.as<float>());
 		break;
 	case 2:
 		hipLaunchKernelGGL(k_emit_gradient_linear<2>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, n, pos, nrm,
-		                   pw, gw, off, key, val, G.rhs.as<float>());
+		                   pw, gw, pos_scale, nrm_scale, off, key, val, G.rhs.as<float>());
 		break;
 	default:
 		hipLaunchKernelGGL(k_emit_gradient_linear<3>, dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, n, pos, nrm,
-		                   pw, gw, off, key, val, G.rhs.as<float>());
+		                   pw, gw, pos_scale, nrm_scale, off, key, val, G.rhs.as<float>());
 		break;
 	}
 	FI_HIP_TRY(hipGetLastError());

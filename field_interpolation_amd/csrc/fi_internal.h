@@ -153,6 +153,16 @@ struct Pending {  // one fi_add_points batch, already turned into cell rows on t
 	DevBuf  rhs;        // float[nrows]
 };
 
+// The caller's points of one fi_add_points call, kept on the device so that coarser levels of the same
+// problem (multilevel solve) can be assembled from them without another upload.
+struct PointBatch {
+	long   n = 0;
+	DevBuf pos, nrm, pw, val;  // float; nrm/pw/val may be empty
+	bool   has_nrm = false, has_pw = false, has_val = false;
+	float  vw = 0, gw = 0;
+	int    vk = 0, gk = 0;
+};
+
 struct Comm;  // RCCL state (fi_comm.cpp)
 
 struct CgScalars {  // lives in device memory; kernels read/write it, the host polls it
@@ -178,6 +188,14 @@ struct fi_ctx {
 
 	std::vector<fi::Pending*> pending;
 	std::vector<fi::Pending*> pending_pool;  // buffers of cleared batches, reused by the next fi_add_points
+	std::vector<fi::PointBatch*> batches, batches_pool;  // the points themselves (for coarser levels)
+
+	// multilevel: coarser replicas of this problem (lattice halved per level), owned by the finest context
+	int        levels_wanted = 0;
+	double     coarse_tol = 1e-3;
+	fi_ctx*    coarse = nullptr;   // next coarser level
+	fi_ctx*    finer = nullptr;
+	int        level = 0;
 	fi::CellData              cells;
 	fi::MarchState            march;
 	fi::GenericRows           generic;
@@ -220,15 +238,17 @@ bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
 
 // fi_generic.hip
 void generic_add_coo(fi_ctx* c, int64_t nrows, int64_t ntrip, const fi_triplet* trip, const float* rhs, int memory);
-void generic_add_gradient_linear(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, float gw);
+void generic_add_gradient_linear(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, float gw,
+                                 float pos_scale = 1.0f, float nrm_scale = 1.0f);
 void generic_clear(fi_ctx* c);
 void generic_assemble(fi_ctx* c);                      // after assemble(): adds A^T b and diag, builds CSR/CSC
 int  generic_num_partials(const fi_ctx* c);
 void generic_apply(fi_ctx* c, const void* x, void* y, double* partial);  // y += A^T (A x)
 
 // fi_assembly.hip
+// positions are multiplied by pos_scale and normals by nrm_scale before use (coarser levels: 1/2^l and 2^l)
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val,
-                     float vw, int vk, float gw, int gk);
+                     float vw, int vk, float gw, int gk, float pos_scale = 1.0f, float nrm_scale = 1.0f);
 void assemble(fi_ctx* c);
 
 // fi_comm.cpp

@@ -405,6 +405,45 @@ __global__ __launch_bounds__(kThreads) void k_upscale(UpscaleArgs a, int64_t nla
 	out[li] = (wsum == 0.0f) ? 0.0f : fsum / wsum;
 }
 
+// Coarse -> fine interpolation between two levels of the multilevel hierarchy: fine point 2i coincides with
+// coarse point i, odd fine points take the mean of their two coarse neighbours (the last one copies when the
+// neighbour does not exist).  One thread per fine point; mode 0: fine = P coarse, mode 1: fine += P coarse.
+struct LevelPair {
+	int ndim;
+	int nf[3], nc[3];
+};
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, int64_t nfine, const T* __restrict__ coarse,
+                                                       T* __restrict__ fine, int mode)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= nfine) { return; }
+	int     c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+	T       w1[3] = {T(0), T(0), T(0)};
+	int64_t rest = i;
+	for (int d = 0; d < L.ndim; ++d) {
+		const int f = static_cast<int>(rest % L.nf[d]);
+		rest /= L.nf[d];
+		c0[d] = f >> 1;
+		if (c0[d] > L.nc[d] - 1) { c0[d] = L.nc[d] - 1; }
+		c1[d] = (c0[d] + 1 < L.nc[d]) ? c0[d] + 1 : c0[d];
+		w1[d] = (f & 1) ? T(0.5) : T(0);
+	}
+	T acc = T(0);
+	for (int q = 0; q < (1 << L.ndim); ++q) {
+		T       w = T(1);
+		int64_t idx = 0, stride = 1;
+		for (int d = 0; d < L.ndim; ++d) {
+			const int up = (q >> d) & 1;
+			w *= up ? w1[d] : T(1) - w1[d];
+			idx += stride * (up ? c1[d] : c0[d]);
+			stride *= L.nc[d];
+		}
+		acc += w * coarse[idx];
+	}
+	fine[i] = mode ? fine[i] + acc : acc;
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 
 void compute_geom(fi_ctx* c, int ndim, const int* sizes)
@@ -760,12 +799,51 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
 }
 
+// Coarse-to-fine start (the reference's own remedy for large lattices: solve a coarser lattice, upscale, use
+// as the guess -- src/sdf_field.cpp:272-288, README.md "My resolution is huge"): every coarser level is
+// solved from the interpolated solution of the level below it, to a loose tolerance; x of `c` receives the
+// interpolated guess.  All on the device.
+template <typename T>
+void cascade_guess(fi_ctx* c)
+{
+	std::vector<fi_ctx*> chain;
+	for (fi_ctx* l = c; l; l = l->coarse) { chain.push_back(l); }
+	for (fi_ctx* l : chain) { ensure_vectors(l); }
+	fi_ctx* bottom = chain.back();
+	FI_HIP_TRY(hipMemsetAsync(bottom->x.p, 0, sizeof(T) * bottom->g.nloc, bottom->stream));
+	for (size_t k = chain.size(); k-- > 1;) {
+		fi_ctx* lc = chain[k];
+		fi_ctx* lf = chain[k - 1];
+		RankSet R{lc};
+		try {
+			cg_run<T>(R, 0, static_cast<float>(c->coarse_tol));
+		} catch (const Fail& f) {
+			if (f.code != FI_ERR_BREAKDOWN) { throw; }  // a coarse level without data: keep what it has
+		}
+		c->stats.coarse_iterations += lc->stats.iterations;
+		LevelPair L{};
+		L.ndim = lf->g.ndim;
+		for (int d = 0; d < 3; ++d) {
+			L.nf[d] = lf->g.gn[d];
+			L.nc[d] = lc->g.gn[d];
+		}
+		hipLaunchKernelGGL((k_prolong<T>), dim3(blocks_for(lf->g.nown)), dim3(kThreads), 0, lf->stream, L, lf->g.nown,
+		                   lc->x.as<T>(), lf->x.as<T>(), 0);
+		FI_HIP_TRY(hipGetLastError());
+	}
+}
+
 template <typename T>
 void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
                 float* rel_residual, int memory)
 {
 	ensure_vectors(c);
-	load_owned<T>(c, c->x, guess, memory);
+	c->stats.coarse_iterations = 0;
+	if (!guess && c->coarse && c->nranks == 1) {
+		cascade_guess<T>(c);
+	} else {
+		load_owned<T>(c, c->x, guess, memory);
+	}
 	RankSet R{c};
 	struct Report {
 		fi_ctx* c; int* it; float* rel;
@@ -887,6 +965,100 @@ void get_vec_f64_t(fi_ctx* c, const DevBuf& v, double* out)
 	FI_HIP_TRY(hipStreamSynchronize(c->stream));
 }
 
+fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks);
+
+// Coarser replicas of the assembled problem, each with the lattice halved (fine point 2i <-> coarse point i):
+//   * model weights rescaled so that the smoothness energy stays the same functional of the field: a k-th
+//     difference on the coarse lattice is 2^k times the fine one and there are 2^D times fewer rows, hence
+//     w_k,coarse^2 = w_k^2 * 2^D / 4^k  (gradient_smoothness like k = 2);
+//   * the same data points, positions halved; gradients double in coarse lattice units and their rows get
+//     half the weight (value rows keep theirs).
+// Levels stop when an axis would drop below 8 points.  Hand-built rows (fi_add_rows_coo) have no geometry to
+// coarsen: contexts holding them stay single-level.
+void build_levels(fi_ctx* c)
+{
+	if (c->level != 0) { return; }
+	bool wanted = c->levels_wanted > 0 && c->nranks == 1;
+	if (wanted && c->generic.ntrip > 0) {
+		// generic rows that came from points (gradient kLinearInterpolation) can be re-emitted; hand-built ones cannot
+		long from_points = 0;
+		for (auto* b : c->batches) {
+			if (b->has_nrm && b->gk == FI_GRADIENT_LINEAR_INTERPOLATION && b->gw != 0.0f) { from_points += b->n * c->g.ndim; }
+		}
+		wanted = from_points == c->generic.nrows;
+	}
+	if (!wanted) {
+		if (c->coarse) {
+			fi_ctx_destroy(c->coarse);
+			c->coarse = nullptr;
+		}
+		return;
+	}
+	fi_ctx* fine = c;
+	const int D = c->g.ndim;
+	for (int l = 1; l <= c->levels_wanted; ++l) {
+		int sizes[3] = {1, 1, 1};
+		bool ok = true;
+		for (int d = 0; d < D; ++d) {
+			sizes[d] = (fine->g.gn[d] + 1) / 2;
+			ok = ok && sizes[d] >= 8;
+		}
+		if (!ok) { break; }
+		fi_ctx* co = fine->coarse;
+		if (co && (co->g.gn[0] != sizes[0] || co->g.gn[1] != sizes[1] || co->g.gn[2] != sizes[2] || co->dtype != c->dtype)) {
+			fi_ctx_destroy(co);
+			co = nullptr;
+		}
+		if (co) {  // same shape as last time: keep its HBM, drop its rows
+			for (auto* pb : co->pending) { co->pending_pool.push_back(pb); }
+			co->pending.clear();
+			generic_clear(co);
+		} else {
+			co = create_ctx(D, sizes, c->dtype, 0, 1);
+			(void)hipStreamDestroy(co->stream);
+			co->stream      = c->stream;
+			co->owns_stream = false;
+			co->level       = l;
+			co->finer       = fine;
+			co->verify_residual = 0;
+			fine->coarse    = co;
+		}
+		const float vol = static_cast<float>(1 << D);
+		fi_weights w = fine->w;
+		w.model_0 = fine->w.model_0 * std::sqrt(vol);
+		w.model_1 = fine->w.model_1 * std::sqrt(vol / 4.0f);
+		w.model_2 = fine->w.model_2 * std::sqrt(vol / 16.0f);
+		w.model_3 = fine->w.model_3 * std::sqrt(vol / 64.0f);
+		w.model_4 = fine->w.model_4 * std::sqrt(vol / 256.0f);
+		w.gradient_smoothness = fine->w.gradient_smoothness * std::sqrt(vol / 16.0f);
+		co->w = w;
+		const float ps = 1.0f / static_cast<float>(1 << l), ns = static_cast<float>(1 << l);
+		for (auto* b : c->batches) {
+			const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
+			const float* pw  = b->has_pw ? b->pw.as<float>() : nullptr;
+			const float* val = b->has_val ? b->val.as<float>() : nullptr;
+			const bool   lin = nrm && b->gk == FI_GRADIENT_LINEAR_INTERPOLATION;
+			emit_point_rows(co, b->n, b->pos.as<float>(), nrm, pw, val, b->vw, b->vk, lin ? 0.0f : b->gw * ps,
+			                lin ? FI_GRADIENT_CELL_EDGES : b->gk, ps, ns);
+			if (lin && b->gw != 0.0f) {
+				generic_add_gradient_linear(co, b->n, b->pos.as<float>(), nrm, pw, b->gw * ps, ps, ns);
+			}
+		}
+		assemble(co);
+		generic_assemble(co);
+		stencil_prepare(co);
+		operator_prepare(co);
+		co->assembled = true;
+		co->vectors_ready = co->vectors_ready && co->max_blocks >= apply_num_partials(co);
+		co->stats.num_unknowns = co->g.nown;
+		fine = co;
+	}
+	if (fine->coarse) {  // deeper levels left over from an earlier, larger request
+		fi_ctx_destroy(fine->coarse);
+		fine->coarse = nullptr;
+	}
+}
+
 void check_ctx(const fi_ctx* c) { FI_REQUIRE(c != nullptr, FI_ERR_INVALID, "null context"); }
 
 void check_assembled(const fi_ctx* c)
@@ -993,6 +1165,9 @@ int fi_ctx_destroy(fi_ctx* c)
 	if (c->stream) { (void)hipStreamSynchronize(c->stream); }
 	for (auto* pb : c->pending) { delete pb; }
 	for (auto* pb : c->pending_pool) { delete pb; }
+	for (auto* b : c->batches) { delete b; }
+	for (auto* b : c->batches_pool) { delete b; }
+	if (c->coarse) { fi_ctx_destroy(c->coarse); }
 	c->pending.clear();
 	c->pending_pool.clear();
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
@@ -1077,6 +1252,31 @@ int fi_add_points(fi_ctx* c, long n, const float* positions, const float* normal
 		w = up(dpw, point_weights, static_cast<size_t>(n));
 		v = up(dval, values, static_cast<size_t>(n));
 	}
+	{   // keep the points on the device: coarser levels of a multilevel solve are assembled from them
+		fi::PointBatch* b = nullptr;
+		if (!c->batches_pool.empty()) {
+			b = c->batches_pool.back();
+			c->batches_pool.pop_back();
+		} else {
+			b = new fi::PointBatch();
+		}
+		c->batches.push_back(b);
+		auto keep = [&](fi::DevBuf& dst, const float* src, size_t count) {
+			if (!src) { return false; }
+			dst.alloc(sizeof(float) * count);
+			FI_HIP_TRY(hipMemcpyAsync(dst.p, src, sizeof(float) * count, hipMemcpyDeviceToDevice, c->stream));
+			return true;
+		};
+		b->n = n;
+		keep(b->pos, p, static_cast<size_t>(n) * D);
+		b->has_nrm = keep(b->nrm, g, static_cast<size_t>(n) * D);
+		b->has_pw  = keep(b->pw, w, static_cast<size_t>(n));
+		b->has_val = keep(b->val, v, static_cast<size_t>(n));
+		b->vw = value_weight;
+		b->gw = gradient_weight;
+		b->vk = value_kernel;
+		b->gk = gradient_kernel;
+	}
 	const bool lin = g && gradient_kernel == FI_GRADIENT_LINEAR_INTERPOLATION;
 	// cell-local rows (value rows; gradient rows of the nearest-neighbour / cell-edge kernels) ...
 	fi::emit_point_rows(c, n, p, g, w, v, value_weight, value_kernel, lin ? 0.0f : gradient_weight,
@@ -1108,6 +1308,8 @@ int fi_clear_points(fi_ctx* c)
 	fi::check_ctx(c);
 	for (auto* pb : c->pending) { c->pending_pool.push_back(pb); }  // keep the HBM buffers for the next batch
 	c->pending.clear();
+	for (auto* b : c->batches) { c->batches_pool.push_back(b); }
+	c->batches.clear();
 	fi::generic_clear(c);
 	c->assembled = false;
 	FI_API_END
@@ -1140,6 +1342,7 @@ int fi_assemble(fi_ctx* c)
 	fi::generic_assemble(c);
 	fi::stencil_prepare(c);
 	fi::operator_prepare(c);
+	fi::build_levels(c);
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
@@ -1147,6 +1350,8 @@ int fi_assemble(fi_ctx* c)
 	(void)hipEventDestroy(e0);
 	(void)hipEventDestroy(e1);
 	c->stats.assemble_ms  = ms;
+	c->stats.num_levels   = 1;
+	for (fi_ctx* l = c->coarse; l; l = l->coarse) { c->stats.num_levels += 1; }
 	c->stats.num_unknowns = c->g.nown;
 	c->stats.spmv_bytes   = fi::apply_algorithmic_bytes(c);
 	c->assembled          = true;
@@ -1173,8 +1378,15 @@ int fi_set_option(fi_ctx* c, int option, double value)
 {
 	FI_API_BEGIN
 	fi::check_ctx(c);
-	FI_REQUIRE(option == FI_OPT_VERIFY_RESIDUAL, FI_ERR_INVALID, "unknown option %d", option);
-	c->verify_residual = value != 0.0;
+	switch (option) {
+	case FI_OPT_VERIFY_RESIDUAL: c->verify_residual = value != 0.0; break;
+	case FI_OPT_LEVELS:
+		c->levels_wanted = value > 0 ? static_cast<int>(value) : 0;
+		c->assembled = false;
+		break;
+	case FI_OPT_COARSE_TOLERANCE: c->coarse_tol = value > 0 ? value : 1e-3; break;
+	default: FI_REQUIRE(false, FI_ERR_INVALID, "unknown option %d", option);
+	}
 	FI_API_END
 }
 

@@ -91,6 +91,8 @@ typedef struct fi_stats {
 	double spmv_bytes;         /* algorithmic bytes of one AtA apply */
 	int    restarts;           /* residual replacements: b - A x was evaluated this many times at convergence */
 	double verified_residual;  /* ||b - A x||/||b|| at the last such evaluation (-1: none) */
+	int    num_levels;         /* 1 + coarser levels built by the last fi_assemble */
+	int    coarse_iterations;  /* CG iterations spent on coarser levels by the last solve (cascade start) */
 } fi_stats;
 
 const char* fi_last_error(void);
@@ -166,8 +168,15 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
 
 /* Solver options.  FI_OPT_VERIFY_RESIDUAL (default 1): when the recurrence residual meets the tolerance,
  * evaluate b - A x; if it misses the tolerance (fp32 drift) restart CG from it, at most 3 times.  0 gives
- * the reference's stop rule on the recurrence residual alone. */
+ * the reference's stop rule on the recurrence residual alone.
+ * FI_OPT_LEVELS (default 0): coarser replicas of the problem (lattice halved per level, weights rescaled,
+ * the same data points) built by fi_assemble; with guess == NULL, fi_solve_cg then starts from a coarse-to-fine
+ * cascade (each level solved to FI_OPT_COARSE_TOLERANCE, default 1e-3, and interpolated to the next) -- the
+ * reference's recipe for large lattices (src/sdf_field.cpp:272-288, README.md "My resolution is huge"),
+ * generalised to several levels and kept on the device. */
 #define FI_OPT_VERIFY_RESIDUAL 1
+#define FI_OPT_LEVELS 2
+#define FI_OPT_COARSE_TOLERANCE 3
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */
