@@ -261,6 +261,11 @@ class LatticeField:
             check(_capi.lib().fi_set_option(self._h, 3, float(coarse_tolerance)))
         self._dirty = True
 
+    def set_multigrid(self, on=True):
+        """FI_OPT_MULTIGRID: V-cycle preconditioned CG over the levels of set_levels()."""
+        check(_capi.lib().fi_set_option(self._h, 4, 1.0 if on else 0.0))
+        self._dirty = True
+
     def jacobi(self, guess, num_iterations, weight):
         self._ready()
         g, kg, _kg = _buf(guess)

@@ -204,6 +204,10 @@ struct fi_ctx {
 	fi::DevBuf atb, diag, dinv;
 	// solver vectors
 	fi::DevBuf x, r, p, q;
+	// multigrid work vectors of this level: V-cycle rhs / result, smoother residual and direction
+	fi::DevBuf mg_b, mg_x, mg_r, mg_d;
+	double     lambda_max = 0;    // estimate of the largest eigenvalue of Dinv * AtA on this level
+	int        mg_mode = 0;       // 0: Jacobi-PCG (+ cascade start when levels exist); 1: V-cycle preconditioned CG
 	fi::DevBuf partial;       // double[4 * max_blocks]
 	fi::DevBuf scal;          // CgScalars
 	fi::CgScalars* scal_host = nullptr;  // pinned

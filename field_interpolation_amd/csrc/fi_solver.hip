@@ -322,6 +322,15 @@ __global__ void k_set_done(CgScalars* sc, int value)
 	if (threadIdx.x == 0 && blockIdx.x == 0) { sc->done = value; }
 }
 
+__global__ void k_set_sum2(CgScalars* sc)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) { sc->sums[2] = sc->sums[0]; }
+}
+__global__ void k_bump_restarts(CgScalars* sc)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) { sc->restarts += 1; sc->done = 0; }
+}
+
 __global__ void k_cg_logic(CgScalars* sc, int phase)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) { cg_logic(sc, phase); }
@@ -416,33 +425,35 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, int64_t nfine, const T* __restrict__ coarse,
                                                        T* __restrict__ fine, int mode)
 {
-	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-	if (i >= nfine) { return; }
-	int     c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
-	T       w1[3] = {T(0), T(0), T(0)};
-	int64_t rest = i;
+	// grid: (x blocks, y, z) of the FINE lattice -- no integer division per point
+	const int fx = blockIdx.x * kThreads + threadIdx.x;
+	const int fy = blockIdx.y, fz = blockIdx.z;
+	if (fx >= L.nf[0]) { return; }
+	(void)nfine;
+	const int f[3] = {fx, fy, fz};
+	int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+	T   w1[3] = {T(0), T(0), T(0)};
 	for (int d = 0; d < L.ndim; ++d) {
-		const int f = static_cast<int>(rest % L.nf[d]);
-		rest /= L.nf[d];
-		c0[d] = f >> 1;
+		c0[d] = f[d] >> 1;
 		if (c0[d] > L.nc[d] - 1) { c0[d] = L.nc[d] - 1; }
 		c1[d] = (c0[d] + 1 < L.nc[d]) ? c0[d] + 1 : c0[d];
-		w1[d] = (f & 1) ? T(0.5) : T(0);
+		w1[d] = (f[d] & 1) ? T(0.5) : T(0);
 	}
+	const int sy = L.nc[0], sz = L.nc[0] * L.nc[1];
 	T acc = T(0);
 	for (int q = 0; q < (1 << L.ndim); ++q) {
-		T       w = T(1);
-		int64_t idx = 0, stride = 1;
-		for (int d = 0; d < L.ndim; ++d) {
-			const int up = (q >> d) & 1;
-			w *= up ? w1[d] : T(1) - w1[d];
-			idx += stride * (up ? c1[d] : c0[d]);
-			stride *= L.nc[d];
-		}
-		acc += w * coarse[idx];
+		const int ux = q & 1, uy = (q >> 1) & 1, uz = (q >> 2) & 1;
+		T w = ux ? w1[0] : T(1) - w1[0];
+		int idx = ux ? c1[0] : c0[0];
+		if (L.ndim > 1) { w *= uy ? w1[1] : T(1) - w1[1]; idx += sy * (uy ? c1[1] : c0[1]); }
+		if (L.ndim > 2) { w *= uz ? w1[2] : T(1) - w1[2]; idx += sz * (uz ? c1[2] : c0[2]); }
+		if (w != T(0)) { acc += w * coarse[idx]; }
 	}
+	const int64_t i = (static_cast<int64_t>(fz) * L.nf[1] + fy) * L.nf[0] + fx;
 	fine[i] = mode ? fine[i] + acc : acc;
 }
+
+inline dim3 lattice_grid(const int* n) { return dim3((n[0] + kThreads - 1) / kThreads, n[1], n[2]); }
 
 // ---- host side -------------------------------------------------------------------------------------
 
@@ -827,10 +838,454 @@ void cascade_guess(fi_ctx* c)
 			L.nf[d] = lf->g.gn[d];
 			L.nc[d] = lc->g.gn[d];
 		}
-		hipLaunchKernelGGL((k_prolong<T>), dim3(blocks_for(lf->g.nown)), dim3(kThreads), 0, lf->stream, L, lf->g.nown,
+		hipLaunchKernelGGL((k_prolong<T>), lattice_grid(L.nf), dim3(kThreads), 0, lf->stream, L, lf->g.nown,
 		                   lc->x.as<T>(), lf->x.as<T>(), 0);
 		FI_HIP_TRY(hipGetLastError());
 	}
+}
+
+
+// ---- multigrid V-cycle preconditioner ----------------------------------------------------------------
+// With FI_OPT_MULTIGRID the coarser replicas (build_levels) precondition CG on the finest level:
+//   z = V(r):  pre-smooth from zero, restrict the residual (R = P^T), recurse, interpolate and add, post-smooth.
+// Smoother: a degree-k Chebyshev polynomial in Dinv*AtA on [lambda_max/ratio, 1.1 lambda_max] -- only operator
+// applies and axpys, no dot products (nothing to all-reduce), and the same polynomial before and after the
+// coarse correction makes V symmetric positive definite, as CG needs.  lambda_max comes from 10 steps of the
+// power method per level at assemble time (one host read per level).
+
+// restriction = transpose of k_prolong: coarse point c gathers fine 2c (weight 1) and 2c-1, 2c+1 (weight 1/2;
+// the last coarse point also takes the full weight of a fine point beyond it)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, int64_t ncoarse, const T* __restrict__ fine,
+                                                        T* __restrict__ coarse)
+{
+	// grid: (x blocks, y, z) of the COARSE lattice
+	const int cx = blockIdx.x * kThreads + threadIdx.x;
+	const int cy = blockIdx.y, cz = blockIdx.z;
+	if (cx >= L.nc[0]) { return; }
+	(void)ncoarse;
+	const int c[3] = {cx, cy, cz};
+	int f[3][3];
+	T   w[3][3];
+	for (int d = 0; d < 3; ++d) {
+		for (int k = 0; k < 3; ++k) { f[d][k] = 0; w[d][k] = (k == 1) ? T(1) : T(0); }
+	}
+	for (int d = 0; d < L.ndim; ++d) {
+		for (int k = 0; k < 3; ++k) {
+			const int ff = 2 * c[d] + k - 1;
+			T ww = (k == 1) ? T(1) : T(0.5);
+			f[d][k] = ff;
+			if (ff < 0 || ff >= L.nf[d]) { ww = T(0); f[d][k] = 0; }
+			// fine point 2c+1 when coarse c+1 does not exist: P put all of it on c
+			if (k == 2 && c[d] + 1 >= L.nc[d] && ff < L.nf[d]) { ww = T(1); }
+			w[d][k] = ww;
+		}
+	}
+	const int sy = L.nf[0];
+	const int64_t sz = static_cast<int64_t>(L.nf[0]) * L.nf[1];
+	T acc = T(0);
+	const int n1 = L.ndim > 1 ? 3 : 1, n2 = L.ndim > 2 ? 3 : 1;
+	for (int k2 = 0; k2 < n2; ++k2) {
+		for (int k1 = 0; k1 < n1; ++k1) {
+			const T w12 = (L.ndim > 1 ? w[1][k1 + (n1 == 1)] : T(1)) * (L.ndim > 2 ? w[2][k2 + (n2 == 1)] : T(1));
+			if (w12 == T(0)) { continue; }
+			const int64_t base = (L.ndim > 1 ? static_cast<int64_t>(sy) * f[1][k1 + (n1 == 1)] : 0) +
+			                     (L.ndim > 2 ? sz * f[2][k2 + (n2 == 1)] : 0);
+#pragma unroll
+			for (int k0 = 0; k0 < 3; ++k0) {
+				if (w[0][k0] != T(0)) { acc += w[0][k0] * w12 * fine[base + f[0][k0]]; }
+			}
+		}
+	}
+	coarse[(static_cast<int64_t>(cz) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
+}
+
+// r = b - q (q may be null: r = b);  d = alpha * Dinv r;  x = zero_x ? d : x + d
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cheb_init(int64_t n, const T* __restrict__ b, const T* __restrict__ q,
+                                                         const T* __restrict__ dinv, T* __restrict__ r,
+                                                         T* __restrict__ d, T* __restrict__ x, T alpha, int zero_x)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T ri = q ? b[i] - q[i] : b[i];
+		const T di = alpha * dinv[i] * ri;
+		r[i] = ri;
+		d[i] = di;
+		x[i] = zero_x ? di : x[i] + di;
+	}
+}
+
+// r -= q;  d = c1 d + c2 Dinv r;  x += d
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cheb_iter(int64_t n, const T* __restrict__ q, const T* __restrict__ dinv,
+                                                         T* __restrict__ r, T* __restrict__ d, T* __restrict__ x, T c1,
+                                                         T c2)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T ri = r[i] - q[i];
+		const T di = c1 * d[i] + c2 * dinv[i] * ri;
+		r[i] = ri;
+		d[i] = di;
+		x[i] += di;
+	}
+}
+
+// r = b - q
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_sub(int64_t n, const T* __restrict__ b, const T* __restrict__ q,
+                                                   T* __restrict__ r)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		r[i] = b[i] - q[i];
+	}
+}
+
+// power method: v = Dinv q, partial of v.v
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_power_step(int64_t n, const T* __restrict__ q, const T* __restrict__ dinv,
+                                                          T* __restrict__ v, double* __restrict__ partial)
+{
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T w = dinv[i] * q[i];
+		v[i] = w;
+		acc[0] += static_cast<double>(w) * static_cast<double>(w);
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_seed(int64_t n, T* __restrict__ v)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		uint32_t h = static_cast<uint32_t>(i) * 2654435761u;
+		h ^= h >> 15;
+		h *= 2246822519u;
+		h ^= h >> 13;
+		v[i] = static_cast<T>(static_cast<double>(h & 0xFFFFu) / 65536.0 - 0.5);
+	}
+}
+
+// CG with a preconditioner: r -= alpha q, x += alpha p (p is still the direction of this step), partial r.r
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, const CgScalars* __restrict__ sc, const T* __restrict__ p,
+                                                       const T* __restrict__ q, T* __restrict__ x, T* __restrict__ r,
+                                                       double* __restrict__ partial)
+{
+	if (sc->done) { return; }
+	const T alpha = static_cast<T>(sc->alpha);
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += alpha * p[i];
+		const T ri = r[i] - alpha * q[i];
+		r[i] = ri;
+		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+
+// partial of a.b
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_dot(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                   double* __restrict__ partial)
+{
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		acc[0] += static_cast<double>(a[i]) * static_cast<double>(b[i]);
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+
+// p = z + beta p
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_mg_direction(int64_t n, const CgScalars* __restrict__ sc,
+                                                            const T* __restrict__ z, T* __restrict__ p, int first)
+{
+	const T beta = first ? T(0) : static_cast<T>(sc->beta);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		p[i] = z[i] + beta * p[i];
+	}
+}
+
+// scalar steps of the preconditioned recurrence (single block, thread 0)
+enum MgPhase { kMgInitRz = 10, kMgAlpha = 11, kMgResid = 12, kMgBeta = 13, kMgInitRr = 14 };
+__global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const double* __restrict__ partial, int count,
+                                                        int phase)
+{
+	if (sc->done && phase != kMgInitRr && phase != kMgInitRz) { return; }
+	double acc[1] = {0};
+	for (int i = threadIdx.x; i < count; i += kThreads) { acc[0] += partial[i]; }
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x != 0) { return; }
+	const double s = out[0];
+	switch (phase) {
+	case kMgInitRr:  // sums: r.r (partial 0) -- b.b was stored by the caller in sums[2]
+		sc->rr = s;
+		if (sc->bb == 0.0) { sc->bb = sc->sums[2]; sc->tol2 *= sc->bb; }
+		sc->done = 0;
+		if (sc->bb == 0.0) {
+			sc->done = 4;
+		} else if (!(sc->rr > sc->tol2)) {
+			sc->done = sc->restarts > 0 ? 5 : 1;
+		} else if (sc->iter >= sc->max_iter) {
+			sc->done = 3;
+		}
+		break;
+	case kMgInitRz: sc->rz = s; break;
+	case kMgAlpha:
+		sc->pq    = s;
+		sc->alpha = sc->rz / s;
+		if (!(s > 0.0) || !isfinite(s)) { sc->done = 2; }
+		break;
+	case kMgResid:
+		sc->rr = s;
+		sc->iter += 1;
+		if (!isfinite(s)) {
+			sc->done = 2;
+		} else if (!(s > sc->tol2)) {
+			sc->done = 1;
+		} else if (sc->iter >= sc->max_iter) {
+			sc->done = 3;
+		}
+		break;
+	case kMgBeta:
+		sc->beta = s / sc->rz;
+		sc->rz   = s;
+		break;
+	}
+}
+
+int mg_degree() { const char* e = getenv("FI_MG_DEGREE"); return e && atoi(e) > 0 ? atoi(e) : 2; }
+double mg_ratio() { const char* e = getenv("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : 10.0; }
+
+template <typename T>
+void mg_alloc(fi_ctx* c)
+{
+	ensure_vectors(c);
+	const size_t bytes = sizeof(T) * c->g.nloc;
+	c->mg_b.alloc(bytes);
+	c->mg_x.alloc(bytes);
+	c->mg_r.alloc(bytes);
+	c->mg_d.alloc(bytes);
+}
+
+// largest eigenvalue of Dinv*AtA by the power method (10 steps, unnormalised: growth <= 8^10, fine in fp32)
+template <typename T>
+void estimate_lambda(fi_ctx* c)
+{
+	mg_alloc<T>(c);
+	const int64_t n = c->g.nown;
+	const int nb = stream_blocks(n);
+	CgScalars init{};
+	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+	T* v = c->mg_d.as<T>();
+	hipLaunchKernelGGL((k_seed<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, v);
+	const int steps = 10;
+	for (int k = 0; k < steps; ++k) {
+		apply_AtA(c, v, c->q.p, nullptr);
+		hipLaunchKernelGGL((k_power_step<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, c->q.as<T>(), c->dinv.as<T>(), v,
+		                   c->partial.as<double>() + (k & 1) * nb);
+	}
+	std::vector<double> h(2 * nb);
+	FI_HIP_TRY(hipMemcpyAsync(h.data(), c->partial.p, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	double last = 0, prev = 0;
+	for (int i = 0; i < nb; ++i) {
+		last += h[((steps - 1) & 1) * nb + i];
+		prev += h[((steps - 2) & 1) * nb + i];
+	}
+	c->lambda_max = (prev > 0 && last > 0) ? std::sqrt(last / prev) : 2.0;
+}
+
+// degree-k Chebyshev smoothing of AtA x = b on [lmax/ratio, 1.1 lmax]; from_zero: x starts at 0
+template <typename T>
+void cheb_smooth(fi_ctx* c, const T* b, T* x, int degree, double ratio, bool from_zero)
+{
+	const int64_t n = c->g.nown;
+	const int nb = stream_blocks(n);
+	const double hi = 1.1 * c->lambda_max, lo = hi / ratio;
+	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	T* r = c->mg_r.as<T>();
+	T* d = c->mg_d.as<T>();
+	T* q = c->q.as<T>();
+	const T* dinv = c->dinv.as<T>();
+	if (!from_zero) { apply_AtA(c, x, q, nullptr); }
+	hipLaunchKernelGGL((k_cheb_init<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, b, from_zero ? static_cast<const T*>(nullptr) : q,
+	                   dinv, r, d, x, static_cast<T>(1.0 / theta), from_zero ? 1 : 0);
+	double rho = 1.0 / sigma;
+	for (int k = 1; k < degree; ++k) {
+		const double rho_new = 1.0 / (2.0 * sigma - rho);
+		apply_AtA(c, d, q, nullptr);
+		hipLaunchKernelGGL((k_cheb_iter<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, q, dinv, r, d, x,
+		                   static_cast<T>(rho_new * rho), static_cast<T>(2.0 * rho_new / delta));
+		rho = rho_new;
+	}
+}
+
+// x = V(b) on level c (single-rank, undivided lattice)
+template <typename T>
+void vcycle(fi_ctx* c, const T* b, T* x)
+{
+	const int deg = mg_degree();
+	const double ratio = mg_ratio();
+	if (!c->coarse) {  // coarsest level: a longer polynomial over a wider band
+		cheb_smooth<T>(c, b, x, 4 * deg + 4, 10.0 * ratio, true);
+		return;
+	}
+	fi_ctx* co = c->coarse;
+	const int64_t n = c->g.nown;
+	const int nb = stream_blocks(n);
+	cheb_smooth<T>(c, b, x, deg, ratio, true);
+	apply_AtA(c, x, c->q.p, nullptr);
+	hipLaunchKernelGGL((k_sub<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, b, c->q.as<T>(), c->mg_r.as<T>());
+	LevelPair L{};
+	L.ndim = c->g.ndim;
+	for (int d = 0; d < 3; ++d) {
+		L.nf[d] = c->g.gn[d];
+		L.nc[d] = co->g.gn[d];
+	}
+	hipLaunchKernelGGL((k_restrict<T>), lattice_grid(L.nc), dim3(kThreads), 0, c->stream, L, co->g.nown,
+	                   c->mg_r.as<T>(), co->mg_b.as<T>());
+	vcycle<T>(co, co->mg_b.as<T>(), co->mg_x.as<T>());
+	hipLaunchKernelGGL((k_prolong<T>), lattice_grid(L.nf), dim3(kThreads), 0, c->stream, L, n, co->mg_x.as<T>(), x, 1);
+	cheb_smooth<T>(c, b, x, deg, ratio, false);
+}
+
+// V-cycle preconditioned CG on the finest level; x holds the guess on entry
+template <typename T>
+void cg_run_mg(fi_ctx* c, int max_iterations, float tol)
+{
+	const Geom& g = c->g;
+	hipStream_t st = c->stream;
+	for (fi_ctx* l = c; l; l = l->coarse) {
+		mg_alloc<T>(l);
+		if (l != c) {  // the operator kernels of a level exit early while ITS stop flag is up: clear stale ones
+			CgScalars clear{};
+			FI_HIP_TRY(hipMemcpyAsync(l->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, st));
+		}
+	}
+	if (max_iterations <= 0) {
+		const int64_t dflt = 2 * static_cast<int64_t>(g.gn[0]) * g.gn[1] * g.gn[2];
+		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
+	}
+	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
+	hipEvent_t e0, e1;
+	FI_HIP_TRY(hipEventCreate(&e0));
+	FI_HIP_TRY(hipEventCreate(&e1));
+	FI_HIP_TRY(hipEventRecord(e0, st));
+	CgScalars init{};
+	init.tol2     = tolerance * tolerance;
+	init.max_iter = max_iterations;
+	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
+	CgScalars* sc = c->scal.as<CgScalars>();
+	const int64_t n = g.nown;
+	const int nb = stream_blocks(n);
+	double* partial = c->partial.as<double>();
+	T* x = c->x.as<T>();
+	T* r = c->r.as<T>();
+	T* p = c->p.as<T>();
+	T* q = c->q.as<T>();
+	T* z = c->mg_x.as<T>();
+	const T* b = c->atb.as<T>();
+	const int nb_apply = apply_num_partials(c);
+	while (static_cast<int>(c->ev.size()) < 2 * kMaxSamples) {
+		hipEvent_t e;
+		FI_HIP_TRY(hipEventCreate(&e));
+		c->ev.push_back(e);
+	}
+	int samples = 0;
+
+	auto restart = [&]() {  // r = b - A x, z = V(r), p = z, rz, rr (b.b on the first call)
+		apply_AtA(c, x, q, nullptr);
+		hipLaunchKernelGGL((k_sub<T>), dim3(nb), dim3(kThreads), 0, st, n, b, q, r);
+		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, b, b, partial);
+		hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, st, sc, partial, 1, 0, nb, 0);  // -> sums[0]
+		hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, st, sc);                             // sums[2] = sums[0]
+		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, r, r, partial);
+		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgInitRr);
+		vcycle<T>(c, r, z);
+		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, r, z, partial);
+		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgInitRz);
+		hipLaunchKernelGGL((k_mg_direction<T>), dim3(nb), dim3(kThreads), 0, st, n, sc, z, p, 1);
+	};
+	restart();
+
+	double limit_s = 600.0;
+	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
+	const auto wall0 = std::chrono::steady_clock::now();
+	bool timed_out = false;
+	int restarts_left = c->verify_residual ? 3 : 0;
+	for (;;) {
+		FI_HIP_TRY(hipMemcpyAsync(c->scal_host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		const int done = c->scal_host->done;
+		if (done) {
+			if (done != 1 || restarts_left <= 0) { break; }
+			--restarts_left;  // recurrence converged: check b - A x, continue from it if it misses the tolerance
+			hipLaunchKernelGGL(k_bump_restarts, dim3(1), dim3(1), 0, st, sc);
+			restart();
+			continue;
+		}
+		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
+			timed_out = true;
+			break;
+		}
+		const bool sample = samples < kMaxSamples;
+		if (sample) { FI_HIP_TRY(hipEventRecord(c->ev[2 * samples], st)); }
+		apply_AtA(c, p, q, partial);
+		if (sample) {
+			FI_HIP_TRY(hipEventRecord(c->ev[2 * samples + 1], st));
+			++samples;
+		}
+		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb_apply, kMgAlpha);
+		hipLaunchKernelGGL((k_mg_step<T>), dim3(nb), dim3(kThreads), 0, st, n, sc, p, q, x, r, partial);
+		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgResid);
+		vcycle<T>(c, r, z);   // wasted when this step just converged; one V-cycle at most
+		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, r, z, partial);
+		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgBeta);
+		hipLaunchKernelGGL((k_mg_direction<T>), dim3(nb), dim3(kThreads), 0, st, n, sc, z, p, 0);
+		FI_HIP_TRY(hipGetLastError());
+	}
+	FI_HIP_TRY(hipEventRecord(e1, st));
+	FI_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	const CgScalars h = *c->scal_host;
+	int used = samples < h.iter ? samples : h.iter;
+	double sum_ms = 0;
+	for (int k = 0; k < used; ++k) {
+		float t = 0;
+		FI_HIP_TRY(hipEventElapsedTime(&t, c->ev[2 * k], c->ev[2 * k + 1]));
+		sum_ms += t;
+	}
+	c->stats.spmv_samples = used;
+	c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
+	c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+	c->stats.solve_ms     = ms;
+	c->stats.iterations   = h.iter;
+	c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4 || h.done == 5)) ? 1 : 0;
+	c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+	c->stats.restarts     = h.restarts;
+	c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.rr / h.bb) : -1.0;
+	if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * g.nloc, st)); }
+	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
 }
 
 template <typename T>
@@ -849,7 +1304,11 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 		fi_ctx* c; int* it; float* rel;
 		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
 	} report{c, iterations, rel_residual};
-	cg_run<T>(R, max_iterations, tol);
+	if (c->mg_mode == 1 && c->coarse && c->nranks == 1) {
+		cg_run_mg<T>(c, max_iterations, tol);
+	} else {
+		cg_run<T>(R, max_iterations, tol);
+	}
 	store_owned<T>(c, c->x, out, memory);
 }
 
@@ -1056,6 +1515,15 @@ void build_levels(fi_ctx* c)
 	if (fine->coarse) {  // deeper levels left over from an earlier, larger request
 		fi_ctx_destroy(fine->coarse);
 		fine->coarse = nullptr;
+	}
+	if (c->mg_mode == 1 && c->coarse) {
+		// smoother bounds: power method on every coarser level; the finest level (8x the work) takes the
+		// estimate of the level below it -- same operator family, and the smoother interval has 10 % headroom
+		for (fi_ctx* l = c->coarse; l; l = l->coarse) {
+			c->dtype == FI_F64 ? estimate_lambda<double>(l) : estimate_lambda<float>(l);
+		}
+		c->lambda_max = c->coarse->lambda_max;
+		if (getenv("FI_MG_FINE_POWER")) { c->dtype == FI_F64 ? estimate_lambda<double>(c) : estimate_lambda<float>(c); }
 	}
 }
 
@@ -1385,6 +1853,7 @@ int fi_set_option(fi_ctx* c, int option, double value)
 		c->assembled = false;
 		break;
 	case FI_OPT_COARSE_TOLERANCE: c->coarse_tol = value > 0 ? value : 1e-3; break;
+	case FI_OPT_MULTIGRID: c->mg_mode = value != 0.0 ? 1 : 0; break;
 	default: FI_REQUIRE(false, FI_ERR_INVALID, "unknown option %d", option);
 	}
 	FI_API_END

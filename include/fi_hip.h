@@ -177,6 +177,9 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
 #define FI_OPT_VERIFY_RESIDUAL 1
 #define FI_OPT_LEVELS 2
 #define FI_OPT_COARSE_TOLERANCE 3
+/* FI_OPT_MULTIGRID (default 0): with levels, precondition CG with one V-cycle over them (Chebyshev-Jacobi
+ * smoothing, R = P^T, coarse operators re-assembled from the same points) instead of the Jacobi diagonal. */
+#define FI_OPT_MULTIGRID 4
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */

@@ -1,0 +1,102 @@
+"""Multilevel solves on the GPU: coarse-to-fine cascade start (FI_OPT_LEVELS; the reference's recipe of
+src/sdf_field.cpp:272-288 generalised) and V-cycle preconditioned CG (FI_OPT_MULTIGRID).  Neither changes the
+system being solved: the converged solution must equal the plain Jacobi-PCG / oracle solution."""
+import numpy as np
+import pytest
+
+from util import build_pair, rel_inf, sphere_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fi():
+    import field_interpolation_amd as fi
+    from field_interpolation_amd import _capi
+    assert _capi.device_count() >= 1
+    return fi
+
+
+def _problem(oracle, fi, sizes, dtype, n=600, kw=None):
+    rng = np.random.default_rng(2)
+    pos, nrm = sphere_points(rng, sizes, n)
+    w = fi.Weights(**(kw or {}))
+    return build_pair(oracle, fi, sizes, w, pos, nrm, None, None, dtype=dtype), (w, pos, nrm)
+
+
+@pytest.mark.parametrize("sizes", [[40, 36], [24, 20, 28], [33, 17, 19]])
+@pytest.mark.parametrize("mode", ["cascade", "multigrid"])
+def test_multilevel_converges_to_the_same_solution(oracle, fi, sizes, mode):
+    (fo, fg), (w, pos, nrm) = _problem(oracle, fi, sizes, "f64")
+    x_ref = fo.solve_exact_f64()
+    plain_iters = fg.solve_cg(None, 0, 1e-10)[1]
+    ml = fi.LatticeField(sizes, dtype="f64")
+    ml.add_field_constraints(w)
+    ml.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    ml.set_levels(3)
+    if mode == "multigrid":
+        ml.set_multigrid(True)
+    ml.assemble()
+    st = ml.stats()
+    assert st["num_levels"] >= 2
+    x, iters, rel = ml.solve_cg(None, 0, 1e-10)
+    assert rel <= 1e-10 and ml.stats()["converged"] == 1
+    assert rel_inf(ml.solution_f64(), x_ref) <= 1e-5          # BASELINE.json tolerance
+    assert rel_inf(ml.solution_f64(), x_ref) <= 1e-6
+    assert iters < plain_iters                                   # the point of having levels
+    if mode == "multigrid":
+        assert iters <= plain_iters // 3
+
+
+def test_levels_stop_at_small_lattices_and_ignore_hand_built_rows(fi):
+    f = fi.LatticeField([20, 9])          # 9 -> 5 < 8: no coarser level
+    f.add_field_constraints(fi.Weights())
+    f.set_levels(4)
+    f.add_points(1.0, 1, 0.0, 1, np.array([[3.2, 4.1]], np.float32), None, None, values=np.array([1.0], np.float32))
+    f.assemble()
+    assert f.stats()["num_levels"] == 1
+    g = fi.LatticeField([64, 64])
+    g.add_field_constraints(fi.Weights())
+    g.set_levels(2)
+    g.add_points(1.0, 1, 0.0, 1, np.array([[3.2, 4.1]], np.float32), None, None, values=np.array([1.0], np.float32))
+    g.add_rows_coo(np.array([0]), np.array([7]), np.array([1.0], np.float32), np.array([2.0], np.float32))
+    g.assemble()
+    assert g.stats()["num_levels"] == 1     # hand-built rows have no geometry to coarsen
+    x, it, rel = g.solve_cg(None, 0, 1e-4)
+    assert rel <= 1e-4
+
+
+def test_gradient_linear_kernel_is_coarsened_too(oracle, fi):
+    sizes = [32, 36]
+    rng = np.random.default_rng(8)
+    pos, nrm = sphere_points(rng, sizes, 300)
+    w = fi.Weights(gradient_kernel=fi.GradientKernel.kLinearInterpolation)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, None, None, dtype="f64")
+    fg.set_levels(2)
+    fg.set_multigrid(True)
+    fg.assemble()
+    assert fg.stats()["num_levels"] == 3
+    x, it, rel = fg.solve_cg(None, 0, 1e-10)
+    assert rel_inf(fg.solution_f64(), fo.solve_exact_f64()) <= 1e-6
+
+
+def test_fp32_multigrid_reaches_a_verified_residual(oracle, fi):
+    sizes = [48, 40, 44]
+    (fo, fg), _ = _problem(oracle, fi, sizes, "f32", n=2500)
+    fg.set_levels(3)
+    fg.set_multigrid(True)
+    fg.assemble()
+    x, it, rel = fg.solve_cg(None, 0, 1e-5)
+    st = fg.stats()
+    assert st["converged"] == 1 and st["restarts"] >= 1 and st["verified_residual"] <= 1e-5
+    assert fg.true_residual() <= 1.2e-5
+    # independent check of the residual with the oracle's rows: ||A^T(A x - b)|| / ||A^T b||
+    rows, cols, vals, rhs = fo.get()
+    r = np.zeros(len(rhs))
+    np.add.at(r, rows, vals.astype(np.float64) * x.astype(np.float64)[cols])
+    r -= rhs
+    g = np.zeros(fo.num_unknowns)
+    np.add.at(g, cols, vals.astype(np.float64) * r[rows])
+    gb = np.zeros(fo.num_unknowns)
+    np.add.at(gb, cols, vals.astype(np.float64) * rhs.astype(np.float64)[rows])
+    assert np.linalg.norm(g) / np.linalg.norm(gb) <= 2e-5

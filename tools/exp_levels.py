@@ -22,6 +22,8 @@ for levels in [int(v) for v in os.environ.get("LEVELS", "0,1,2,3,4,5").split(","
         f = fi.LatticeField(sizes, dtype="f32")
         f.add_field_constraints(w)
         f.set_levels(levels, ctol)
+        if os.environ.get("MG"):
+            f.set_multigrid(True)
         if nrm is None:
             f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
         else:
