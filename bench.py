@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--tol", type=float, default=1e-5)
     ap.add_argument("--cpu-side", type=int, default=112, help="lattice side of the CPU baseline sample (0: skip)")
+    ap.add_argument("--levels", type=int, default=3, help="coarser levels for the coarse-to-fine start (0: plain Jacobi-PCG)")
+    ap.add_argument("--coarse-tol", type=float, default=1e-4)
+    ap.add_argument("--multigrid", action="store_true", help="V-cycle preconditioned CG instead of Jacobi-PCG")
     args = ap.parse_args()
 
     import numpy as np
@@ -96,6 +99,10 @@ def main():
     torch.cuda.synchronize()
 
     field.add_field_constraints(w)
+    if args.levels > 0:
+        field.set_levels(args.levels, args.coarse_tol)
+        if args.multigrid and world == 1:   # the V-cycle preconditioner needs an undivided lattice (this round)
+            field.set_multigrid(True)
 
     def step():
         field.clear_points()
@@ -145,6 +152,9 @@ def main():
         "config": {"workload": "config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5, "
                                "Jacobi-PCG to rel. residual %g" % (side, side, depth, npts, args.tol),
                    "parallelism": "slab%d" % world, "iterations": iters, "rel_residual": rel,
+                   "levels": st["num_levels"], "coarse_iterations": st["coarse_iterations"],
+                   "solver": ("V-cycle PCG" if (args.multigrid and st["num_levels"] > 1) else
+                              "Jacobi-PCG" + (" from a coarse-to-fine cascade" if st["num_levels"] > 1 else "")),
                    "true_rel_residual": true_rel, "assemble_ms": asm_ms / args.steps,
                    "solve_ms": solve_ms / args.steps, "occupied_cells": st["num_cells"],
                    "data_rows": st["num_data_rows"]},

@@ -351,6 +351,10 @@ class LatticeGroup:
         for m in self.members:          # every rank sees every point and keeps the cells touching its slab
             m.add_points(*a, **kw)
 
+    def set_levels(self, levels, coarse_tolerance=None):
+        for m in self.members:
+            m.set_levels(levels, coarse_tolerance)
+
     def assemble(self):
         check(_capi.lib().fi_group_assemble(self._g))
         for m in self.members:
@@ -376,6 +380,9 @@ class LatticeGroup:
         check(_capi.lib().fi_group_solve_cg(self._g, None if g is None else C.c_void_p(g.ctypes.data), int(max_iterations),
                                             float(error_tolerance), C.c_void_p(out.ctypes.data), C.byref(it), C.byref(rel)))
         return out, it.value, rel.value
+
+    def stats(self):
+        return self.members[0].stats()
 
     def solution_f64(self):
         out = np.empty(self.num_unknowns, np.float64)

@@ -179,6 +179,7 @@ struct fi_ctx {
 	int        rank = 0, nranks = 1;
 	int        halo = 0;
 	int        slab_lo = 0, slab_hi = 0;
+	bool       slab_fixed = false;   // coarser levels: the slab range follows the finest level's, not the equal split
 	fi::Geom   g{};
 	fi_weights w{};
 	bool       model_set = false;
@@ -219,6 +220,7 @@ struct fi_ctx {
 	fi::Comm*  comm = nullptr;
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
 	bool       owns_stream = true;
+	bool       owns_comm = true;     // coarser levels share the RCCL communicator of the finest level
 	int        verify_residual = 1;  // check b - A x when the recurrence converges, restart CG if it misses
 	fi_stats   stats{};
 	std::vector<hipEvent_t> ev;  // sampled events around AtA applies

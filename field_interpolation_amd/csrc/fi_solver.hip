@@ -419,18 +419,40 @@ __global__ __launch_bounds__(kThreads) void k_upscale(UpscaleArgs a, int64_t nla
 // neighbour does not exist).  One thread per fine point; mode 0: fine = P coarse, mode 1: fine += P coarse.
 struct LevelPair {
 	int ndim;
-	int nf[3], nc[3];
+	int nf[3], nc[3];  // GLOBAL extents of the fine and the coarse lattice
+	// slabs (slowest axis L = ndim-1): the kernels walk `f_planes` owned fine planes starting at global plane
+	// f_z0 / `c_planes` owned coarse planes from c_z0; local storage of either level starts at global plane *_base
+	int f_z0, f_planes, f_base;
+	int c_z0, c_planes, c_base;
 };
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, int64_t nfine, const T* __restrict__ coarse,
-                                                       T* __restrict__ fine, int mode)
+
+LevelPair level_pair(const fi_ctx* fine, const fi_ctx* coarse)
 {
-	// grid: (x blocks, y, z) of the FINE lattice -- no integer division per point
-	const int fx = blockIdx.x * kThreads + threadIdx.x;
-	const int fy = blockIdx.y, fz = blockIdx.z;
-	if (fx >= L.nf[0]) { return; }
-	(void)nfine;
-	const int f[3] = {fx, fy, fz};
+	LevelPair L{};
+	L.ndim = fine->g.ndim;
+	for (int d = 0; d < 3; ++d) {
+		L.nf[d] = fine->g.gn[d];
+		L.nc[d] = coarse->g.gn[d];
+	}
+	const int a = L.ndim - 1;
+	L.f_z0     = fine->g.off[a] + fine->g.own_lo[a];
+	L.f_planes = fine->g.own_hi[a] - fine->g.own_lo[a];
+	L.f_base   = fine->g.off[a];
+	L.c_z0     = coarse->g.off[a] + coarse->g.own_lo[a];
+	L.c_planes = coarse->g.own_hi[a] - coarse->g.own_lo[a];
+	L.c_base   = coarse->g.off[a];
+	return L;
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine,
+                                                       int mode)
+{
+	// grid: (x blocks, y, z) over the OWNED fine points; `fine` / `coarse` are the local arrays (ghosts included)
+	const int a = L.ndim - 1;
+	int f[3] = {static_cast<int>(blockIdx.x * kThreads + threadIdx.x), static_cast<int>(blockIdx.y),
+	            static_cast<int>(blockIdx.z)};
+	if (f[0] >= (a == 0 ? L.f_planes : L.nf[0])) { return; }
+	f[a] += L.f_z0;  // global coordinate along the decomposed axis
 	int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
 	T   w1[3] = {T(0), T(0), T(0)};
 	for (int d = 0; d < L.ndim; ++d) {
@@ -439,21 +461,31 @@ __global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, int64_t nfine
 		c1[d] = (c0[d] + 1 < L.nc[d]) ? c0[d] + 1 : c0[d];
 		w1[d] = (f[d] & 1) ? T(0.5) : T(0);
 	}
-	const int sy = L.nc[0], sz = L.nc[0] * L.nc[1];
+	c0[a] -= L.c_base;  // local plane indices of the coarse slab (ghost planes hold the neighbours' values)
+	c1[a] -= L.c_base;
+	f[a] -= L.f_base;
+	const int64_t csy = L.nc[0], csz = (L.ndim > 2 ? static_cast<int64_t>(L.nc[0]) * L.nc[1] : 0);
 	T acc = T(0);
 	for (int q = 0; q < (1 << L.ndim); ++q) {
 		const int ux = q & 1, uy = (q >> 1) & 1, uz = (q >> 2) & 1;
 		T w = ux ? w1[0] : T(1) - w1[0];
-		int idx = ux ? c1[0] : c0[0];
-		if (L.ndim > 1) { w *= uy ? w1[1] : T(1) - w1[1]; idx += sy * (uy ? c1[1] : c0[1]); }
-		if (L.ndim > 2) { w *= uz ? w1[2] : T(1) - w1[2]; idx += sz * (uz ? c1[2] : c0[2]); }
+		int64_t idx = ux ? c1[0] : c0[0];
+		if (L.ndim > 1) { w *= uy ? w1[1] : T(1) - w1[1]; idx += csy * (uy ? c1[1] : c0[1]); }
+		if (L.ndim > 2) { w *= uz ? w1[2] : T(1) - w1[2]; idx += csz * (uz ? c1[2] : c0[2]); }
 		if (w != T(0)) { acc += w * coarse[idx]; }
 	}
-	const int64_t i = (static_cast<int64_t>(fz) * L.nf[1] + fy) * L.nf[0] + fx;
+	const int64_t i = (L.ndim > 2 ? static_cast<int64_t>(f[2]) * L.nf[1] * L.nf[0] : 0) +
+	                  (L.ndim > 1 ? static_cast<int64_t>(f[1]) * L.nf[0] : 0) + f[0];
 	fine[i] = mode ? fine[i] + acc : acc;
 }
 
-inline dim3 lattice_grid(const int* n) { return dim3((n[0] + kThreads - 1) / kThreads, n[1], n[2]); }
+// grid over the owned points of a level: x in blocks of 256, then y, z (the decomposed axis counts planes)
+inline dim3 owned_grid(const int* n, int ndim, int planes)
+{
+	int e[3] = {n[0], n[1], n[2]};
+	e[ndim - 1] = planes;
+	return dim3((e[0] + kThreads - 1) / kThreads, e[1], e[2]);
+}
 
 // ---- host side -------------------------------------------------------------------------------------
 
@@ -473,8 +505,10 @@ void compute_geom(fi_ctx* c, int ndim, const int* sizes)
 		g.coff[d]   = d < ndim ? -1 : 0;
 	}
 	const int G = g.gn[L];
-	c->slab_lo = static_cast<int>(static_cast<int64_t>(c->rank) * G / c->nranks);
-	c->slab_hi = static_cast<int>(static_cast<int64_t>(c->rank + 1) * G / c->nranks);
+	if (!c->slab_fixed) {
+		c->slab_lo = static_cast<int>(static_cast<int64_t>(c->rank) * G / c->nranks);
+		c->slab_hi = static_cast<int>(static_cast<int64_t>(c->rank + 1) * G / c->nranks);
+	}
 	const int H = c->nranks > 1 ? c->halo : 0;
 	g.n[L]      = (c->slab_hi - c->slab_lo) + 2 * H;
 	g.off[L]    = c->slab_lo - H;
@@ -815,35 +849,45 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 // solved from the interpolated solution of the level below it, to a loose tolerance; x of `c` receives the
 // interpolated guess.  All on the device.
 template <typename T>
-void cascade_guess(fi_ctx* c)
+void cascade_guess(RankSet& R)
 {
-	std::vector<fi_ctx*> chain;
-	for (fi_ctx* l = c; l; l = l->coarse) { chain.push_back(l); }
-	for (fi_ctx* l : chain) { ensure_vectors(l); }
-	fi_ctx* bottom = chain.back();
-	FI_HIP_TRY(hipMemsetAsync(bottom->x.p, 0, sizeof(T) * bottom->g.nloc, bottom->stream));
-	for (size_t k = chain.size(); k-- > 1;) {
-		fi_ctx* lc = chain[k];
-		fi_ctx* lf = chain[k - 1];
-		RankSet R{lc};
+	// chains[l] = the level-l contexts of all members
+	std::vector<RankSet> chains;
+	{
+		RankSet cur = R;
+		for (;;) {
+			chains.push_back(cur);
+			RankSet next;
+			for (fi_ctx* c : cur) {
+				if (c->coarse) { next.push_back(c->coarse); }
+			}
+			if (next.size() != cur.size()) { break; }
+			cur = next;
+		}
+	}
+	for (auto& lev : chains) {
+		for (fi_ctx* c : lev) { ensure_vectors(c); }
+	}
+	for (fi_ctx* c : chains.back()) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
+	fi_ctx* root = R[0];
+	for (size_t k = chains.size(); k-- > 1;) {
+		RankSet& lc = chains[k];
+		RankSet& lf = chains[k - 1];
 		try {
-			cg_run<T>(R, 0, static_cast<float>(c->coarse_tol));
+			cg_run<T>(lc, 0, static_cast<float>(root->coarse_tol));
 		} catch (const Fail& f) {
 			if (f.code != FI_ERR_BREAKDOWN) { throw; }  // a coarse level without data: keep what it has
 		}
-		c->stats.coarse_iterations += lc->stats.iterations;
-		LevelPair L{};
-		L.ndim = lf->g.ndim;
-		for (int d = 0; d < 3; ++d) {
-			L.nf[d] = lf->g.gn[d];
-			L.nc[d] = lc->g.gn[d];
+		root->stats.coarse_iterations += lc[0]->stats.iterations;
+		halo_exchange(lc, &fi_ctx::x);  // interpolation reads one coarse plane beyond the slab
+		for (size_t i = 0; i < lf.size(); ++i) {
+			const LevelPair L = level_pair(lf[i], lc[i]);
+			hipLaunchKernelGGL((k_prolong<T>), owned_grid(L.nf, L.ndim, L.f_planes), dim3(kThreads), 0, lf[i]->stream, L,
+			                   lc[i]->x.as<T>(), lf[i]->x.as<T>(), 0);
 		}
-		hipLaunchKernelGGL((k_prolong<T>), lattice_grid(L.nf), dim3(kThreads), 0, lf->stream, L, lf->g.nown,
-		                   lc->x.as<T>(), lf->x.as<T>(), 0);
 		FI_HIP_TRY(hipGetLastError());
 	}
 }
-
 
 // ---- multigrid V-cycle preconditioner ----------------------------------------------------------------
 // With FI_OPT_MULTIGRID the coarser replicas (build_levels) precondition CG on the finest level:
@@ -856,15 +900,14 @@ void cascade_guess(fi_ctx* c)
 // restriction = transpose of k_prolong: coarse point c gathers fine 2c (weight 1) and 2c-1, 2c+1 (weight 1/2;
 // the last coarse point also takes the full weight of a fine point beyond it)
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, int64_t ncoarse, const T* __restrict__ fine,
-                                                        T* __restrict__ coarse)
+__global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, const T* __restrict__ fine, T* __restrict__ coarse)
 {
-	// grid: (x blocks, y, z) of the COARSE lattice
-	const int cx = blockIdx.x * kThreads + threadIdx.x;
-	const int cy = blockIdx.y, cz = blockIdx.z;
-	if (cx >= L.nc[0]) { return; }
-	(void)ncoarse;
-	const int c[3] = {cx, cy, cz};
+	// grid: (x blocks, y, z) over the OWNED coarse points; local arrays, ghost planes of `fine` up to date
+	const int a = L.ndim - 1;
+	int c[3] = {static_cast<int>(blockIdx.x * kThreads + threadIdx.x), static_cast<int>(blockIdx.y),
+	            static_cast<int>(blockIdx.z)};
+	if (c[0] >= (a == 0 ? L.c_planes : L.nc[0])) { return; }
+	c[a] += L.c_z0;
 	int f[3][3];
 	T   w[3][3];
 	for (int d = 0; d < 3; ++d) {
@@ -875,29 +918,33 @@ __global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, int64_t ncoa
 			const int ff = 2 * c[d] + k - 1;
 			T ww = (k == 1) ? T(1) : T(0.5);
 			f[d][k] = ff;
-			if (ff < 0 || ff >= L.nf[d]) { ww = T(0); f[d][k] = 0; }
+			if (ff < 0 || ff >= L.nf[d]) { ww = T(0); f[d][k] = (d == a) ? L.f_base : 0; }
 			// fine point 2c+1 when coarse c+1 does not exist: P put all of it on c
 			if (k == 2 && c[d] + 1 >= L.nc[d] && ff < L.nf[d]) { ww = T(1); }
 			w[d][k] = ww;
+			if (d == a) { f[d][k] -= L.f_base; }
 		}
 	}
-	const int sy = L.nf[0];
+	c[a] -= L.c_base;
+	const int64_t sy = L.nf[0];
 	const int64_t sz = static_cast<int64_t>(L.nf[0]) * L.nf[1];
 	T acc = T(0);
 	const int n1 = L.ndim > 1 ? 3 : 1, n2 = L.ndim > 2 ? 3 : 1;
 	for (int k2 = 0; k2 < n2; ++k2) {
 		for (int k1 = 0; k1 < n1; ++k1) {
-			const T w12 = (L.ndim > 1 ? w[1][k1 + (n1 == 1)] : T(1)) * (L.ndim > 2 ? w[2][k2 + (n2 == 1)] : T(1));
+			const int i1 = k1 + (n1 == 1), i2 = k2 + (n2 == 1);
+			const T w12 = (L.ndim > 1 ? w[1][i1] : T(1)) * (L.ndim > 2 ? w[2][i2] : T(1));
 			if (w12 == T(0)) { continue; }
-			const int64_t base = (L.ndim > 1 ? static_cast<int64_t>(sy) * f[1][k1 + (n1 == 1)] : 0) +
-			                     (L.ndim > 2 ? sz * f[2][k2 + (n2 == 1)] : 0);
+			const int64_t base = (L.ndim > 1 ? sy * f[1][i1] : 0) + (L.ndim > 2 ? sz * f[2][i2] : 0);
 #pragma unroll
 			for (int k0 = 0; k0 < 3; ++k0) {
 				if (w[0][k0] != T(0)) { acc += w[0][k0] * w12 * fine[base + f[0][k0]]; }
 			}
 		}
 	}
-	coarse[(static_cast<int64_t>(cz) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
+	const int64_t i = (L.ndim > 2 ? static_cast<int64_t>(c[2]) * L.nc[1] * L.nc[0] : 0) +
+	                  (L.ndim > 1 ? static_cast<int64_t>(c[1]) * L.nc[0] : 0) + c[0];
+	coarse[i] = acc;
 }
 
 // r = b - q (q may be null: r = b);  d = alpha * Dinv r;  x = zero_x ? d : x + d
@@ -1153,16 +1200,12 @@ void vcycle(fi_ctx* c, const T* b, T* x)
 	cheb_smooth<T>(c, b, x, deg, ratio, true);
 	apply_AtA(c, x, c->q.p, nullptr);
 	hipLaunchKernelGGL((k_sub<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, b, c->q.as<T>(), c->mg_r.as<T>());
-	LevelPair L{};
-	L.ndim = c->g.ndim;
-	for (int d = 0; d < 3; ++d) {
-		L.nf[d] = c->g.gn[d];
-		L.nc[d] = co->g.gn[d];
-	}
-	hipLaunchKernelGGL((k_restrict<T>), lattice_grid(L.nc), dim3(kThreads), 0, c->stream, L, co->g.nown,
+	const LevelPair L = level_pair(c, co);
+	hipLaunchKernelGGL((k_restrict<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, c->stream, L,
 	                   c->mg_r.as<T>(), co->mg_b.as<T>());
 	vcycle<T>(co, co->mg_b.as<T>(), co->mg_x.as<T>());
-	hipLaunchKernelGGL((k_prolong<T>), lattice_grid(L.nf), dim3(kThreads), 0, c->stream, L, n, co->mg_x.as<T>(), x, 1);
+	hipLaunchKernelGGL((k_prolong<T>), owned_grid(L.nf, L.ndim, L.f_planes), dim3(kThreads), 0, c->stream, L,
+	                   co->mg_x.as<T>(), x, 1);
 	cheb_smooth<T>(c, b, x, deg, ratio, false);
 }
 
@@ -1294,12 +1337,12 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 {
 	ensure_vectors(c);
 	c->stats.coarse_iterations = 0;
-	if (!guess && c->coarse && c->nranks == 1) {
-		cascade_guess<T>(c);
+	RankSet R{c};
+	if (!guess && c->coarse) {
+		cascade_guess<T>(R);
 	} else {
 		load_owned<T>(c, c->x, guess, memory);
 	}
-	RankSet R{c};
 	struct Report {
 		fi_ctx* c; int* it; float* rel;
 		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
@@ -1437,7 +1480,7 @@ fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks);
 void build_levels(fi_ctx* c)
 {
 	if (c->level != 0) { return; }
-	bool wanted = c->levels_wanted > 0 && c->nranks == 1;
+	bool wanted = c->levels_wanted > 0;
 	if (wanted && c->generic.ntrip > 0) {
 		// generic rows that came from points (gradient kLinearInterpolation) can be re-emitted; hand-built ones cannot
 		long from_points = 0;
@@ -1455,6 +1498,12 @@ void build_levels(fi_ctx* c)
 	}
 	fi_ctx* fine = c;
 	const int D = c->g.ndim;
+	// slab ranges of EVERY rank on the current level (pure arithmetic: all ranks agree on where the levels stop)
+	std::vector<int> lo(c->nranks), hi(c->nranks);
+	for (int r = 0; r < c->nranks; ++r) {
+		lo[r] = static_cast<int>(static_cast<int64_t>(r) * c->g.gn[D - 1] / c->nranks);
+		hi[r] = static_cast<int>(static_cast<int64_t>(r + 1) * c->g.gn[D - 1] / c->nranks);
+	}
 	for (int l = 1; l <= c->levels_wanted; ++l) {
 		int sizes[3] = {1, 1, 1};
 		bool ok = true;
@@ -1462,9 +1511,16 @@ void build_levels(fi_ctx* c)
 			sizes[d] = (fine->g.gn[d] + 1) / 2;
 			ok = ok && sizes[d] >= 8;
 		}
+		// coarse plane k sits on fine plane 2k: a rank keeps the coarse planes whose fine plane it owns
+		for (int r = 0; r < c->nranks; ++r) {
+			lo[r] = (lo[r] + 1) / 2;
+			hi[r] = (hi[r] + 1) / 2;
+			if (c->nranks > 1) { ok = ok && (hi[r] - lo[r]) >= (c->halo > 4 ? c->halo : 4); }
+		}
 		if (!ok) { break; }
 		fi_ctx* co = fine->coarse;
-		if (co && (co->g.gn[0] != sizes[0] || co->g.gn[1] != sizes[1] || co->g.gn[2] != sizes[2] || co->dtype != c->dtype)) {
+		if (co && (co->g.gn[0] != sizes[0] || co->g.gn[1] != sizes[1] || co->g.gn[2] != sizes[2] || co->dtype != c->dtype ||
+		           co->halo != c->halo)) {
 			fi_ctx_destroy(co);
 			co = nullptr;
 		}
@@ -1473,15 +1529,23 @@ void build_levels(fi_ctx* c)
 			co->pending.clear();
 			generic_clear(co);
 		} else {
-			co = create_ctx(D, sizes, c->dtype, 0, 1);
+			co = create_ctx(D, sizes, c->dtype, c->rank, c->nranks);
 			(void)hipStreamDestroy(co->stream);
 			co->stream      = c->stream;
 			co->owns_stream = false;
+			co->comm        = c->comm;
+			co->owns_comm   = false;
 			co->level       = l;
 			co->finer       = fine;
 			co->verify_residual = 0;
+			co->slab_fixed  = true;
+			co->slab_lo     = lo[c->rank];
+			co->slab_hi     = hi[c->rank];
+			co->halo        = c->halo;
+			compute_geom(co, D, sizes);
 			fine->coarse    = co;
 		}
+		co->comm = c->comm;
 		const float vol = static_cast<float>(1 << D);
 		fi_weights w = fine->w;
 		w.model_0 = fine->w.model_0 * std::sqrt(vol);
@@ -1516,7 +1580,7 @@ void build_levels(fi_ctx* c)
 		fi_ctx_destroy(fine->coarse);
 		fine->coarse = nullptr;
 	}
-	if (c->mg_mode == 1 && c->coarse) {
+	if (c->mg_mode == 1 && c->coarse && c->nranks == 1) {
 		// smoother bounds: power method on every coarser level; the finest level (8x the work) takes the
 		// estimate of the level below it -- same operator family, and the smoother interval has 10 % headroom
 		for (fi_ctx* l = c->coarse; l; l = l->coarse) {
@@ -1639,7 +1703,7 @@ int fi_ctx_destroy(fi_ctx* c)
 	c->pending.clear();
 	c->pending_pool.clear();
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
-	if (c->comm) { fi::comm_destroy(c->comm); }
+	if (c->comm && c->owns_comm) { fi::comm_destroy(c->comm); }
 	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
 	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }
 	delete c;
@@ -2051,6 +2115,19 @@ int fi_group_assemble(fi_group* g)
 		const int rc = fi_assemble(c);
 		if (rc != FI_OK) { return rc; }
 	}
+	// coarser levels: the loop-back dot-product sum needs the scalar blocks of every member of a level
+	std::vector<fi_ctx*> lev;
+	for (fi_ctx* c : g->members) { lev.push_back(c->coarse); }
+	while (lev[0]) {
+		std::vector<fi::CgScalars*> ptrs;
+		for (fi_ctx*& c : lev) {
+			FI_REQUIRE(c != nullptr, FI_ERR_STATE, "members disagree on the number of levels");
+			ptrs.push_back(c->scal.as<fi::CgScalars>());
+		}
+		lev[0]->group_scal.alloc(sizeof(fi::CgScalars*) * ptrs.size());
+		FI_HIP_TRY(hipMemcpy(lev[0]->group_scal.p, ptrs.data(), sizeof(fi::CgScalars*) * ptrs.size(), hipMemcpyHostToDevice));
+		for (fi_ctx*& c : lev) { c = c->coarse; }
+	}
 	FI_API_END
 }
 
@@ -2070,15 +2147,20 @@ int fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float
 	FI_API_BEGIN
 	group_ready(g);
 	int64_t at = 0;
-	for (fi_ctx* c : g->members) {
-		if (g->dtype == FI_F64) {
-			fi::load_owned<double>(c, c->x, guess ? guess + at : nullptr, FI_HOST);
-		} else {
-			fi::load_owned<float>(c, c->x, guess ? guess + at : nullptr, FI_HOST);
-		}
-		at += c->g.nown;
-	}
 	fi_ctx* c0 = g->members[0];
+	c0->stats.coarse_iterations = 0;
+	if (!guess && c0->coarse) {
+		g->dtype == FI_F64 ? fi::cascade_guess<double>(g->members) : fi::cascade_guess<float>(g->members);
+	} else {
+		for (fi_ctx* c : g->members) {
+			if (g->dtype == FI_F64) {
+				fi::load_owned<double>(c, c->x, guess ? guess + at : nullptr, FI_HOST);
+			} else {
+				fi::load_owned<float>(c, c->x, guess ? guess + at : nullptr, FI_HOST);
+			}
+			at += c->g.nown;
+		}
+	}
 	struct Report {
 		fi_ctx* c; int* it; float* rel;
 		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }

@@ -76,3 +76,33 @@ def test_cg_equals_undivided(fi, sizes, nranks, dtype):
     assert relg <= tol and rel1 <= tol
     assert grp.true_residual() <= tol * 1.01 and one.true_residual() <= tol * 1.01
     assert rel_inf(grp.solution_f64(), one.solution_f64()) <= (1e-5 if dtype == "f64" else 2e-2)
+
+
+@pytest.mark.parametrize("sizes,nranks,levels", [([48, 64], 4, 2), ([32, 32, 64], 4, 2), ([32, 32, 96], 3, 2)])
+def test_coarse_to_fine_start_over_slabs(fi, sizes, nranks, levels):
+    """The multilevel start in slab form: every coarse level is a slab decomposition of its own (coarse plane k
+    lives with fine plane 2k), interpolation reads one ghost plane of the coarse solution."""
+    rng = np.random.default_rng(6)
+    pos, nrm = sphere_points(rng, sizes, 500)
+    w = fi.Weights(model_1=0.05)
+    one = fi.LatticeField(sizes, dtype="f64")
+    grp = fi.LatticeGroup(sizes, nranks, dtype="f64")
+    plain = fi.LatticeField(sizes, dtype="f64")
+    for f in (one, grp, plain):
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    one.set_levels(levels)
+    grp.set_levels(levels)
+    for f in (one, grp, plain):
+        f.assemble()
+    assert one.stats()["num_levels"] == grp.stats()["num_levels"] == levels + 1
+    tol = 1e-9
+    x0, it0, _ = plain.solve_cg(None, 0, tol)
+    x1, it1, r1 = one.solve_cg(None, 0, tol)
+    xg, itg, rg = grp.solve_cg(None, 0, tol)
+    assert r1 <= tol and rg <= tol
+    assert it1 < it0 and itg < it0                      # the cascade start pays off in both forms
+    assert abs(itg - it1) <= max(3, it1 // 20)
+    assert grp.stats()["coarse_iterations"] > 0
+    assert rel_inf(grp.solution_f64(), plain.solution_f64()) <= 1e-5
+    assert rel_inf(one.solution_f64(), plain.solution_f64()) <= 1e-5
