@@ -833,7 +833,9 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
-		c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4 || h.done == 5)) ? 1 : 0;
+		// with the verified stop on, "converged" means b - A x itself met the tolerance (done == 5); a recurrence
+		// that converged while the true residual stagnated above it (fp32 on an ill-conditioned system) is not
+		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
 		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
 		c->stats.restarts     = h.restarts;
 		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
@@ -1083,6 +1085,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 	switch (phase) {
 	case kMgInitRr:  // sums: r.r (partial 0) -- b.b was stored by the caller in sums[2]
 		sc->rr = s;
+		sc->true_rr = s;
 		if (sc->bb == 0.0) { sc->bb = sc->sums[2]; sc->tol2 *= sc->bb; }
 		sc->done = 0;
 		if (sc->bb == 0.0) {
@@ -1323,10 +1326,10 @@ void cg_run_mg(fi_ctx* c, int max_iterations, float tol)
 	c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
 	c->stats.solve_ms     = ms;
 	c->stats.iterations   = h.iter;
-	c->stats.converged    = (!timed_out && (h.done == 1 || h.done == 4 || h.done == 5)) ? 1 : 0;
+	c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c->verify_residual))) ? 1 : 0;
 	c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
 	c->stats.restarts     = h.restarts;
-	c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.rr / h.bb) : -1.0;
+	c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
 	if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * g.nloc, st)); }
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
 }

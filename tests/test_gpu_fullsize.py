@@ -1,0 +1,139 @@
+"""BASELINE.json configurations at FULL size on one MI355X, checked through size-independent properties
+(the oracle cannot solve these sizes in test time): verified residual b - A x, symmetry and bitwise
+reproducibility of the operator, the physical meaning of the field (signed distance near the surface),
+slab decomposition equal to the undivided solve.  fp64 contexts where the tolerance (1e-5 / 1e-6 true
+residual on systems with kappa ~ side^4) is out of fp32's reach -- SURVEY.md section 7, hard part 1."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fi():
+    import field_interpolation_amd as fi
+    from field_interpolation_amd import _capi
+    assert _capi.device_count() >= 1
+    return fi
+
+
+def _symmetry_and_determinism(f, n, seed=0):
+    rng = np.random.default_rng(seed)
+    x, y = rng.normal(size=n), rng.normal(size=n)
+    Ax, Ay = f.apply_AtA(x), f.apply_AtA(y)
+    assert abs(y @ Ax - x @ Ay) <= 1e-9 * abs(y @ Ax)            # A^T A is symmetric
+    assert x @ Ax > 0                                             # and positive
+    np.testing.assert_array_equal(Ax, f.apply_AtA(x))             # bitwise reproducible
+    Axy = f.apply_AtA(2.0 * x - 3.0 * y)
+    assert np.abs(Axy - (2.0 * Ax - 3.0 * Ay)).max() <= 1e-9 * np.abs(Ax).max()   # linear
+
+
+def test_config2_1024x1024_noisy_values(fi):
+    """2D 1024x1024, 10k random noisy value constraints + smoothness prior (model_2 = 10)."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, val = synth.config2()
+    f = fi.LatticeField(sizes, dtype="f64")
+    f.add_field_constraints(w)
+    f.set_levels(6, 1e-4)
+    f.set_multigrid(True)
+    f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    f.assemble()
+    assert f.stats()["num_data_rows"] == 10000
+    _symmetry_and_determinism(f, 1024 * 1024)
+    x, it, rel = f.solve_cg(None, 2000, 1e-5)
+    st = f.stats()
+    assert st["converged"] == 1 and st["verified_residual"] <= 1e-5 and f.true_residual() <= 1.01e-5
+    # a smooth field through noisy data: it tracks the noise-free signal better than the noisy samples do
+    u, v = pos[:, 0] / 1023.0, pos[:, 1] / 1023.0
+    truth = 0.5 * np.sin(10.0 * u * (1.0 + 2.0 * u)) * np.cos(7.0 * v)
+    ix, iy = np.round(pos[:, 0]).astype(int), np.round(pos[:, 1]).astype(int)
+    fitted = x.reshape(1024, 1024)[iy, ix]
+    assert np.sqrt(np.mean((fitted - truth) ** 2)) < np.sqrt(np.mean((val - truth) ** 2))
+
+
+def test_config3_4096x4096_sdf_from_oriented_points(fi):
+    """2D 4096x4096 SDF from 200k oriented point-cloud samples (value + gradient rows)."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, nrm = synth.config3()
+    f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
+    f.set_levels(7, 1e-4)
+    f.set_multigrid(True)
+    f.assemble()
+    assert f.stats()["num_data_rows"] == 3 * 200000
+    x, it, rel = f.solve_cg(None, 3000, 1e-5)
+    st = f.stats()
+    assert st["converged"] == 1 and f.true_residual() <= 1.01e-5
+    field = x.reshape(4096, 4096)
+    c = 0.5 * 4095
+    assert field[int(c), int(c + 0.05 * 4095)] > 0        # inside the inverted circle (r = 0.1): outside the shape
+    assert field[int(c), int(c + 0.2 * 4095)] < 0         # between circle and triangle: inside
+    assert field[10, 10] > 0                               # far corner: outside
+
+
+def test_config4_256cubed_bench_workload(fi):
+    """3D 256^3, 1M scattered value constraints: the bench.py workload, fp32, coarse-to-fine start."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, val = synth.config4()
+    f = fi.LatticeField(sizes, dtype="f32")
+    f.add_field_constraints(w)
+    f.set_levels(3, 1e-4)
+    f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    f.assemble()
+    st = f.stats()
+    assert st["num_data_rows"] == 1000000 and st["num_levels"] == 4
+    x, it, rel = f.solve_cg(None, 0, 1e-5)
+    st = f.stats()
+    assert st["converged"] == 1 and st["verified_residual"] <= 1e-5 and it < 150
+    # the field is the (noisy) signed distance to the sphere, smoothed: check it on the lattice
+    z, y, xx = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    d = np.sqrt((xx - 127.5) ** 2 + (y - 127.5) ** 2 + (z - 127.5) ** 2) - 0.3 * 255
+    err = x.reshape(256, 256, 256) - d
+    inner = (slice(8, -8),) * 3
+    assert np.abs(err[inner]).mean() < 0.15 and np.abs(err[inner]).max() < 2.0
+
+
+def test_config4_slabs_equal_undivided_at_128cubed(fi):
+    """3D lattice domain-split across 4 slabs (loop-back group = the RCCL path's kernels and rules)."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, val = synth.config4(side=128, num_points=125000)
+    one = fi.LatticeField(sizes, dtype="f32")
+    grp = fi.LatticeGroup(sizes, 4, dtype="f32")
+    for f in (one, grp):
+        f.add_field_constraints(w)
+        f.set_levels(2, 1e-4)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.assemble()
+    x1, it1, r1 = one.solve_cg(None, 0, 1e-5)
+    xg, itg, rg = grp.solve_cg(None, 0, 1e-5)
+    assert abs(it1 - itg) <= 5 and r1 <= 1e-5 and rg <= 1e-5
+    assert np.abs(xg - x1).max() <= 2e-3 * np.abs(x1).max()
+    assert grp.true_residual() <= 1.5e-5
+
+
+def test_config5_512cubed_sdf_tol_1e6(fi):
+    """3D 512^3 SDF from 5M oriented points, CG to 1e-6 (fp64, V-cycle preconditioned): verified residual and
+    the meaning of the result -- a signed distance near the sphere."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, nrm = synth.config5()
+    f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
+    f.set_levels(6, 1e-4)
+    f.set_multigrid(True)
+    f.assemble()
+    st = f.stats()
+    assert st["num_data_rows"] == 4 * 5000000 and st["num_levels"] == 7
+    x, it, rel = f.solve_cg(None, 1000, 1e-6)
+    st = f.stats()
+    assert st["converged"] == 1 and st["verified_residual"] <= 1e-6 and it < 400
+    field = x.reshape(512, 512, 512)
+    c, R = 255.5, 0.3 * 511
+    # "only accurate near field = 0" (field_interpolation.hpp:165): a signed distance close to the surface,
+    # the right sign and monotone away from it
+    prev = None
+    for r_off in (-8.0, -4.0, -2.0, 0.0, 2.0, 4.0, 8.0):          # along +x through the centre
+        ix = int(round(c + R + r_off))
+        v = float(field[255, 255, ix])
+        if abs(r_off) <= 2.0:
+            assert abs(v - ((ix - c) - R)) < 0.6, (r_off, v)
+        assert prev is None or v > prev
+        prev = v
+    assert field[255, 255, 255] < 0 and field[5, 5, 5] > 0
