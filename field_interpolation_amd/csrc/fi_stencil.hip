@@ -105,8 +105,12 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 	constexpr int W    = TX + 2 * PADX;  // LDS row length
 	constexpr int ROWS = kTY + 2 * kR;
 	constexpr int R    = HAS2 ? 2 : 1;
-	constexpr int NHALO = 2 * R * (TX + 2 * R) + 2 * R * kTY;
-	constexpr int NH    = (NHALO + kThreads - 1) / kThreads;
+	// halo ring of the plane tile: the 2R rows above/below the tile over the own columns go as 16-byte loads
+	// (threads 0 .. NVEC-1, one each); the 2R columns left/right of the tile, corners included, as scalars
+	// (threads NVEC .. NVEC+NSC-1).  At most one halo load and one LDS store per thread and plane.
+	constexpr int NVEC = 2 * R * kTXT;
+	constexpr int NSC  = 2 * R * (kTY + 2 * R);
+	static_assert(NVEC + NSC <= kThreads, "halo slots exceed the workgroup");
 	constexpr int NYB   = CELLS ? 8 : 1;
 
 	__shared__ __attribute__((aligned(16))) T xs[3][ROWS][W];
@@ -140,28 +144,34 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 	const int64_t col = static_cast<int64_t>(gy) * P.nx + gx;  // offset inside a plane
 
 	// ---- per-thread constants: halo slots and x/y boundary masks --------------------------------
-	int  h_lds[NH];
-	int  h_glb[NH];
-#pragma unroll
-	for (int s = 0; s < NH; ++s) {
-		const int h = threadIdx.x + s * kThreads;
-		int hlx = 0, hly = 0;
-		bool in = h < NHALO;
-		if (h < 2 * R * (TX + 2 * R)) {
-			const int r = h / (TX + 2 * R), c = h % (TX + 2 * R);
-			hly = r < R ? (kR - R + r) : (kR + kTY + (r - R));
-			hlx = PADX - R + c;
-		} else {
-			const int hh = h - 2 * R * (TX + 2 * R);
-			const int r = hh / (2 * R), k = hh % (2 * R);
-			hly = kR + r;
-			hlx = k < R ? (PADX - R + k) : (PADX + TX + (k - R));
-		}
-		int hgx = x0 + hlx - PADX, hgy = y0 + hly - kR;
-		hgx = hgx < 0 ? 0 : (hgx >= P.nx ? P.nx - 1 : hgx);
+	struct HaloRegs {
+		V vec;
+		T sc;
+	};
+	const bool hv_on = threadIdx.x < NVEC;
+	const bool hs_on = threadIdx.x >= NVEC && threadIdx.x < NVEC + NSC;
+	int hv_lds = 0, hs_lds = 0;   // LDS element offsets inside a plane buffer
+	int hv_glb = 0, hs_glb = 0;   // element offsets inside a lattice plane (clamped into the lattice)
+	{
+		const int t    = hv_on ? static_cast<int>(threadIdx.x) : 0;
+		const int hrow = t / kTXT, vx = t % kTXT;
+		const int hly  = hrow < R ? (kR - R + hrow) : (kR + kTY + (hrow - R));
+		int hgy = y0 + hly - kR, hgx = x0 + VX * vx;
 		hgy = hgy < 0 ? 0 : (hgy >= P.ny ? P.ny - 1 : hgy);
-		h_lds[s] = in ? hly * W + hlx : -1;
-		h_glb[s] = hgy * P.nx + hgx;
+		hgx = hgx > P.nx - VX ? P.nx - VX : hgx;
+		hv_lds = hly * W + PADX + VX * vx;
+		hv_glb = hgy * P.nx + hgx;
+	}
+	{
+		const int u   = hs_on ? static_cast<int>(threadIdx.x) - NVEC : 0;
+		const int row = u / (2 * R), k = u % (2 * R);
+		const int hly = kR - R + row;
+		const int hlx = k < R ? (PADX - R + k) : (PADX + TX + (k - R));
+		int hgy = y0 + hly - kR, hgx = x0 + hlx - PADX;
+		hgy = hgy < 0 ? 0 : (hgy >= P.ny ? P.ny - 1 : hgy);
+		hgx = hgx < 0 ? 0 : (hgx >= P.nx ? P.nx - 1 : hgx);
+		hs_lds = hly * W + hlx;
+		hs_glb = hgy * P.nx + hgx;
 	}
 
 	// model_2 rows along x anchored at gx-2 .. gx+VX-1; along y anchored at gy-2, gy-1, gy
@@ -200,22 +210,17 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 	auto load_own = [&](int lz) -> V {
 		return *reinterpret_cast<const V*>(xcol + static_cast<int64_t>(clamp_plane(lz)) * P.plane);
 	};
-	auto load_halo = [&](int lz, T* hv) {
+	auto load_halo = [&](int lz, HaloRegs& h) {
 		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
-		if (P.dbg & 1) {
-#pragma unroll
-			for (int s = 0; s < NH; ++s) { hv[s] = T(0); }
-			return;
-		}
-#pragma unroll
-		for (int s = 0; s < NH; ++s) { hv[s] = xp[h_glb[s]]; }
+		if (P.dbg & 1) { return; }
+		if (hv_on) { h.vec = *reinterpret_cast<const V*>(xp + hv_glb); }
+		if (hs_on) { h.sc = xp[hs_glb]; }
 	};
-	auto write_plane = [&](int buf, const V& own, const T* hv) {
+	auto write_plane = [&](int buf, const V& own, const HaloRegs& h) {
+		T* base = &xs[buf][0][0];
 		*reinterpret_cast<V*>(&xs[buf][ly][lx]) = own;
-#pragma unroll
-		for (int s = 0; s < NH; ++s) {
-			if (h_lds[s] >= 0) { (&xs[buf][0][0])[h_lds[s]] = hv[s]; }
-		}
+		if (hv_on) { *reinterpret_cast<V*>(base + hv_lds) = h.vec; }
+		if (hs_on) { base[hs_lds] = h.sc; }
 	};
 
 	// ---- data cells of one layer: corner products into the 8 corner planes ------------------------------
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 	// Software pipeline, all ring indices relative to the step number s = z - z_begin:
 	//   own x values: plane s lives in register slot X[s % 6]; step s reads slots s, s+1, s+2 and issues the
 	//                 load of plane s+5 into the slot plane s-1 left (3 steps of lead);
-	//   halo values : plane s in H[s % 3]; step s stages plane s+1 and loads plane s+3 (2 steps of lead);
+	//   halo values : plane s in H[s % 2]; step s stages plane s+1 and loads plane s+2 (1 step of lead);
 	//   row records : layer s in PF[s % 3]; consumed at step s, refilled with layer s+3;
 	//   carried     : u1 = masked u(z-1), u2 = masked u(z-2), d1 = masked (x(z) - x(z-1)), carry = upper
 	//                 cell products of layer z-1.
@@ -354,10 +359,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 	};
 	V X0 = load_own(z_begin), X1 = load_own(z_begin + 1), X2 = load_own(z_begin + 2);
 	V X3 = load_own(z_begin + 3), X4 = load_own(z_begin + 4), X5 = V{};
-	T H0[NH], H1[NH], H2[NH];
+	HaloRegs H0{}, H1{};  // ring of 2: plane s in H[s % 2]; step s stages plane s+1 and loads plane s+2
 	load_halo(z_begin, H0);
 	load_halo(z_begin + 1, H1);
-	load_halo(z_begin + 2, H2);
 	if (CELLS) {  // issued after the plane loads so that the two latencies overlap
 		if (threadIdx.x < P.zc + 2) {
 			const int64_t o = static_cast<int64_t>(wg) * (P.zc + 1) + threadIdx.x;
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 			prefetch_rows(3, PF2);
 			const uint32_t rsR = layR[0], reR = layR[1], rsB = layB[0], reB = layB[1];
 			if (reR > rsR || reB > rsB) {
-				T hprev[NH];
+				HaloRegs hprev{};
 				load_halo(z_begin - 1, hprev);
 				write_plane(2, xb, hprev);  // plane z_begin-1 borrows ring slot 2 (rewritten at step 1)
 				write_plane(0, X0, H0);
@@ -425,12 +429,13 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 
 	double dot_acc = 0.0;
 
-	auto step = [&](int s, const V& xc, const V& xp1, const V& xp2, V& xload, const T* h_use, T* h_load, RowPF& pf,
+	auto step = [&](int s, const V& xc, const V& xp1, const V& xp2, V& xload, const HaloRegs& h_use, HaloRegs& h_load,
+	                RowPF& pf,
 	                const T* uA, const T* uB, T* uC, const T* dA, T* dC) {
 		const int z = z_begin + s;
 		// stage plane z+1 into the LDS ring (needed by the cells of layer z) and prefetch ahead
 		write_plane((s + 1) % 3, xp1, h_use);
-		if (s + 3 <= nsteps) { load_halo(z + 3, h_load); }      // staged planes end at z_end, own planes at z_end+1
+		if (s + 2 <= nsteps) { load_halo(z + 2, h_load); }      // staged planes end at z_end, own planes at z_end+1
 		if (s + 5 <= nsteps + 1) { xload = load_own(z + 5); }
 		__syncthreads();
 
@@ -569,15 +574,15 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_m
 	for (int s0 = 0; s0 < nsteps; s0 += 6) {
 		step(s0, X0, X1, X2, X5, H1, H0, PF0, U1, U2, U0, D1, D0);
 		if (s0 + 1 >= nsteps) { break; }
-		step(s0 + 1, X1, X2, X3, X0, H2, H1, PF1, U2, U0, U1, D0, D1);
+		step(s0 + 1, X1, X2, X3, X0, H0, H1, PF1, U2, U0, U1, D0, D1);
 		if (s0 + 2 >= nsteps) { break; }
-		step(s0 + 2, X2, X3, X4, X1, H0, H2, PF2, U0, U1, U2, D1, D0);
+		step(s0 + 2, X2, X3, X4, X1, H1, H0, PF2, U0, U1, U2, D1, D0);
 		if (s0 + 3 >= nsteps) { break; }
-		step(s0 + 3, X3, X4, X5, X2, H1, H0, PF0, U1, U2, U0, D0, D1);
+		step(s0 + 3, X3, X4, X5, X2, H0, H1, PF0, U1, U2, U0, D0, D1);
 		if (s0 + 4 >= nsteps) { break; }
-		step(s0 + 4, X4, X5, X0, X3, H2, H1, PF1, U2, U0, U1, D1, D0);
+		step(s0 + 4, X4, X5, X0, X3, H1, H0, PF1, U2, U0, U1, D1, D0);
 		if (s0 + 5 >= nsteps) { break; }
-		step(s0 + 5, X5, X0, X1, X4, H0, H2, PF2, U0, U1, U2, D0, D1);
+		step(s0 + 5, X5, X0, X1, X4, H0, H1, PF2, U0, U1, U2, D0, D1);
 	}
 
 	if (partial) {
