@@ -27,6 +27,21 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(side, points, dtype):
+    """HBM bytes per launch of the AtA-apply kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_traffic.py).  Counters cannot be
+    read from inside this process, so the figure is the committed measurement of exactly this workload
+    (profiles/r1_traffic_apply_c4.json); any other workload reports null."""
+    if (side, points, dtype) != (256, 1_000_000, "f32"):
+        return None
+    path = os.path.join(ROOT, "profiles", "r1_traffic_apply_c4.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(side, tol):
     """Oracle ("port") on a bounded sample: config 4 scaled to side^3 with the same point density."""
     import numpy as np
@@ -166,8 +181,8 @@ def main():
                    "solve_ms": solve_ms / args.steps, "occupied_cells": st["num_cells"],
                    "data_rows": st["num_data_rows"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "AtA apply (matrix-free stencil + cell blocks)", "launch_ms": spmv_avg_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(side, args.points, args.dtype) if world == 1 else None,
+                     "kernel": "k_apply_march3d: AtA apply, matrix-free stencil + fused data cells (finest level)", "launch_ms": spmv_avg_ms,
                      "algorithmic_bytes": st["spmv_bytes"], "samples": spmv_n},
     }
     if rank == 0 and world == 1 and args.cpu_side > 0:

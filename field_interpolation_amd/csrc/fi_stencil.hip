@@ -45,6 +45,9 @@ constexpr int kThreads = 256;
 #ifndef FI_TXT
 #define FI_TXT 16
 #endif
+#ifndef FI_BASE_WAVES
+#define FI_BASE_WAVES 4  // waves per SIMD the model-only variant is register-allocated for
+#endif
 #ifndef FI_CELL_WAVES
 #define FI_CELL_WAVES 3  // waves per SIMD the fused (data cell) variant is register-allocated for
 #endif
@@ -93,7 +96,7 @@ __host__ __device__ constexpr int tri(int i, int j)  // packed upper-triangle in
 }
 
 template <typename T, bool HAS1, bool HAS2, bool CELLS>
-__global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : 4) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
+__global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done)
