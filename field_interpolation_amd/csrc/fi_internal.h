@@ -134,6 +134,26 @@ struct MarchState {
 	int64_t     cells_row = 0, cells_blk = 0;  // distinct cells of each kind
 };
 
+// Tiling of the 2-D tile kernel (fi_stencil2d.hip): one workgroup per TX x 16 tile of the owned rows.
+struct Tile2Params {
+	int nx;              // lattice extent in x
+	int nyl;             // local rows (incl. ghost rows)
+	int gy;              // global extent of y
+	int yoff;            // global y of local row 0
+	int own_y0, own_y1;  // owned local rows [y0, y1)
+	int tx;              // tile extent in x
+	int tiles_x, tiles_y, ntiles;
+};
+
+struct Tile2State {
+	bool        valid = false, fused = false;
+	Tile2Params P{};
+	DevBuf      off;   // uint32[ntiles + 1] record range of every tile
+	DevBuf      pos;   // uint32[nrec] (tcx+1) | (tcy+1) << 16
+	DevBuf      blk;   // T[nrec][16] full symmetric 4x4 block
+	int64_t     nrec = 0;
+};
+
 // Arbitrary sparse rows (fi_add_rows_coo and GradientKernel::kLinearInterpolation): fi_generic.hip
 struct GenericRows {
 	int64_t ntrip = 0, nrows = 0;  // accumulated input
@@ -199,6 +219,7 @@ struct fi_ctx {
 	int        level = 0;
 	fi::CellData              cells;
 	fi::MarchState            march;
+	fi::Tile2State            tile2;
 	fi::GenericRows           generic;
 
 	// operator pieces (T arrays over local storage)
@@ -241,6 +262,13 @@ void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.
 void stencil_prepare(fi_ctx* c);   // after assemble(): tiling + per-workgroup cell lists
 int  stencil_partials(const fi_ctx* c);
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
+
+bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also applies the cell blocks
+
+// fi_stencil2d.hip: LDS-tiled kernel for 2-D lattices (model_0/1/2), called through the stencil_* entry points
+void tile2d_prepare(fi_ctx* c);
+int  tile2d_partials(const fi_ctx* c);
+bool tile2d_apply(fi_ctx* c, const void* x, void* y, double* partial);
 
 // fi_generic.hip
 void generic_add_coo(fi_ctx* c, int64_t nrows, int64_t ntrip, const fi_triplet* trip, const float* rhs, int memory);

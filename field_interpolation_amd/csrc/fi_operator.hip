@@ -308,7 +308,7 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 		hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial,
 		                   done);
 	}
-	if (c->cells.ncell > 0 && !(c->march.valid && c->march.fused)) {
+	if (c->cells.ncell > 0 && !cells_fused(c)) {
 		nb_cells = capped_blocks(c->cells.ncell);
 		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(nb_cells), dim3(kThreads), 0, c->stream, g,
 		                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), x, y,
@@ -327,7 +327,7 @@ int apply_num_partials(const fi_ctx* c)
 	int nb_model = stencil_partials(c);
 	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
 	int n = nb_model + generic_num_partials(c);
-	if (!(c->march.valid && c->march.fused) && c->cells.ncell > 0) { n += capped_blocks(c->cells.ncell); }
+	if (!cells_fused(c) && c->cells.ncell > 0) { n += capped_blocks(c->cells.ncell); }
 	return n;
 }
 
@@ -343,6 +343,7 @@ double apply_algorithmic_bytes(const fi_ctx* c)
 		return lattice + static_cast<double>(c->march.cells_row) * (4.0 + s * 8.0) +
 		       static_cast<double>(c->march.cells_blk) * (4.0 + s * 36.0);  // a multi-row cell at its packed-block size
 	}
+	if (c->tile2.valid && c->tile2.fused) { return lattice + static_cast<double>(c->cells.ncell) * (4.0 + s * 16.0); }
 	return lattice + static_cast<double>(c->cells.ncell) * (4.0 + s * static_cast<double>(c->cells.nb));
 }
 

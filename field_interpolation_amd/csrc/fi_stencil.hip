@@ -852,6 +852,8 @@ void stencil_prepare(fi_ctx* c)
 	m.valid = c->dtype == FI_F64 ? march_setup<double>(c, &m.P) : march_setup<float>(c, &m.P);
 	m.fused = false;
 	m.n_row = m.n_blk = 0;
+	c->tile2.valid = c->tile2.fused = false;
+	if (c->g.ndim == 2) { tile2d_prepare(c); }
 	if (!m.valid) { return; }
 	if (c->cells.ncell > 0 && !getenv("FI_NO_FUSE")) {
 		c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
@@ -860,10 +862,13 @@ void stencil_prepare(fi_ctx* c)
 }
 
 // Number of p.q partials the stencil kernel writes, or 0 when the generic kernel must run.
-int stencil_partials(const fi_ctx* c) { return c->march.valid ? c->march.P.nwg : 0; }
+int stencil_partials(const fi_ctx* c) { return c->march.valid ? c->march.P.nwg : tile2d_partials(c); }
+
+bool cells_fused(const fi_ctx* c) { return (c->march.valid && c->march.fused) || (c->tile2.valid && c->tile2.fused); }
 
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial)
 {
+	if (c->tile2.valid) { return tile2d_apply(c, x, y, partial); }
 	if (!c->march.valid) { return false; }
 	if (c->dtype == FI_F64) {
 		c->march.fused ? march_launch_cells<double, true>(c, static_cast<const double*>(x), static_cast<double*>(y), partial)

@@ -41,4 +41,8 @@ for cfg in which:
               % (cfg, sizes, mode, st["num_levels"], st["iterations"], st["coarse_iterations"], st["assemble_ms"],
                  (t1 - t0) * 1e3, st["solve_ms"], (t2 - t1) * 1e3, st["rel_residual"], f.true_residual(), st["converged"],
                  st["num_cells"]), flush=True)
+        if os.environ.get("TIME_APPLY"):
+            ms = f.time_apply(50)
+            print("   apply %.1f us, algorithmic %.1f MB -> %.0f GB/s" % (ms * 1e3, f.stats()["spmv_bytes"] / 1e6,
+                  f.stats()["spmv_bytes"] / ms / 1e6), flush=True)
         del f
