@@ -19,16 +19,20 @@
 //   * x/y neighbours come from an LDS copy of the plane (tile + halo ring), 3-deep ring => one barrier per
 //     plane; own columns are 16-byte aligned in LDS (ds_read_b128 for the y rows);
 //   * boundary masks for x/y are per-thread constants hoisted out of the march; z masks are wave-uniform;
-//   * data cells of layer z (corners on planes z and z+1, both in the LDS ring): one thread per cell.  A
+//   * data cells of layer z (corners on planes z and z+1, both in the LDS ring): one lane per cell.  A
 //     cell holding a single data row a is kept as that row (y += a (a.x), 32 B in fp32); a cell holding
-//     more rows is kept as its packed symmetric block (144 B).  The thread stores its 8 corner products
-//     into 8 LDS planes indexed by corner -- for a fixed corner index two cells never hit the same lattice
-//     point, so no value is ever added by two writers: no float atomics, no ordering, bitwise reproducible.
-//     After one extra barrier the owner of a lattice point adds the 4 "lower" products to its output,
-//     carries the 4 "upper" ones to the next plane in registers and re-zeroes the slots it read.  Row
-//     records are prefetched three planes ahead.  Layers without data (the common case for surface point
-//     clouds) skip all of it.  The scatter/gather code is kept branch-free (clamped addresses, a dump slot
-//     for corners outside the tile): the kernel is instruction-issue sensitive.
+//     more rows as up to 8 factor rows (fp64: the packed symmetric block).  The 8 corner products are
+//     ADDED into LDS accumulation planes, one pair per lattice plane: [corner y-bit][TY][TX], ring of 3
+//     planes.  Ordering without barriers or races: the cells of a layer are split into 4 bands by the
+//     y-row of their origin, one band per wave; a lattice point of the by=0 plane only receives products
+//     from cells whose origin row is the point's row (one band, one wave), of the by=1 plane only from the
+//     row below (one band, one wave).  Inside a wave one LDS add instruction handles one corner index of
+//     up to 64 distinct cells -- distinct addresses -- and LDS instructions of a wave execute in order, so
+//     every sum is formed in the same order on every run: bitwise reproducible, although ds_add is used.
+//     The owner of a lattice point collects plane z-1 one step late (after the barrier of step z, when
+//     layers z-2 and z-1 are complete), so the data path needs no barrier of its own; the stencil result
+//     of plane z-1 waits in registers for that one step.  Row records are prefetched three planes ahead.
+//     The scatter code is branch-free (a per-thread dump slot for corners outside the tile).
 //   * p.q partials: fp32 products per plane, fp64 per-thread accumulation, wave64 shuffle tree, one
 //     partial per workgroup;
 //   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. (same XCD, same L2) get adjacent tiles.
@@ -49,7 +53,8 @@ constexpr int kThreads = 256;
 #define FI_BASE_WAVES 4  // waves per SIMD the model-only variant is register-allocated for
 #endif
 #ifndef FI_CELL_WAVES
-#define FI_CELL_WAVES 3  // waves per SIMD the fused (data cell) variant is register-allocated for
+#define FI_CELL_WAVES 3  // waves per SIMD the fused (data cell) variant is register-allocated for (one less with both
+                         // model_1 and model_2 on: that variant would spill, and a spill reload drains the load pipeline)
 #endif
 constexpr int kTXT     = FI_TXT;             // threads along x
 constexpr int kTY      = kThreads / kTXT;   // tile rows (= threads along y)
@@ -76,8 +81,8 @@ struct MarchCoef {
 };
 
 struct CellLists {
-	const uint32_t* lay_row;   // [nwg*(zc+1)+1]
-	const uint32_t* lay_blk;   // [nwg*(zc+1)+1]
+	const uint32_t* lay_row;   // [nwg*(zc+1)*4+1]
+	const uint32_t* lay_blk;   // [nwg*(zc+1)*4+1]
 	const uint32_t* pos_row;   // (tcx+1) | (tcy+1)<<16
 	const uint32_t* pos_blk;
 	const void*     coef_row;  // T[n_row][8]
@@ -96,7 +101,7 @@ __host__ __device__ constexpr int tri(int i, int j)  // packed upper-triangle in
 }
 
 template <typename T, bool HAS1, bool HAS2, bool CELLS>
-__global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
+__global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1 : FI_CELL_WAVES) : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done)
@@ -114,12 +119,13 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 	constexpr int NVEC = 2 * R * kTXT;
 	constexpr int NSC  = 2 * R * (kTY + 2 * R);
 	static_assert(NVEC + NSC <= kThreads, "halo slots exceed the workgroup");
-	constexpr int NYB   = CELLS ? 8 : 1;
+	constexpr int NLAY  = 4 * 66 + 1;  // (zc + 2) layers x 4 bands of record bounds, zc <= 64
 
 	__shared__ __attribute__((aligned(16))) T xs[3][ROWS][W];
-	__shared__ __attribute__((aligned(16))) T yb[NYB][CELLS ? kTY : 1][CELLS ? TX : VX];
-	__shared__ T ydump[CELLS ? 64 : 1];  // write-only target of corner products that fall outside the tile
-	__shared__ uint32_t s_lay[2][CELLS ? 72 : 1];  // record ranges of this workgroup's layers (rows, blocks)
+	// accumulation planes of the data term: [plane ring of 3][corner y-bit][TY][TX]
+	__shared__ __attribute__((aligned(16))) T yb[CELLS ? 3 : 1][CELLS ? 2 : 1][CELLS ? kTY : 1][CELLS ? TX : VX];
+	__shared__ T ydump[CELLS ? kThreads : 1];  // write-only target of corner products that fall outside the tile
+	__shared__ uint32_t s_lay[2][CELLS ? NLAY : 1];  // record bounds of this workgroup's (layer, band) lists
 	__shared__ double red[kThreads / 64];
 
 	if (done && *done) { return; }
@@ -144,12 +150,15 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 	int       z_end   = z_begin + P.zc;
 	if (z_end > P.own_z1) { z_end = P.own_z1; }
 
-	const int64_t col = static_cast<int64_t>(gy) * P.nx + gx;  // offset inside a plane
+	// offsets inside a plane stay 32-bit and unsigned: the plane base is wave-uniform (SGPR pair), so every
+	// global access is `saddr + 32-bit voffset` and no 64-bit address lives in VGPRs
+	const uint32_t col = static_cast<uint32_t>(gy) * static_cast<uint32_t>(P.nx) + static_cast<uint32_t>(gx);
 
 	// ---- per-thread constants: halo slots and x/y boundary masks --------------------------------
+	typedef T NV __attribute__((ext_vector_type(VX)));
 	struct HaloRegs {
-		V vec;
-		T sc;
+		NV vec;
+		T  sc;
 	};
 	const bool hv_on = threadIdx.x < NVEC;
 	const bool hs_on = threadIdx.x >= NVEC && threadIdx.x < NVEC + NSC;
@@ -177,16 +186,19 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 		hs_glb = hgy * P.nx + hgx;
 	}
 
+	const int      h_lds = hv_on ? hv_lds : hs_lds;
+	const uint32_t hvg = static_cast<uint32_t>(hv_on ? hv_glb : 0), hsg = static_cast<uint32_t>(hs_on ? hs_glb : 0);
+
 	// model_2 rows along x anchored at gx-2 .. gx+VX-1; along y anchored at gy-2, gy-1, gy
-	T m2x[VX + 2];
+	bool m2x[VX + 2];  // lane masks (SGPR pairs), applied by select
 	T c2y[3];
-	T m1x[VX + 1];
+	bool m1x[VX + 1];
 	T c1y[2];
 	if (HAS2) {
 #pragma unroll
 		for (int k = 0; k < VX + 2; ++k) {
 			const int a = gx - 2 + k;
-			m2x[k] = (a >= 0 && a + 2 < P.nx) ? T(1) : T(0);
+			m2x[k] = (a >= 0 && a + 2 < P.nx);
 		}
 		c2y[0] = (gy - 2 >= 0 && gy < P.ny) ? T(1) : T(0);
 		c2y[1] = (gy - 1 >= 0 && gy + 1 < P.ny) ? T(-2) : T(0);
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 #pragma unroll
 		for (int k = 0; k < VX + 1; ++k) {
 			const int a = gx - 1 + k;  // rows [-1,+1] anchored at a: x_{a+1} - x_a
-			m1x[k] = (a >= 0 && a + 1 < P.nx) ? T(1) : T(0);
+			m1x[k] = (a >= 0 && a + 1 < P.nx);
 		}
 		c1y[0] = (gy - 1 >= 0 && gy < P.ny) ? T(1) : T(0);   // row anchored at gy-1 touches gy with +1
 		c1y[1] = (gy + 1 < P.ny) ? T(-1) : T(0);             // row anchored at gy touches gy with -1
@@ -208,22 +220,23 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 	const int lz_hi = (P.nzl < P.gz - P.zoff ? P.nzl : P.gz - P.zoff) - 1;
 	const int gxc = gx < P.nx ? gx : P.nx - VX;
 	const int gyc = gy < P.ny ? gy : P.ny - 1;
-	const T* xcol = x + static_cast<int64_t>(gyc) * P.nx + gxc;
+	const uint32_t xoff = static_cast<uint32_t>(gyc) * static_cast<uint32_t>(P.nx) + static_cast<uint32_t>(gxc);
 	auto clamp_plane = [&](int lz) { return lz < lz_lo ? lz_lo : (lz > lz_hi ? lz_hi : lz); };
 	auto load_own = [&](int lz) -> V {
-		return *reinterpret_cast<const V*>(xcol + static_cast<int64_t>(clamp_plane(lz)) * P.plane);
+		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
+		return *reinterpret_cast<const V*>(xp + xoff);
 	};
 	auto load_halo = [&](int lz, HaloRegs& h) {
 		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
 		if (P.dbg & 1) { return; }
-		if (hv_on) { h.vec = *reinterpret_cast<const V*>(xp + hv_glb); }
-		if (hs_on) { h.sc = xp[hs_glb]; }
+		h.vec = *reinterpret_cast<const NV*>(xp + hvg);
+		h.sc  = xp[hsg];
 	};
 	auto write_plane = [&](int buf, const V& own, const HaloRegs& h) {
 		T* base = &xs[buf][0][0];
 		*reinterpret_cast<V*>(&xs[buf][ly][lx]) = own;
-		if (hv_on) { *reinterpret_cast<V*>(base + hv_lds) = h.vec; }
-		if (hs_on) { base[hs_lds] = h.sc; }
+		if (hv_on) { *reinterpret_cast<NV*>(base + h_lds) = h.vec; }
+		if (hs_on) { base[h_lds] = h.sc; }
 	};
 
 	// ---- data cells of one layer: corner products into the 8 corner planes ------------------------------
@@ -231,18 +244,39 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 	// per plane would put its latency on every step of the march)
 	const uint32_t* layR = s_lay[0];
 	const uint32_t* layB = s_lay[1];
-	// store the 8 corner products of a cell; corners outside the tile go to the dump slot (no branches)
-	auto put8 = [&](int tcx, int tcy, const T* out) {
-		T* const dump = &ydump[threadIdx.x & 63];
+	// cells: one band of origin rows per wave (wave-uniform values are kept in SGPRs)
+	const int band = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+	auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+	// add the 8 corner products of a cell into the accumulation planes of lattice planes slot_lo (corner z-bit
+	// 0) and slot_hi (z-bit 1); corners outside the tile -- and the lower ones when lo_ok is false -- go to
+	// the thread's dump slot (no branches)
+	auto put8 = [&](int tcx, int tcy, const T* out, int slot_lo, int slot_hi, bool lo_ok) {
+		T* const dump = &ydump[threadIdx.x];
 		const bool vx0 = tcx >= 0, vx1 = tcx + 1 < TX, vy0 = tcy >= 0, vy1 = tcy + 1 < kTY;
-		T* const base = &yb[0][0][0] + tcy * TX + tcx;
+		T* const base = &yb[0][0][0][0] + tcy * TX + tcx;
+		// Plain read-add-write (LDS float atomics cost ~3 cycles per lane here).  Two phases by the corner's
+		// x-bit: inside a phase the 4 corners of a cell go to 4 different planes and the cells of a wave
+		// instruction are distinct, so no two lanes touch one address; across phases (and across the batches
+		// of a loop) the LDS instructions of the wave execute in program order -- the clobbers keep the compiler
+		// from moving a phase's reads above the previous phase's writes.
 #pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			const bool ok = ((i & 1) ? vx1 : vx0) && ((i & 2) ? vy1 : vy0);
-			T* dst = base + i * (kTY * TX) + ((i >> 1) & 1) * TX + (i & 1);
-			dst = ok ? dst : dump;
-			*dst = out[i];
+		for (int bx = 0; bx < 2; ++bx) {
+			asm volatile("" ::: "memory");
+			T* dst[4];
+			T  cur[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int by = k & 1, bz = k >> 1;
+				const bool ok = (bx ? vx1 : vx0) && (by ? vy1 : vy0) && (bz ? true : lo_ok);
+				T* d = base + ((bz ? slot_hi : slot_lo) * 2 + by) * (kTY * TX) + by * TX + bx;
+				dst[k] = ok ? d : dump;
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { cur[k] = *dst[k]; }
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { *dst[k] = cur[k] + out[bx + 2 * (k & 1) + 4 * (k >> 1)]; }
 		}
+		asm volatile("" ::: "memory");
 	};
 	auto corners = [&](int tcx, int tcy, int buf_lo, int buf_hi, T* xv) {
 #pragma unroll
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 			xv[q] = xs[bz ? buf_hi : buf_lo][kR + tcy + by][PADX + tcx + bx];
 		}
 	};
-	auto row_apply = [&](uint32_t pos, const T* a, int buf_lo, int buf_hi) {
+	auto row_apply = [&](uint32_t pos, const T* a, int buf_lo, int buf_hi, int slot_lo, int slot_hi, bool lo_ok) {
 		const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
 		T xv[8];
 		corners(tcx, tcy, buf_lo, buf_hi, xv);
@@ -261,7 +295,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 		T out[8];
 #pragma unroll
 		for (int i = 0; i < 8; ++i) { out[i] = a[i] * t; }
-		put8(tcx, tcy, out);
+		put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok);
 	};
 	auto load_row = [&](uint32_t r, uint32_t* pos, T* a) {
 		*pos = L.pos_row[r];
@@ -274,16 +308,24 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 			for (int j = 0; j < VX; ++j) { a[k * VX + j] = pv[j]; }
 		}
 	};
-	// rows beyond the prefetched first 256 of a layer, and all block records
-	auto cells_scatter = [&](uint32_t rsR, uint32_t reR, uint32_t rsB, uint32_t reB, int buf_lo, int buf_hi) {
-		for (uint32_t r = rsR + threadIdx.x; r < reR; r += kThreads) {
+	// this wave's band of layer `layer`: rows from record rsR on (the first 64 may have been prefetched) and
+	// all block records
+	auto cells_scatter = [&](uint32_t rsR, uint32_t reR, uint32_t rsB, uint32_t reB, int buf_lo, int buf_hi, int slot_lo,
+	                         int slot_hi, bool lo_ok) {
+#ifdef FI_EXP_NOTAIL
+		reR = rsR;
+#endif
+		for (uint32_t r = rsR + lane; r < reR; r += 64) {
 			uint32_t pos;
 			T a[8];
 			load_row(r, &pos, a);
-			row_apply(pos, a, buf_lo, buf_hi);
+			row_apply(pos, a, buf_lo, buf_hi, slot_lo, slot_hi, lo_ok);
 		}
 		const T* multi = static_cast<const T*>(L.coef_blk);
-		for (uint32_t r = rsB + threadIdx.x; r < reB; r += kThreads) {
+#ifdef FI_EXP_NOBLK
+		reB = rsB;
+#endif
+		for (uint32_t r = rsB + lane; r < reB; r += 64) {
 			const uint32_t pos = L.pos_blk[r];
 			const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
 			const int nrows = static_cast<int>((pos >> 8) & 0xFFu);
@@ -306,7 +348,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 #pragma unroll
 					for (int j = 0; j < 8; ++j) { out[i] += b[i <= j ? tri(i, j) : tri(j, i)] * xv[j]; }
 				}
-				put8(tcx, tcy, out);
+				put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok);
 				continue;
 			}
 			for (int k = 0; k < nrows; ++k) {  // the cell's factor rows, one after another: out += a (a.x)
@@ -324,25 +366,21 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 #pragma unroll
 				for (int i = 0; i < 8; ++i) { out[i] += a[i] * t; }
 			}
-			put8(tcx, tcy, out);
+			put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok);
 		}
 	};
-	// owner side: lower 4 planes -> this plane, upper 4 planes -> carry; the slots are zeroed for the next layer
-	auto cells_gather = [&](T* lower, T* upper) {
+	// owner side: the finished sums of one lattice plane; the slots are zeroed for the plane 3 steps on
+	auto cells_gather = [&](int slot, T* data) {
 		const V zero = V{};
+		V* s0 = reinterpret_cast<V*>(&yb[slot][0][ty][VX * tx]);
+		V* s1 = reinterpret_cast<V*>(&yb[slot][1][ty][VX * tx]);
+		const V  v0 = *s0, v1 = *s1;
+		const T* p0 = reinterpret_cast<const T*>(&v0);
+		const T* p1 = reinterpret_cast<const T*>(&v1);
 #pragma unroll
-		for (int j = 0; j < VX; ++j) { lower[j] = T(0); upper[j] = T(0); }
-#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			V* slot = reinterpret_cast<V*>(&yb[q][ty][VX * tx]);
-			const V  v  = *slot;
-			const T* pv = reinterpret_cast<const T*>(&v);
-#pragma unroll
-			for (int j = 0; j < VX; ++j) {
-				if (q < 4) { lower[j] += pv[j]; } else { upper[j] += pv[j]; }
-			}
-			*slot = zero;
-		}
+		for (int j = 0; j < VX; ++j) { data[j] = p0[j] + p1[j]; }
+		*s0 = zero;
+		*s1 = zero;
 	};
 
 	// ---- prologue ---------------------------------------------------------------------------------
@@ -351,8 +389,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 	//                 load of plane s+5 into the slot plane s-1 left (3 steps of lead);
 	//   halo values : plane s in H[s % 2]; step s stages plane s+1 and loads plane s+2 (1 step of lead);
 	//   row records : layer s in PF[s % 3]; consumed at step s, refilled with layer s+3;
-	//   carried     : u1 = masked u(z-1), u2 = masked u(z-2), d1 = masked (x(z) - x(z-1)), carry = upper
-	//                 cell products of layer z-1.
+	//   carried     : u1 = masked u(z-1), u2 = masked u(z-2), d1 = masked (x(z) - x(z-1)); with data cells
+	//                 also the stencil result of plane z-1, which is completed (data sums added, stored)
+	//                 at step s after the barrier.
 	// The loop body is instantiated six times so that no ring ever needs a register move (a move would
 	// wait for the load it copies and cut the lead to less than one step).
 	struct RowPF {
@@ -362,30 +401,40 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 	};
 	V X0 = load_own(z_begin), X1 = load_own(z_begin + 1), X2 = load_own(z_begin + 2);
 	V X3 = load_own(z_begin + 3), X4 = load_own(z_begin + 4), X5 = V{};
-	HaloRegs H0{}, H1{};  // ring of 2: plane s in H[s % 2]; step s stages plane s+1 and loads plane s+2
+	// ring of 2: plane s in H[s % 2]; step s stages plane s+1 and loads plane s+2.  The fused variant is short of
+	// registers: there H1 alone carries every plane from z_begin+1 on (the load follows the LDS store of the same step)
+	HaloRegs H0{}, H1{};
 	load_halo(z_begin, H0);
 	load_halo(z_begin + 1, H1);
 	if (CELLS) {  // issued after the plane loads so that the two latencies overlap
-		if (threadIdx.x < P.zc + 2) {
-			const int64_t o = static_cast<int64_t>(wg) * (P.zc + 1) + threadIdx.x;
-			s_lay[0][threadIdx.x] = L.lay_row[o];
-			s_lay[1][threadIdx.x] = L.lay_blk[o];
+		for (int i = threadIdx.x; i < 4 * (P.zc + 1) + 1; i += kThreads) {
+			const int64_t o = static_cast<int64_t>(wg) * (P.zc + 1) * 4 + i;
+			s_lay[0][i] = L.lay_row[o];
+			s_lay[1][i] = L.lay_blk[o];
 		}
 		__syncthreads();
 	}
-	T U0[VX], U1[VX], U2[VX], D0[VX], D1[VX], carry[VX];  // U: u(z) ring of 3, D: d(z) ring of 2
+	T U0[VX], U1[VX], U2[VX], D0[VX], D1[VX], held[VX];  // U: u(z) ring of 3, D: d(z) ring of 2
 #pragma unroll
-	for (int j = 0; j < VX; ++j) { carry[j] = T(0); U0[j] = T(0); D0[j] = T(0); }
+	for (int j = 0; j < VX; ++j) { held[j] = T(0); U0[j] = T(0); D0[j] = T(0); }
 	const int nsteps = z_end - z_begin;
-	RowPF PF0, PF1, PF2;
-	PF0.ok = PF1.ok = PF2.ok = false;
+	RowPF PF0;
+	PF0.ok = false;
+	// A layer with at most 64 records is scattered by ONE wave (wave s % 4 at step s, all 4 bands, one lane per
+	// cell): the other waves skip the code, which matters because the kernel is instruction-issue bound.  That
+	// wave prefetches the layer's row records 4 steps ahead.  Denser layers: every wave takes its band, direct loads.
+	auto layer_dense = [&](int layer) {
+		return (uni(layR[layer * 4 + 4]) - uni(layR[layer * 4])) + (uni(layB[layer * 4 + 4]) - uni(layB[layer * 4])) > 64u;
+	};
+	// Every wave issues the record loads of the next layer in every step, unconditionally (clamped index):
+	// loads that cross a step must sit in straight-line code, or the compiler's s_waitcnt bookkeeping gives up
+	// and drains the whole pipeline (vmcnt(0)) at the first use.  The three extra waves hit the same lines in L1.
 	auto prefetch_rows = [&](int layer, RowPF& pf) {  // layer index l: cell plane z_begin - 1 + l
-		pf.ok = false;
-		if (CELLS && layer <= nsteps) {
-			const uint32_t r = layR[layer] + threadIdx.x;
-			pf.ok = r < layR[layer + 1];
-			if (pf.ok) { load_row(r, &pf.pos, pf.a); }
-		}
+		const int      lc = layer <= nsteps ? layer : nsteps;
+		const uint32_t r0 = uni(layR[lc * 4]), r1 = uni(layR[lc * 4 + 4]);
+		const uint32_t r  = r0 + lane;
+		pf.ok = layer <= nsteps && !layer_dense(lc) && r < r1;
+		load_row(r < r1 ? r : r0, &pf.pos, pf.a);  // r0 <= n_row, and the arrays hold n_row + 1 records
 	};
 	{
 		const V xa = load_own(z_begin - 2), xb = load_own(z_begin - 1);
@@ -404,27 +453,21 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 			D1[j] = md1 * (pc[j] - pb[j]);                 // d(z_begin-1)
 		}
 		if (CELLS) {
-			// layer z_begin-1 (l = 0): its upper corners sit on plane z_begin
+			// layer z_begin-1 (l = 0): its upper corners sit on plane z_begin (accumulation slot 0); the lower
+			// ones belong to the workgroup below and go to the dump slots
 			{
 				const V zero = V{};
 #pragma unroll
-				for (int q = 0; q < 8; ++q) { *reinterpret_cast<V*>(&yb[q][ty][VX * tx]) = zero; }
+				for (int q = 0; q < 6; ++q) { *reinterpret_cast<V*>(&yb[q >> 1][q & 1][ty][VX * tx]) = zero; }
 			}
 			prefetch_rows(1, PF0);
-			prefetch_rows(2, PF1);
-			prefetch_rows(3, PF2);
-			const uint32_t rsR = layR[0], reR = layR[1], rsB = layB[0], reB = layB[1];
-			if (reR > rsR || reB > rsB) {
+			if (layR[4] > layR[0] || layB[4] > layB[0]) {  // workgroup-uniform
 				HaloRegs hprev{};
 				load_halo(z_begin - 1, hprev);
 				write_plane(2, xb, hprev);  // plane z_begin-1 borrows ring slot 2 (rewritten at step 1)
 				write_plane(0, X0, H0);
 				__syncthreads();
-				cells_scatter(rsR, reR, rsB, reB, 2, 0);
-				__syncthreads();
-				T lower[VX];
-				cells_gather(lower, carry);
-				__syncthreads();
+				cells_scatter(uni(layR[band]), uni(layR[band + 1]), uni(layB[band]), uni(layB[band + 1]), 2, 0, 2, 0, false);
 			}
 		}
 	}
@@ -438,8 +481,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 		const int z = z_begin + s;
 		// stage plane z+1 into the LDS ring (needed by the cells of layer z) and prefetch ahead
 		write_plane((s + 1) % 3, xp1, h_use);
-		if (s + 2 <= nsteps) { load_halo(z + 2, h_load); }      // staged planes end at z_end, own planes at z_end+1
-		if (s + 5 <= nsteps + 1) { xload = load_own(z + 5); }
+		load_halo(z + 2, h_load);
+		if (!CELLS) { xload = load_own(z + 5); }
 		__syncthreads();
 
 		const int gzc = z + P.zoff;
@@ -449,15 +492,38 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 		const T* pp1 = reinterpret_cast<const T*>(&xp1);
 		const T* pp2 = reinterpret_cast<const T*>(&xp2);
 
-		bool has_cells = false;
 		if (CELLS) {
-			const uint32_t rsR = layR[s + 1], reR = layR[s + 2], rsB = layB[s + 1], reB = layB[s + 2];
-			has_cells = (reR > rsR) || (reB > rsB);
-			if (has_cells) {
-				if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1); }
-				cells_scatter(rsR + kThreads < reR ? rsR + kThreads : reR, reR, rsB, reB, b0, b1);
+			// plane z-1 is complete: its layers z-2 and z-1 were scattered before this step's barrier
+			if (s > 0) {
+				T data[VX];
+				cells_gather((s + 2) % 3, data);
+				const T* pm = reinterpret_cast<const T*>(&xload);  // still x(z-1): reloaded below
+				V out;
+				T* po = reinterpret_cast<T*>(&out);
+				T  dsum = T(0);
+#pragma unroll
+				for (int j = 0; j < VX; ++j) {
+					po[j] = held[j] + data[j];
+					dsum += pm[j] * po[j];
+				}
+				if (active) {
+					*reinterpret_cast<V*>((y + static_cast<int64_t>(z - 1) * P.plane) + col) = out;
+					dot_acc += static_cast<double>(dsum);
+				}
 			}
-			prefetch_rows(s + 4, pf);  // layer of step s+3
+			xload = load_own(z + 5);
+			// layer z into the accumulation planes of z and z+1
+			if (layer_dense(s + 1)) {
+				const int o = (s + 1) * 4 + band;
+				cells_scatter(uni(layR[o]), uni(layR[o + 1]), uni(layB[o]), uni(layB[o + 1]), b0, b1, b0, b1, true);
+			} else if (band == (s & 3)) {
+				const int o = (s + 1) * 4;
+#ifndef FI_EXP_NOAPPLY
+				if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1, b0, b1, true); }
+#endif
+				cells_scatter(0u, 0u, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
+			}
+			prefetch_rows(s + 2, pf);
 		}
 
 		T acc2[VX], acc1[VX];
@@ -476,14 +542,14 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 			if (HAS2) {
 				T u[VX + 2];
 #pragma unroll
-				for (int k = 0; k < VX + 2; ++k) { u[k] = m2x[k] * (w[k] - T(2) * w[k + 1] + w[k + 2]); }
+				for (int k = 0; k < VX + 2; ++k) { u[k] = m2x[k] ? (w[k] - T(2) * w[k + 1] + w[k + 2]) : T(0); }
 #pragma unroll
 				for (int j = 0; j < VX; ++j) { acc2[j] += u[j] - T(2) * u[j + 1] + u[j + 2]; }
 			}
 			if (HAS1) {
 				T d[VX + 1];
 #pragma unroll
-				for (int k = 0; k < VX + 1; ++k) { d[k] = m1x[k] * (w[k + 2] - w[k + 1]); }  // anchor gx-1+k
+				for (int k = 0; k < VX + 1; ++k) { d[k] = m1x[k] ? (w[k + 2] - w[k + 1]) : T(0); }  // anchor gx-1+k
 #pragma unroll
 				for (int j = 0; j < VX; ++j) { acc1[j] += d[j] - d[j + 1]; }
 			}
@@ -534,58 +600,65 @@ __global__ __launch_bounds__(kThreads, CELLS ? FI_CELL_WAVES : FI_BASE_WAVES) vo
 			}
 		}
 
-		// ---- data term: lower products of this layer + upper products carried from the layer below
-		T data[VX];
-#pragma unroll
-		for (int j = 0; j < VX; ++j) { data[j] = carry[j]; carry[j] = T(0); }
-		if (CELLS && has_cells) {
-			__syncthreads();
-			T lower[VX];
-			cells_gather(lower, carry);
-#pragma unroll
-			for (int j = 0; j < VX; ++j) { data[j] += lower[j]; }
-		}
-
 		V out;
 		T* po = reinterpret_cast<T*>(&out);
 		T  dsum = T(0);
 #pragma unroll
 		for (int j = 0; j < VX; ++j) {
-			T v = C.w0x3 * pc[j] + data[j];
+			T v = C.w0x3 * pc[j];
 			if (HAS2) { v += C.w2sq * acc2[j]; }
 			if (HAS1) { v += C.w1sq * acc1[j]; }
 			po[j] = v;
 			dsum += pc[j] * v;
 		}
-		if (active) {
-			if (!(P.dbg & 2)) {
-				V* dst = reinterpret_cast<V*>(y + static_cast<int64_t>(z) * P.plane + col);
-				if (P.dbg & 4) {
-					typedef T NV __attribute__((ext_vector_type(VX)));
-					NV nv;
+		if (CELLS) {  // completed at the next step, when the data sums of this plane are final
 #pragma unroll
-					for (int j = 0; j < VX; ++j) { nv[j] = po[j]; }
-					__builtin_nontemporal_store(nv, reinterpret_cast<NV*>(dst));
-				} else {
-					*dst = out;
-				}
-			}
+			for (int j = 0; j < VX; ++j) { held[j] = po[j]; }
+		} else if (active) {
+			if (!(P.dbg & 2)) { *reinterpret_cast<V*>((y + static_cast<int64_t>(z) * P.plane) + col) = out; }
 			dot_acc += static_cast<double>(dsum);
 		}
 	};
 
 	for (int s0 = 0; s0 < nsteps; s0 += 6) {
-		step(s0, X0, X1, X2, X5, H1, H0, PF0, U1, U2, U0, D1, D0);
+		step(s0, X0, X1, X2, X5, H1, CELLS ? H1 : H0, PF0, U1, U2, U0, D1, D0);
 		if (s0 + 1 >= nsteps) { break; }
-		step(s0 + 1, X1, X2, X3, X0, H0, H1, PF1, U2, U0, U1, D0, D1);
+		step(s0 + 1, X1, X2, X3, X0, CELLS ? H1 : H0, H1, PF0, U2, U0, U1, D0, D1);
 		if (s0 + 2 >= nsteps) { break; }
-		step(s0 + 2, X2, X3, X4, X1, H1, H0, PF2, U0, U1, U2, D1, D0);
+		step(s0 + 2, X2, X3, X4, X1, H1, CELLS ? H1 : H0, PF0, U0, U1, U2, D1, D0);
 		if (s0 + 3 >= nsteps) { break; }
-		step(s0 + 3, X3, X4, X5, X2, H0, H1, PF0, U1, U2, U0, D0, D1);
+		step(s0 + 3, X3, X4, X5, X2, CELLS ? H1 : H0, H1, PF0, U1, U2, U0, D0, D1);
 		if (s0 + 4 >= nsteps) { break; }
-		step(s0 + 4, X4, X5, X0, X3, H1, H0, PF1, U2, U0, U1, D1, D0);
+		step(s0 + 4, X4, X5, X0, X3, H1, CELLS ? H1 : H0, PF0, U2, U0, U1, D1, D0);
 		if (s0 + 5 >= nsteps) { break; }
-		step(s0 + 5, X5, X0, X1, X4, H0, H1, PF2, U0, U1, U2, D0, D1);
+		step(s0 + 5, X5, X0, X1, X4, CELLS ? H1 : H0, H1, PF0, U0, U1, U2, D0, D1);
+	}
+	if (CELLS) {  // the last plane of the chunk: x(z_end-1) sits in ring slot (nsteps-1) % 6
+		__syncthreads();
+		T data[VX];
+		cells_gather((nsteps - 1) % 3, data);
+		V xl;
+		switch ((nsteps - 1) % 6) {
+		case 0: xl = X0; break;
+		case 1: xl = X1; break;
+		case 2: xl = X2; break;
+		case 3: xl = X3; break;
+		case 4: xl = X4; break;
+		default: xl = X5; break;
+		}
+		const T* pm = reinterpret_cast<const T*>(&xl);
+		V out;
+		T* po = reinterpret_cast<T*>(&out);
+		T  dsum = T(0);
+#pragma unroll
+		for (int j = 0; j < VX; ++j) {
+			po[j] = held[j] + data[j];
+			dsum += pm[j] * po[j];
+		}
+		if (active) {
+			*reinterpret_cast<V*>((y + static_cast<int64_t>(z_end - 1) * P.plane) + col) = out;
+			dot_acc += static_cast<double>(dsum);
+		}
 	}
 
 	if (partial) {
@@ -651,7 +724,8 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 		uint32_t k = kNoKey, pp = 0;
 		if (z_ok[a] && y_ok[b] && x_ok[d]) {
 			const int     wg     = (z_tk[a] * P.tiles_y + y_ti[b]) * P.tiles_x + x_ti[d];
-			const int64_t bucket = static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a];
+			const int     band   = (y_tc[b] + 1) / 4 > 3 ? 3 : (y_tc[b] + 1) / 4;  // origin rows -1..2, 3..6, 7..10, 11..15
+			const int64_t bucket = (static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a]) * 4 + band;
 			k  = static_cast<uint32_t>(kind * nbuckets + bucket);
 			pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(y_tc[b] + 1) << 16);
 			atomicAdd(&count[kind * (nbuckets + 1) + bucket], 1u);
@@ -699,16 +773,30 @@ __global__ void k_iota32(uint32_t* v, int64_t n)
 	if (i < n) { v[i] = static_cast<uint32_t>(i); }
 }
 
-int pick_chunk(int tiles_xy, int nz_own)
+// Planes per workgroup.  A workgroup pays ~5 planes of pipeline fill and re-reads 4 halo planes of its
+// neighbours, so long chunks are cheaper per plane; but the grid should cover the CUs in whole rounds --
+// `slots` workgroups run at a time (256 CUs x 4 / 3 / 2 resident workgroups, see the launch bounds).
+// Cost model: rounds(zc) * (zc + 5); a fractional last round counts in full while the grid is only a few rounds.
+int pick_chunk(int tiles_xy, int nz_own, int slots)
 {
 	if (const char* env = getenv("FI_ZC")) {
 		const int v = atoi(env);
-		if (v > 0) { return v > 64 ? 64 : v; }  // s_lay holds at most 64 + 2 range bounds
+		if (v > 0) { return v > 64 ? 64 : v; }  // s_lay holds the bounds of at most 64 + 2 layers
 	}
-	// aim for >= 2048 workgroups (8 per CU), planes per chunk between 8 and 64
-	int zc = 64;
-	while (zc > 8 && static_cast<int64_t>(tiles_xy) * ((nz_own + zc - 1) / zc) < 2048) { zc /= 2; }
-	return zc;
+	int    best = 4;
+	double best_cost = 1e300;
+	for (int zc = 4; zc <= 64; ++zc) {
+		if (zc > nz_own && zc > 4) { break; }
+		const int64_t nwg = static_cast<int64_t>(tiles_xy) * ((nz_own + zc - 1) / zc);
+		const double  r   = static_cast<double>(nwg) / slots;
+		const double  rounds = r < 6.0 ? static_cast<double>((nwg + slots - 1) / slots) : r;
+		const double  cost = rounds * (zc + 5);
+		if (cost < best_cost * 0.999) {
+			best_cost = cost;
+			best = zc;
+		}
+	}
+	return best;
 }
 
 template <typename T>
@@ -734,7 +822,11 @@ bool march_setup(const fi_ctx* c, MarchParams* P)
 	P->tiles_x = (P->nx + TX - 1) / TX;
 	P->tiles_y = (P->ny + kTY - 1) / kTY;
 	const int nz_own = P->own_z1 - P->own_z0;
-	P->zc     = pick_chunk(P->tiles_x * P->tiles_y, nz_own);
+	int cus = 256;
+	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+	const bool fused = c->cells.ncell > 0 && !getenv("FI_NO_FUSE");
+	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : (w.model_1 > 0 && w.model_2 > 0 ? FI_CELL_WAVES - 1 : FI_CELL_WAVES);
+	P->zc     = pick_chunk(P->tiles_x * P->tiles_y, nz_own, (cus > 0 ? cus : 256) * wgs_per_cu);
 	P->chunks = (nz_own + P->zc - 1) / P->zc;
 	P->nwg    = P->tiles_x * P->tiles_y * P->chunks;
 	P->plane  = static_cast<int64_t>(P->nx) * P->ny;
@@ -785,7 +877,7 @@ void build_cell_lists(fi_ctx* c)
 	MarchState& m = c->march;
 	const MarchParams& P = m.P;
 	const int64_t ncell = c->cells.ncell;
-	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1);
+	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1) * 4;  // (workgroup, layer, band of origin rows)
 	const int64_t nslots = ncell * 8;
 	FI_REQUIRE(nslots < (1LL << 31) && 2 * nbuckets < (1LL << 31), FI_ERR_UNSUPPORTED, "too many data cells for one context");
 	hipStream_t st = c->stream;
