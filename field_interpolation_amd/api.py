@@ -274,6 +274,15 @@ class LatticeField:
         check(_capi.lib().fi_jacobi(self._h, g, int(num_iterations), float(weight), o, _same_memory(kg, ko)))
         return out
 
+    def tile_pass(self, guess, tile_size=16):
+        """tile_solver_square (sparse_linear.cpp:246-390) on the device: fi_tile_pass."""
+        self._ready()
+        g, kg, _kg = _buf(guess)
+        out = self._out(guess)
+        o, ko, _ko = _buf(out)
+        check(_capi.lib().fi_tile_pass(self._h, g, int(tile_size), o, _same_memory(kg, ko)))
+        return out
+
     def solution_f64(self):
         out = np.empty(self.num_owned, np.float64)
         check(_capi.lib().fi_get_solution_f64(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
@@ -422,16 +431,16 @@ def jacobi_iterations(field, guess, num_iterations, weight):
 
 
 def solve_tiled_with_guess(field, guess, sizes, options):
-    """solve_tiled_with_guess (sparse_linear.cpp:392-443): wrong guess length -> None (:402-405); the tile
-    pre-pass (options.tile) is not implemented on the GPU yet and is rejected rather than skipped."""
+    """solve_tiled_with_guess (sparse_linear.cpp:392-443): wrong guess length -> None (:402-405); optional tile
+    pre-pass (options.tile, :415-425), then optional CG (options.cg, :427-440)."""
     n = int(np.prod(sizes))
     glen = guess.numel() if hasattr(guess, "numel") else np.asarray(guess).size
     if glen != n:
         return None
     if options.tile:
-        raise NotImplementedError("SolveOptions.tile: the tile pre-solver has no GPU implementation yet")
+        guess = field.tile_pass(guess, options.tile_size)
     if not options.cg:
-        return np.array(guess, np.float32, copy=True)
+        return guess if options.tile else np.array(guess, np.float32, copy=True)
     res = field.solve_cg(guess, options.max_iterations, options.error_tolerance)
     return None if res is None else res[0]
 

@@ -242,6 +242,7 @@ struct fi_ctx {
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
 	bool       owns_stream = true;
 	bool       owns_comm = true;     // coarser levels share the RCCL communicator of the finest level
+	int        tile_ts = 0;          // > 0 while fi_tile_pass runs: apply_AtA applies the tile operator of that tile size
 	int        verify_residual = 1;  // check b - A x when the recurrence converges, restart CG if it misses
 	fi_stats   stats{};
 	std::vector<hipEvent_t> ev;  // sampled events around AtA applies

@@ -69,8 +69,11 @@ __device__ inline int64_t owned_to_local(const Geom& g, int64_t o, int* li)
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T> mc, const T* __restrict__ x,
                                                              T* __restrict__ y, double* __restrict__ partial,
-                                                             const int* __restrict__ done)
+                                                             const int* __restrict__ done, int ts)
 {
+	// ts > 0: the tile operator of tile_solver_square (sparse_linear.cpp:246-390): entries (i, j) of AtA are kept
+	// only when i and j lie in the same ts^D tile, plus 1e-6 on the diagonal (:296-300).  Row by row that is
+	// "every row split into its per-tile pieces": a row member j contributes to point c iff tile(j) == tile(c).
 	if (done && *done) { return; }
 	double contrib = 0.0;
 	for (int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; o < g.nown;
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T>
 				for (int m = -4; m <= 4; ++m) {
 					const int gc = c + m;
 					const bool in = (m >= -mc.maxk) && (m <= mc.maxk) && (gc >= 0) && (gc < n);
-					win[m + 4] = in ? x[idx + m * s] : T(0);
+					const bool same = ts <= 0 || (in && gc / ts == c / ts);
+					win[m + 4] = (in && same) ? x[idx + m * s] : T(0);
 				}
 				for (int k = 1; k <= 4; ++k) {
 					if (!mc.on[k]) { continue; }
@@ -116,7 +120,16 @@ __global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T>
 							const int ad = cd - bd, ae = ce - be;
 							if (ad >= 0 && ad + 1 < g.gn[d] && ae >= 0 && ae + 1 < g.gn[e]) {
 								const int64_t a = idx - bd * sd - be * se;
-								const T row = mc.gs * (-x[a] + x[a + sd] + x[a + se] - x[a + sd + se]);
+								T m00 = T(1), m10 = T(1), m01 = T(1), m11 = T(1);  // members in the tile of this point
+								if (ts > 0) {
+									const bool d0 = ad / ts == cd / ts, d1 = (ad + 1) / ts == cd / ts;
+									const bool e0 = ae / ts == ce / ts, e1 = (ae + 1) / ts == ce / ts;
+									m00 = (d0 && e0) ? T(1) : T(0);
+									m10 = (d1 && e0) ? T(1) : T(0);
+									m01 = (d0 && e1) ? T(1) : T(0);
+									m11 = (d1 && e1) ? T(1) : T(0);
+								}
+								const T row = mc.gs * (-m00 * x[a] + m10 * x[a + sd] + m01 * x[a + se] - m11 * x[a + sd + se]);
 								const T sign = (bd ^ be) ? T(1) : T(-1);
 								acc += T(2) * (sign * mc.gs) * row;
 							}
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T>
 				}
 			}
 		}
+		if (ts > 0) { acc += T(1e-6f) * xi; }
 		y[idx] = acc;
 		contrib += static_cast<double>(xi) * static_cast<double>(acc);
 	}
@@ -146,7 +160,7 @@ template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell, const uint32_t* __restrict__ cell_id,
                                                            const T* __restrict__ blk, const T* __restrict__ x,
                                                            T* __restrict__ y, double* __restrict__ partial,
-                                                           const int* __restrict__ done)
+                                                           const int* __restrict__ done, int ts)
 {
 	if (done && *done) { return; }
 	constexpr int NC = 1 << D;
@@ -162,11 +176,14 @@ __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell,
 		int64_t idx[NC];
 		bool    in[NC], own[NC];
 		T       xv[NC];
+		int     tid[NC];  // tile of the corner (tile operator only)
 		for (int q = 0; q < NC; ++q) {
 			int64_t ix = 0;
 			bool ok = true, ow = true;
+			tid[q] = 0;
 			for (int d = 0; d < D; ++d) {
 				const int gq = l[d] + g.coff[d] + ((q >> d) & 1);
+				if (ts > 0) { tid[q] = tid[q] * 2 + ((gq >= 0 ? gq : 0) / ts - (l[d] + g.coff[d] >= 0 ? l[d] + g.coff[d] : 0) / ts); }
 				const int li = gq - g.off[d];
 				ok = ok && (0 <= gq) && (gq < g.gn[d]);
 				ow = ow && (g.own_lo[d] <= li) && (li < g.own_hi[d]);
@@ -182,6 +199,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell,
 			T s = 0;
 			for (int j = 0; j < NC; ++j) {
 				const int e = i <= j ? packed_index(i, j, NC) : packed_index(j, i, NC);
+				if (ts > 0 && tid[i] != tid[j]) { continue; }
 				s += blk[c * (NC * (NC + 1) / 2) + e] * xv[j];
 			}
 			atomic_add(&y[idx[i]], s);
@@ -299,20 +317,25 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 	const Geom& g = c->g;
 	const ModelCoef<T> mc = make_coef<T>(c->w);
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
-	int nb_model = stencil_partials(c);
+	const int ts = c->tile_ts;  // > 0: the tile operator (fi_tile_pass) through the plain kernels
+	int nb_model = ts > 0 ? 0 : stencil_partials(c);
 	int nb_cells = 0;
 	if (nb_model > 0) {
 		stencil_apply(c, x, y, partial);
 	} else {
 		nb_model = capped_blocks(g.nown);
 		hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial,
-		                   done);
+		                   done, ts);
 	}
-	if (c->cells.ncell > 0 && !cells_fused(c)) {
+	if (c->cells.ncell > 0 && (ts > 0 || !cells_fused(c))) {
 		nb_cells = capped_blocks(c->cells.ncell);
 		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(nb_cells), dim3(kThreads), 0, c->stream, g,
 		                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), x, y,
-		                   partial ? partial + nb_model : nullptr, done);
+		                   partial ? partial + nb_model : nullptr, done, ts);
+	}
+	if (ts > 0) {
+		FI_HIP_TRY(hipGetLastError());
+		return;
 	}
 	generic_apply(c, x, y, partial ? partial + nb_model + nb_cells : nullptr);
 	FI_HIP_TRY(hipGetLastError());
@@ -324,6 +347,7 @@ size_t elem_size(const fi_ctx* c) { return c->dtype == FI_F64 ? sizeof(double) :
 
 int apply_num_partials(const fi_ctx* c)
 {
+	if (c->tile_ts > 0) { return capped_blocks(c->g.nown) + (c->cells.ncell > 0 ? capped_blocks(c->cells.ncell) : 0); }
 	int nb_model = stencil_partials(c);
 	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
 	int n = nb_model + generic_num_partials(c);

@@ -559,7 +559,7 @@ void ensure_vectors(fi_ctx* c)
 	FI_HIP_TRY(hipMemsetAsync(c->p.p, 0, es * g.nloc, c->stream));
 	FI_HIP_TRY(hipMemsetAsync(c->q.p, 0, es * g.nloc, c->stream));
 	int nb = apply_num_partials(c);
-	if (nb < 2048) { nb = 2048; }
+	if (nb < 4096) { nb = 4096; }  // also covers the plain kernels of the tile operator (fi_tile_pass)
 	c->max_blocks = nb;
 	c->partial.alloc(sizeof(double) * 4 * nb);
 	c->vectors_ready = true;
@@ -1358,6 +1358,55 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	store_owned<T>(c, c->x, out, memory);
 }
 
+// rhs of the tile systems: b - 2 (AtA g - B g), B = same-tile entries of AtA.  `bg` holds (B + 1e-6 I) g.
+// The factor 2 is the reference's: tile_solver_square visits every stored off-tile entry of the symmetric
+// matrix -- (i, j) and (j, i) -- and moves it to BOTH rows' right-hand sides (sparse_linear.cpp:327-334).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_tile_rhs(int64_t n, const T* __restrict__ b, const T* __restrict__ ag,
+                                                        const T* __restrict__ bg, const T* __restrict__ g,
+                                                        T* __restrict__ out)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		out[i] = b[i] - T(2) * (ag[i] - (bg[i] - T(1e-6f) * g[i]));
+	}
+}
+
+// tile_solver_square (sparse_linear.cpp:246-390) as one CG solve of the block-diagonal tile operator: every
+// tile is an independent SPD system ((AtA restricted to the tile) + 1e-6 I) x_t = rhs_t, so CG on the whole
+// lattice solves all of them at once; the couplings to other tiles enter through the guess, as in the reference.
+template <typename T>
+void tile_pass_t(fi_ctx* c, const float* guess, int tile_size, float* out, int memory)
+{
+	ensure_vectors(c);
+	FI_REQUIRE(c->generic.ntrip == 0 && c->generic.nnz == 0, FI_ERR_UNSUPPORTED,
+	           "the tile pre-solver works on lattice rows (fi_set_model / fi_add_points), not on fi_add_rows_coo rows");
+	load_owned<T>(c, c->x, guess, memory);
+	RankSet R{c};
+	CgScalars init{};
+	reset_scalars(R, init);
+	halo_exchange(R, &fi_ctx::x);
+	DevBuf& rhs = c->scratch[21];
+	rhs.alloc(elem_size(c) * c->g.nloc);
+	FI_HIP_TRY(hipMemsetAsync(rhs.p, 0, elem_size(c) * c->g.nloc, c->stream));
+	apply_AtA(c, c->x.p, c->q.p, nullptr);
+	c->tile_ts = tile_size;
+	struct Restore {
+		fi_ctx* c; DevBuf* rhs; bool swapped;
+		~Restore() { c->tile_ts = 0; if (swapped) { std::swap(c->atb.p, rhs->p); std::swap(c->atb.bytes, rhs->bytes); } }
+	} restore{c, &rhs, false};
+	apply_AtA(c, c->x.p, c->r.p, nullptr);
+	const int64_t o = c->g.own_first;
+	hipLaunchKernelGGL((k_tile_rhs<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+	                   c->atb.as<T>() + o, c->q.as<T>() + o, c->r.as<T>() + o, c->x.as<T>() + o, rhs.as<T>() + o);
+	FI_HIP_TRY(hipGetLastError());
+	std::swap(c->atb.p, rhs.p);
+	std::swap(c->atb.bytes, rhs.bytes);
+	restore.swapped = true;
+	cg_run<T>(R, 4000, sizeof(T) == 8 ? 1e-12f : 1e-6f);  // the reference factorises: iterate to the precision's floor
+	store_owned<T>(c, c->x, out, memory);
+}
+
 template <typename T>
 void jacobi_run(RankSet& R, int sweeps, float weight)
 {
@@ -1937,6 +1986,22 @@ int fi_jacobi(fi_ctx* c, const float* guess, int num_iterations, float weight, f
 		fi::jacobi_t<double>(c, guess, num_iterations, weight, out, memory);
 	} else {
 		fi::jacobi_t<float>(c, guess, num_iterations, weight, out, memory);
+	}
+	FI_API_END
+}
+
+int fi_tile_pass(fi_ctx* c, const float* guess, int tile_size, float* out, int memory)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	FI_REQUIRE(tile_size >= 2, FI_ERR_INVALID, "tile_size %d < 2 (sparse_linear.cpp:254)", tile_size);
+	FI_REQUIRE(guess && out, FI_ERR_INVALID, "fi_tile_pass needs a guess and an output buffer");
+	if (c->dtype == FI_F64) {
+		fi::tile_pass_t<double>(c, guess, tile_size, out, memory);
+	} else {
+		fi::tile_pass_t<float>(c, guess, tile_size, out, memory);
 	}
 	FI_API_END
 }

@@ -148,8 +148,16 @@ std::vector<float> GpuLatticeField::solve_tiled_with_guess(const std::vector<flo
 		std::fprintf(stderr, "field_interpolation: Incomplete guess.\n");  // sparse_linear.cpp:402-405
 		return {};
 	}
-	if (!options.cg) { return guess; }
-	return solve_with_guess(guess, options.max_iterations, options.error_tolerance);
+	std::vector<float> start = guess;
+	if (options.tile) {  // tile_solver_square pre-pass (sparse_linear.cpp:415-425)
+		if (!assemble()) { return {}; }
+		if (fi_tile_pass(ctx_, guess.data(), options.tile_size, start.data(), FI_HOST) != FI_OK) {
+			warn("tile pre-solver");
+			return {};
+		}
+	}
+	if (!options.cg) { return start; }
+	return solve_with_guess(start, options.max_iterations, options.error_tolerance);
 }
 
 std::vector<float> GpuLatticeField::jacobi_iterations(const std::vector<float>& guess, int num_iterations, float weight)

@@ -140,9 +140,10 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 		return {};
 	}
 	if (options.tile) {
-		// The tile pre-pass only improves the starting guess of the iterative phase; it is not implemented on
-		// the GPU yet, so the iteration starts from the caller's guess.
-		std::fprintf(stderr, "field_interpolation: SolveOptions.tile is ignored (no GPU tile pre-solver yet)\n");
+		// The tile pre-pass only improves the starting guess of the iterative phase.  The device version
+		// (fi_tile_pass) works on lattice rows; a materialised LinearEquation goes through the generic sparse-row
+		// path, where it is not available: the iteration starts from the caller's guess.  GpuLatticeField honours it.
+		std::fprintf(stderr, "field_interpolation: SolveOptions.tile is ignored for materialised rows (use GpuLatticeField)\n");
 	}
 	if (!options.cg) { return guess; }
 	return iterate(eq, &guess, static_cast<int>(n), FI_F32, options.max_iterations, options.error_tolerance, false);

@@ -185,6 +185,15 @@ int fi_set_option(fi_ctx* ctx, int option, double value);
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */
 int fi_jacobi(fi_ctx* ctx, const float* guess, int num_iterations, float weight, float* out, int memory);
 
+/* Replaces tile_solver_square (sparse_linear.cpp:246-390), the pre-solver behind SolveOptions.tile
+ * (solve_tiled_with_guess :415-425): non-overlapping tile_size^D tiles, every tile solved for its own unknowns
+ * with the couplings to other tiles moved to the right-hand side using `guess` (the reference moves every
+ * off-tile coupling twice, :327-334 -- reproduced), 1e-6 added to the tile diagonals (:296-300).  The tiles are
+ * independent SPD systems; they are solved together by one CG run on the block-diagonal tile operator
+ * (fp32 contexts to a relative residual of 1e-6, fp64 to 1e-12) instead of one sparse Cholesky per tile.
+ * Lattice rows only (fi_set_model / fi_add_points); tile_size >= 2 (:254). */
+int fi_tile_pass(fi_ctx* ctx, const float* guess, int tile_size, float* out, int memory);
+
 /* fp64 copy of the last solution (FI_F64 contexts keep full precision; FI_F32 widens). Host buffer. */
 int fi_get_solution_f64(fi_ctx* ctx, double* out);
 

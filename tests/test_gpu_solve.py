@@ -158,3 +158,46 @@ def test_upscale_field_bit_exact(oracle, fi):
         got = fi.upscale_field(f, small, large)
         ref = oracle.upscale_field(f, small, large)
         np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("sizes,ts,kw", [([20, 18], 8, dict()), ([37], 16, dict(model_1=0.3)),
+                                        ([12, 9, 10], 4, dict(model_0=0.1, model_1=0.2)),
+                                        ([14, 10], 5, dict(model_2=0.3, model_3=0.2, gradient_smoothness=0.3)),
+                                        ([9, 8, 7], 16, dict())])
+def test_tile_pass_equals_tile_solver(oracle, fi, dtype, sizes, ts, kw):
+    """fi_tile_pass against the oracle's tile_solver_square (sparse_linear.cpp:246-390) and against a dense
+    float64 re-derivation: every tile solved with its couplings moved to the rhs TWICE (:327-334), 1e-6 on
+    the diagonal.  fp64: 1e-7 of the largest entry (CG to 1e-12); fp32: 5e-3 (the reference's float Cholesky
+    and CG-to-1e-6 in fp32 both sit at that level on these kappa ~ 1e4 tiles)."""
+    rng = np.random.default_rng(len(sizes) + ts)
+    pos, nrm, pw, val = random_points(rng, sizes, 150, margin=0.8)
+    w = fi.Weights(data_pos=0.8, data_gradient=1.25, **kw)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, pw, None, dtype=dtype)
+    n = int(np.prod(sizes))
+    AtA, atb, _ = fo.normal_equations()
+    M = AtA.toarray()
+    g = rng.normal(size=n).astype(np.float32)
+    coords = np.stack(np.unravel_index(np.arange(n), sizes[::-1])[::-1], 1)     # x fastest
+    tile_of = np.zeros(n, np.int64)
+    for d in range(len(sizes) - 1, -1, -1):
+        tile_of = tile_of * 64 + coords[:, d] // ts
+    expect = g.astype(np.float64).copy()
+    for t in np.unique(tile_of):
+        mine, other = np.where(tile_of == t)[0], np.where(tile_of != t)[0]
+        rhs = atb[mine] - 2.0 * M[np.ix_(mine, other)] @ g[other].astype(np.float64)
+        expect[mine] = np.linalg.solve(M[np.ix_(mine, mine)] + 1e-6 * np.eye(len(mine)), rhs)
+    x = fg.tile_pass(g, ts)
+    tol = 1e-7 if dtype == "f64" else 5e-3
+    assert np.abs(fg.solution_f64() - expect).max() <= tol * np.abs(expect).max()
+    assert x.dtype == np.float32 and np.abs(x - expect).max() <= max(tol, 1e-6) * np.abs(expect).max()
+    # the oracle (float Cholesky per tile) agrees at fp32 level
+    o = oracle.SolveOptions(tile=1, tile_size=ts, cg=0)
+    xo, _, _ = fo.solve_tiled_with_guess(g, sizes, o)
+    assert np.abs(xo - expect).max() <= 5e-3 * np.abs(expect).max()
+    # SolveOptions.tile through the mirrored entry point: tile pass, then CG from its result
+    so = fi.SolveOptions(tile=True, tile_size=ts, cg=True, error_tolerance=1e-5 if dtype == "f32" else 1e-9)
+    xs = fi.solve_tiled_with_guess(fg, np.zeros(n, np.float32), sizes, so)
+    assert fg.true_residual() <= so.error_tolerance * 1.01
+    with pytest.raises(fi.FiError):
+        fg.tile_pass(g, 1)                                     # CHECK_GE_F(tile_size, 2), sparse_linear.cpp:254
