@@ -5,6 +5,6 @@ C ABI of libfi_hip.so (include/fi_hip.h).  All arithmetic runs in hand-written H
 GPU; importing the API without the built library raises ImportError (no CPU fallback).
 """
 from .api import (GradientKernel, LatticeField, LatticeGroup, SolveOptions, ValueKernel, Weights,  # noqa: F401
-                  jacobi_iterations, sdf_from_points, solve_sparse_linear_exact,
+                  generate_error_map, jacobi_iterations, sdf_from_points, solve_sparse_linear_exact,
                   solve_sparse_linear_with_guess, solve_tiled_with_guess, upscale_field)
 from ._capi import FiError  # noqa: F401

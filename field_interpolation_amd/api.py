@@ -274,6 +274,15 @@ class LatticeField:
         check(_capi.lib().fi_jacobi(self._h, g, int(num_iterations), float(weight), o, _same_memory(kg, ko)))
         return out
 
+    def error_map(self, solution):
+        """generate_error_map (field_interpolation.cpp:402-429) on the device: fi_error_map."""
+        self._ready()
+        g, kg, _kg = _buf(solution)
+        out = self._out(solution)
+        o, ko, _ko = _buf(out)
+        check(_capi.lib().fi_error_map(self._h, g, o, _same_memory(kg, ko)))
+        return out
+
     def tile_pass(self, guess, tile_size=16):
         """tile_solver_square (sparse_linear.cpp:246-390) on the device: fi_tile_pass."""
         self._ready()
@@ -428,6 +437,12 @@ def jacobi_iterations(field, guess, num_iterations, weight):
     if num_iterations <= 0:
         return np.array(guess, np.float32, copy=True) if not hasattr(guess, "data_ptr") else guess.clone()
     return field.jacobi(guess, num_iterations, weight)
+
+
+def generate_error_map(field, solution):
+    """generate_error_map(field.eq.triplets, solution, field.eq.rhs) (field_interpolation.cpp:402-429); the rows
+    live on the device, so the field stands in for its triplet list."""
+    return field.error_map(solution)
 
 
 def solve_tiled_with_guess(field, guess, sizes, options):

@@ -447,6 +447,70 @@ static void generic_apply_t(fi_ctx* c, const T* x, T* y, double* partial)
 	FI_HIP_TRY(hipGetLastError());
 }
 
+// generate_error_map over the raw triplets (duplicates NOT summed: the reference walks eq.triplets,
+// field_interpolation.cpp:408-427).  Row residuals and |a|^2 are accumulated with fp64 atomics.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_errmap_rows(int64_t ntrip, const uint64_t* __restrict__ key,
+                                                           const float* __restrict__ val, const T* __restrict__ x,
+                                                           double* __restrict__ res, double* __restrict__ sq)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < ntrip;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const uint32_t row = static_cast<uint32_t>(key[i] >> 32), col = static_cast<uint32_t>(key[i] & 0xFFFFFFFFull);
+		const double a = static_cast<double>(val[i]);
+		if (a == 0.0) { continue; }
+		unsafeAtomicAdd(&res[row], -a * static_cast<double>(x[col]));
+		unsafeAtomicAdd(&sq[row], a * a);
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_errmap_blame(int64_t ntrip, const uint64_t* __restrict__ key,
+                                                            const float* __restrict__ val, const double* __restrict__ res,
+                                                            const double* __restrict__ sq, T* __restrict__ out)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < ntrip;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const uint32_t row = static_cast<uint32_t>(key[i] >> 32), col = static_cast<uint32_t>(key[i] & 0xFFFFFFFFull);
+		const double a = static_cast<double>(val[i]);
+		if (a == 0.0 || !(sq[row] > 0.0)) { continue; }
+		unsafeAtomicAdd(&out[col], static_cast<T>(a * a / sq[row] * res[row] * res[row]));
+	}
+}
+
+__global__ __launch_bounds__(kThreads) void k_errmap_init(int64_t nrows, const float* __restrict__ rhs,
+                                                           double* __restrict__ res, double* __restrict__ sq)
+{
+	const int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (r < nrows) {
+		res[r] = static_cast<double>(rhs[r]);
+		sq[r]  = 0.0;
+	}
+}
+
+template <typename T>
+static void generic_error_map_t(fi_ctx* c, const T* x, T* out)
+{
+	GenericRows& G = c->generic;
+	DevBuf &res = c->scratch[22], &sq = c->scratch[23];
+	res.alloc(sizeof(double) * G.nrows);
+	sq.alloc(sizeof(double) * G.nrows);
+	hipLaunchKernelGGL(k_errmap_init, dim3(blocks_for(G.nrows)), dim3(kThreads), 0, c->stream, G.nrows, G.rhs.as<float>(),
+	                   res.as<double>(), sq.as<double>());
+	hipLaunchKernelGGL((k_errmap_rows<T>), dim3(capped_blocks(G.ntrip)), dim3(kThreads), 0, c->stream, G.ntrip,
+	                   G.key.as<uint64_t>(), G.val.as<float>(), x, res.as<double>(), sq.as<double>());
+	hipLaunchKernelGGL((k_errmap_blame<T>), dim3(capped_blocks(G.ntrip)), dim3(kThreads), 0, c->stream, G.ntrip,
+	                   G.key.as<uint64_t>(), G.val.as<float>(), res.as<double>(), sq.as<double>(), out);
+	FI_HIP_TRY(hipGetLastError());
+}
+
+void generic_error_map(fi_ctx* c, const void* x, void* out)
+{
+	if (c->generic.ntrip == 0 || c->generic.nrows == 0) { return; }
+	c->dtype == FI_F64 ? generic_error_map_t<double>(c, static_cast<const double*>(x), static_cast<double*>(out))
+	                   : generic_error_map_t<float>(c, static_cast<const float*>(x), static_cast<float*>(out));
+}
+
 void generic_apply(fi_ctx* c, const void* x, void* y, double* partial)
 {
 	if (c->generic.nnz == 0) { return; }

@@ -257,6 +257,7 @@ void operator_prepare(fi_ctx* c);                                   // model dia
 void apply_AtA(fi_ctx* c, const void* x, void* y, double* pq_partial);  // y = AtA x (+ fused x.y partials)
 int  apply_num_partials(const fi_ctx* c);
 double apply_algorithmic_bytes(const fi_ctx* c);
+void error_map(fi_ctx* c, const void* x, void* out);                 // generate_error_map; x with valid ghost planes
 void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.hip
 
 // fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
@@ -279,6 +280,7 @@ void generic_clear(fi_ctx* c);
 void generic_assemble(fi_ctx* c);                      // after assemble(): adds A^T b and diag, builds CSR/CSC
 int  generic_num_partials(const fi_ctx* c);
 void generic_apply(fi_ctx* c, const void* x, void* y, double* partial);  // y += A^T (A x)
+void generic_error_map(fi_ctx* c, const void* x, void* out);             // out += blame of the generic rows
 
 // fi_assembly.hip
 // positions are multiplied by pos_scale and normals by nrm_scale before use (coarser levels: 1/2^l and 2^l)

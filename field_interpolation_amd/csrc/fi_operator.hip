@@ -371,6 +371,139 @@ double apply_algorithmic_bytes(const fi_ctx* c)
 	return lattice + static_cast<double>(c->cells.ncell) * (4.0 + s * static_cast<double>(c->cells.nb));
 }
 
+// ---- generate_error_map (field_interpolation.cpp:402-429) --------------------------------------------------
+// Every row r = (a, b) blames its unknowns for its squared residual: out[j] += a_j^2 / |a|^2 * (b - a.x)^2.
+// Model rows are enumerated per lattice point exactly like k_apply_generic does (row anchored at c-m touches c
+// with coefficient c[k][m]); data rows come from the row tables the assembly was built from.
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_error_model(Geom g, ModelCoef<T> mc, const T* __restrict__ x,
+                                                           T* __restrict__ out)
+{
+	for (int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; o < g.nown;
+	     o += static_cast<int64_t>(gridDim.x) * kThreads) {
+		int li[3] = {0, 0, 0};
+		const int64_t idx = owned_to_local<D>(g, o, li);
+		const T xi = x[idx];
+		T acc = 0;
+		for (int d = 0; d < D; ++d) {
+			const int     c = li[d] + g.off[d];
+			const int     n = g.gn[d];
+			const int64_t s = g.stride[d];
+			if (mc.on[0]) { acc += mc.w0sq * xi * xi; }  // row [w0], alone in its row: all the blame
+			for (int k = 1; k <= 4; ++k) {
+				if (!mc.on[k]) { continue; }
+				T sq = 0;
+				for (int j = 0; j <= k; ++j) { sq += mc.c[k][j] * mc.c[k][j]; }
+				for (int m = 0; m <= k; ++m) {
+					const int a = c - m;
+					if (a >= 0 && a + k < n) {
+						T t = 0;
+						for (int j = 0; j <= k; ++j) { t += mc.c[k][j] * x[idx + (j - m) * s]; }
+						acc += (mc.c[k][m] * mc.c[k][m] / sq) * t * t;
+					}
+				}
+			}
+		}
+		if (mc.on[5]) {  // rows [-1,+1,+1,-1]*gs, each unordered axis pair emitted twice (cpp:303-315): blame 1/4 each
+			for (int d = 0; d < D; ++d) {
+				for (int e = d + 1; e < D; ++e) {
+					const int cd = li[d] + g.off[d], ce = li[e] + g.off[e];
+					const int64_t sd = g.stride[d], se = g.stride[e];
+					for (int bd = 0; bd < 2; ++bd) {
+						for (int be = 0; be < 2; ++be) {
+							const int ad = cd - bd, ae = ce - be;
+							if (ad >= 0 && ad + 1 < g.gn[d] && ae >= 0 && ae + 1 < g.gn[e]) {
+								const int64_t a = idx - bd * sd - be * se;
+								const T row = mc.gs * (-x[a] + x[a + sd] + x[a + se] - x[a + sd + se]);
+								acc += T(2) * T(0.25) * row * row;
+							}
+						}
+					}
+				}
+			}
+		}
+		out[idx] = acc;
+	}
+}
+
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_error_rows(Geom g, int64_t nrows, const uint32_t* __restrict__ key,
+                                                          const float* __restrict__ coef, const float* __restrict__ rhs,
+                                                          const T* __restrict__ x, T* __restrict__ out)
+{
+	constexpr int NC = 1 << D;
+	for (int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; r < nrows;
+	     r += static_cast<int64_t>(gridDim.x) * kThreads) {
+		uint32_t id = key[r];
+		if (id == 0xFFFFFFFFu) { continue; }
+		int l[3] = {0, 0, 0};
+		for (int d = 0; d < D; ++d) {
+			l[d] = static_cast<int>(id % static_cast<uint32_t>(g.cn[d]));
+			id /= static_cast<uint32_t>(g.cn[d]);
+		}
+		int64_t idx[NC];
+		bool    own[NC];
+		T       a[NC];
+		T       res = static_cast<T>(rhs[r]), sq = 0;
+		for (int q = 0; q < NC; ++q) {
+			int64_t ix = 0;
+			bool ok = true, ow = true;
+			for (int d = 0; d < D; ++d) {
+				const int gq = l[d] + g.coff[d] + ((q >> d) & 1);
+				const int lq = gq - g.off[d];
+				ok = ok && (0 <= gq) && (gq < g.gn[d]);
+				ow = ow && (g.own_lo[d] <= lq) && (lq < g.own_hi[d]);
+				ix += static_cast<int64_t>(lq) * g.stride[d];
+			}
+			idx[q] = ix;
+			own[q] = ok && ow;
+			a[q]   = ok ? static_cast<T>(coef[r * NC + q]) : T(0);
+			if (ok) { res -= a[q] * x[ix]; }
+			sq += a[q] * a[q];
+		}
+		if (!(sq > 0)) { continue; }
+		const T e = res * res / sq;
+		for (int q = 0; q < NC; ++q) {
+			if (own[q] && a[q] != T(0)) { atomic_add(&out[idx[q]], a[q] * a[q] * e); }
+		}
+	}
+}
+
+template <int D, typename T>
+void error_map_dim(fi_ctx* c, const T* x, T* out)
+{
+	const Geom& g = c->g;
+	const ModelCoef<T> mc = make_coef<T>(c->w);
+	hipLaunchKernelGGL((k_error_model<D, T>), dim3(capped_blocks(g.nown)), dim3(kThreads), 0, c->stream, g, mc, x, out);
+	for (const Pending* pb : c->pending) {
+		if (pb->nrows == 0) { continue; }
+		hipLaunchKernelGGL((k_error_rows<D, T>), dim3(capped_blocks(pb->nrows)), dim3(kThreads), 0, c->stream, g,
+		                   static_cast<int64_t>(pb->nrows), pb->key.as<uint32_t>(), pb->coef.as<float>(),
+		                   pb->rhs.as<float>(), x, out);
+	}
+	FI_HIP_TRY(hipGetLastError());
+	generic_error_map(c, x, out);
+}
+
+void error_map(fi_ctx* c, const void* x, void* out)
+{
+	const bool f64 = c->dtype == FI_F64;
+	switch (c->g.ndim) {
+	case 1:
+		f64 ? error_map_dim<1, double>(c, static_cast<const double*>(x), static_cast<double*>(out))
+		    : error_map_dim<1, float>(c, static_cast<const float*>(x), static_cast<float*>(out));
+		break;
+	case 2:
+		f64 ? error_map_dim<2, double>(c, static_cast<const double*>(x), static_cast<double*>(out))
+		    : error_map_dim<2, float>(c, static_cast<const float*>(x), static_cast<float*>(out));
+		break;
+	default:
+		f64 ? error_map_dim<3, double>(c, static_cast<const double*>(x), static_cast<double*>(out))
+		    : error_map_dim<3, float>(c, static_cast<const float*>(x), static_cast<float*>(out));
+		break;
+	}
+}
+
 void operator_prepare(fi_ctx* c)
 {
 	const bool f64 = c->dtype == FI_F64;

@@ -1990,6 +1990,29 @@ int fi_jacobi(fi_ctx* c, const float* guess, int num_iterations, float weight, f
 	FI_API_END
 }
 
+int fi_error_map(fi_ctx* c, const float* solution, float* out, int memory)
+{
+	FI_API_BEGIN
+	fi::check_assembled(c);
+	fi::bind_device(c);
+	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	FI_REQUIRE(solution && out, FI_ERR_INVALID, "fi_error_map needs a solution and an output buffer");
+	fi::ensure_vectors(c);
+	fi::RankSet R{c};
+	if (c->dtype == FI_F64) {
+		fi::load_owned<double>(c, c->x, solution, memory);
+		fi::halo_exchange(R, &fi_ctx::x);
+		fi::error_map(c, c->x.p, c->q.p);
+		fi::store_owned<double>(c, c->q, out, memory);
+	} else {
+		fi::load_owned<float>(c, c->x, solution, memory);
+		fi::halo_exchange(R, &fi_ctx::x);
+		fi::error_map(c, c->x.p, c->q.p);
+		fi::store_owned<float>(c, c->q, out, memory);
+	}
+	FI_API_END
+}
+
 int fi_tile_pass(fi_ctx* c, const float* guess, int tile_size, float* out, int memory)
 {
 	FI_API_BEGIN

@@ -172,6 +172,17 @@ std::vector<float> GpuLatticeField::jacobi_iterations(const std::vector<float>& 
 	return out;
 }
 
+std::vector<float> GpuLatticeField::generate_error_map(const std::vector<float>& solution)
+{
+	if (solution.size() != num_unknowns() || !assemble()) { return {}; }
+	std::vector<float> out(solution.size());
+	if (fi_error_map(ctx_, solution.data(), out.data(), FI_HOST) != FI_OK) {
+		warn("generate_error_map");
+		return {};
+	}
+	return out;
+}
+
 std::unique_ptr<GpuLatticeField> gpu_sdf_from_points(const std::vector<int>& sizes, const Weights& weights,
                                                      int num_points, const float positions[], const float* normals,
                                                      const float* point_weights)

@@ -194,6 +194,12 @@ int fi_jacobi(fi_ctx* ctx, const float* guess, int num_iterations, float weight,
  * Lattice rows only (fi_set_model / fi_add_points); tile_size >= 2 (:254). */
 int fi_tile_pass(fi_ctx* ctx, const float* guess, int tile_size, float* out, int memory);
 
+/* Replaces generate_error_map (field_interpolation.cpp:402-429): the blame heat-map of a solution.  Every
+ * equation (model row, data row, fi_add_rows_coo row) distributes its squared residual (rhs - a.x)^2 over its
+ * unknowns in proportion to a_j^2.  `solution` and `out`: owned unknowns, x fastest, fp32.  Rows added by
+ * fi_add_points are read from the row tables of the last batches (kept until fi_clear_points). */
+int fi_error_map(fi_ctx* ctx, const float* solution, float* out, int memory);
+
 /* fp64 copy of the last solution (FI_F64 contexts keep full precision; FI_F32 widens). Host buffer. */
 int fi_get_solution_f64(fi_ctx* ctx, double* out);
 

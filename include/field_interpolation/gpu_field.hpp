@@ -38,6 +38,8 @@ public:
 	std::vector<float> solve_with_guess(const std::vector<float>& guess, int max_iterations, float error_tolerance);
 	std::vector<float> solve_tiled_with_guess(const std::vector<float>& guess, const SolveOptions& options);
 	std::vector<float> jacobi_iterations(const std::vector<float>& guess, int num_iterations, float weight);
+	// generate_error_map(field.eq.triplets, solution, field.eq.rhs) of the reference, from the rows on the device.
+	std::vector<float> generate_error_map(const std::vector<float>& solution);
 
 	int    last_iterations() const { return iterations_; }
 	float  last_error() const { return error_; }

@@ -134,6 +134,14 @@ int main()
 		float total = 0;
 		for (float h : heat) { total += h; }
 		require(heat.size() == n && total > 0, "generate_error_map");
+		auto heat_gpu = gpu.generate_error_map(exact);
+		require(heat_gpu.size() == n && max_rel(heat_gpu, heat) <= 1e-4f, "generate_error_map: device rows == host triplets");
+		fi::SolveOptions tiled;
+		tiled.tile = true;
+		tiled.tile_size = 8;
+		tiled.error_tolerance = 1e-5f;
+		auto via_tiles = gpu.solve_tiled_with_guess(std::vector<float>(n, 0.0f), tiled);
+		require(via_tiles.size() == n && max_rel(via_tiles, exact) <= 5e-3f, "SolveOptions.tile: tile pre-solver + CG");
 		auto big = fi::upscale_field(exact.data(), sizes, {47, 39});
 		require(big.size() == 47u * 39u && std::fabs(big[0] - exact[0]) < 1e-6f && std::fabs(big.back() - exact.back()) < 1e-6f,
 		        "upscale_field keeps the corners");

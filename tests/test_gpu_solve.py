@@ -201,3 +201,27 @@ def test_tile_pass_equals_tile_solver(oracle, fi, dtype, sizes, ts, kw):
     assert fg.true_residual() <= so.error_tolerance * 1.01
     with pytest.raises(fi.FiError):
         fg.tile_pass(g, 1)                                     # CHECK_GE_F(tile_size, 2), sparse_linear.cpp:254
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("sizes,kw,gk", [([40], dict(), 1), ([17, 12], dict(model_1=0.3), 1),
+                                        ([9, 8, 7], dict(model_0=0.2, model_3=0.4, gradient_smoothness=0.3), 0),
+                                        ([14, 11], dict(model_4=0.2), 2), ([8, 7, 9], dict(), 2)])
+def test_error_map_equals_reference_blame(oracle, fi, dtype, sizes, kw, gk):
+    """fi_error_map against the oracle's generate_error_map (field_interpolation.cpp:402-429) on the very same
+    rows: model rows (every order), cell rows, and the generic rows of GradientKernel::kLinearInterpolation
+    (duplicate (row, col) entries blamed per triplet).  2e-4 of the largest entry (the oracle sums in fp32)."""
+    rng = np.random.default_rng(len(sizes) * 5 + gk)
+    pos, nrm, pw, val = random_points(rng, sizes, 80, margin=0.8)
+    w = fi.Weights(data_pos=0.8, data_gradient=1.25, gradient_kernel=fi.GradientKernel(gk), **kw)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, pw, None, dtype=dtype)
+    x = rng.normal(size=int(np.prod(sizes))).astype(np.float32)
+    expect = fo.error_map(x)
+    heat = fi.generate_error_map(fg, x)
+    assert heat.dtype == np.float32 and heat.shape == expect.shape
+    assert np.abs(heat - expect).max() <= 2e-4 * np.abs(expect).max()
+    # an exact solution of a consistent system blames nobody: model rows only, constant field
+    f0 = fi.LatticeField(sizes, dtype=dtype)
+    f0.add_field_constraints(fi.Weights(model_1=0.3, model_2=0.5))
+    f0.assemble()
+    assert np.abs(f0.error_map(np.full(int(np.prod(sizes)), 3.0, np.float32))).max() <= 1e-10
