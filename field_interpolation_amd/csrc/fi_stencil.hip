@@ -692,10 +692,13 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 	const int  kind = (live && nrow[c] == 1u) ? 0 : 1;    // 0: single-row cell, 1: block cell
 	{
 		// distinct cells of each kind: one atomic per wave (a single hot address serialises in L2)
+		// distinct cells of each kind (statistics): one atomic per wave, spread over 64 counter pairs -- atomics on
+		// a single hot address serialise at ~10 ns each, 15 k waves would cost 0.15 ms
 		const unsigned long long rows = __ballot(live && kind == 0), blks = __ballot(live && kind == 1);
 		if ((threadIdx.x & 63) == 0) {
-			if (rows) { atomicAdd(&count[2 * (nbuckets + 1) + 0], static_cast<uint32_t>(__popcll(rows))); }
-			if (blks) { atomicAdd(&count[2 * (nbuckets + 1) + 1], static_cast<uint32_t>(__popcll(blks))); }
+			const int w = (blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) & 63;
+			if (rows) { atomicAdd(&count[2 * w], static_cast<uint32_t>(__popcll(rows))); }
+			if (blks) { atomicAdd(&count[2 * w + 1], static_cast<uint32_t>(__popcll(blks))); }
 		}
 	}
 	if (!live) { return; }
@@ -728,7 +731,6 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 			const int64_t bucket = (static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a]) * 4 + band;
 			k  = static_cast<uint32_t>(kind * nbuckets + bucket);
 			pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(y_tc[b] + 1) << 16);
-			atomicAdd(&count[kind * (nbuckets + 1) + bucket], 1u);
 		}
 		key[c * 8 + m] = k;
 		pos[c * 8 + m] = pp;
@@ -765,6 +767,32 @@ __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_
 		const uint32_t nvec = (k == 0xFFu ? 36u : k * 8u) / VX;  // 255: the packed block (fp64 contexts)
 		for (uint32_t r = 0; r < nvec; ++r) { dst[r] = src[r]; }
 	}
+}
+
+// List bounds straight from the sorted keys (no per-bucket counters: 10^6 scattered atomics cost 0.3 ms):
+// bound[k] = first sorted slot whose key is >= k, for k = 0 .. nkeys: one binary search per key value
+// (unused slots carry 0xFFFFFFFF and sort behind every real key).
+__global__ __launch_bounds__(kThreads) void k_list_bounds(int64_t nslots, int64_t nkeys, const uint32_t* __restrict__ key_sorted,
+                                                           uint32_t* __restrict__ bound)
+{
+	const int64_t k = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (k > nkeys) { return; }
+	int64_t lo = 0, hi = nslots;  // first index with key_sorted[i] >= k
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if (static_cast<int64_t>(key_sorted[mid]) < k) { lo = mid + 1; } else { hi = mid; }
+	}
+	bound[k] = static_cast<uint32_t>(lo);
+}
+
+// bounds of the block records are counted from the first block record
+__global__ __launch_bounds__(kThreads) void k_split_bounds(int64_t nbuckets, const uint32_t* __restrict__ bound,
+                                                            uint32_t* __restrict__ lay_row, uint32_t* __restrict__ lay_blk)
+{
+	const int64_t b = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (b > nbuckets) { return; }
+	lay_row[b] = bound[b];
+	lay_blk[b] = bound[nbuckets + b] - bound[nbuckets];
 }
 
 __global__ void k_iota32(uint32_t* v, int64_t n)
@@ -883,7 +911,7 @@ void build_cell_lists(fi_ctx* c)
 	hipStream_t st = c->stream;
 	DevBuf &count = c->scratch[14], &key = c->scratch[15], &pos = c->scratch[16], &slot_in = c->scratch[17],
 	       &key_sorted = c->scratch[18], &slot_sorted = c->scratch[19], &tmp = c->scratch[20];
-	count.alloc(sizeof(uint32_t) * (2 * (nbuckets + 1) + 2));
+	count.alloc(sizeof(uint32_t) * (2 * nbuckets + 130));  // [0..127]: distinct cells per kind (64 pairs), [128..]: list bounds
 	key.alloc(sizeof(uint32_t) * nslots);
 	pos.alloc(sizeof(uint32_t) * nslots);
 	slot_in.alloc(sizeof(uint32_t) * nslots);
@@ -891,7 +919,7 @@ void build_cell_lists(fi_ctx* c)
 	slot_sorted.alloc(sizeof(uint32_t) * nslots);
 	m.lay_row.alloc(sizeof(uint32_t) * (nbuckets + 1));
 	m.lay_blk.alloc(sizeof(uint32_t) * (nbuckets + 1));
-	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * (2 * (nbuckets + 1) + 2), st));
+	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * 128, st));
 	const int nb = static_cast<int>((ncell + kThreads - 1) / kThreads);
 	hipLaunchKernelGGL(k_cell_members, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
 	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), key.as<uint32_t>(),
@@ -899,25 +927,28 @@ void build_cell_lists(fi_ctx* c)
 	hipLaunchKernelGGL(k_iota32, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
 	                   slot_in.as<uint32_t>(), nslots);
 	// unused slots carry key 0xFFFFFFFF and sort to the end: all 32 key bits take part
-	size_t tb = 0, tb2 = 0;
+	size_t tb = 0;
 	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
 	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
 	                                              static_cast<int>(nslots), 0, 32, st));
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
-	                                            static_cast<int>(nbuckets + 1), st));
-	tmp.alloc(tb > tb2 ? tb : tb2);
+	tmp.alloc(tb);
 	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
 	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
 	                                              static_cast<int>(nslots), 0, 32, st));
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, count.as<uint32_t>(), m.lay_row.as<uint32_t>(),
-	                                            static_cast<int>(nbuckets + 1), st));
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, count.as<uint32_t>() + (nbuckets + 1),
-	                                            m.lay_blk.as<uint32_t>(), static_cast<int>(nbuckets + 1), st));
-	uint32_t totals[2] = {0, 0}, uniq[2] = {0, 0};
+	uint32_t* bound = count.as<uint32_t>() + 128;  // [2 * nbuckets + 1]
+	hipLaunchKernelGGL(k_list_bounds, dim3(static_cast<int>((2 * nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+	                   st, nslots, 2 * nbuckets, key_sorted.as<uint32_t>(), bound);
+	hipLaunchKernelGGL(k_split_bounds, dim3(static_cast<int>((nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+	                   nbuckets, bound, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>());
+	uint32_t totals[2] = {0, 0}, uniq[2] = {0, 0}, uniq64[128];
 	FI_HIP_TRY(hipMemcpyAsync(&totals[0], m.lay_row.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipMemcpyAsync(&totals[1], m.lay_blk.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	FI_HIP_TRY(hipMemcpyAsync(uniq, count.as<uint32_t>() + 2 * (nbuckets + 1), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipMemcpyAsync(uniq64, count.as<uint32_t>(), sizeof(uniq64), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
+	for (int w = 0; w < 64; ++w) {
+		uniq[0] += uniq64[2 * w];
+		uniq[1] += uniq64[2 * w + 1];
+	}
 	m.n_row = totals[0];
 	m.n_blk = totals[1];
 	m.cells_row = uniq[0];
