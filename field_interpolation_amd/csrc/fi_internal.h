@@ -189,6 +189,7 @@ struct CgScalars {  // lives in device memory; kernels read/write it, the host p
 	double rz, rz_new, pq, rr, bb, tol2, alpha, beta, true_rr;
 	double sums[4];
 	int    iter, done, max_iter, restarts;
+	int    tag, pad_;  // second slot only (single-rank fused CG): the iteration whose first half filled it
 };
 
 }  // namespace fi

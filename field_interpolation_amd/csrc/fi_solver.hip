@@ -210,6 +210,149 @@ __global__ __launch_bounds__(kThreads) void k_cg_xp(int64_t n, const CgScalars* 
 	}
 }
 
+// ---- single-rank CG with the reductions folded into the consumers -------------------------------------------
+// The separate one-block reduce launches (4.8 us each plus two kernel boundaries per iteration) disappear:
+// every block of the consumer kernel sums the producer's partials itself, in the same fixed order, so all
+// blocks hold bit-identical scalars.  Block 0 publishes them into the OTHER scalar slot (no block reads the slot
+// its kernel writes): k_cg_resid_f reads slot 0 and writes slot 1, k_cg_xp_f reads slot 1 and writes slot 0.
+__device__ inline double block_sum_all(double v)  // the sum, in every thread
+{
+	__shared__ double s[kThreads / 64];
+	const double w = wave_sum(v);
+	if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = w; }
+	__syncthreads();
+	double r = 0;
+	for (int k = 0; k < kThreads / 64; ++k) { r += s[k]; }
+	__syncthreads();
+	return r;
+}
+
+__device__ inline double sum_partials(const double* __restrict__ partial, int count)
+{
+	double acc = 0;
+	for (int i = threadIdx.x; i < count; i += kThreads) { acc += partial[i]; }
+	return block_sum_all(acc);
+}
+
+// first half: alpha from the p.q partials of the apply, r -= alpha q, partials of r.(Dinv r) and r.r
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_cg_resid_f(int64_t n, const CgScalars* __restrict__ in,
+                                                          CgScalars* __restrict__ mid, int tag,
+                                                          const double* __restrict__ pq_partial, int pq_count,
+                                                          const T* __restrict__ q, const T* __restrict__ dinv,
+                                                          T* __restrict__ r, double* __restrict__ partial, int nblk)
+{
+	if (in->done) { return; }
+	const double pq    = sum_partials(pq_partial, pq_count);
+	const double alpha_d = in->rz / pq;
+	const bool   bad   = !(pq > 0.0) || !isfinite(pq);
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		CgScalars s = *in;
+		s.sums[0] = pq;
+		s.pq      = pq;
+		s.alpha   = alpha_d;
+		s.tag     = tag;
+		if (bad) { s.done = 2; }  // breakdown; the second half publishes it
+		*mid = s;
+	}
+	if (bad) { return; }
+	using V = typename Vec16<T>::V;
+	constexpr int N = VEC ? Vec16<T>::N : 1;
+	const T alpha = static_cast<T>(alpha_d);
+	double acc[2] = {0, 0};
+	const int64_t nv = n / N;
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		T rv[N], qv[N], dv[N];
+		if (VEC) {
+			*reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i];
+			*reinterpret_cast<V*>(qv) = reinterpret_cast<const V*>(q)[i];
+			*reinterpret_cast<V*>(dv) = reinterpret_cast<const V*>(dinv)[i];
+		} else {
+			rv[0] = r[i]; qv[0] = q[i]; dv[0] = dinv[i];
+		}
+		T s0 = T(0), s1 = T(0);
+#pragma unroll
+		for (int j = 0; j < N; ++j) {
+			rv[j] -= alpha * qv[j];
+			s0 += rv[j] * (dv[j] * rv[j]);
+			s1 += rv[j] * rv[j];
+		}
+		if (VEC) { reinterpret_cast<V*>(r)[i] = *reinterpret_cast<V*>(rv); } else { r[i] = rv[0]; }
+		acc[0] += static_cast<double>(s0);
+		acc[1] += static_cast<double>(s1);
+	}
+	double out[2];
+	block_sum<2>(acc, out);
+	if (threadIdx.x == 0) {
+		partial[blockIdx.x]        = out[0];
+		partial[nblk + blockIdx.x] = out[1];
+	}
+}
+
+// second half: beta and the stop test from the partials of the first half, x += alpha p, p = Dinv r + beta p
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_cg_xp_f(int64_t n, const CgScalars* __restrict__ mid,
+                                                       CgScalars* __restrict__ out_sc, int tag,
+                                                       const double* __restrict__ partial, int nblk,
+                                                       const T* __restrict__ r, const T* __restrict__ dinv,
+                                                       T* __restrict__ x, T* __restrict__ p)
+{
+	if (mid->tag != tag) { return; }  // the first half of this iteration did not run: the solve had finished
+	if (mid->done == 2) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = *mid; }
+		return;
+	}
+	const double rz_new = sum_partials(partial, nblk);
+	const double rr     = sum_partials(partial + nblk, nblk);
+	const double beta_d = rz_new / mid->rz;
+	const int    iter   = mid->iter + 1;
+	const int    done   = !isfinite(rr) ? 2 : (!(rr > mid->tol2) ? 1 : (iter >= mid->max_iter ? 3 : 0));
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		CgScalars s = *mid;
+		s.sums[0] = rz_new;
+		s.sums[1] = rr;
+		s.rz_new  = rz_new;
+		s.rr      = rr;
+		s.beta    = beta_d;
+		s.rz      = rz_new;
+		s.iter    = iter;
+		s.done    = done;
+		*out_sc   = s;
+	}
+	if (done == 2) { return; }
+	using V = typename Vec16<T>::V;
+	constexpr int N = VEC ? Vec16<T>::N : 1;
+	const T    alpha = static_cast<T>(mid->alpha);
+	const T    beta  = static_cast<T>(beta_d);
+	const bool go_on = done == 0;
+	const int64_t nv = n / N;
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		T xv[N], pv[N], rv[N], dv[N];
+		if (VEC) {
+			*reinterpret_cast<V*>(xv) = reinterpret_cast<const V*>(x)[i];
+			*reinterpret_cast<V*>(pv) = reinterpret_cast<const V*>(p)[i];
+		} else {
+			xv[0] = x[i]; pv[0] = p[i];
+		}
+#pragma unroll
+		for (int j = 0; j < N; ++j) { xv[j] += alpha * pv[j]; }
+		if (VEC) { reinterpret_cast<V*>(x)[i] = *reinterpret_cast<V*>(xv); } else { x[i] = xv[0]; }
+		if (go_on) {
+			if (VEC) {
+				*reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i];
+				*reinterpret_cast<V*>(dv) = reinterpret_cast<const V*>(dinv)[i];
+			} else {
+				rv[0] = r[i]; dv[0] = dinv[i];
+			}
+#pragma unroll
+			for (int j = 0; j < N; ++j) { pv[j] = dv[j] * rv[j] + beta * pv[j]; }
+			if (VEC) { reinterpret_cast<V*>(p)[i] = *reinterpret_cast<V*>(pv); } else { p[i] = pv[0]; }
+		}
+	}
+}
+
 // x <- x + w * (b - q) * Dinv     (jacobi_iterations, sparse_linear.cpp:233-239, algebraically identical)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_jacobi_update(int64_t n, T w, const T* __restrict__ b,
@@ -742,6 +885,8 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		constexpr int N = Vec16<T>::N;
 		return (c->g.own_first % N == 0) && (c->g.nown % N == 0);
 	};
+	// one context, one process: the dot-product reductions are folded into the vector kernels (3 launches per step)
+	const bool folded = R.size() == 1 && c0->nranks == 1 && !getenv("FI_NO_FOLD");
 	int issued = 0;         // CG steps enqueued so far (the device runs step k only while it is not done)
 	int restarts_left = c0->verify_residual ? 3 : 0;
 	for (;;) {
@@ -775,12 +920,33 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		for (int k = 0; k < kCheckEvery; ++k) {
 			++issued;
 			halo_exchange(R, &fi_ctx::p);
-			const bool sample = samples < kMaxSamples;
+			// every 4th apply is timed: an event record is a barrier packet of its own in the queue
+			const bool sample = samples < kMaxSamples && (issued & 3) == 1;
 			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
 			for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>()); }
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples + 1], st));
 				++samples;
+			}
+			if (folded) {
+				fi_ctx* c = c0;
+				const int64_t o   = c->g.own_first;
+				const int     nbf = nbv(c) > 1024 ? 1024 : nbv(c);  // every block re-reads all partials: keep them few
+				CgScalars*    sc  = c->scal.as<CgScalars>();
+				double*       pp  = c->partial.as<double>();
+				double*       pr  = pp + c->max_blocks;  // the apply partials are still being read: separate region
+				if (vec_ok(c)) {
+					hipLaunchKernelGGL((k_cg_resid_f<T, true>), dim3(nbf), dim3(kThreads), 0, st, c->g.nown, sc, sc + 1, issued, pp,
+					                   nb_apply(c), c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, pr, nbf);
+					hipLaunchKernelGGL((k_cg_xp_f<T, true>), dim3(nbf), dim3(kThreads), 0, st, c->g.nown, sc + 1, sc, issued, pr, nbf,
+					                   c->r.as<T>() + o, c->dinv.as<T>() + o, c->x.as<T>() + o, c->p.as<T>() + o);
+				} else {
+					hipLaunchKernelGGL((k_cg_resid_f<T, false>), dim3(nbf), dim3(kThreads), 0, st, c->g.nown, sc, sc + 1, issued, pp,
+					                   nb_apply(c), c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, pr, nbf);
+					hipLaunchKernelGGL((k_cg_xp_f<T, false>), dim3(nbf), dim3(kThreads), 0, st, c->g.nown, sc + 1, sc, issued, pr, nbf,
+					                   c->r.as<T>() + o, c->dinv.as<T>() + o, c->x.as<T>() + o, c->p.as<T>() + o);
+				}
+				continue;
 			}
 			reduce_phase(R, 1, nb_apply, zero, kPhaseSpmv);
 			for (fi_ctx* c : R) {
@@ -819,8 +985,8 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	(void)hipEventDestroy(e1);
 
 	const CgScalars h = *c0->scal_host;
-	int used = samples;  // iterations that actually ran (kernels of later iterations exited on the flag)
-	if (h.iter < used) { used = h.iter; }
+	int used = samples;  // samples of iterations that actually ran (kernels of later iterations exited on the flag)
+	if ((h.iter + 3) / 4 < used) { used = (h.iter + 3) / 4; }  // sample k belongs to iteration 4k + 1
 	double sum_ms = 0;
 	for (int k = 0; k < used; ++k) {
 		float t = 0;
@@ -1678,7 +1844,8 @@ fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks)
 		FI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->halo = 1;
 		compute_geom(c, ndim, sizes);
-		c->scal.alloc(sizeof(CgScalars));
+		c->scal.alloc(2 * sizeof(CgScalars));  // [0]: the state every kernel and the host look at, [1]: mid-iteration copy
+		FI_HIP_TRY(hipMemset(c->scal.p, 0, 2 * sizeof(CgScalars)));
 		FI_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->scal_host), sizeof(CgScalars), hipHostMallocDefault));
 		// default Weights (field_interpolation.hpp:75-95)
 		c->w = fi_weights{1.0f, 1.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, FI_VALUE_LINEAR_INTERPOLATION,
