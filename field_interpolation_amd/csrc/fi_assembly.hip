@@ -209,36 +209,17 @@ __global__ void k_iota(uint32_t* v, long n)
 	if (i < n) { v[i] = static_cast<uint32_t>(i); }
 }
 
+constexpr uint32_t kHeavyRows = 192;  // cells with more rows are summed by a whole workgroup (k_build_heavy)
+
+// everything after the sums of a cell: block, first row, rhs, factor rows
 template <int D, typename T>
-__global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uint32_t* __restrict__ start,
-                                                            const uint32_t* __restrict__ count,
-                                                            const uint32_t* __restrict__ sorted_row,
-                                                            const float* __restrict__ coef,
-                                                            const float* __restrict__ rhs, T* __restrict__ blk,
-                                                            double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
-                                                            T* __restrict__ row1, T* __restrict__ mrow,
-                                                            uint32_t* __restrict__ nfac)
+__device__ inline void finish_cell(long c, long ncell, uint32_t s, uint32_t m, double* B, const double* gvec,
+                                   const uint32_t* __restrict__ sorted_row, const float* __restrict__ coef,
+                                   T* __restrict__ blk, double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
+                                   T* __restrict__ row1, T* __restrict__ mrow, uint32_t* __restrict__ nfac)
 {
 	constexpr int NC = 1 << D;
 	constexpr int NB = NC * (NC + 1) / 2;
-	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
-	if (c >= ncell) { return; }
-	double B[NB];
-	double gvec[NC];
-	for (int e = 0; e < NB; ++e) { B[e] = 0.0; }
-	for (int q = 0; q < NC; ++q) { gvec[q] = 0.0; }
-	const uint32_t s = start[c], m = count[c];
-	for (uint32_t r = 0; r < m; ++r) {
-		const long row = sorted_row[s + r];
-		double     a[NC];
-		for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(coef[row * NC + q]); }
-		const double b = static_cast<double>(rhs[row]);
-		int e = 0;
-		for (int i = 0; i < NC; ++i) {
-			for (int j = i; j < NC; ++j) { B[e++] += a[i] * a[j]; }
-			gvec[i] += a[i] * b;
-		}
-	}
 	for (int e = 0; e < NB; ++e) { blk[c * NB + e] = static_cast<T>(B[e]); }
 	nrow[c] = m;
 	{
@@ -297,6 +278,96 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 			}
 		}
 		nfac[c] = k;
+	}
+}
+
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uint32_t* __restrict__ start,
+                                                            const uint32_t* __restrict__ count,
+                                                            const uint32_t* __restrict__ sorted_row,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ rhs, T* __restrict__ blk,
+                                                            double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
+                                                            T* __restrict__ row1, T* __restrict__ mrow,
+                                                            uint32_t* __restrict__ nfac, uint32_t* __restrict__ heavy)
+{
+	constexpr int NC = 1 << D;
+	constexpr int NB = NC * (NC + 1) / 2;
+	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c >= ncell) { return; }
+	const uint32_t s = start[c], m = count[c];
+	if (m > kHeavyRows) {  // coarse levels put 10^4..10^6 rows into one cell: not a job for one thread
+		heavy[1 + atomicAdd(&heavy[0], 1u)] = static_cast<uint32_t>(c);
+		return;
+	}
+	double B[NB];
+	double gvec[NC];
+	for (int e = 0; e < NB; ++e) { B[e] = 0.0; }
+	for (int q = 0; q < NC; ++q) { gvec[q] = 0.0; }
+	for (uint32_t r = 0; r < m; ++r) {
+		const long row = sorted_row[s + r];
+		double     a[NC];
+		for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(coef[row * NC + q]); }
+		const double b = static_cast<double>(rhs[row]);
+		int e = 0;
+		for (int i = 0; i < NC; ++i) {
+			for (int j = i; j < NC; ++j) { B[e++] += a[i] * a[j]; }
+			gvec[i] += a[i] * b;
+		}
+	}
+	finish_cell<D, T>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_rhs, nrow, row1, mrow, nfac);
+}
+
+// One workgroup per heavy cell: threads stride over the cell's rows, then a fixed-shape tree (wave shuffles,
+// 4 wave sums added in order) -- the same bits on every run, whatever order the list was filled in.
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_build_heavy(long ncell, const uint32_t* __restrict__ start,
+                                                           const uint32_t* __restrict__ count,
+                                                           const uint32_t* __restrict__ sorted_row,
+                                                           const float* __restrict__ coef,
+                                                           const float* __restrict__ rhs, T* __restrict__ blk,
+                                                           double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
+                                                           T* __restrict__ row1, T* __restrict__ mrow,
+                                                           uint32_t* __restrict__ nfac, const uint32_t* __restrict__ heavy)
+{
+	constexpr int NC = 1 << D;
+	constexpr int NB = NC * (NC + 1) / 2;
+	__shared__ double part[kThreads / 64][NB + NC];
+	const uint32_t nheavy = heavy[0];
+	for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+		const long     c = heavy[1 + h];
+		const uint32_t s = start[c], m = count[c];
+		double B[NB];
+		double gvec[NC];
+		for (int e = 0; e < NB; ++e) { B[e] = 0.0; }
+		for (int q = 0; q < NC; ++q) { gvec[q] = 0.0; }
+		for (uint32_t r = threadIdx.x; r < m; r += kThreads) {
+			const long row = sorted_row[s + r];
+			double     a[NC];
+			for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(coef[row * NC + q]); }
+			const double b = static_cast<double>(rhs[row]);
+			int e = 0;
+			for (int i = 0; i < NC; ++i) {
+				for (int j = i; j < NC; ++j) { B[e++] += a[i] * a[j]; }
+				gvec[i] += a[i] * b;
+			}
+		}
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		for (int e = 0; e < NB + NC; ++e) {
+			double v = e < NB ? B[e] : gvec[e - NB];
+			for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); }
+			if (lane == 0) { part[wave][e] = v; }
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			for (int e = 0; e < NB + NC; ++e) {
+				double v = 0;
+				for (int w = 0; w < kThreads / 64; ++w) { v += part[w][e]; }
+				if (e < NB) { B[e] = v; } else { gvec[e - NB] = v; }
+			}
+			finish_cell<D, T>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_rhs, nrow, row1, mrow, nfac);
+		}
+		__syncthreads();
 	}
 }
 
@@ -490,11 +561,24 @@ void assemble_dim(fi_ctx* c)
 	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
 	DevBuf& cell_rhs = c->scratch[13];
 	cell_rhs.alloc(sizeof(double) * NC * ncell);
+	// cells with very many rows (coarse levels) are listed by the first kernel and summed by workgroups in the second
+	DevBuf& heavy = c->scratch[11];
+	heavy.alloc(sizeof(uint32_t) * (static_cast<size_t>(total / kHeavyRows) + 2));
+	FI_HIP_TRY(hipMemsetAsync(heavy.p, 0, sizeof(uint32_t), st));
 	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
 	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,
 	                   c->cells.blk.as<T>(), cell_rhs.as<double>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
 	                   D == 3 ? c->cells.mrow.as<T>() : static_cast<T*>(nullptr),
-	                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr));
+	                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr), heavy.as<uint32_t>());
+	{
+		const long max_heavy = total / kHeavyRows + 1;
+		const int  grid = static_cast<int>(max_heavy < 2048 ? max_heavy : 2048);
+		hipLaunchKernelGGL((k_build_heavy<D, T>), dim3(grid), dim3(kThreads), 0, st, ncell, starts.as<uint32_t>(),
+		                   counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs, c->cells.blk.as<T>(),
+		                   cell_rhs.as<double>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
+		                   D == 3 ? c->cells.mrow.as<T>() : static_cast<T*>(nullptr),
+		                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr), heavy.as<uint32_t>());
+	}
 	FI_HIP_TRY(hipGetLastError());
 	for (int colour = 0; colour < NC; ++colour) {
 		hipLaunchKernelGGL((k_scatter_cells<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, g, ncell,
