@@ -12,7 +12,7 @@
 // and are applied inside the same kernel.  Algorithmic traffic: read x once, write y once, read every
 // block once = 2*sizeof(T) B per lattice point + (8 + 36*sizeof(T)) B per occupied cell.
 //
-// Work decomposition (CDNA4): one workgroup = 256 threads = a TX x 16 tile of (x, y) marching over ZC
+// Work decomposition (CDNA4): one workgroup = 256 threads = a TX x TY tile of (x, y) (128 x 8 in fp32, 64 x 8 in fp64) marching over ZC
 // planes of z; a thread owns VX consecutive x (one 16-byte global load/store per plane: float4/double2).
 //   * z neighbours live in registers: x(z), x(z+1), x(z+2) plus the two carried row values u(z-1), u(z-2)
 //     -- each plane is read from HBM once;
@@ -47,7 +47,7 @@ namespace {
 
 constexpr int kThreads = 256;
 #ifndef FI_TXT
-#define FI_TXT 16
+#define FI_TXT 32  // 128 x 8 tiles (fp32): 512-byte runs per row; 64 x 16 is 7 % slower at 512^3, equal at 256^3
 #endif
 #ifndef FI_BASE_WAVES
 #define FI_BASE_WAVES 4  // waves per SIMD the model-only variant is register-allocated for
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 		uint32_t k = kNoKey, pp = 0;
 		if (z_ok[a] && y_ok[b] && x_ok[d]) {
 			const int     wg     = (z_tk[a] * P.tiles_y + y_ti[b]) * P.tiles_x + x_ti[d];
-			const int     band   = (y_tc[b] + 1) / 4 > 3 ? 3 : (y_tc[b] + 1) / 4;  // origin rows -1..2, 3..6, 7..10, 11..15
+			const int     band   = (y_tc[b] + 1) * 4 / (kTY + 1);  // 4 bands of consecutive origin rows -1 .. kTY-1
 			const int64_t bucket = (static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a]) * 4 + band;
 			k  = static_cast<uint32_t>(kind * nbuckets + bucket);
 			pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(y_tc[b] + 1) << 16);
