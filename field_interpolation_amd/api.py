@@ -373,6 +373,10 @@ class LatticeGroup:
         for m in self.members:
             m.set_levels(levels, coarse_tolerance)
 
+    def set_multigrid(self, on=True):
+        for m in self.members:
+            m.set_multigrid(on)
+
     def assemble(self):
         check(_capi.lib().fi_group_assemble(self._g))
         for m in self.members:

@@ -1176,11 +1176,11 @@ __global__ __launch_bounds__(kThreads) void k_power_step(int64_t n, const T* __r
 }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_seed(int64_t n, T* __restrict__ v)
+__global__ __launch_bounds__(kThreads) void k_seed(int64_t n, int64_t first, T* __restrict__ v)
 {
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		uint32_t h = static_cast<uint32_t>(i) * 2654435761u;
+		uint32_t h = static_cast<uint32_t>(first + i) * 2654435761u;
 		h ^= h >> 15;
 		h *= 2246822519u;
 		h ^= h >> 13;
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x != 0) { return; }
-	const double s = out[0];
+	const double s = partial ? out[0] : sc->sums[0];  // no partials: the sum over blocks and ranks is in sums[0]
 	switch (phase) {
 	case kMgInitRr:  // sums: r.r (partial 0) -- b.b was stored by the caller in sums[2]
 		sc->rr = s;
@@ -1294,105 +1294,197 @@ void mg_alloc(fi_ctx* c)
 {
 	ensure_vectors(c);
 	const size_t bytes = sizeof(T) * c->g.nloc;
+	const bool fresh = c->mg_b.bytes < bytes;
 	c->mg_b.alloc(bytes);
 	c->mg_x.alloc(bytes);
 	c->mg_r.alloc(bytes);
 	c->mg_d.alloc(bytes);
+	if (fresh) {  // ghost planes outside the lattice are never written: keep them finite
+		FI_HIP_TRY(hipMemsetAsync(c->mg_b.p, 0, bytes, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->mg_x.p, 0, bytes, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->mg_r.p, 0, bytes, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->mg_d.p, 0, bytes, c->stream));
+	}
+}
+
+// The multigrid drivers work on a rank set like cg_run: one member = an undivided lattice or this process's
+// slab (halo planes and sums over RCCL), several members = the loop-back group.  A vector is named by its
+// fi_ctx member so that every member's copy can be addressed: base pointer for the operator / transfer
+// kernels (ghost planes included), owned part for the elementwise ones.
+using Vec = DevBuf fi_ctx::*;
+template <typename T>
+T* vbase(fi_ctx* c, Vec v) { return (c->*v).template as<T>(); }
+template <typename T>
+T* vown(fi_ctx* c, Vec v) { return (c->*v).template as<T>() + c->g.own_first; }
+
+RankSet coarse_of(const RankSet& R)
+{
+	RankSet r;
+	for (fi_ctx* c : R) { r.push_back(c->coarse); }
+	return r;
+}
+
+void apply_all(RankSet& R, Vec in, Vec out, bool partials)
+{
+	halo_exchange(R, in);
+	for (fi_ctx* c : R) { apply_AtA(c, (c->*in).p, (c->*out).p, partials ? c->partial.as<double>() : nullptr); }
+}
+
+// global index of the first owned unknown (seeds of the power method must not depend on the decomposition)
+int64_t global_first(const fi_ctx* c)
+{
+	const Geom& g = c->g;
+	const int a = g.ndim - 1;
+	int64_t plane = 1;
+	for (int d = 0; d < a; ++d) { plane *= g.gn[d]; }
+	return plane * (g.off[a] + g.own_lo[a]);
 }
 
 // largest eigenvalue of Dinv*AtA by the power method (10 steps, unnormalised: growth <= 8^10, fine in fp32)
 template <typename T>
-void estimate_lambda(fi_ctx* c)
+void estimate_lambda(RankSet& R)
 {
-	mg_alloc<T>(c);
-	const int64_t n = c->g.nown;
-	const int nb = stream_blocks(n);
+	for (fi_ctx* c : R) { mg_alloc<T>(c); }
 	CgScalars init{};
-	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-	T* v = c->mg_d.as<T>();
-	hipLaunchKernelGGL((k_seed<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, v);
+	reset_scalars(R, init);
+	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	for (fi_ctx* c : R) {
+		hipLaunchKernelGGL((k_seed<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, global_first(c),
+		                   vown<T>(c, &fi_ctx::mg_d));
+	}
 	const int steps = 10;
+	double sums[2] = {0, 0};
 	for (int k = 0; k < steps; ++k) {
-		apply_AtA(c, v, c->q.p, nullptr);
-		hipLaunchKernelGGL((k_power_step<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, c->q.as<T>(), c->dinv.as<T>(), v,
-		                   c->partial.as<double>() + (k & 1) * nb);
+		apply_all(R, &fi_ctx::mg_d, &fi_ctx::q, false);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_power_step<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, &fi_ctx::q),
+			                   vown<T>(c, &fi_ctx::dinv), vown<T>(c, &fi_ctx::mg_d), c->partial.as<double>());
+		}
+		if (k >= steps - 2) {  // |v|^2 after the last two steps, summed over all slabs
+			reduce_phase(R, 1, nbv, nbv, -1);
+			fi_ctx* c0 = R[0];
+			FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, c0->scal.p, sizeof(CgScalars), hipMemcpyDeviceToHost, c0->stream));
+			FI_HIP_TRY(hipStreamSynchronize(c0->stream));
+			sums[k - (steps - 2)] = c0->scal_host->sums[0];
+		}
 	}
-	std::vector<double> h(2 * nb);
-	FI_HIP_TRY(hipMemcpyAsync(h.data(), c->partial.p, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, c->stream));
-	FI_HIP_TRY(hipStreamSynchronize(c->stream));
-	double last = 0, prev = 0;
-	for (int i = 0; i < nb; ++i) {
-		last += h[((steps - 1) & 1) * nb + i];
-		prev += h[((steps - 2) & 1) * nb + i];
-	}
-	c->lambda_max = (prev > 0 && last > 0) ? std::sqrt(last / prev) : 2.0;
+	const double lambda = (sums[0] > 0 && sums[1] > 0) ? std::sqrt(sums[1] / sums[0]) : 2.0;
+	for (fi_ctx* c : R) { c->lambda_max = lambda; }
 }
 
 // degree-k Chebyshev smoothing of AtA x = b on [lmax/ratio, 1.1 lmax]; from_zero: x starts at 0
 template <typename T>
-void cheb_smooth(fi_ctx* c, const T* b, T* x, int degree, double ratio, bool from_zero)
+void cheb_smooth(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_zero)
 {
-	const int64_t n = c->g.nown;
-	const int nb = stream_blocks(n);
-	const double hi = 1.1 * c->lambda_max, lo = hi / ratio;
+	const double hi = 1.1 * R[0]->lambda_max, lo = hi / ratio;
 	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
-	T* r = c->mg_r.as<T>();
-	T* d = c->mg_d.as<T>();
-	T* q = c->q.as<T>();
-	const T* dinv = c->dinv.as<T>();
-	if (!from_zero) { apply_AtA(c, x, q, nullptr); }
-	hipLaunchKernelGGL((k_cheb_init<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, b, from_zero ? static_cast<const T*>(nullptr) : q,
-	                   dinv, r, d, x, static_cast<T>(1.0 / theta), from_zero ? 1 : 0);
+	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	if (!from_zero) { apply_all(R, x, &fi_ctx::q, false); }
+	for (fi_ctx* c : R) {
+		hipLaunchKernelGGL((k_cheb_init<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
+		                   from_zero ? static_cast<const T*>(nullptr) : vown<T>(c, &fi_ctx::q), vown<T>(c, &fi_ctx::dinv),
+		                   vown<T>(c, &fi_ctx::mg_r), vown<T>(c, &fi_ctx::mg_d), vown<T>(c, x), static_cast<T>(1.0 / theta),
+		                   from_zero ? 1 : 0);
+	}
 	double rho = 1.0 / sigma;
 	for (int k = 1; k < degree; ++k) {
 		const double rho_new = 1.0 / (2.0 * sigma - rho);
-		apply_AtA(c, d, q, nullptr);
-		hipLaunchKernelGGL((k_cheb_iter<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, q, dinv, r, d, x,
-		                   static_cast<T>(rho_new * rho), static_cast<T>(2.0 * rho_new / delta));
+		apply_all(R, &fi_ctx::mg_d, &fi_ctx::q, false);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_cheb_iter<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, &fi_ctx::q),
+			                   vown<T>(c, &fi_ctx::dinv), vown<T>(c, &fi_ctx::mg_r), vown<T>(c, &fi_ctx::mg_d), vown<T>(c, x),
+			                   static_cast<T>(rho_new * rho), static_cast<T>(2.0 * rho_new / delta));
+		}
 		rho = rho_new;
 	}
 }
 
-// x = V(b) on level c (single-rank, undivided lattice)
+// x = V(b) on the level of R.  Over slabs every level is a slab decomposition of its own (coarse plane k lives
+// with fine plane 2k): restriction reads one ghost plane of the fine residual, interpolation one of the coarse
+// correction.
 template <typename T>
-void vcycle(fi_ctx* c, const T* b, T* x)
+void vcycle(RankSet& R, Vec b, Vec x)
 {
 	const int deg = mg_degree();
 	const double ratio = mg_ratio();
-	if (!c->coarse) {  // coarsest level: a longer polynomial over a wider band
-		cheb_smooth<T>(c, b, x, 4 * deg + 4, 10.0 * ratio, true);
+	if (!R[0]->coarse) {  // coarsest level: a longer polynomial over a wider band
+		cheb_smooth<T>(R, b, x, 4 * deg + 4, 10.0 * ratio, true);
 		return;
 	}
-	fi_ctx* co = c->coarse;
-	const int64_t n = c->g.nown;
-	const int nb = stream_blocks(n);
-	cheb_smooth<T>(c, b, x, deg, ratio, true);
-	apply_AtA(c, x, c->q.p, nullptr);
-	hipLaunchKernelGGL((k_sub<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, b, c->q.as<T>(), c->mg_r.as<T>());
-	const LevelPair L = level_pair(c, co);
-	hipLaunchKernelGGL((k_restrict<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, c->stream, L,
-	                   c->mg_r.as<T>(), co->mg_b.as<T>());
-	vcycle<T>(co, co->mg_b.as<T>(), co->mg_x.as<T>());
-	hipLaunchKernelGGL((k_prolong<T>), owned_grid(L.nf, L.ndim, L.f_planes), dim3(kThreads), 0, c->stream, L,
-	                   co->mg_x.as<T>(), x, 1);
-	cheb_smooth<T>(c, b, x, deg, ratio, false);
+	RankSet Rc = coarse_of(R);
+	cheb_smooth<T>(R, b, x, deg, ratio, true);
+	apply_all(R, x, &fi_ctx::q, false);
+	for (fi_ctx* c : R) {
+		hipLaunchKernelGGL((k_sub<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
+		                   vown<T>(c, &fi_ctx::q), vown<T>(c, &fi_ctx::mg_r));
+	}
+	halo_exchange(R, &fi_ctx::mg_r);
+	for (size_t i = 0; i < R.size(); ++i) {
+		const LevelPair L = level_pair(R[i], Rc[i]);
+		hipLaunchKernelGGL((k_restrict<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, R[i]->stream, L,
+		                   vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b));
+	}
+	vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
+	halo_exchange(Rc, &fi_ctx::mg_x);
+	for (size_t i = 0; i < R.size(); ++i) {
+		const LevelPair L = level_pair(R[i], Rc[i]);
+		hipLaunchKernelGGL((k_prolong<T>), owned_grid(L.nf, L.ndim, L.f_planes), dim3(kThreads), 0, R[i]->stream, L,
+		                   vbase<T>(Rc[i], &fi_ctx::mg_x), vbase<T>(R[i], x), 1);
+	}
+	cheb_smooth<T>(R, b, x, deg, ratio, false);
 }
 
-// V-cycle preconditioned CG on the finest level; x holds the guess on entry
-template <typename T>
-void cg_run_mg(fi_ctx* c, int max_iterations, float tol)
+// one dot-product reduction of the preconditioned recurrence: partials -> sum over blocks and ranks -> `phase`
+template <typename CountFn>
+void mg_reduce(RankSet& R, CountFn count_of, int phase)
 {
-	const Geom& g = c->g;
-	hipStream_t st = c->stream;
-	for (fi_ctx* l = c; l; l = l->coarse) {
-		mg_alloc<T>(l);
-		if (l != c) {  // the operator kernels of a level exit early while ITS stop flag is up: clear stale ones
-			CgScalars clear{};
-			FI_HIP_TRY(hipMemcpyAsync(l->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, st));
+	if (R.size() == 1 && R[0]->nranks == 1) {
+		fi_ctx* c = R[0];
+		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(), c->partial.as<double>(),
+		                   count_of(c), phase);
+		return;
+	}
+	reduce_phase(R, 1, count_of, count_of, -1);  // sums[0] on every member, summed over all of them
+	for (fi_ctx* c : R) {
+		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(),
+		                   static_cast<const double*>(nullptr), 0, phase);
+	}
+}
+
+// V-cycle preconditioned CG on the finest level; x of every member holds the guess on entry
+template <typename T>
+void cg_run_mg(RankSet& R, int max_iterations, float tol)
+{
+	fi_ctx* c0 = R[0];
+	hipStream_t st = c0->stream;
+	{
+		RankSet lev = R;
+		while (!lev.empty() && lev[0]) {
+			for (fi_ctx* l : lev) {
+				mg_alloc<T>(l);
+				if (l->level > 0 || l->finer) {  // the operator kernels of a level exit early while ITS stop flag is up
+					CgScalars clear{};
+					FI_HIP_TRY(hipMemcpyAsync(l->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, l->stream));
+				}
+			}
+			if (!lev[0]->coarse) { break; }
+			lev = coarse_of(lev);
+		}
+		// smoother bounds: power method on every coarser level (once per assemble); the finest level (8x the work)
+		// takes the estimate of the level below it -- same operator family, and the interval has 10 % headroom
+		if (!(c0->lambda_max > 0)) {
+			RankSet l = coarse_of(R);
+			while (!l.empty() && l[0]) {
+				estimate_lambda<T>(l);
+				if (!l[0]->coarse) { break; }
+				l = coarse_of(l);
+			}
+			for (fi_ctx* c : R) { c->lambda_max = c->coarse->lambda_max; }
+			if (getenv("FI_MG_FINE_POWER")) { estimate_lambda<T>(R); }
 		}
 	}
 	if (max_iterations <= 0) {
-		const int64_t dflt = 2 * static_cast<int64_t>(g.gn[0]) * g.gn[1] * g.gn[2];
+		const int64_t dflt = 2 * static_cast<int64_t>(c0->g.gn[0]) * c0->g.gn[1] * c0->g.gn[2];
 		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
 	}
 	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
@@ -1403,37 +1495,45 @@ void cg_run_mg(fi_ctx* c, int max_iterations, float tol)
 	CgScalars init{};
 	init.tol2     = tolerance * tolerance;
 	init.max_iter = max_iterations;
-	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
-	CgScalars* sc = c->scal.as<CgScalars>();
-	const int64_t n = g.nown;
-	const int nb = stream_blocks(n);
-	double* partial = c->partial.as<double>();
-	T* x = c->x.as<T>();
-	T* r = c->r.as<T>();
-	T* p = c->p.as<T>();
-	T* q = c->q.as<T>();
-	T* z = c->mg_x.as<T>();
-	const T* b = c->atb.as<T>();
-	const int nb_apply = apply_num_partials(c);
-	while (static_cast<int>(c->ev.size()) < 2 * kMaxSamples) {
+	reset_scalars(R, init);
+	CgScalars* sc0 = c0->scal.as<CgScalars>();
+	auto nbv      = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	auto nb_apply = [](fi_ctx* c) { return apply_num_partials(c); };
+	const Vec X = &fi_ctx::x, Rv = &fi_ctx::r, P = &fi_ctx::p, Q = &fi_ctx::q, Z = &fi_ctx::mg_x, B = &fi_ctx::atb;
+	while (static_cast<int>(c0->ev.size()) < 2 * kMaxSamples) {
 		hipEvent_t e;
 		FI_HIP_TRY(hipEventCreate(&e));
-		c->ev.push_back(e);
+		c0->ev.push_back(e);
 	}
 	int samples = 0;
+	auto dot = [&](Vec a, Vec b) {
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_dot<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, a), vown<T>(c, b),
+			                   c->partial.as<double>());
+		}
+	};
+	auto direction = [&](int first) {
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_mg_direction<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   c->scal.as<CgScalars>(), vown<T>(c, Z), vown<T>(c, P), first);
+		}
+	};
 
 	auto restart = [&]() {  // r = b - A x, z = V(r), p = z, rz, rr (b.b on the first call)
-		apply_AtA(c, x, q, nullptr);
-		hipLaunchKernelGGL((k_sub<T>), dim3(nb), dim3(kThreads), 0, st, n, b, q, r);
-		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, b, b, partial);
-		hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, st, sc, partial, 1, 0, nb, 0);  // -> sums[0]
-		hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, st, sc);                             // sums[2] = sums[0]
-		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, r, r, partial);
-		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgInitRr);
-		vcycle<T>(c, r, z);
-		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, r, z, partial);
-		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgInitRz);
-		hipLaunchKernelGGL((k_mg_direction<T>), dim3(nb), dim3(kThreads), 0, st, n, sc, z, p, 1);
+		apply_all(R, X, Q, false);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_sub<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, B), vown<T>(c, Q),
+			                   vown<T>(c, Rv));
+		}
+		dot(B, B);
+		reduce_phase(R, 1, nbv, nbv, -1);  // -> sums[0]
+		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
+		dot(Rv, Rv);
+		mg_reduce(R, nbv, kMgInitRr);
+		vcycle<T>(R, Rv, Z);
+		dot(Rv, Z);
+		mg_reduce(R, nbv, kMgInitRz);
+		direction(1);
 	};
 	restart();
 
@@ -1441,15 +1541,15 @@ void cg_run_mg(fi_ctx* c, int max_iterations, float tol)
 	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
 	const auto wall0 = std::chrono::steady_clock::now();
 	bool timed_out = false;
-	int restarts_left = c->verify_residual ? 3 : 0;
+	int restarts_left = c0->verify_residual ? 3 : 0;
 	for (;;) {
-		FI_HIP_TRY(hipMemcpyAsync(c->scal_host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
-		const int done = c->scal_host->done;
+		const int done = c0->scal_host->done;
 		if (done) {
 			if (done != 1 || restarts_left <= 0) { break; }
 			--restarts_left;  // recurrence converged: check b - A x, continue from it if it misses the tolerance
-			hipLaunchKernelGGL(k_bump_restarts, dim3(1), dim3(1), 0, st, sc);
+			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_bump_restarts, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
 			restart();
 			continue;
 		}
@@ -1458,19 +1558,23 @@ void cg_run_mg(fi_ctx* c, int max_iterations, float tol)
 			break;
 		}
 		const bool sample = samples < kMaxSamples;
-		if (sample) { FI_HIP_TRY(hipEventRecord(c->ev[2 * samples], st)); }
-		apply_AtA(c, p, q, partial);
+		halo_exchange(R, P);
+		if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
+		for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>()); }
 		if (sample) {
-			FI_HIP_TRY(hipEventRecord(c->ev[2 * samples + 1], st));
+			FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples + 1], st));
 			++samples;
 		}
-		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb_apply, kMgAlpha);
-		hipLaunchKernelGGL((k_mg_step<T>), dim3(nb), dim3(kThreads), 0, st, n, sc, p, q, x, r, partial);
-		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgResid);
-		vcycle<T>(c, r, z);   // wasted when this step just converged; one V-cycle at most
-		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, st, n, r, z, partial);
-		hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, st, sc, partial, nb, kMgBeta);
-		hipLaunchKernelGGL((k_mg_direction<T>), dim3(nb), dim3(kThreads), 0, st, n, sc, z, p, 0);
+		mg_reduce(R, nb_apply, kMgAlpha);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_mg_step<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+			                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>());
+		}
+		mg_reduce(R, nbv, kMgResid);
+		vcycle<T>(R, Rv, Z);  // wasted when this step just converged; one V-cycle at most
+		dot(Rv, Z);
+		mg_reduce(R, nbv, kMgBeta);
+		direction(0);
 		FI_HIP_TRY(hipGetLastError());
 	}
 	FI_HIP_TRY(hipEventRecord(e1, st));
@@ -1479,24 +1583,26 @@ void cg_run_mg(fi_ctx* c, int max_iterations, float tol)
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
 	(void)hipEventDestroy(e0);
 	(void)hipEventDestroy(e1);
-	const CgScalars h = *c->scal_host;
+	const CgScalars h = *c0->scal_host;
 	int used = samples < h.iter ? samples : h.iter;
 	double sum_ms = 0;
 	for (int k = 0; k < used; ++k) {
 		float t = 0;
-		FI_HIP_TRY(hipEventElapsedTime(&t, c->ev[2 * k], c->ev[2 * k + 1]));
+		FI_HIP_TRY(hipEventElapsedTime(&t, c0->ev[2 * k], c0->ev[2 * k + 1]));
 		sum_ms += t;
 	}
-	c->stats.spmv_samples = used;
-	c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
-	c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
-	c->stats.solve_ms     = ms;
-	c->stats.iterations   = h.iter;
-	c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c->verify_residual))) ? 1 : 0;
-	c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
-	c->stats.restarts     = h.restarts;
-	c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
-	if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * g.nloc, st)); }
+	for (fi_ctx* c : R) {
+		c->stats.spmv_samples = used;
+		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
+		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		c->stats.solve_ms     = ms;
+		c->stats.iterations   = h.iter;
+		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
+		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+		c->stats.restarts     = h.restarts;
+		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
+		if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
+	}
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
 }
 
@@ -1516,8 +1622,8 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 		fi_ctx* c; int* it; float* rel;
 		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
 	} report{c, iterations, rel_residual};
-	if (c->mg_mode == 1 && c->coarse && c->nranks == 1) {
-		cg_run_mg<T>(c, max_iterations, tol);
+	if (c->mg_mode == 1 && c->coarse) {
+		cg_run_mg<T>(R, max_iterations, tol);
 	} else {
 		cg_run<T>(R, max_iterations, tol);
 	}
@@ -1798,15 +1904,8 @@ void build_levels(fi_ctx* c)
 		fi_ctx_destroy(fine->coarse);
 		fine->coarse = nullptr;
 	}
-	if (c->mg_mode == 1 && c->coarse && c->nranks == 1) {
-		// smoother bounds: power method on every coarser level; the finest level (8x the work) takes the
-		// estimate of the level below it -- same operator family, and the smoother interval has 10 % headroom
-		for (fi_ctx* l = c->coarse; l; l = l->coarse) {
-			c->dtype == FI_F64 ? estimate_lambda<double>(l) : estimate_lambda<float>(l);
-		}
-		c->lambda_max = c->coarse->lambda_max;
-		if (getenv("FI_MG_FINE_POWER")) { c->dtype == FI_F64 ? estimate_lambda<double>(c) : estimate_lambda<float>(c); }
-	}
+	// smoother bounds of the V-cycle (a global power method over all slabs) are estimated by the next multigrid solve
+	for (fi_ctx* l = c; l; l = l->coarse) { l->lambda_max = 0; }
 }
 
 void check_ctx(const fi_ctx* c) { FI_REQUIRE(c != nullptr, FI_ERR_INVALID, "null context"); }
@@ -2423,7 +2522,12 @@ int fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float
 		fi_ctx* c; int* it; float* rel;
 		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
 	} report{c0, iterations, rel_residual};
-	g->dtype == FI_F64 ? fi::cg_run<double>(g->members, max_iterations, tol) : fi::cg_run<float>(g->members, max_iterations, tol);
+	if (c0->mg_mode == 1 && c0->coarse) {
+		g->dtype == FI_F64 ? fi::cg_run_mg<double>(g->members, max_iterations, tol)
+		                   : fi::cg_run_mg<float>(g->members, max_iterations, tol);
+	} else {
+		g->dtype == FI_F64 ? fi::cg_run<double>(g->members, max_iterations, tol) : fi::cg_run<float>(g->members, max_iterations, tol);
+	}
 	at = 0;
 	for (fi_ctx* c : g->members) {
 		if (g->dtype == FI_F64) {

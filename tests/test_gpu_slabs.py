@@ -106,3 +106,35 @@ def test_coarse_to_fine_start_over_slabs(fi, sizes, nranks, levels):
     assert grp.stats()["coarse_iterations"] > 0
     assert rel_inf(grp.solution_f64(), plain.solution_f64()) <= 1e-5
     assert rel_inf(one.solution_f64(), plain.solution_f64()) <= 1e-5
+
+
+@pytest.mark.parametrize("sizes,nranks,levels", [([64, 96], 3, 3), ([32, 32, 64], 4, 2), ([48, 32, 80], 2, 2)])
+def test_vcycle_preconditioner_over_slabs(fi, sizes, nranks, levels):
+    """V-cycle preconditioned CG (FI_OPT_MULTIGRID) over slabs: smoother applies, restriction and interpolation
+    all cross slab seams through the ghost planes, the power-method bounds and every dot product are global.
+    An SDF problem (oriented points) that plain Jacobi-PCG needs many more iterations for: the decomposed
+    solve takes the same number of iterations as the undivided one (+-2) and gives the same field."""
+    rng = np.random.default_rng(11)
+    pos, nrm = sphere_points(rng, sizes, 600)
+    w = fi.Weights()
+    one = fi.LatticeField(sizes, dtype="f64")
+    grp = fi.LatticeGroup(sizes, nranks, dtype="f64")
+    plain = fi.LatticeField(sizes, dtype="f64")
+    for f in (one, grp, plain):
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    for f in (one, grp):
+        f.set_levels(levels)
+        f.set_multigrid(True)
+    for f in (one, grp, plain):
+        f.assemble()
+    tol = 1e-9
+    x0, it0, r0 = plain.solve_cg(None, 20000, tol)
+    x1, it1, r1 = one.solve_cg(None, 0, tol)
+    xg, itg, rg = grp.solve_cg(None, 0, tol)
+    assert r1 <= tol and rg <= tol
+    assert grp.true_residual() <= tol * 1.01
+    assert itg < it0 / 3 and it1 < it0 / 3              # the preconditioner pays off in both forms
+    assert abs(itg - it1) <= 2
+    assert rel_inf(grp.solution_f64(), one.solution_f64()) <= 1e-6
+    assert rel_inf(grp.solution_f64(), plain.solution_f64()) <= 1e-5
