@@ -266,6 +266,11 @@ class LatticeField:
         check(_capi.lib().fi_set_option(self._h, 4, 1.0 if on else 0.0))
         self._dirty = True
 
+    def set_mixed_precision(self, on=True):
+        """FI_OPT_MIXED_PRECISION (dtype="f64" fields with levels + multigrid): CG in fp64, V-cycle in fp32."""
+        check(_capi.lib().fi_set_option(self._h, 5, 1.0 if on else 0.0))
+        self._dirty = True
+
     def jacobi(self, guess, num_iterations, weight):
         self._ready()
         g, kg, _kg = _buf(guess)
@@ -376,6 +381,10 @@ class LatticeGroup:
     def set_multigrid(self, on=True):
         for m in self.members:
             m.set_multigrid(on)
+
+    def set_mixed_precision(self, on=True):
+        for m in self.members:
+            m.set_mixed_precision(on)
 
     def assemble(self):
         check(_capi.lib().fi_group_assemble(self._g))

@@ -243,6 +243,10 @@ struct fi_ctx {
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
 	bool       owns_stream = true;
 	bool       owns_comm = true;     // coarser levels share the RCCL communicator of the finest level
+	// mixed precision (FI_OPT_MIXED_PRECISION on an FI_F64 context): an fp32 replica of the same problem carries
+	// the levels and runs the V-cycle preconditioner; CG itself stays on this context in fp64
+	int        mixed = 0;
+	fi_ctx*    twin = nullptr;
 	int        tile_ts = 0;          // > 0 while fi_tile_pass runs: apply_AtA applies the tile operator of that tile size
 	int        verify_residual = 1;  // check b - A x when the recurrence converges, restart CG if it misses
 	fi_stats   stats{};

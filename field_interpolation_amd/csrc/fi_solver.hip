@@ -1451,37 +1451,131 @@ void mg_reduce(RankSet& R, CountFn count_of, int phase)
 	}
 }
 
+// work vectors, cleared stop flags and smoother bounds for every level below (and including) R
+template <typename T>
+void mg_prepare(RankSet& R, bool clear_finest)
+{
+	RankSet lev = R;
+	bool finest = true;
+	while (!lev.empty() && lev[0]) {
+		for (fi_ctx* l : lev) {
+			mg_alloc<T>(l);
+			if (!finest || clear_finest) {  // the operator kernels of a level exit early while ITS stop flag is up
+				CgScalars clear{};
+				FI_HIP_TRY(hipMemcpyAsync(l->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, l->stream));
+			}
+		}
+		finest = false;
+		if (!lev[0]->coarse) { break; }
+		lev = coarse_of(lev);
+	}
+	// smoother bounds: power method on every coarser level (once per assemble); the finest level (8x the work)
+	// takes the estimate of the level below it -- same operator family, and the interval has 10 % headroom
+	if (!(R[0]->lambda_max > 0) && R[0]->coarse) {
+		RankSet l = coarse_of(R);
+		while (!l.empty() && l[0]) {
+			estimate_lambda<T>(l);
+			if (!l[0]->coarse) { break; }
+			l = coarse_of(l);
+		}
+		for (fi_ctx* c : R) { c->lambda_max = c->coarse->lambda_max; }
+		if (getenv("FI_MG_FINE_POWER")) { estimate_lambda<T>(R); }
+	}
+}
+
+// mixed precision: r32 = r / s and z = s * z32 with s = ||r|| / ||b|| from the device-resident scalars (the V-cycle
+// is linear, the scaling only keeps its fp32 operands near the size of b while r shrinks by ten decades)
+__device__ inline double mixed_scale(const CgScalars* sc)
+{
+	return (sc->rr > 0.0 && sc->bb > 0.0) ? sqrt(sc->rr / sc->bb) : 1.0;
+}
+__global__ __launch_bounds__(kThreads) void k_to_twin(int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ r,
+                                                       float* __restrict__ r32)
+{
+	const double inv = 1.0 / mixed_scale(sc);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		r32[i] = static_cast<float>(r[i] * inv);
+	}
+}
+__global__ __launch_bounds__(kThreads) void k_from_twin(int64_t n, const CgScalars* __restrict__ sc, const float* __restrict__ z32,
+                                                         double* __restrict__ z)
+{
+	const double s = mixed_scale(sc);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		z[i] = s * static_cast<double>(z32[i]);
+	}
+}
+
+template <typename T>
+void precondition(RankSet& R, RankSet& Tw, Vec r, Vec z)
+{
+	vcycle<T>(R, r, z);
+}
+template <>
+void precondition<double>(RankSet& R, RankSet& Tw, Vec r, Vec z)
+{
+	if (Tw.empty()) {
+		vcycle<double>(R, r, z);
+		return;
+	}
+	for (size_t i = 0; i < R.size(); ++i) {
+		fi_ctx* c = R[i];
+		fi_ctx* t = Tw[i];
+		hipLaunchKernelGGL(k_to_twin, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+		                   c->scal.as<CgScalars>(), vown<double>(c, r), vown<float>(t, &fi_ctx::r));
+	}
+	vcycle<float>(Tw, &fi_ctx::r, &fi_ctx::mg_x);
+	for (size_t i = 0; i < R.size(); ++i) {
+		fi_ctx* c = R[i];
+		fi_ctx* t = Tw[i];
+		hipLaunchKernelGGL(k_from_twin, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+		                   c->scal.as<CgScalars>(), vown<float>(t, &fi_ctx::mg_x), vown<double>(c, z));
+	}
+}
+
+// coarse-to-fine start on the fp32 replicas of FI_F64 contexts (mixed precision), widened into x
+__global__ __launch_bounds__(kThreads) void k_widen(int64_t n, const float* __restrict__ src, double* __restrict__ dst)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		dst[i] = static_cast<double>(src[i]);
+	}
+}
+void twin_cascade_guess(RankSet& R)
+{
+	RankSet Tw;
+	for (fi_ctx* c : R) {
+		ensure_vectors(c->twin);
+		c->twin->stats.coarse_iterations = 0;
+		Tw.push_back(c->twin);
+	}
+	cascade_guess<float>(Tw);
+	for (fi_ctx* c : R) {
+		fi_ctx* t = c->twin;
+		FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->g.nloc, c->stream));
+		hipLaunchKernelGGL(k_widen, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+		                   t->x.as<float>() + t->g.own_first, c->x.as<double>() + c->g.own_first);
+		c->stats.coarse_iterations = t->stats.coarse_iterations;
+	}
+	FI_HIP_TRY(hipGetLastError());
+}
+
 // V-cycle preconditioned CG on the finest level; x of every member holds the guess on entry
 template <typename T>
 void cg_run_mg(RankSet& R, int max_iterations, float tol)
 {
 	fi_ctx* c0 = R[0];
 	hipStream_t st = c0->stream;
-	{
-		RankSet lev = R;
-		while (!lev.empty() && lev[0]) {
-			for (fi_ctx* l : lev) {
-				mg_alloc<T>(l);
-				if (l->level > 0 || l->finer) {  // the operator kernels of a level exit early while ITS stop flag is up
-					CgScalars clear{};
-					FI_HIP_TRY(hipMemcpyAsync(l->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, l->stream));
-				}
-			}
-			if (!lev[0]->coarse) { break; }
-			lev = coarse_of(lev);
-		}
-		// smoother bounds: power method on every coarser level (once per assemble); the finest level (8x the work)
-		// takes the estimate of the level below it -- same operator family, and the interval has 10 % headroom
-		if (!(c0->lambda_max > 0)) {
-			RankSet l = coarse_of(R);
-			while (!l.empty() && l[0]) {
-				estimate_lambda<T>(l);
-				if (!l[0]->coarse) { break; }
-				l = coarse_of(l);
-			}
-			for (fi_ctx* c : R) { c->lambda_max = c->coarse->lambda_max; }
-			if (getenv("FI_MG_FINE_POWER")) { estimate_lambda<T>(R); }
-		}
+	// mixed precision: the V-cycle runs on the fp32 replicas (RankSet Tw), CG itself stays in T = double
+	RankSet Tw;
+	if (sizeof(T) == 8 && c0->twin && c0->twin->coarse) {
+		for (fi_ctx* c : R) { Tw.push_back(c->twin); }
+		for (fi_ctx* c : R) { mg_alloc<T>(c); }
+		mg_prepare<float>(Tw, true);
+	} else {
+		mg_prepare<T>(R, false);
 	}
 	if (max_iterations <= 0) {
 		const int64_t dflt = 2 * static_cast<int64_t>(c0->g.gn[0]) * c0->g.gn[1] * c0->g.gn[2];
@@ -1530,7 +1624,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
 		dot(Rv, Rv);
 		mg_reduce(R, nbv, kMgInitRr);
-		vcycle<T>(R, Rv, Z);
+		precondition<T>(R, Tw, Rv, Z);
 		dot(Rv, Z);
 		mg_reduce(R, nbv, kMgInitRz);
 		direction(1);
@@ -1571,7 +1665,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>());
 		}
 		mg_reduce(R, nbv, kMgResid);
-		vcycle<T>(R, Rv, Z);  // wasted when this step just converged; one V-cycle at most
+		precondition<T>(R, Tw, Rv, Z);  // wasted when this step just converged; one V-cycle at most
 		dot(Rv, Z);
 		mg_reduce(R, nbv, kMgBeta);
 		direction(0);
@@ -1613,16 +1707,18 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	ensure_vectors(c);
 	c->stats.coarse_iterations = 0;
 	RankSet R{c};
-	if (!guess && c->coarse) {
-		cascade_guess<T>(R);
-	} else {
-		load_owned<T>(c, c->x, guess, memory);
-	}
 	struct Report {
 		fi_ctx* c; int* it; float* rel;
 		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
 	} report{c, iterations, rel_residual};
-	if (c->mg_mode == 1 && c->coarse) {
+	if (!guess && c->twin && c->twin->coarse) {
+		twin_cascade_guess(R);  // coarse-to-fine start on the fp32 replica, widened
+	} else if (!guess && c->coarse) {
+		cascade_guess<T>(R);
+	} else {
+		load_owned<T>(c, c->x, guess, memory);
+	}
+	if (c->mg_mode == 1 && (c->coarse || (c->twin && c->twin->coarse))) {
 		cg_run_mg<T>(R, max_iterations, tol);
 	} else {
 		cg_run<T>(R, max_iterations, tol);
@@ -1801,14 +1897,15 @@ fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks);
 //     half the weight (value rows keep theirs).
 // Levels stop when an axis would drop below 8 points.  Hand-built rows (fi_add_rows_coo) have no geometry to
 // coarsen: contexts holding them stay single-level.
-void build_levels(fi_ctx* c)
+void build_levels(fi_ctx* c, fi_ctx* src = nullptr)  // src: the context holding the point batches (default: c)
 {
 	if (c->level != 0) { return; }
+	if (!src) { src = c; }
 	bool wanted = c->levels_wanted > 0;
 	if (wanted && c->generic.ntrip > 0) {
 		// generic rows that came from points (gradient kLinearInterpolation) can be re-emitted; hand-built ones cannot
 		long from_points = 0;
-		for (auto* b : c->batches) {
+		for (auto* b : src->batches) {
 			if (b->has_nrm && b->gk == FI_GRADIENT_LINEAR_INTERPOLATION && b->gw != 0.0f) { from_points += b->n * c->g.ndim; }
 		}
 		wanted = from_points == c->generic.nrows;
@@ -1880,7 +1977,7 @@ void build_levels(fi_ctx* c)
 		w.gradient_smoothness = fine->w.gradient_smoothness * std::sqrt(vol / 16.0f);
 		co->w = w;
 		const float ps = 1.0f / static_cast<float>(1 << l), ns = static_cast<float>(1 << l);
-		for (auto* b : c->batches) {
+		for (auto* b : src->batches) {
 			const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
 			const float* pw  = b->has_pw ? b->pw.as<float>() : nullptr;
 			const float* val = b->has_val ? b->val.as<float>() : nullptr;
@@ -1906,6 +2003,78 @@ void build_levels(fi_ctx* c)
 	}
 	// smoother bounds of the V-cycle (a global power method over all slabs) are estimated by the next multigrid solve
 	for (fi_ctx* l = c; l; l = l->coarse) { l->lambda_max = 0; }
+}
+
+// fp32 replica of an FI_F64 context for the mixed-precision solve: same lattice, same slab, same weights, the
+// same data points (re-emitted from the batches kept in HBM), with the levels and solver options of `c`.
+void build_twin(fi_ctx* c)
+{
+	if (c->level != 0) { return; }
+	if (!(c->mixed && c->dtype == FI_F64)) {
+		if (c->twin) {
+			fi_ctx_destroy(c->twin);
+			c->twin = nullptr;
+		}
+		return;
+	}
+	const int D = c->g.ndim;
+	{
+		long from_points = 0;
+		for (auto* b : c->batches) {
+			if (b->has_nrm && b->gk == FI_GRADIENT_LINEAR_INTERPOLATION && b->gw != 0.0f) { from_points += b->n * D; }
+		}
+		FI_REQUIRE(from_points == c->generic.nrows, FI_ERR_UNSUPPORTED,
+		           "mixed precision needs rows that came from points; fi_add_rows_coo rows cannot be replicated");
+	}
+	int sizes[3] = {c->g.gn[0], c->g.gn[1], c->g.gn[2]};
+	fi_ctx* t = c->twin;
+	if (t && t->halo != c->halo) {
+		fi_ctx_destroy(t);
+		t = nullptr;
+	}
+	if (t) {
+		for (auto* pb : t->pending) { t->pending_pool.push_back(pb); }
+		t->pending.clear();
+		generic_clear(t);
+	} else {
+		t = create_ctx(D, sizes, FI_F32, c->rank, c->nranks);
+		(void)hipStreamDestroy(t->stream);
+		t->stream      = c->stream;
+		t->owns_stream = false;
+		t->owns_comm   = false;
+		t->slab_fixed  = true;
+		t->slab_lo     = c->slab_lo;
+		t->slab_hi     = c->slab_hi;
+		t->halo        = c->halo;
+		compute_geom(t, D, sizes);
+		c->twin = t;
+	}
+	t->comm            = c->comm;
+	t->w               = c->w;
+	t->model_set       = true;
+	t->verify_residual = 0;
+	t->levels_wanted   = c->levels_wanted;
+	t->coarse_tol      = c->coarse_tol;
+	t->mg_mode         = c->mg_mode;
+	for (auto* b : c->batches) {
+		const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
+		const float* pw  = b->has_pw ? b->pw.as<float>() : nullptr;
+		const float* val = b->has_val ? b->val.as<float>() : nullptr;
+		const bool   lin = nrm && b->gk == FI_GRADIENT_LINEAR_INTERPOLATION;
+		emit_point_rows(t, b->n, b->pos.as<float>(), nrm, pw, val, b->vw, b->vk, lin ? 0.0f : b->gw,
+		                lin ? FI_GRADIENT_CELL_EDGES : b->gk, 1.0f, 1.0f);
+		if (lin && b->gw != 0.0f) { generic_add_gradient_linear(t, b->n, b->pos.as<float>(), nrm, pw, b->gw, 1.0f, 1.0f); }
+	}
+	assemble(t);
+	generic_assemble(t);
+	stencil_prepare(t);
+	operator_prepare(t);
+	build_levels(t, c);
+	t->assembled = true;
+	t->vectors_ready = t->vectors_ready && t->max_blocks >= apply_num_partials(t);
+	t->stats.num_unknowns = t->g.nown;
+	t->stats.num_levels = 1;
+	for (fi_ctx* l = t->coarse; l; l = l->coarse) { t->stats.num_levels += 1; }
 }
 
 void check_ctx(const fi_ctx* c) { FI_REQUIRE(c != nullptr, FI_ERR_INVALID, "null context"); }
@@ -2018,6 +2187,7 @@ int fi_ctx_destroy(fi_ctx* c)
 	for (auto* b : c->batches) { delete b; }
 	for (auto* b : c->batches_pool) { delete b; }
 	if (c->coarse) { fi_ctx_destroy(c->coarse); }
+	if (c->twin) { fi_ctx_destroy(c->twin); }
 	c->pending.clear();
 	c->pending_pool.clear();
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
@@ -2192,7 +2362,15 @@ int fi_assemble(fi_ctx* c)
 	fi::generic_assemble(c);
 	fi::stencil_prepare(c);
 	fi::operator_prepare(c);
-	fi::build_levels(c);
+	if (c->mixed && c->dtype == FI_F64) {  // the fp32 replica carries the levels
+		const int keep = c->levels_wanted;
+		c->levels_wanted = 0;
+		fi::build_levels(c);
+		c->levels_wanted = keep;
+	} else {
+		fi::build_levels(c);
+	}
+	fi::build_twin(c);
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
@@ -2202,6 +2380,7 @@ int fi_assemble(fi_ctx* c)
 	c->stats.assemble_ms  = ms;
 	c->stats.num_levels   = 1;
 	for (fi_ctx* l = c->coarse; l; l = l->coarse) { c->stats.num_levels += 1; }
+	if (c->twin) { c->stats.num_levels = c->twin->stats.num_levels; }
 	c->stats.num_unknowns = c->g.nown;
 	c->stats.spmv_bytes   = fi::apply_algorithmic_bytes(c);
 	c->assembled          = true;
@@ -2236,6 +2415,11 @@ int fi_set_option(fi_ctx* c, int option, double value)
 		break;
 	case FI_OPT_COARSE_TOLERANCE: c->coarse_tol = value > 0 ? value : 1e-3; break;
 	case FI_OPT_MULTIGRID: c->mg_mode = value != 0.0 ? 1 : 0; break;
+	case FI_OPT_MIXED_PRECISION:
+		FI_REQUIRE(value == 0.0 || c->dtype == FI_F64, FI_ERR_INVALID, "FI_OPT_MIXED_PRECISION needs an FI_F64 context");
+		c->mixed = value != 0.0 ? 1 : 0;
+		c->assembled = false;
+		break;
 	default: FI_REQUIRE(false, FI_ERR_INVALID, "unknown option %d", option);
 	}
 	FI_API_END
@@ -2472,19 +2656,27 @@ int fi_group_assemble(fi_group* g)
 		const int rc = fi_assemble(c);
 		if (rc != FI_OK) { return rc; }
 	}
-	// coarser levels: the loop-back dot-product sum needs the scalar blocks of every member of a level
-	std::vector<fi_ctx*> lev;
-	for (fi_ctx* c : g->members) { lev.push_back(c->coarse); }
-	while (lev[0]) {
-		std::vector<fi::CgScalars*> ptrs;
-		for (fi_ctx*& c : lev) {
-			FI_REQUIRE(c != nullptr, FI_ERR_STATE, "members disagree on the number of levels");
-			ptrs.push_back(c->scal.as<fi::CgScalars>());
+	// coarser levels (and the fp32 replicas of mixed precision with theirs): the loop-back dot-product sum needs
+	// the scalar blocks of every member of a level
+	auto link_chain = [&](std::vector<fi_ctx*> lev) {
+		while (lev[0]) {
+			std::vector<fi::CgScalars*> ptrs;
+			for (fi_ctx*& c : lev) {
+				FI_REQUIRE(c != nullptr, FI_ERR_STATE, "members disagree on the number of levels");
+				ptrs.push_back(c->scal.as<fi::CgScalars>());
+			}
+			lev[0]->group_scal.alloc(sizeof(fi::CgScalars*) * ptrs.size());
+			FI_HIP_TRY(hipMemcpy(lev[0]->group_scal.p, ptrs.data(), sizeof(fi::CgScalars*) * ptrs.size(), hipMemcpyHostToDevice));
+			for (fi_ctx*& c : lev) { c = c->coarse; }
 		}
-		lev[0]->group_scal.alloc(sizeof(fi::CgScalars*) * ptrs.size());
-		FI_HIP_TRY(hipMemcpy(lev[0]->group_scal.p, ptrs.data(), sizeof(fi::CgScalars*) * ptrs.size(), hipMemcpyHostToDevice));
-		for (fi_ctx*& c : lev) { c = c->coarse; }
+	};
+	std::vector<fi_ctx*> lev, twins;
+	for (fi_ctx* c : g->members) {
+		lev.push_back(c->coarse);
+		twins.push_back(c->twin);
 	}
+	link_chain(lev);
+	link_chain(twins);
 	FI_API_END
 }
 
@@ -2506,7 +2698,9 @@ int fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float
 	int64_t at = 0;
 	fi_ctx* c0 = g->members[0];
 	c0->stats.coarse_iterations = 0;
-	if (!guess && c0->coarse) {
+	if (!guess && c0->twin && c0->twin->coarse) {
+		fi::twin_cascade_guess(g->members);
+	} else if (!guess && c0->coarse) {
 		g->dtype == FI_F64 ? fi::cascade_guess<double>(g->members) : fi::cascade_guess<float>(g->members);
 	} else {
 		for (fi_ctx* c : g->members) {
@@ -2522,7 +2716,7 @@ int fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float
 		fi_ctx* c; int* it; float* rel;
 		~Report() { if (it) { *it = c->stats.iterations; } if (rel) { *rel = static_cast<float>(c->stats.rel_residual); } }
 	} report{c0, iterations, rel_residual};
-	if (c0->mg_mode == 1 && c0->coarse) {
+	if (c0->mg_mode == 1 && (c0->coarse || (c0->twin && c0->twin->coarse))) {
 		g->dtype == FI_F64 ? fi::cg_run_mg<double>(g->members, max_iterations, tol)
 		                   : fi::cg_run_mg<float>(g->members, max_iterations, tol);
 	} else {

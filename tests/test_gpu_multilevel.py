@@ -100,3 +100,43 @@ def test_fp32_multigrid_reaches_a_verified_residual(oracle, fi):
     gb = np.zeros(fo.num_unknowns)
     np.add.at(gb, cols, vals.astype(np.float64) * rhs.astype(np.float64)[rows])
     assert np.linalg.norm(g) / np.linalg.norm(gb) <= 2e-5
+
+
+@pytest.mark.parametrize("sizes,levels", [([96, 80], 3), ([40, 32, 48], 2), ([48, 40, 32], 1)])
+def test_mixed_precision_vcycle(oracle, fi, sizes, levels):
+    """FI_OPT_MIXED_PRECISION: CG in fp64 with the V-cycle preconditioner on an fp32 replica.  The stop test is the
+    fp64 residual, so 1e-10 is reached although fp32 alone stalls near 1e-4 on these SDF systems; iteration counts
+    stay those of the pure-fp64 solve (+-10 %: the preconditioner is only perturbed by fp32 rounding); the solution
+    equals the pure-fp64 one to 1e-7 and the float64 direct solution of the oracle's rows to 1e-6."""
+    rng = np.random.default_rng(5)
+    pos, nrm = sphere_points(rng, sizes, 800)
+    w = fi.Weights()
+    fo, pure = build_pair(oracle, fi, sizes, w, pos, nrm, None, None, dtype="f64")
+    mixed = fi.LatticeField(sizes, dtype="f64")
+    mixed.add_field_constraints(w)
+    mixed.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    for f in (pure, mixed):
+        f.set_levels(levels)
+        f.set_multigrid(True)
+    mixed.set_mixed_precision(True)
+    for f in (pure, mixed):
+        f.assemble()
+    assert mixed.stats()["num_levels"] == pure.stats()["num_levels"] == levels + 1
+    tol = 1e-10
+    xp, itp, rp = pure.solve_cg(None, 0, tol)
+    xm, itm, rm = mixed.solve_cg(None, 0, tol)
+    st = mixed.stats()
+    assert st["converged"] == 1 and rm <= tol
+    assert mixed.true_residual() <= tol * 1.01
+    assert abs(itm - itp) <= max(2, itp // 10)
+    assert rel_inf(mixed.solution_f64(), pure.solution_f64()) <= 1e-7
+    if len(sizes) == 2:   # sparse Cholesky of a 3-D lattice this size takes minutes on the CPU
+        x64 = fo.solve_exact_f64()
+        assert rel_inf(mixed.solution_f64(), x64) <= 1e-6
+    # a caller's guess is honoured (warm start from the fp32-rounded answer: a handful of iterations)
+    xw, itw, rw = mixed.solve_cg(xm, 0, 1e-6)
+    assert rw <= 1e-6 and itw <= itm // 2
+    # only FI_F64 contexts take the option
+    f32 = fi.LatticeField(sizes, dtype="f32")
+    with pytest.raises(fi.FiError):
+        f32.set_mixed_precision(True)

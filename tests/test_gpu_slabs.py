@@ -138,3 +138,27 @@ def test_vcycle_preconditioner_over_slabs(fi, sizes, nranks, levels):
     assert abs(itg - it1) <= 2
     assert rel_inf(grp.solution_f64(), one.solution_f64()) <= 1e-6
     assert rel_inf(grp.solution_f64(), plain.solution_f64()) <= 1e-5
+
+
+def test_mixed_precision_over_slabs(fi):
+    """fp64 CG + fp32 V-cycle with the fp32 replicas decomposed like the fp64 contexts (loop-back group)."""
+    sizes, nranks = [32, 32, 64], 4
+    rng = np.random.default_rng(12)
+    pos, nrm = sphere_points(rng, sizes, 600)
+    w = fi.Weights()
+    one = fi.LatticeField(sizes, dtype="f64")
+    grp = fi.LatticeGroup(sizes, nranks, dtype="f64")
+    for f in (one, grp):
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        f.set_levels(2)
+        f.set_multigrid(True)
+    grp.set_mixed_precision(True)
+    for f in (one, grp):
+        f.assemble()
+    tol = 1e-9
+    x1, it1, r1 = one.solve_cg(None, 0, tol)
+    xg, itg, rg = grp.solve_cg(None, 0, tol)
+    assert rg <= tol and grp.true_residual() <= tol * 1.01
+    assert abs(itg - it1) <= max(2, it1 // 10)
+    assert rel_inf(grp.solution_f64(), one.solution_f64()) <= 1e-6

@@ -26,7 +26,9 @@ for cfg in which:
         f = fi.LatticeField(sizes, dtype=os.environ.get("DTYPE", "f32"))
         f.add_field_constraints(w)
         f.set_levels(int(os.environ.get("NLEV", "6")), 1e-4)
-        f.set_multigrid(mode == "mg")
+        f.set_multigrid(mode in ("mg", "mixed"))
+        if mode == "mixed":
+            f.set_mixed_precision(True)
         t0 = time.perf_counter()
         if nrm is None:
             f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
