@@ -1131,19 +1131,37 @@ __global__ __launch_bounds__(kThreads) void k_cheb_init(int64_t n, const T* __re
 	}
 }
 
-// r -= q;  d = c1 d + c2 Dinv r;  x += d
+// r = r_in - q;  d = c1 d + c2 Dinv r;  x = x_in + d.  Passes that nobody would read are skipped: r_in is the
+// right-hand side itself on the first step of a smoother that started from zero (then x_in is d: x == d so far),
+// and the last step of a polynomial stores neither r nor d.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_cheb_iter(int64_t n, const T* __restrict__ q, const T* __restrict__ dinv,
-                                                         T* __restrict__ r, T* __restrict__ d, T* __restrict__ x, T c1,
-                                                         T c2)
+                                                         const T* r_in, T* r, T* d, const T* x_in, T* x, T c1, T c2,
+                                                         int store_rd)
 {
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		const T ri = r[i] - q[i];
-		const T di = c1 * d[i] + c2 * dinv[i] * ri;
-		r[i] = ri;
-		d[i] = di;
-		x[i] += di;
+		const T ri = r_in[i] - q[i];
+		const T d0 = d[i];
+		const T di = c1 * d0 + c2 * dinv[i] * ri;
+		const T xi = (x_in == d ? d0 : x_in[i]) + di;
+		if (store_rd) {
+			r[i] = ri;
+			d[i] = di;
+		}
+		x[i] = xi;
+	}
+}
+
+// start of a smoother from zero: d = alpha Dinv b (x == d and r == b are not stored; a polynomial of degree 1
+// stores x instead)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cheb_first(int64_t n, const T* __restrict__ b, const T* __restrict__ dinv,
+                                                          T* __restrict__ d, T alpha)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		d[i] = alpha * dinv[i] * b[i];
 	}
 }
 
@@ -1379,21 +1397,33 @@ void cheb_smooth(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_z
 	const double hi = 1.1 * R[0]->lambda_max, lo = hi / ratio;
 	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
 	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
-	if (!from_zero) { apply_all(R, x, &fi_ctx::q, false); }
-	for (fi_ctx* c : R) {
-		hipLaunchKernelGGL((k_cheb_init<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
-		                   from_zero ? static_cast<const T*>(nullptr) : vown<T>(c, &fi_ctx::q), vown<T>(c, &fi_ctx::dinv),
-		                   vown<T>(c, &fi_ctx::mg_r), vown<T>(c, &fi_ctx::mg_d), vown<T>(c, x), static_cast<T>(1.0 / theta),
-		                   from_zero ? 1 : 0);
+	if (from_zero) {
+		// x == d and r == b until the first update: only d is written (straight into x when the polynomial ends here)
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_cheb_first<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
+			                   vown<T>(c, &fi_ctx::dinv), degree > 1 ? vown<T>(c, &fi_ctx::mg_d) : vown<T>(c, x),
+			                   static_cast<T>(1.0 / theta));
+		}
+	} else {
+		apply_all(R, x, &fi_ctx::q, false);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_cheb_init<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
+			                   vown<T>(c, &fi_ctx::q), vown<T>(c, &fi_ctx::dinv), vown<T>(c, &fi_ctx::mg_r),
+			                   vown<T>(c, &fi_ctx::mg_d), vown<T>(c, x), static_cast<T>(1.0 / theta), 0);
+		}
 	}
 	double rho = 1.0 / sigma;
 	for (int k = 1; k < degree; ++k) {
 		const double rho_new = 1.0 / (2.0 * sigma - rho);
 		apply_all(R, &fi_ctx::mg_d, &fi_ctx::q, false);
+		const bool first = from_zero && k == 1, last = k == degree - 1;
 		for (fi_ctx* c : R) {
+			T* d = vown<T>(c, &fi_ctx::mg_d);
+			T* r = vown<T>(c, &fi_ctx::mg_r);
 			hipLaunchKernelGGL((k_cheb_iter<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, &fi_ctx::q),
-			                   vown<T>(c, &fi_ctx::dinv), vown<T>(c, &fi_ctx::mg_r), vown<T>(c, &fi_ctx::mg_d), vown<T>(c, x),
-			                   static_cast<T>(rho_new * rho), static_cast<T>(2.0 * rho_new / delta));
+			                   vown<T>(c, &fi_ctx::dinv), first ? static_cast<const T*>(vown<T>(c, b)) : static_cast<const T*>(r), r,
+			                   d, first ? static_cast<const T*>(d) : static_cast<const T*>(vown<T>(c, x)), vown<T>(c, x),
+			                   static_cast<T>(rho_new * rho), static_cast<T>(2.0 * rho_new / delta), last ? 0 : 1);
 		}
 		rho = rho_new;
 	}
