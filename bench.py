@@ -72,8 +72,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--tol", type=float, default=1e-5)
     ap.add_argument("--cpu-side", type=int, default=112, help="lattice side of the CPU baseline sample (0: skip)")
-    ap.add_argument("--levels", type=int, default=3, help="coarser levels for the coarse-to-fine start (0: plain Jacobi-PCG)")
-    ap.add_argument("--coarse-tol", type=float, default=1e-4)
+    ap.add_argument("--levels", type=int, default=2, help="coarser levels for the coarse-to-fine start (0: plain Jacobi-PCG)")
+    ap.add_argument("--coarse-tol", type=float, default=1e-5)
     ap.add_argument("--multigrid", action="store_true", help="V-cycle preconditioned CG instead of Jacobi-PCG")
     args = ap.parse_args()
 
