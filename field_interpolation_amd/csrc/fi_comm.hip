@@ -12,6 +12,7 @@
 
 #include <dlfcn.h>
 #include <cstring>
+#include <vector>
 #include <rccl/rccl.h>
 
 #include "fi_internal.h"
@@ -137,6 +138,51 @@ int fi_comm_unique_id(void* out128)
 		ncclUniqueId id;
 		FI_NCCL_TRY(fi::rccl().GetUniqueId(&id));
 		memcpy(out128, &id, sizeof(id));
+	} catch (const fi::Fail& f) {
+		return f.code;
+	}
+	return FI_OK;
+}
+
+int fi_comm_self_test(int device, long count)
+{
+	// The exact RCCL call pattern of exchange_halo / allreduce_sum on a one-rank communicator: a grouped
+	// ncclSend + ncclRecv (to and from rank 0 = self) of `count` floats on a stream, then an in-place fp64 all-reduce.
+	try {
+		FI_REQUIRE(count > 0, FI_ERR_INVALID, "count must be positive");
+		FI_HIP_TRY(hipSetDevice(device));
+		fi::Rccl& r = fi::rccl();
+		ncclUniqueId id;
+		FI_NCCL_TRY(r.GetUniqueId(&id));
+		ncclComm_t comm = nullptr;
+		FI_NCCL_TRY(r.CommInitRank(&comm, 1, id, 0));
+		hipStream_t st = nullptr;
+		FI_HIP_TRY(hipStreamCreate(&st));
+		fi::DevBuf src, dst, sums;
+		src.alloc(sizeof(float) * count);
+		dst.alloc(sizeof(float) * count);
+		sums.alloc(sizeof(double) * 4);
+		std::vector<float> h(count), back(count);
+		for (long i = 0; i < count; ++i) { h[i] = static_cast<float>((i * 2654435761u) % 1000003u) * 1e-3f; }
+		const double hs[4] = {1.5, -2.25, 3.0e10, 7.0e-10};
+		double       hb[4] = {0, 0, 0, 0};
+		FI_HIP_TRY(hipMemcpyAsync(src.p, h.data(), sizeof(float) * count, hipMemcpyHostToDevice, st));
+		FI_HIP_TRY(hipMemsetAsync(dst.p, 0, sizeof(float) * count, st));
+		FI_HIP_TRY(hipMemcpyAsync(sums.p, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+		FI_NCCL_TRY(r.GroupStart());
+		FI_NCCL_TRY(r.Send(src.p, static_cast<size_t>(count), ncclFloat32, 0, comm, st));
+		FI_NCCL_TRY(r.Recv(dst.p, static_cast<size_t>(count), ncclFloat32, 0, comm, st));
+		FI_NCCL_TRY(r.GroupEnd());
+		FI_NCCL_TRY(r.AllReduce(sums.p, sums.p, 4, ncclFloat64, ncclSum, comm, st));
+		FI_HIP_TRY(hipMemcpyAsync(back.data(), dst.p, sizeof(float) * count, hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipMemcpyAsync(hb, sums.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		(void)r.CommDestroy(comm);
+		(void)hipStreamDestroy(st);
+		for (long i = 0; i < count; ++i) {
+			FI_REQUIRE(back[i] == h[i], FI_ERR_COMM, "self send/recv: element %ld differs", i);
+		}
+		for (int k = 0; k < 4; ++k) { FI_REQUIRE(hb[k] == hs[k], FI_ERR_COMM, "one-rank all-reduce changed element %d", k); }
 	} catch (const fi::Fail& f) {
 		return f.code;
 	}

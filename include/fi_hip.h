@@ -119,6 +119,11 @@ int fi_slab_partition(int planes, int rank, int nranks, int* lo, int* hi);
  * at least 1 (cell blocks and gradient_smoothness reach one plane). */
 int fi_halo_width(const fi_weights* w, int* width);
 
+/* Diagnostic: runs the RCCL call pattern of the slab exchange (grouped ncclSend/ncclRecv on a stream, in-place
+ * fp64 all-reduce) on a ONE-rank communicator of `device` and checks the data -- the part of the multi-GPU path
+ * a single-GPU machine can execute against the real library. */
+int fi_comm_self_test(int device, long count);
+
 /* RCCL bootstrap (no reference counterpart: the reference is single-process).  Rank 0 calls
  * fi_comm_unique_id, the 128 bytes are broadcast by the launcher (torch.distributed), every rank calls
  * fi_comm_init.  Halo planes of the CG search direction and the dot products then travel over xGMI. */

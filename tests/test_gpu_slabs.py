@@ -162,3 +162,11 @@ def test_mixed_precision_over_slabs(fi):
     assert rg <= tol and grp.true_residual() <= tol * 1.01
     assert abs(itg - it1) <= max(2, it1 // 10)
     assert rel_inf(grp.solution_f64(), one.solution_f64()) <= 1e-6
+
+
+def test_rccl_call_pattern_on_a_one_rank_communicator(fi):
+    """The multi-GPU exchange against the real librccl, as far as one GPU allows: grouped ncclSend/ncclRecv of a
+    halo-sized buffer on a stream and the in-place fp64 all-reduce, on a communicator of one rank (send to self)."""
+    from field_interpolation_amd import _capi
+    _capi.check(_capi.lib().fi_comm_self_test(0, 2 * 256 * 256))      # two 256 x 256 fp32 planes: the bench's halo
+    _capi.check(_capi.lib().fi_comm_self_test(0, 7))
