@@ -102,15 +102,16 @@ def test_fp32_multigrid_reaches_a_verified_residual(oracle, fi):
     assert np.linalg.norm(g) / np.linalg.norm(gb) <= 2e-5
 
 
-@pytest.mark.parametrize("sizes,levels", [([96, 80], 3), ([40, 32, 48], 2), ([48, 40, 32], 1)])
-def test_mixed_precision_vcycle(oracle, fi, sizes, levels):
+@pytest.mark.parametrize("sizes,levels,gk", [([96, 80], 3, 1), ([40, 32, 48], 2, 1), ([48, 40, 32], 1, 1), ([80, 64], 2, 2),
+                                            ([32, 40, 32], 1, 0)])
+def test_mixed_precision_vcycle(oracle, fi, sizes, levels, gk):
     """FI_OPT_MIXED_PRECISION: CG in fp64 with the V-cycle preconditioner on an fp32 replica.  The stop test is the
     fp64 residual, so 1e-10 is reached although fp32 alone stalls near 1e-4 on these SDF systems; iteration counts
     stay those of the pure-fp64 solve (+-10 %: the preconditioner is only perturbed by fp32 rounding); the solution
     equals the pure-fp64 one to 1e-7 and the float64 direct solution of the oracle's rows to 1e-6."""
     rng = np.random.default_rng(5)
     pos, nrm = sphere_points(rng, sizes, 800)
-    w = fi.Weights()
+    w = fi.Weights(gradient_kernel=fi.GradientKernel(gk))     # 2: rows 3 points wide -> the generic sparse-row path
     fo, pure = build_pair(oracle, fi, sizes, w, pos, nrm, None, None, dtype="f64")
     mixed = fi.LatticeField(sizes, dtype="f64")
     mixed.add_field_constraints(w)
