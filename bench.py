@@ -123,7 +123,7 @@ def main():
     field.add_field_constraints(w)
     if args.levels > 0:
         field.set_levels(args.levels, args.coarse_tol)
-        if args.multigrid and world == 1:   # the V-cycle preconditioner needs an undivided lattice (this round)
+        if args.multigrid:
             field.set_multigrid(True)
 
     def step():
