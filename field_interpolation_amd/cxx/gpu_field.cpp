@@ -28,6 +28,15 @@ GpuLatticeField::GpuLatticeField(const std::vector<int>& sizes, bool double_prec
 
 GpuLatticeField::~GpuLatticeField() { fi_ctx_destroy(ctx_); }
 
+void GpuLatticeField::set_levels(int levels, bool multigrid, bool mixed_precision)
+{
+	if (fi_set_option(ctx_, FI_OPT_LEVELS, levels) != FI_OK || fi_set_option(ctx_, FI_OPT_MULTIGRID, multigrid ? 1 : 0) != FI_OK ||
+	    fi_set_option(ctx_, FI_OPT_MIXED_PRECISION, mixed_precision ? 1 : 0) != FI_OK) {
+		warn("set_levels");
+	}
+	dirty_ = true;
+}
+
 size_t GpuLatticeField::num_unknowns() const
 {
 	size_t n = 1;
@@ -136,6 +145,17 @@ std::vector<float> GpuLatticeField::solve_with_guess(const std::vector<float>& g
 	std::vector<float> out(guess.size());
 	if (fi_solve_cg(ctx_, guess.data(), max_iterations, error_tolerance, out.data(), &iterations_, &error_, FI_HOST) !=
 	    FI_OK) {
+		warn("solver failed");
+		return {};
+	}
+	return out;
+}
+
+std::vector<float> GpuLatticeField::solve(int max_iterations, float error_tolerance)
+{
+	if (!assemble()) { return {}; }
+	std::vector<float> out(num_unknowns());
+	if (fi_solve_cg(ctx_, nullptr, max_iterations, error_tolerance, out.data(), &iterations_, &error_, FI_HOST) != FI_OK) {
 		warn("solver failed");
 		return {};
 	}

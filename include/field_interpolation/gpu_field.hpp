@@ -26,6 +26,12 @@ public:
 	const std::vector<int>& sizes() const { return sizes_; }
 	size_t num_unknowns() const;
 
+	// Large lattices (the reference's recipe is app code: src/sdf_field.cpp:272-288).  `levels` coarser replicas of
+	// the problem are built on the GPU; a zero-length guess then starts from the coarse-to-fine cascade.
+	// multigrid: V-cycle preconditioned CG over the levels (needed by SDF problems from oriented points).
+	// mixed_precision (double_precision fields): CG in fp64, the V-cycle on an fp32 replica.
+	void set_levels(int levels, bool multigrid = false, bool mixed_precision = false);
+
 	void add_field_constraints(const Weights& weights);
 	bool add_value_constraint(const float pos[], float value, float weight);
 	bool add_value_constraint_nearest_neighbor(const float pos[], const float gradient[], float value, float weight);
@@ -36,6 +42,8 @@ public:
 	// solve_sparse_linear_with_guess / solve_tiled_with_guess / jacobi_iterations of the reference.
 	// An empty result means failure (wrong guess length, solver breakdown), as in the reference.
 	std::vector<float> solve_with_guess(const std::vector<float>& guess, int max_iterations, float error_tolerance);
+	// No guess: starts from the coarse-to-fine cascade when set_levels() built levels, from zero otherwise.
+	std::vector<float> solve(int max_iterations, float error_tolerance);
 	std::vector<float> solve_tiled_with_guess(const std::vector<float>& guess, const SolveOptions& options);
 	std::vector<float> jacobi_iterations(const std::vector<float>& guess, int num_iterations, float weight);
 	// generate_error_map(field.eq.triplets, solution, field.eq.rhs) of the reference, from the rows on the device.

@@ -142,6 +142,15 @@ int main()
 		tiled.error_tolerance = 1e-5f;
 		auto via_tiles = gpu.solve_tiled_with_guess(std::vector<float>(n, 0.0f), tiled);
 		require(via_tiles.size() == n && max_rel(via_tiles, exact) <= 5e-3f, "SolveOptions.tile: tile pre-solver + CG");
+		// levels + V-cycle + mixed precision through the C++ fast path
+		fi::GpuLatticeField deep(sizes, true);
+		deep.set_levels(2, true, true);
+		deep.add_field_constraints(weights);
+		deep.add_points(weights.data_pos, weights.value_kernel, weights.data_gradient, weights.gradient_kernel, 160,
+		                positions.data(), normals.data(), nullptr);
+		auto leveled = deep.solve(0, 1e-7f);
+		require(leveled.size() == n && deep.last_error() <= 1e-7f && max_rel(leveled, exact) <= 1e-4f,
+		        "set_levels(2, multigrid, mixed): V-cycle CG with an fp32 replica");
 		auto big = fi::upscale_field(exact.data(), sizes, {47, 39});
 		require(big.size() == 47u * 39u && std::fabs(big[0] - exact[0]) < 1e-6f && std::fabs(big.back() - exact.back()) < 1e-6f,
 		        "upscale_field keeps the corners");
