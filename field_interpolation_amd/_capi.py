@@ -20,7 +20,7 @@ SYMBOLS = [
     "fi_get_solution_f64", "fi_true_residual", "fi_apply_AtA_f64", "fi_get_Atb_f64", "fi_get_diag_f64",
     "fi_get_stats", "fi_time_apply", "fi_upscale_field",
     "fi_group_create", "fi_group_destroy", "fi_group_size", "fi_group_rank", "fi_group_assemble",
-    "fi_group_solve_cg", "fi_group_apply_AtA_f64", "fi_group_true_residual", "fi_group_get_solution_f64",
+    "fi_group_solve_cg", "fi_group_apply_AtA_f64", "fi_group_true_residual", "fi_group_get_solution_f64", "fi_group_tile_pass", "fi_group_error_map",
 ]
 
 
@@ -106,6 +106,8 @@ def lib():
     L.fi_group_apply_AtA_f64.argtypes = [vp, dp, dp]
     L.fi_group_true_residual.argtypes = [vp, dp]
     L.fi_group_get_solution_f64.argtypes = [vp, dp]
+    L.fi_group_tile_pass.argtypes = [vp, fp, C.c_int, fp]
+    L.fi_group_error_map.argtypes = [vp, fp, fp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError if the .so lacks a declared symbol
     _LIB = L

@@ -415,6 +415,20 @@ class LatticeGroup:
     def stats(self):
         return self.members[0].stats()
 
+    def tile_pass(self, guess, tile_size=16):
+        g = np.ascontiguousarray(guess, np.float32)
+        out = np.empty(self.num_unknowns, np.float32)
+        fp = C.POINTER(C.c_float)
+        check(_capi.lib().fi_group_tile_pass(self._g, g.ctypes.data_as(fp), int(tile_size), out.ctypes.data_as(fp)))
+        return out
+
+    def error_map(self, solution):
+        s = np.ascontiguousarray(solution, np.float32)
+        out = np.empty(self.num_unknowns, np.float32)
+        fp = C.POINTER(C.c_float)
+        check(_capi.lib().fi_group_error_map(self._g, s.ctypes.data_as(fp), out.ctypes.data_as(fp)))
+        return out
+
     def solution_f64(self):
         out = np.empty(self.num_unknowns, np.float64)
         check(_capi.lib().fi_group_get_solution_f64(self._g, out.ctypes.data_as(C.POINTER(C.c_double))))

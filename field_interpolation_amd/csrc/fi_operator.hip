@@ -427,7 +427,8 @@ __global__ __launch_bounds__(kThreads) void k_error_model(Geom g, ModelCoef<T> m
 }
 
 template <int D, typename T>
-__global__ __launch_bounds__(kThreads) void k_error_rows(Geom g, int64_t nrows, const uint32_t* __restrict__ key,
+__global__ __launch_bounds__(kThreads) void k_error_rows(Geom g, int64_t nrows, uint32_t invalid,
+                                                          const uint32_t* __restrict__ key,
                                                           const float* __restrict__ coef, const float* __restrict__ rhs,
                                                           const T* __restrict__ x, T* __restrict__ out)
 {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void k_error_rows(Geom g, int64_t nrows, 
 	for (int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; r < nrows;
 	     r += static_cast<int64_t>(gridDim.x) * kThreads) {
 		uint32_t id = key[r];
-		if (id == 0xFFFFFFFFu) { continue; }
+		if (id >= invalid) { continue; }  // slots of rows that were not emitted carry the number of extended cells
 		int l[3] = {0, 0, 0};
 		for (int d = 0; d < D; ++d) {
 			l[d] = static_cast<int>(id % static_cast<uint32_t>(g.cn[d]));
@@ -478,7 +479,9 @@ void error_map_dim(fi_ctx* c, const T* x, T* out)
 	for (const Pending* pb : c->pending) {
 		if (pb->nrows == 0) { continue; }
 		hipLaunchKernelGGL((k_error_rows<D, T>), dim3(capped_blocks(pb->nrows)), dim3(kThreads), 0, c->stream, g,
-		                   static_cast<int64_t>(pb->nrows), pb->key.as<uint32_t>(), pb->coef.as<float>(),
+		                   static_cast<int64_t>(pb->nrows),
+		                   static_cast<uint32_t>(static_cast<int64_t>(g.cn[0]) * g.cn[1] * g.cn[2]), pb->key.as<uint32_t>(),
+		                   pb->coef.as<float>(),
 		                   pb->rhs.as<float>(), x, out);
 	}
 	FI_HIP_TRY(hipGetLastError());

@@ -1774,34 +1774,56 @@ __global__ __launch_bounds__(kThreads) void k_tile_rhs(int64_t n, const T* __res
 // tile is an independent SPD system ((AtA restricted to the tile) + 1e-6 I) x_t = rhs_t, so CG on the whole
 // lattice solves all of them at once; the couplings to other tiles enter through the guess, as in the reference.
 template <typename T>
-void tile_pass_t(fi_ctx* c, const float* guess, int tile_size, float* out, int memory)
+void tile_pass_run(RankSet& R, int tile_size)  // x of every member: the guess on entry, the tile solutions on return
 {
-	ensure_vectors(c);
-	FI_REQUIRE(c->generic.ntrip == 0 && c->generic.nnz == 0, FI_ERR_UNSUPPORTED,
-	           "the tile pre-solver works on lattice rows (fi_set_model / fi_add_points), not on fi_add_rows_coo rows");
-	load_owned<T>(c, c->x, guess, memory);
-	RankSet R{c};
+	for (fi_ctx* c : R) {
+		FI_REQUIRE(c->generic.ntrip == 0 && c->generic.nnz == 0, FI_ERR_UNSUPPORTED,
+		           "the tile pre-solver works on lattice rows (fi_set_model / fi_add_points), not on fi_add_rows_coo rows");
+	}
 	CgScalars init{};
 	reset_scalars(R, init);
 	halo_exchange(R, &fi_ctx::x);
-	DevBuf& rhs = c->scratch[21];
-	rhs.alloc(elem_size(c) * c->g.nloc);
-	FI_HIP_TRY(hipMemsetAsync(rhs.p, 0, elem_size(c) * c->g.nloc, c->stream));
-	apply_AtA(c, c->x.p, c->q.p, nullptr);
-	c->tile_ts = tile_size;
 	struct Restore {
-		fi_ctx* c; DevBuf* rhs; bool swapped;
-		~Restore() { c->tile_ts = 0; if (swapped) { std::swap(c->atb.p, rhs->p); std::swap(c->atb.bytes, rhs->bytes); } }
-	} restore{c, &rhs, false};
-	apply_AtA(c, c->x.p, c->r.p, nullptr);
-	const int64_t o = c->g.own_first;
-	hipLaunchKernelGGL((k_tile_rhs<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
-	                   c->atb.as<T>() + o, c->q.as<T>() + o, c->r.as<T>() + o, c->x.as<T>() + o, rhs.as<T>() + o);
-	FI_HIP_TRY(hipGetLastError());
-	std::swap(c->atb.p, rhs.p);
-	std::swap(c->atb.bytes, rhs.bytes);
-	restore.swapped = true;
+		RankSet& R;
+		std::vector<bool> swapped;
+		~Restore()
+		{
+			for (size_t i = 0; i < R.size(); ++i) {
+				fi_ctx* c = R[i];
+				c->tile_ts = 0;
+				if (swapped[i]) {
+					std::swap(c->atb.p, c->scratch[21].p);
+					std::swap(c->atb.bytes, c->scratch[21].bytes);
+				}
+			}
+		}
+	} restore{R, std::vector<bool>(R.size(), false)};
+	for (size_t i = 0; i < R.size(); ++i) {
+		fi_ctx* c = R[i];
+		DevBuf& rhs = c->scratch[21];
+		rhs.alloc(elem_size(c) * c->g.nloc);
+		FI_HIP_TRY(hipMemsetAsync(rhs.p, 0, elem_size(c) * c->g.nloc, c->stream));
+		apply_AtA(c, c->x.p, c->q.p, nullptr);
+		c->tile_ts = tile_size;
+		apply_AtA(c, c->x.p, c->r.p, nullptr);
+		const int64_t o = c->g.own_first;
+		hipLaunchKernelGGL((k_tile_rhs<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+		                   c->atb.as<T>() + o, c->q.as<T>() + o, c->r.as<T>() + o, c->x.as<T>() + o, rhs.as<T>() + o);
+		FI_HIP_TRY(hipGetLastError());
+		std::swap(c->atb.p, rhs.p);
+		std::swap(c->atb.bytes, rhs.bytes);
+		restore.swapped[i] = true;
+	}
 	cg_run<T>(R, 4000, sizeof(T) == 8 ? 1e-12f : 1e-6f);  // the reference factorises: iterate to the precision's floor
+}
+
+template <typename T>
+void tile_pass_t(fi_ctx* c, const float* guess, int tile_size, float* out, int memory)
+{
+	ensure_vectors(c);
+	load_owned<T>(c, c->x, guess, memory);
+	RankSet R{c};
+	tile_pass_run<T>(R, tile_size);
 	store_owned<T>(c, c->x, out, memory);
 }
 
@@ -2779,6 +2801,46 @@ int fi_group_true_residual(fi_group* g, double* rel)
 	group_ready(g);
 	FI_REQUIRE(rel != nullptr, FI_ERR_INVALID, "null output");
 	*rel = g->dtype == FI_F64 ? fi::true_residual_run<double>(g->members) : fi::true_residual_run<float>(g->members);
+	FI_API_END
+}
+
+int fi_group_tile_pass(fi_group* g, const float* guess, int tile_size, float* out)
+{
+	FI_API_BEGIN
+	group_ready(g);
+	FI_REQUIRE(tile_size >= 2 && guess && out, FI_ERR_INVALID, "fi_group_tile_pass: tile_size >= 2, guess and out required");
+	int64_t at = 0;
+	for (fi_ctx* c : g->members) {
+		g->dtype == FI_F64 ? fi::load_owned<double>(c, c->x, guess + at, FI_HOST) : fi::load_owned<float>(c, c->x, guess + at, FI_HOST);
+		at += c->g.nown;
+	}
+	g->dtype == FI_F64 ? fi::tile_pass_run<double>(g->members, tile_size) : fi::tile_pass_run<float>(g->members, tile_size);
+	at = 0;
+	for (fi_ctx* c : g->members) {
+		g->dtype == FI_F64 ? fi::store_owned<double>(c, c->x, out + at, FI_HOST) : fi::store_owned<float>(c, c->x, out + at, FI_HOST);
+		at += c->g.nown;
+	}
+	FI_API_END
+}
+
+int fi_group_error_map(fi_group* g, const float* solution, float* out)
+{
+	FI_API_BEGIN
+	group_ready(g);
+	FI_REQUIRE(solution && out, FI_ERR_INVALID, "fi_group_error_map needs a solution and an output buffer");
+	int64_t at = 0;
+	for (fi_ctx* c : g->members) {
+		g->dtype == FI_F64 ? fi::load_owned<double>(c, c->x, solution + at, FI_HOST)
+		                   : fi::load_owned<float>(c, c->x, solution + at, FI_HOST);
+		at += c->g.nown;
+	}
+	fi::halo_exchange(g->members, &fi_ctx::x);
+	at = 0;
+	for (fi_ctx* c : g->members) {
+		fi::error_map(c, c->x.p, c->q.p);
+		g->dtype == FI_F64 ? fi::store_owned<double>(c, c->q, out + at, FI_HOST) : fi::store_owned<float>(c, c->q, out + at, FI_HOST);
+		at += c->g.nown;
+	}
 	FI_API_END
 }
 

@@ -243,6 +243,8 @@ int     fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, f
 int     fi_group_apply_AtA_f64(fi_group* g, const double* x, double* y);
 int     fi_group_true_residual(fi_group* g, double* rel_residual);
 int     fi_group_get_solution_f64(fi_group* g, double* out);
+int     fi_group_tile_pass(fi_group* g, const float* guess, int tile_size, float* out);
+int     fi_group_error_map(fi_group* g, const float* solution, float* out);
 
 /* ---- helpers either side of the path ---------------------------------------------------------
  * Replaces upscale_field (field_interpolation.cpp:431-485): multilinear resampling small -> large. */

@@ -170,3 +170,18 @@ def test_rccl_call_pattern_on_a_one_rank_communicator(fi):
     from field_interpolation_amd import _capi
     _capi.check(_capi.lib().fi_comm_self_test(0, 2 * 256 * 256))      # two 256 x 256 fp32 planes: the bench's halo
     _capi.check(_capi.lib().fi_comm_self_test(0, 7))
+
+
+@pytest.mark.parametrize("sizes,nranks,ts", [([40, 36], 3, 8), ([16, 12, 24], 4, 5)])
+def test_tile_pass_and_error_map_over_slabs(fi, sizes, nranks, ts):
+    """The tile pre-solver (tiles straddle slab seams) and generate_error_map (cell rows kept by two ranks blame
+    only the points each rank owns) over slabs equal the undivided results."""
+    rng = np.random.default_rng(ts)
+    pos, nrm, pw, val = random_points(rng, sizes, 400, margin=0.8)
+    w = fi.Weights(model_1=0.2, model_2=0.5, gradient_smoothness=0.1 if len(sizes) == 2 else 0.0)
+    one, grp = _pair(fi, sizes, nranks, w, pos, nrm, pw, None, "f64")
+    n = int(np.prod(sizes))
+    g = rng.normal(size=n).astype(np.float32)
+    assert rel_inf(grp.error_map(g), one.error_map(g)) <= 1e-6
+    t1, tg = one.tile_pass(g, ts), grp.tile_pass(g, ts)
+    assert np.abs(tg - t1).max() <= 1e-5 * np.abs(t1).max()
