@@ -107,33 +107,40 @@ def main():
     side = args.side
     depth = side * world
     npts = args.points * world
-    sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3, depth=depth)
 
-    field = fi.LatticeField(sizes, dtype=args.dtype, rank=rank, nranks=world)
-    if world > 1:
-        fdist.init_comm(field, dev)          # RCCL unique id from rank 0, broadcast by torch.distributed
-    lo, hi = field.slab
-    # each rank uploads the points whose cells touch its slab (the library drops the rest anyway)
-    keep = fdist.points_of_slab(pos, 3, lo, hi)
-    d_pos = torch.from_numpy(np.ascontiguousarray(pos[keep])).to(dev)
-    d_val = torch.from_numpy(np.ascontiguousarray(val[keep])).to(dev)
-    d_out = torch.empty(field.num_owned, dtype=torch.float32, device=dev)   # the solution stays in HBM
-    torch.cuda.synchronize()
+    def build(slabs):
+        """slabs: ONE lattice of 256 x 256 x (256 * world), a slab per rank, halo planes and dot products over RCCL.
+        not slabs (only if the communicator cannot be set up): every rank solves its own 256^3 replica."""
+        if slabs:
+            sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3, depth=depth)
+            field = fi.LatticeField(sizes, dtype=args.dtype, rank=rank, nranks=world)
+            if world > 1:
+                fdist.init_comm(field, dev)      # RCCL unique id from rank 0, broadcast by torch.distributed
+        else:
+            sizes, w, pos, val = synth.config4(side=side, num_points=args.points, seed=3 + rank)
+            field = fi.LatticeField(sizes, dtype=args.dtype)
+        lo, hi = field.slab
+        # each rank uploads the points whose cells touch its slab (the library drops the rest anyway)
+        keep = fdist.points_of_slab(pos, 3, lo, hi)
+        d_pos = torch.from_numpy(np.ascontiguousarray(pos[keep])).to(dev)
+        d_val = torch.from_numpy(np.ascontiguousarray(val[keep])).to(dev)
+        d_out = torch.empty(field.num_owned, dtype=torch.float32, device=dev)   # the solution stays in HBM
+        torch.cuda.synchronize()
+        field.add_field_constraints(w)
+        if args.levels > 0:
+            field.set_levels(args.levels, args.coarse_tol)
+            if args.multigrid:
+                field.set_multigrid(True)
 
-    field.add_field_constraints(w)
-    if args.levels > 0:
-        field.set_levels(args.levels, args.coarse_tol)
-        if args.multigrid:
-            field.set_multigrid(True)
-
-    def step():
-        field.clear_points()
-        field.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, d_pos, None, None, values=d_val)
-        field.assemble()
-        out = field.solve_cg(None, 0, args.tol, out=d_out)
-        if out is None:
-            raise RuntimeError("CG breakdown")
-        return out
+        def step():
+            field.clear_points()
+            field.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, d_pos, None, None, values=d_val)
+            field.assemble()
+            out = field.solve_cg(None, 0, args.tol, out=d_out)
+            if out is None:
+                raise RuntimeError("CG breakdown")
+            return out
+        return field, step
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,8 +148,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    parallelism, note = "slab%d" % world, None
+    try:
+        field, step = build(True)
+        for _ in range(args.warmup):
+            step()
+        ok = 1
+    except Exception as e:          # noqa: BLE001 -- any failure of the exchange path is reported, not hidden
+        if world == 1:
+            raise
+        ok, note = 0, "%s: %s" % (type(e).__name__, e)
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=("cpu" if one_device else dev))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:   # some rank could not run the slab exchange: independent replicas, said so in the line
+            parallelism = "replicas%d (slab exchange failed: %s)" % (world, note or "on another rank")
+            field, step = build(False)
+            for _ in range(args.warmup):
+                step()
     spmv_ms, spmv_n, asm_ms, solve_ms = 0.0, 0, 0.0, 0.0
     barrier()
     t0 = time.perf_counter()
@@ -173,7 +196,7 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5, "
                                "Jacobi-PCG to rel. residual %g" % (side, side, depth, npts, args.tol),
-                   "parallelism": "slab%d" % world, "iterations": iters, "rel_residual": rel,
+                   "parallelism": parallelism, "iterations": iters, "rel_residual": rel,
                    "levels": st["num_levels"], "coarse_iterations": st["coarse_iterations"],
                    "solver": ("V-cycle PCG" if (args.multigrid and st["num_levels"] > 1) else
                               "Jacobi-PCG" + (" from a coarse-to-fine cascade" if st["num_levels"] > 1 else "")),
