@@ -141,3 +141,37 @@ def test_mixed_precision_vcycle(oracle, fi, sizes, levels, gk):
     f32 = fi.LatticeField(sizes, dtype="f32")
     with pytest.raises(fi.FiError):
         f32.set_mixed_precision(True)
+
+
+def test_mixed_precision_reassembly_reuses_the_replica(fi):
+    """clear_points + new points + assemble on a mixed-precision field: the fp32 replica and its levels are rebuilt
+    in place; the second solve equals the solve of a fresh field with the second point set."""
+    sizes = [72, 56]
+    rng = np.random.default_rng(9)
+    w = fi.Weights()
+    f = fi.LatticeField(sizes, dtype="f64")
+    f.add_field_constraints(w)
+    f.set_levels(2)
+    f.set_multigrid(True)
+    f.set_mixed_precision(True)
+    sols = []
+    for k in range(3):
+        pos, nrm = sphere_points(rng, sizes, 500 + 100 * k)
+        f.clear_points()
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-9)
+        assert rel <= 1e-9 and f.true_residual() <= 1.01e-9
+        sols.append((pos, nrm, f.solution_f64().copy()))
+    pos, nrm, x_last = sols[-1]
+    fresh = fi.LatticeField(sizes, dtype="f64")
+    fresh.add_field_constraints(w)
+    fresh.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    fresh.assemble()
+    fresh.solve_cg(None, 20000, 1e-9)
+    assert rel_inf(x_last, fresh.solution_f64()) <= 1e-5
+    # switching the option off drops the replica and the field solves in plain fp64 again
+    f.set_mixed_precision(False)
+    f.assemble()
+    x, it, rel = f.solve_cg(None, 0, 1e-9)
+    assert rel <= 1e-9 and rel_inf(f.solution_f64(), x_last) <= 1e-5
