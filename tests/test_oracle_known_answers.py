@@ -8,23 +8,18 @@ anchors there are:
     (cond(AtA) = 165.7);
   * closed-form row / triplet counts of configs C1..C3 (default Weights).
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
 
-README_A = np.array([
-    [1, 0, 0, 0, 0, 0],
-    [0, 0, 0, 0, 0, 1],
-    [-1, 1, 0, 0, 0, 0],
-    [0, 0, 0, 0, -1, 1],
-    [1, -2, 1, 0, 0, 0],
-    [0, 1, -2, 1, 0, 0],
-    [0, 0, 1, -2, 1, 0],
-    [0, 0, 0, 1, -2, 1]], dtype=np.float64)
-README_B = np.array([4, 2, 1, -1, 0, 0, 0, 0], dtype=np.float64)
-
-SURVEY_FIELD_1D_X = np.array([-0.1846154, -0.1006993, -0.0167832, 0.0671329, 0.1230769, 0.1510490,
-                              0.1510490, 0.1230769, 0.0671329, -0.0167832, -0.1006993, -0.1846154])
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "known_answers.json")) as _f:
+    KNOWN = json.load(_f)          # tests/golden/known_answers.json: the numbers typed in from README.md / SURVEY.md
+README_A = np.array(KNOWN["readme_example"]["A"], dtype=np.float64)
+README_B = np.array(KNOWN["readme_example"]["b"], dtype=np.float64)
+SURVEY_FIELD_1D_X = np.array(KNOWN["field_1d_resolution_12"]["solution"])
 
 
 def _dense(f, n):
@@ -73,7 +68,8 @@ def _field_1d(oracle, resolution):
 
 def test_field_1d_default_matches_survey_probe(oracle):
     f = _field_1d(oracle, 12)
-    assert f.num_rows == 14 and f.num_triplets == 38          # SURVEY.md 8(c) [probe]
+    probe = KNOWN["field_1d_resolution_12"]
+    assert f.num_rows == probe["rows"] and f.num_triplets == probe["triplets"]          # SURVEY.md 8(c) [probe]
     x = f.solve_exact()
     np.testing.assert_allclose(x, SURVEY_FIELD_1D_X, rtol=0, atol=1e-7)
     AtA, _, _ = f.normal_equations()
