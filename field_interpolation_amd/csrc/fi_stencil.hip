@@ -312,9 +312,6 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	// all block records
 	auto cells_scatter = [&](uint32_t rsR, uint32_t reR, uint32_t rsB, uint32_t reB, int buf_lo, int buf_hi, int slot_lo,
 	                         int slot_hi, bool lo_ok) {
-#ifdef FI_EXP_NOTAIL
-		reR = rsR;
-#endif
 		for (uint32_t r = rsR + lane; r < reR; r += 64) {
 			uint32_t pos;
 			T a[8];
@@ -322,9 +319,6 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 			row_apply(pos, a, buf_lo, buf_hi, slot_lo, slot_hi, lo_ok);
 		}
 		const T* multi = static_cast<const T*>(L.coef_blk);
-#ifdef FI_EXP_NOBLK
-		reB = rsB;
-#endif
 		for (uint32_t r = rsB + lane; r < reB; r += 64) {
 			const uint32_t pos = L.pos_blk[r];
 			const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
@@ -518,9 +512,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 				cells_scatter(uni(layR[o]), uni(layR[o + 1]), uni(layB[o]), uni(layB[o + 1]), b0, b1, b0, b1, true);
 			} else if (band == (s & 3)) {
 				const int o = (s + 1) * 4;
-#ifndef FI_EXP_NOAPPLY
 				if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1, b0, b1, true); }
-#endif
 				cells_scatter(0u, 0u, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
 			}
 			prefetch_rows(s + 2, pf);

@@ -1,0 +1,55 @@
+"""The register / LDS contract of the hot kernels, read from the compiler's resource report the build keeps next
+to the objects (field_interpolation_amd/csrc/*.usage.txt, -Rpass-analysis=kernel-resource-usage).  Zero spills is
+a performance requirement here, not a nicety: a scratch reload waits for every older global load and so drains
+the software pipeline of the marching kernel (profiles/r1_ablation.md)."""
+import os
+import re
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "field_interpolation_amd", "csrc")
+
+
+def _report(name):
+    path = os.path.join(CSRC, name)
+    if not os.path.exists(path):
+        pytest.skip("%s not there (library built without the report)" % name)
+    out, cur = {}, None
+    for line in open(path):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([\w /\[\]]+?):\s+(\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def _variants(report, kernel):
+    return {k: v for k, v in report.items() if kernel in k}
+
+
+def test_marching_kernel_budget():
+    rep = _variants(_report("fi_stencil.usage.txt"), "k_apply_march3d")
+    assert len(rep) == 12                                 # {fp32, fp64} x {model_1, model_2, both} x {plain, fused}
+    for name, r in rep.items():
+        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, name
+        assert r["AGPRs"] == 0, name
+        if r["LDS Size [bytes/block]"] > 30000:           # fused variants: 3 workgroups per CU (2 with both models)
+            assert r["LDS Size [bytes/block]"] * 3 <= 160 * 1024, name
+            assert r["VGPRs"] <= 256 and r["Occupancy [waves/SIMD]"] >= 2, name
+        else:                                             # plain variants: 4 waves per SIMD, 4 workgroups per CU
+            assert r["VGPRs"] <= 128 and r["Occupancy [waves/SIMD]"] >= 4, name
+            assert r["LDS Size [bytes/block]"] * 4 <= 160 * 1024, name
+    # the bench variant: fp32, model_2 only, fused -- three workgroups per CU
+    bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1E" in n]
+    assert len(bench) == 1 and bench[0]["VGPRs"] <= 168 and bench[0]["Occupancy [waves/SIMD]"] == 3
+
+
+def test_tile2d_kernel_budget():
+    rep = _variants(_report("fi_stencil2d.usage.txt"), "k_apply_tile2d")
+    assert len(rep) == 12
+    for name, r in rep.items():
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, name
+        assert r["VGPRs"] <= 128 and r["LDS Size [bytes/block]"] <= 40 * 1024, name
