@@ -50,12 +50,16 @@ struct DevBuf {
 		p     = nullptr;
 		bytes = 0;
 	}
+	// 64 zeroed bytes of slack behind every buffer: the tiled kernels read whole 16-byte groups, and the group at
+	// the end of a row whose length is not a multiple of the group reads on into the next row -- behind the very
+	// last row that is this slack (finite values, only ever multiplied by zero masks / zero coefficients)
 	void alloc(size_t nbytes)
 	{
 		if (nbytes <= bytes && p) { return; }
 		release();
 		if (nbytes == 0) { nbytes = 16; }
-		FI_HIP_TRY(hipMalloc(&p, nbytes));
+		FI_HIP_TRY(hipMalloc(&p, nbytes + 64));
+		FI_HIP_TRY(hipMemset(static_cast<char*>(p) + nbytes, 0, 64));
 		bytes = nbytes;
 	}
 	template <typename T>

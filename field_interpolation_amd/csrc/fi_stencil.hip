@@ -143,7 +143,11 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	const int tx = threadIdx.x % kTXT, ty = threadIdx.x / kTXT;
 	const int x0 = tile_x * TX, y0 = tile_y * kTY;
 	const int gx = x0 + VX * tx, gy = y0 + ty;
-	const bool active = (gx < P.nx) && (gy < P.ny);  // nx % VX == 0: a VX group is all in or all out
+	// a thread's VX points are all inside (active), partly inside (the last group of a row whose length is not a
+	// multiple of VX: `tail` points are stored one by one) or outside the lattice
+	const int  nvalid = gy < P.ny ? (P.nx - gx < 0 ? 0 : (P.nx - gx > VX ? VX : P.nx - gx)) : 0;
+	const bool active = nvalid == VX;
+	const bool tail   = nvalid > 0 && nvalid < VX;
 	const int lx = PADX + VX * tx, ly = kR + ty;
 
 	const int z_begin = P.own_z0 + chunk * P.zc;
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 		const int hly  = hrow < R ? (kR - R + hrow) : (kR + kTY + (hrow - R));
 		int hgy = y0 + hly - kR, hgx = x0 + VX * vx;
 		hgy = hgy < 0 ? 0 : (hgy >= P.ny ? P.ny - 1 : hgy);
-		hgx = hgx > P.nx - VX ? P.nx - VX : hgx;
-		hv_lds = hly * W + PADX + VX * vx;
+		hgx = hgx >= P.nx ? (P.nx > VX ? P.nx - VX : 0) : hgx;  // a group that straddles the row end reads on into the
+		hv_lds = hly * W + PADX + VX * vx;                      // next row (finite values under zero masks)
 		hv_glb = hgy * P.nx + hgx;
 	}
 	{
@@ -191,18 +195,18 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 
 	// model_2 rows along x anchored at gx-2 .. gx+VX-1; along y anchored at gy-2, gy-1, gy
 	bool m2x[VX + 2];  // lane masks (SGPR pairs), applied by select
-	T c2y[3];
+	bool c2y[3];  // lane masks like the x masks (SGPR pairs)
 	bool m1x[VX + 1];
-	T c1y[2];
+	bool c1y[2];
 	if (HAS2) {
 #pragma unroll
 		for (int k = 0; k < VX + 2; ++k) {
 			const int a = gx - 2 + k;
 			m2x[k] = (a >= 0 && a + 2 < P.nx);
 		}
-		c2y[0] = (gy - 2 >= 0 && gy < P.ny) ? T(1) : T(0);
-		c2y[1] = (gy - 1 >= 0 && gy + 1 < P.ny) ? T(-2) : T(0);
-		c2y[2] = (gy + 2 < P.ny) ? T(1) : T(0);
+		c2y[0] = (gy - 2 >= 0 && gy < P.ny);
+		c2y[1] = (gy - 1 >= 0 && gy + 1 < P.ny);
+		c2y[2] = (gy + 2 < P.ny);
 	}
 	if (HAS1) {
 #pragma unroll
@@ -210,15 +214,15 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 			const int a = gx - 1 + k;  // rows [-1,+1] anchored at a: x_{a+1} - x_a
 			m1x[k] = (a >= 0 && a + 1 < P.nx);
 		}
-		c1y[0] = (gy - 1 >= 0 && gy < P.ny) ? T(1) : T(0);   // row anchored at gy-1 touches gy with +1
-		c1y[1] = (gy + 1 < P.ny) ? T(-1) : T(0);             // row anchored at gy touches gy with -1
+		c1y[0] = (gy - 1 >= 0 && gy < P.ny);   // row anchored at gy-1 touches gy with +1
+		c1y[1] = (gy + 1 < P.ny);              // row anchored at gy touches gy with -1
 	}
 
 	// Loads never branch: every address is clamped into the lattice.  A clamped (wrong) value is only ever
 	// multiplied by a zero mask / a zero block coefficient, so it just has to be finite.
 	const int lz_lo = P.zoff < 0 ? -P.zoff : 0;
 	const int lz_hi = (P.nzl < P.gz - P.zoff ? P.nzl : P.gz - P.zoff) - 1;
-	const int gxc = gx < P.nx ? gx : P.nx - VX;
+	const int gxc = gx < P.nx ? gx : (P.nx > VX ? P.nx - VX : 0);
 	const int gyc = gy < P.ny ? gy : P.ny - 1;
 	const uint32_t xoff = static_cast<uint32_t>(gyc) * static_cast<uint32_t>(P.nx) + static_cast<uint32_t>(gxc);
 	auto clamp_plane = [&](int lz) { return lz < lz_lo ? lz_lo : (lz > lz_hi ? lz_hi : lz); };
@@ -468,6 +472,18 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	write_plane(0, X0, H0);
 
 	double dot_acc = 0.0;
+	// the last, partly filled group of a row: its points one by one (rows whose length is not a multiple of VX)
+	auto store_tail = [&](T* yplane, const T* xv, const T* ov) {
+		T part = T(0);
+#pragma unroll
+		for (int j = 0; j < VX - 1; ++j) {
+			if (j < nvalid) {
+				yplane[col + j] = ov[j];
+				part += xv[j] * ov[j];
+			}
+		}
+		dot_acc += static_cast<double>(part);
+	};
 
 	auto step = [&](int s, const V& xc, const V& xp1, const V& xp2, V& xload, const HaloRegs& h_use, HaloRegs& h_load,
 	                RowPF& pf,
@@ -503,6 +519,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 				if (active) {
 					*reinterpret_cast<V*>((y + static_cast<int64_t>(z - 1) * P.plane) + col) = out;
 					dot_acc += static_cast<double>(dsum);
+				} else if (tail) {
+					store_tail(y + static_cast<int64_t>(z - 1) * P.plane, pm, po);
 				}
 			}
 			xload = load_own(z + 5);
@@ -562,12 +580,12 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 					const T ua = r0[j] - T(2) * r1[j] + pc[j];
 					const T ub = r1[j] - T(2) * pc[j] + r3[j];
 					const T uc = pc[j] - T(2) * r3[j] + r4[j];
-					acc2[j] += c2y[0] * ua + c2y[1] * ub + c2y[2] * uc;
+					acc2[j] += (c2y[0] ? ua : T(0)) - T(2) * (c2y[1] ? ub : T(0)) + (c2y[2] ? uc : T(0));
 				}
 			}
 			if (HAS1) {
 #pragma unroll
-				for (int j = 0; j < VX; ++j) { acc1[j] += c1y[0] * (pc[j] - r1[j]) + c1y[1] * (r3[j] - pc[j]); }
+				for (int j = 0; j < VX; ++j) { acc1[j] += (c1y[0] ? pc[j] - r1[j] : T(0)) - (c1y[1] ? r3[j] - pc[j] : T(0)); }
 			}
 		}
 		// ---- z axis: carried row values
@@ -609,6 +627,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 		} else if (active) {
 			if (!(P.dbg & 2)) { *reinterpret_cast<V*>((y + static_cast<int64_t>(z) * P.plane) + col) = out; }
 			dot_acc += static_cast<double>(dsum);
+		} else if (tail) {
+			store_tail(y + static_cast<int64_t>(z) * P.plane, pc, po);
 		}
 	};
 
@@ -650,6 +670,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 		if (active) {
 			*reinterpret_cast<V*>((y + static_cast<int64_t>(z_end - 1) * P.plane) + col) = out;
 			dot_acc += static_cast<double>(dsum);
+		} else if (tail) {
+			store_tail(y + static_cast<int64_t>(z_end - 1) * P.plane, pm, po);
 		}
 	}
 
@@ -827,7 +849,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P)
 	constexpr int TX = kTXT * VX;
 	if (getenv("FI_NO_MARCH")) { return false; }
 	if (g.ndim != 3) { return false; }
-	if (g.gn[0] % VX != 0) { return false; }
+	if (g.gn[0] < VX) { return false; }  // rows shorter than one 16-byte group: the plain kernel
 	const fi_weights& w = c->w;
 	if (w.model_3 > 0 || w.model_4 > 0 || w.gradient_smoothness > 0) { return false; }
 	if (!(w.model_1 > 0) && !(w.model_2 > 0)) { return false; }

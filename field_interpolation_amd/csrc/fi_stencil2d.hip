@@ -90,14 +90,18 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 	const int gx = x0 + VX * tx;
 	const int lyr = ly0 + ty;                 // local row of this thread
 	const int gy = lyr + P.yoff;              // global row
-	const bool active = gx < P.nx && lyr < P.own_y1;
+	// all VX points inside (active), the partly filled last group of a row (nvalid of them, stored one by one), or outside
+	const int  nvalid = lyr < P.own_y1 ? (P.nx - gx < 0 ? 0 : (P.nx - gx > VX ? VX : P.nx - gx)) : 0;
+	const bool active = nvalid == VX;
 	const int lx = PADX + VX * tx, ly = kR + ty;
 
 	// clamped addresses: a wrong value is only ever multiplied by a zero mask / zero block coefficient
 	const int lr_lo = P.yoff < 0 ? -P.yoff : 0;
 	const int lr_hi = (P.nyl < P.gy - P.yoff ? P.nyl : P.gy - P.yoff) - 1;
 	auto clamp_row = [&](int r) { return r < lr_lo ? lr_lo : (r > lr_hi ? lr_hi : r); };
-	auto clamp_x = [&](int c, int width) { return c < 0 ? 0 : (c > P.nx - width ? P.nx - width : c); };
+	// a group that straddles the row end reads on into the next row (finite values under zero masks; 64 zeroed bytes
+	// of slack follow every buffer); groups entirely outside are moved inside
+	auto clamp_x = [&](int c, int width) { return c < 0 ? 0 : (c >= P.nx ? (P.nx > width ? P.nx - width : 0) : c); };
 
 	const V own = *reinterpret_cast<const V*>(x + static_cast<int64_t>(clamp_row(lyr)) * P.nx + clamp_x(gx, VX));
 	*reinterpret_cast<V*>(&xs[ly][lx]) = own;
@@ -245,6 +249,16 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 	if (active) {
 		*reinterpret_cast<V*>(y + static_cast<int64_t>(lyr) * P.nx + gx) = out;
 		dot = static_cast<double>(dsum);
+	} else if (nvalid > 0) {
+		T part = T(0);
+#pragma unroll
+		for (int j = 0; j < VX - 1; ++j) {
+			if (j < nvalid) {
+				y[static_cast<int64_t>(lyr) * P.nx + gx + j] = po[j];
+				part += pc[j] * po[j];
+			}
+		}
+		dot = static_cast<double>(part);
 	}
 	if (partial) {
 		const double wsum = wave_sum(dot);
@@ -323,7 +337,7 @@ bool tile2_setup(const fi_ctx* c, Tile2Params* P)
 	constexpr int VX = VecOf<T>::VX;
 	constexpr int TX = kTXT * VX;
 	if (getenv("FI_NO_TILE2D")) { return false; }
-	if (g.ndim != 2 || g.gn[0] % VX != 0) { return false; }
+	if (g.ndim != 2 || g.gn[0] < VX) { return false; }
 	const fi_weights& w = c->w;
 	if (w.model_3 > 0 || w.model_4 > 0 || w.gradient_smoothness > 0) { return false; }
 	if (!(w.model_1 > 0) && !(w.model_2 > 0)) { return false; }

@@ -21,7 +21,8 @@ def fi():
     return fi
 
 
-SIZES = [[64, 16], [68, 40], [128, 33], [36, 20], [4, 3], [8, 1], [200, 7], [12, 130]]
+SIZES = [[64, 16], [68, 40], [128, 33], [36, 20], [4, 3], [8, 1], [200, 7], [12, 130],
+         [66, 20], [13, 9], [131, 5], [65, 17], [7, 40]]          # rows that are not a multiple of the 16-byte group
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

@@ -34,7 +34,8 @@ def test_marching_kernel_budget():
     rep = _variants(_report("fi_stencil.usage.txt"), "k_apply_march3d")
     assert len(rep) == 12                                 # {fp32, fp64} x {model_1, model_2, both} x {plain, fused}
     for name, r in rep.items():
-        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, name
+        # (SGPR spills go to VGPR lanes, not to memory: the both-models fused variant keeps 11 lane masks there)
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0 and r["SGPRs Spill"] <= 16, name
         assert r["AGPRs"] == 0, name
         if r["LDS Size [bytes/block]"] > 30000:           # fused variants: 3 workgroups per CU (2 with both models)
             assert r["LDS Size [bytes/block]"] * 3 <= 160 * 1024, name
