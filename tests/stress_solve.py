@@ -10,10 +10,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import field_interpolation_amd as fi  # noqa: E402
-from oracle import fi_oracle as oracle  # noqa: E402  (test infrastructure: this tool is a test)
+from oracle import fi_oracle as oracle  # noqa: E402  (test infrastructure: this file lives under tests/)
 from util import build_pair, rel_inf, sphere_points  # noqa: E402
 
 

@@ -1,4 +1,4 @@
-"""A fixed-seed slice of the randomised parity sweep (tools/stress_parity.py): random shapes (1-3 D), weights, value /
+"""A fixed-seed slice of the randomised parity sweep (tests/stress_parity.py): random shapes (1-3 D), weights, value /
 gradient kernels, point clouds with edge cases, fp32 / fp64, random slab counts -- operator pieces against the
 oracle's float64 normal equations, slabs against the undivided operator, error map and tile pre-solver against the
 oracle.  3400 further seeds were run by hand on the MI355X box without a failure."""
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def sweep():
     from field_interpolation_amd import _capi
     assert _capi.device_count() >= 1
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_parity.py")
     spec = importlib.util.spec_from_file_location("stress_parity", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
