@@ -119,7 +119,8 @@ struct MarchParams {
 	int     own_z0, own_z1;  // owned local planes [z0, z1)
 	int     tiles_x, tiles_y, chunks, zc;
 	int     nwg;
-	int     tx;              // tile extent in x (lattice points)
+	int     tx, ty;          // tile extent in x and y (lattice points)
+	int     txt;             // threads along x (32: wide tiles, 16: 64 x 16)
 	int     dbg;             // timing experiments only (FI_DBG): 1 = no halo loads, 2 = no stores
 	int64_t plane;           // nx * ny
 };

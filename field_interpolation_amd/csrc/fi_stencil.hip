@@ -46,9 +46,6 @@ namespace fi {
 namespace {
 
 constexpr int kThreads = 256;
-#ifndef FI_TXT
-#define FI_TXT 32  // 128 x 8 tiles (fp32): 512-byte runs per row; 64 x 16 is 7 % slower at 512^3, equal at 256^3
-#endif
 #ifndef FI_BASE_WAVES
 #define FI_BASE_WAVES 4  // waves per SIMD the model-only variant is register-allocated for
 #endif
@@ -56,8 +53,9 @@ constexpr int kThreads = 256;
 #define FI_CELL_WAVES 3  // waves per SIMD the fused (data cell) variant is register-allocated for (one less with both
                          // model_1 and model_2 on: that variant would spill, and a spill reload drains the load pipeline)
 #endif
-constexpr int kTXT     = FI_TXT;             // threads along x
-constexpr int kTY      = kThreads / kTXT;   // tile rows (= threads along y)
+// Tile shapes (threads along x; a thread owns VX points): 32 -> 128 x 8 tiles in fp32 (512-byte runs per row: 7 %
+// faster than 64 x 16 at 512^3, equal at 256^3), 16 -> 64 x 16 for lattices a wide tile would mostly overhang
+// (64^3 levels of the cascade: half of every 128-wide tile would be idle).  Chosen per context by march_setup.
 constexpr int kR       = 2;   // halo rows/cols kept in LDS
 
 template <typename T>
@@ -100,13 +98,15 @@ __host__ __device__ constexpr int tri(int i, int j)  // packed upper-triangle in
 	return i * 8 - (i * (i - 1)) / 2 + (j - i);
 }
 
-template <typename T, bool HAS1, bool HAS2, bool CELLS>
+template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT>
 __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1 : FI_CELL_WAVES) : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done)
 {
 	using V = typename VecOf<T>::V;
+	constexpr int kTXT = TXT;             // threads along x
+	constexpr int kTY  = kThreads / TXT;  // tile rows (= threads along y)
 	constexpr int VX   = VecOf<T>::VX;
 	constexpr int TX   = kTXT * VX;
 	constexpr int PADX = VX;             // own columns start 16-byte aligned
@@ -729,9 +729,9 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 	const bool x_ok[2] = {cx >= 0 && cx / P.tx < P.tiles_x, (cx + 1) % P.tx == 0 && (cx + 1) / P.tx < P.tiles_x};
 	const int  x_ti[2] = {cx >= 0 ? cx / P.tx : 0, (cx + 1) / P.tx};
 	const int  x_tc[2] = {cx >= 0 ? cx % P.tx : 0, -1};
-	const bool y_ok[2] = {cy >= 0 && cy / kTY < P.tiles_y, (cy + 1) % kTY == 0 && (cy + 1) / kTY < P.tiles_y};
-	const int  y_ti[2] = {cy >= 0 ? cy / kTY : 0, (cy + 1) / kTY};
-	const int  y_tc[2] = {cy >= 0 ? cy % kTY : 0, -1};
+	const bool y_ok[2] = {cy >= 0 && cy / P.ty < P.tiles_y, (cy + 1) % P.ty == 0 && (cy + 1) / P.ty < P.tiles_y};
+	const int  y_ti[2] = {cy >= 0 ? cy / P.ty : 0, (cy + 1) / P.ty};
+	const int  y_tc[2] = {cy >= 0 ? cy % P.ty : 0, -1};
 	const bool z_ok[2] = {zz >= 0 && zz < nz_own, zz + 1 >= 0 && zz + 1 < nz_own && (zz + 1) % P.zc == 0};
 	const int  z_tk[2] = {zz >= 0 ? zz / P.zc : 0, (zz + 1) / P.zc};
 	const int  z_tl[2] = {zz >= 0 ? zz % P.zc + 1 : 0, 0};
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 		uint32_t k = kNoKey, pp = 0;
 		if (z_ok[a] && y_ok[b] && x_ok[d]) {
 			const int     wg     = (z_tk[a] * P.tiles_y + y_ti[b]) * P.tiles_x + x_ti[d];
-			const int     band   = (y_tc[b] + 1) * 4 / (kTY + 1);  // 4 bands of consecutive origin rows -1 .. kTY-1
+			const int     band   = (y_tc[b] + 1) * 4 / (P.ty + 1);  // 4 bands of consecutive origin rows -1 .. ty-1
 			const int64_t bucket = (static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a]) * 4 + band;
 			k  = static_cast<uint32_t>(kind * nbuckets + bucket);
 			pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(y_tc[b] + 1) << 16);
@@ -846,7 +846,6 @@ bool march_setup(const fi_ctx* c, MarchParams* P)
 {
 	const Geom& g = c->g;
 	constexpr int VX = VecOf<T>::VX;
-	constexpr int TX = kTXT * VX;
 	if (getenv("FI_NO_MARCH")) { return false; }
 	if (g.ndim != 3) { return false; }
 	if (g.gn[0] < VX) { return false; }  // rows shorter than one 16-byte group: the plain kernel
@@ -860,9 +859,26 @@ bool march_setup(const fi_ctx* c, MarchParams* P)
 	P->zoff = g.off[2];
 	P->own_z0 = g.own_lo[2];
 	P->own_z1 = g.own_hi[2];
+	// tile shape: the one whose tiles overhang the lattice least; the wide one on a tie
+	{
+		double best = 1e300;
+		for (int txt : {32, 16}) {
+			const int tx = txt * VX, ty = kThreads / txt;
+			const double padded = static_cast<double>((P->nx + tx - 1) / tx) * tx * ((P->ny + ty - 1) / ty) * ty;
+			if (padded < best * 0.999) {
+				best   = padded;
+				P->txt = txt;
+			}
+		}
+		if (const char* env = getenv("FI_TXT")) {
+			if (atoi(env) == 16 || atoi(env) == 32) { P->txt = atoi(env); }
+		}
+	}
+	const int TX = P->txt * VX;
 	P->tx      = TX;
+	P->ty      = kThreads / P->txt;
 	P->tiles_x = (P->nx + TX - 1) / TX;
-	P->tiles_y = (P->ny + kTY - 1) / kTY;
+	P->tiles_y = (P->ny + P->ty - 1) / P->ty;
 	const int nz_own = P->own_z1 - P->own_z0;
 	int cus = 256;
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -900,15 +916,25 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial)
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
 	const int  grid = ((P.nwg + 7) / 8) * 8;
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
-	if (h1 && h2) {
-		hipLaunchKernelGGL((k_apply_march3d<T, true, true, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x,
-		                   y, partial, done);
-	} else if (h2) {
-		hipLaunchKernelGGL((k_apply_march3d<T, false, true, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x,
-		                   y, partial, done);
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done);
+	};
+	if (P.txt == 32) {
+		if (h1 && h2) {
+			launch(k_apply_march3d<T, true, true, CELLS, 32>);
+		} else if (h2) {
+			launch(k_apply_march3d<T, false, true, CELLS, 32>);
+		} else {
+			launch(k_apply_march3d<T, true, false, CELLS, 32>);
+		}
 	} else {
-		hipLaunchKernelGGL((k_apply_march3d<T, true, false, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x,
-		                   y, partial, done);
+		if (h1 && h2) {
+			launch(k_apply_march3d<T, true, true, CELLS, 16>);
+		} else if (h2) {
+			launch(k_apply_march3d<T, false, true, CELLS, 16>);
+		} else {
+			launch(k_apply_march3d<T, true, false, CELLS, 16>);
+		}
 	}
 	FI_HIP_TRY(hipGetLastError());
 }

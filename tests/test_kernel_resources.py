@@ -32,7 +32,7 @@ def _variants(report, kernel):
 
 def test_marching_kernel_budget():
     rep = _variants(_report("fi_stencil.usage.txt"), "k_apply_march3d")
-    assert len(rep) == 12                                 # {fp32, fp64} x {model_1, model_2, both} x {plain, fused}
+    assert len(rep) == 24            # {fp32, fp64} x {model_1, model_2, both} x {plain, fused} x {128 x 8, 64 x 16 tiles}
     for name, r in rep.items():
         # (SGPR spills go to VGPR lanes, not to memory: the both-models fused variant keeps 11 lane masks there)
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0 and r["SGPRs Spill"] <= 16, name
@@ -44,7 +44,7 @@ def test_marching_kernel_budget():
             assert r["VGPRs"] <= 128 and r["Occupancy [waves/SIMD]"] >= 4, name
             assert r["LDS Size [bytes/block]"] * 4 <= 160 * 1024, name
     # the bench variant: fp32, model_2 only, fused -- three workgroups per CU
-    bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1E" in n]
+    bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1ELi32E" in n]
     assert len(bench) == 1 and bench[0]["VGPRs"] <= 168 and bench[0]["Occupancy [waves/SIMD]"] == 3
 
 
