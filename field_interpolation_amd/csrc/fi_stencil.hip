@@ -12,13 +12,19 @@
 // and are applied inside the same kernel.  Algorithmic traffic: read x once, write y once, read every
 // block once = 2*sizeof(T) B per lattice point + (8 + 36*sizeof(T)) B per occupied cell.
 //
-// Work decomposition (CDNA4): one workgroup = 256 threads = a TX x TY tile of (x, y) (128 x 8 in fp32, 64 x 8 in fp64) marching over ZC
-// planes of z; a thread owns VX consecutive x (one 16-byte global load/store per plane: float4/double2).
+// Work decomposition (CDNA4): one workgroup = 256 threads = a TX x TY tile of (x, y) (128 x 8 in fp32, 64 x 8 in
+// fp64; 64 x 16 / 32 x 16 where the wide tile would overhang the lattice more) marching over ZC planes of z; a
+// thread owns VX consecutive x (one 16-byte global load/store per plane: float4/double2).
 //   * z neighbours live in registers: x(z), x(z+1), x(z+2) plus the two carried row values u(z-1), u(z-2)
-//     -- each plane is read from HBM once;
+//     -- each plane is read from HBM once, five planes ahead of its use;
 //   * x/y neighbours come from an LDS copy of the plane (tile + halo ring), 3-deep ring => one barrier per
-//     plane; own columns are 16-byte aligned in LDS (ds_read_b128 for the y rows);
-//   * boundary masks for x/y are per-thread constants hoisted out of the march; z masks are wave-uniform;
+//     plane, with or without data; own columns are 16-byte aligned in LDS (ds_read_b128 for the y rows);
+//   * every load that crosses a step is unconditional (clamped addresses, dummy halo slots): conditional ones make
+//     the compiler's s_waitcnt bookkeeping drain the whole pipeline (vmcnt(0)) at the first use, and so does any
+//     register spill -- the kernels are held to zero spills (tests/test_kernel_resources.py);
+//   * boundary masks for x/y are per-thread lane masks (SGPR pairs) hoisted out of the march; z masks are
+//     wave-uniform; rows need not be a multiple of the 16-byte group (the last group of a row reads on into the
+//     next row under zero masks and stores its valid points one by one);
 //   * data cells of layer z (corners on planes z and z+1, both in the LDS ring): one lane per cell.  A
 //     cell holding a single data row a is kept as that row (y += a (a.x), 32 B in fp32); a cell holding
 //     more rows as up to 8 factor rows (fp64: the packed symmetric block).  The 8 corner products are
@@ -26,16 +32,19 @@
 //     planes.  Ordering without barriers or races: the cells of a layer are split into 4 bands by the
 //     y-row of their origin, one band per wave; a lattice point of the by=0 plane only receives products
 //     from cells whose origin row is the point's row (one band, one wave), of the by=1 plane only from the
-//     row below (one band, one wave).  Inside a wave one LDS add instruction handles one corner index of
-//     up to 64 distinct cells -- distinct addresses -- and LDS instructions of a wave execute in order, so
-//     every sum is formed in the same order on every run: bitwise reproducible, although ds_add is used.
+//     row below (one band, one wave).  Inside a wave the add is a plain LDS read-add-write in two phases by
+//     the corner's x-bit: inside a phase the 4 corners of a cell go to 4 different planes and the cells of one
+//     instruction are distinct, and the LDS instructions of a wave execute in order -- so every sum is formed
+//     in the same order on every run: bitwise reproducible.  (LDS float atomics would also be correct here, but
+//     cost ~3 cycles per lane: +31 us per launch.)  Layers with at most 64 cells are scattered by one wave.
 //     The owner of a lattice point collects plane z-1 one step late (after the barrier of step z, when
 //     layers z-2 and z-1 are complete), so the data path needs no barrier of its own; the stencil result
-//     of plane z-1 waits in registers for that one step.  Row records are prefetched three planes ahead.
-//     The scatter code is branch-free (a per-thread dump slot for corners outside the tile).
+//     of plane z-1 waits in registers for that one step.  Row records are prefetched one plane ahead by
+//     every wave.  The scatter code is branch-free (a per-thread dump slot for corners outside the tile).
 //   * p.q partials: fp32 products per plane, fp64 per-thread accumulation, wave64 shuffle tree, one
 //     partial per workgroup;
-//   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. (same XCD, same L2) get adjacent tiles.
+//   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. (same XCD, same L2) get adjacent tiles; the
+//     chunk length ZC is chosen so that the grid covers the CUs in whole rounds (pick_chunk).
 
 #include <hipcub/hipcub.hpp>
 
