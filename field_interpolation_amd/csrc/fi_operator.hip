@@ -13,10 +13,12 @@
 //
 // Kernels in this file
 //   k_apply_generic   any D, any model order, gradient_smoothness; one thread per owned point, direct
-//                     (L1/L2-served) neighbour loads.  Fallback and 1-D path.
-//   k_apply_cells     one thread per occupied cell: y[corners] += B x[corners].
+//                     (L1/L2-served) neighbour loads.  1-D lattices, model_3/4/gradient_smoothness, and the
+//                     tile operator of fi_tile_pass (row members outside the point's tile dropped).
+//   k_apply_cells     one thread per occupied cell: y[corners] += B x[corners] (atomics).
 //   k_model_diag      analytic diag of the model part; k_invert_diag: Jacobi scaling.
-// The LDS-tiled kernels for 2-D / 3-D lattices are in fi_stencil.hip.
+//   k_error_model / k_error_rows   generate_error_map.
+// The LDS-tiled kernels for 3-D / 2-D lattices with model_0/1/2 are in fi_stencil.hip / fi_stencil2d.hip.
 
 #include "fi_internal.h"
 

@@ -7,16 +7,21 @@
 // A^T A is symmetric positive semi-definite, so CG applies ("Planned CDNA4
 // counterpart"); the stop rule is Eigen's: ||r||_2 <= tol * ||A^T b||_2.
 //
-// One CG iteration = 3 vector kernels + 2 single-block scalar kernels, all enqueued on one stream:
-//   apply        q = AtA p, per-block partials of p.q                      (fi_operator / fi_stencil)
-//   k_reduce     partials -> pq                              [all-reduce over ranks when slabbed]
-//   k_update     alpha = rz/pq; x += alpha p; r -= alpha q; partials of r.(Dinv r) and r.r
-//   k_reduce     -> rz_new, rr; beta; iteration count; convergence flag
-//   k_direction  p = Dinv r + beta p
-// Dot products: fp64 per-thread products, wave64 __shfl_down tree, LDS across the 4 waves, one partial
-// per block, summed in a fixed order by one block => bitwise reproducible run to run.
-// No host synchronisation inside an iteration: alpha/beta/flags stay in HBM (`CgScalars`); the host
-// looks at the flag every `kCheckEvery` iterations; kernels of a finished solve exit at once.
+// One CG iteration on one GPU = 3 launches on one stream:
+//   apply         q = AtA p, per-block partials of p.q                      (fi_operator / fi_stencil / fi_stencil2d)
+//   k_cg_resid_f  every block sums those partials (fixed order: bit-identical alpha in all blocks), r -= alpha q,
+//                 partials of r.(Dinv r) and r.r
+//   k_cg_xp_f     every block sums those, beta and the stop test; x += alpha p; p = Dinv r + beta p
+// Block 0 publishes the scalars into the other of two scalar slots (`CgScalars[2]`): no block reads the slot its
+// kernel writes.  Over slabs (loop-back group or one process per GPU) the sums cross ranks, so the reductions are
+// launches of their own: k_reduce -> device sum / ncclAllReduce -> k_cg_logic, around k_cg_resid / k_cg_xp.
+// Dot products: fp64 per-thread products, wave64 __shfl_down tree, LDS across the 4 waves, one partial per block,
+// summed in a fixed order => bitwise reproducible run to run.  No host synchronisation inside an iteration:
+// alpha/beta/flags stay in HBM; the host looks at the flag every `kCheckEvery` iterations; kernels of a finished
+// solve exit at once.
+//
+// Also here: levels (coarser replicas, cascade start), the V-cycle preconditioner over rank sets, the mixed-
+// precision solve (fp64 CG, fp32 V-cycle on a replica), the tile pre-solver, and the C ABI entry points.
 
 #include <chrono>
 #include <cmath>
