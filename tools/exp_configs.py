@@ -25,7 +25,7 @@ for cfg in which:
     for mode in os.environ.get("MODES", "mg").split(","):
         f = fi.LatticeField(sizes, dtype=os.environ.get("DTYPE", "f32"))
         f.add_field_constraints(w)
-        f.set_levels(int(os.environ.get("NLEV", "6")), 1e-4)
+        f.set_levels(int(os.environ.get("NLEV", "6")), float(os.environ.get("CTOL", "1e-4")))
         f.set_multigrid(mode in ("mg", "mixed"))
         if mode == "mixed":
             f.set_mixed_precision(True)
