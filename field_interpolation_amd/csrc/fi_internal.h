@@ -137,6 +137,8 @@ struct MarchState {
 	DevBuf      coef_blk;          // T[n_blk][8][8]
 	int64_t     n_row = 0, n_blk = 0;          // records (cells on tile borders are listed more than once)
 	int64_t     cells_row = 0, cells_blk = 0;  // distinct cells of each kind
+	DevBuf      wg_cells, wg_plain;            // workgroup ids with / without any cell (ascending)
+	int         n_wg_cells = 0, n_wg_plain = 0;
 };
 
 // Tiling of the 2-D tile kernel (fi_stencil2d.hip): one workgroup per TX x 16 tile of the owned rows.

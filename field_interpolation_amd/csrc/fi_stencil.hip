@@ -111,7 +111,8 @@ template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT>
 __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1 : FI_CELL_WAVES) : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
-                                                             const int* __restrict__ done)
+                                                             const int* __restrict__ done,
+                                                             const uint32_t* __restrict__ wg_list, int nlist)
 {
 	using V = typename VecOf<T>::V;
 	constexpr int kTXT = TXT;             // threads along x
@@ -139,10 +140,13 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 
 	if (done && *done) { return; }
 
-	// XCD-aware tile order: consecutive tiles on one XCD.
-	const int per = (P.nwg + 7) / 8;
-	const int wg  = (blockIdx.x % 8) * per + blockIdx.x / 8;
-	if (wg >= P.nwg) { return; }
+	// XCD-aware tile order: consecutive tiles on one XCD.  With a list, the launch covers only the listed
+	// workgroups (the ones with / without data cells: march_launch).
+	const int nrun = wg_list ? nlist : P.nwg;
+	const int per  = (nrun + 7) / 8;
+	const int slot = (blockIdx.x % 8) * per + blockIdx.x / 8;
+	if (slot >= nrun) { return; }
+	const int wg = wg_list ? static_cast<int>(wg_list[slot]) : slot;
 	const int tiles_xy = P.tiles_x * P.tiles_y;
 	const int chunk    = wg / tiles_xy;
 	const int txy      = wg % tiles_xy;
@@ -915,7 +919,7 @@ MarchCoef<T> march_coef(const fi_weights& w)
 }
 
 template <typename T, bool CELLS>
-void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial)
+void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint32_t* wg_list = nullptr, int nlist = 0)
 {
 	const MarchParams& P = c->march.P;
 	const MarchCoef<T> C = march_coef<T>(c->w);
@@ -923,10 +927,12 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial)
 	CellLists L{m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(),
 	            m.coef_row.p, m.coef_blk.p};
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
-	const int  grid = ((P.nwg + 7) / 8) * 8;
+	const int  nrun = wg_list ? nlist : P.nwg;
+	if (nrun <= 0) { return; }
+	const int  grid = ((nrun + 7) / 8) * 8;
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done);
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done, wg_list, nlist);
 	};
 	if (P.txt == 32) {
 		if (h1 && h2) {
@@ -946,6 +952,38 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial)
 		}
 	}
 	FI_HIP_TRY(hipGetLastError());
+}
+
+// Surface-type data (an SDF from oriented points) leaves most workgroups without a single cell: those run the
+// plain variant (4 workgroups per CU, none of the data path's per-plane work), the others the fused one.
+template <typename T>
+void march_launch(fi_ctx* c, const T* x, T* y, double* partial)
+{
+	const MarchState& m = c->march;
+	if (!m.fused) {
+		march_launch_cells<T, false>(c, x, y, partial);
+	} else if (m.n_wg_plain * 16 < m.P.nwg || getenv("FI_NO_SPLIT")) {  // (nearly) every workgroup holds data
+		march_launch_cells<T, true>(c, x, y, partial);
+	} else {
+		// two launches over disjoint workgroups, back to back (running the data workgroups on a side stream next to
+		// the plain ones was tried: 543 instead of 482 us at 512^3 -- the long data columns starve the plain launch)
+		march_launch_cells<T, true>(c, x, y, partial, m.wg_cells.as<uint32_t>(), m.n_wg_cells);
+		march_launch_cells<T, false>(c, x, y, partial, m.wg_plain.as<uint32_t>(), m.n_wg_plain);
+	}
+}
+
+// 1 for a workgroup whose lists (all its layers, both record kinds) hold at least one cell
+__global__ __launch_bounds__(kThreads) void k_classify_wg(int nwg, int per_wg, const uint32_t* __restrict__ lay_row,
+                                                           const uint32_t* __restrict__ lay_blk, uint32_t* __restrict__ ids,
+                                                           uint8_t* __restrict__ has, uint8_t* __restrict__ has_not)
+{
+	const int wg = blockIdx.x * kThreads + threadIdx.x;
+	if (wg >= nwg) { return; }
+	const int64_t a = static_cast<int64_t>(wg) * per_wg, b = a + per_wg;
+	const bool any = lay_row[b] > lay_row[a] || lay_blk[b] > lay_blk[a];
+	ids[wg]     = static_cast<uint32_t>(wg);
+	has[wg]     = any ? 1 : 0;
+	has_not[wg] = any ? 0 : 1;
 }
 
 template <typename T>
@@ -1014,6 +1052,33 @@ void build_cell_lists(fi_ctx* c)
 		                   m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(), m.coef_blk.as<T>());
 	}
 	FI_HIP_TRY(hipGetLastError());
+	// workgroups with and without cells (march_launch)
+	{
+		const int nwg = P.nwg;
+		DevBuf &ids = c->scratch[15], &has = c->scratch[16], &has_not = c->scratch[17], &nsel = c->scratch[18];
+		ids.alloc(sizeof(uint32_t) * nwg);
+		has.alloc(nwg);
+		has_not.alloc(nwg);
+		nsel.alloc(sizeof(int) * 2);
+		m.wg_cells.alloc(sizeof(uint32_t) * nwg);
+		m.wg_plain.alloc(sizeof(uint32_t) * nwg);
+		hipLaunchKernelGGL(k_classify_wg, dim3((nwg + kThreads - 1) / kThreads), dim3(kThreads), 0, st, nwg, (P.zc + 1) * 4,
+		                   m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), ids.as<uint32_t>(), has.as<uint8_t>(),
+		                   has_not.as<uint8_t>());
+		size_t tb3 = 0;
+		FI_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
+		                                         nsel.as<int>(), nwg, st));
+		tmp.alloc(tb3);
+		FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
+		                                         nsel.as<int>(), nwg, st));
+		FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has_not.as<uint8_t>(),
+		                                         m.wg_plain.as<uint32_t>(), nsel.as<int>() + 1, nwg, st));
+		int counts[2] = {0, 0};
+		FI_HIP_TRY(hipMemcpyAsync(counts, nsel.p, sizeof(counts), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		m.n_wg_cells = counts[0];
+		m.n_wg_plain = counts[1];
+	}
 }
 
 }  // namespace
@@ -1043,11 +1108,9 @@ bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial)
 	if (c->tile2.valid) { return tile2d_apply(c, x, y, partial); }
 	if (!c->march.valid) { return false; }
 	if (c->dtype == FI_F64) {
-		c->march.fused ? march_launch_cells<double, true>(c, static_cast<const double*>(x), static_cast<double*>(y), partial)
-		               : march_launch_cells<double, false>(c, static_cast<const double*>(x), static_cast<double*>(y), partial);
+		march_launch<double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial);
 	} else {
-		c->march.fused ? march_launch_cells<float, true>(c, static_cast<const float*>(x), static_cast<float*>(y), partial)
-		               : march_launch_cells<float, false>(c, static_cast<const float*>(x), static_cast<float*>(y), partial);
+		march_launch<float>(c, static_cast<const float*>(x), static_cast<float*>(y), partial);
 	}
 	return true;
 }
