@@ -103,6 +103,14 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 	// of slack follow every buffer); groups entirely outside are moved inside
 	auto clamp_x = [&](int c, int width) { return c < 0 ? 0 : (c >= P.nx ? (P.nx > width ? P.nx - width : 0) : c); };
 
+	// tiles without a single cell (most of them for surface-type data) skip the data path altogether
+	uint32_t rs = 0, re = 0;
+	if (CELLS) {
+		rs = L.off[tile];
+		re = L.off[tile + 1];
+	}
+	const bool has_cells = CELLS && re > rs;  // workgroup-uniform
+
 	const V own = *reinterpret_cast<const V*>(x + static_cast<int64_t>(clamp_row(lyr)) * P.nx + clamp_x(gx, VX));
 	*reinterpret_cast<V*>(&xs[ly][lx]) = own;
 	if (threadIdx.x < NVEC) {
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 		const int hlx = k < R ? (PADX - R + k) : (PADX + TX + (k - R));
 		xs[hly][hlx] = x[static_cast<int64_t>(clamp_row(ly0 + hly - kR)) * P.nx + clamp_x(x0 + hlx - PADX, 1)];
 	}
-	if (CELLS) {
+	if (has_cells) {
 		const V zero = V{};
 #pragma unroll
 		for (int q = 0; q < 4; ++q) { *reinterpret_cast<V*>(&yb[q][ty][VX * tx]) = zero; }
@@ -126,8 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 	__syncthreads();
 
 	// ---- data cells of this tile ---------------------------------------------------------------------
-	if (CELLS) {
-		const uint32_t rs = L.off[tile], re = L.off[tile + 1];
+	if (has_cells) {
 		const T* blk = static_cast<const T*>(L.blk);
 		for (uint32_t r = rs + threadIdx.x; r < re; r += kThreads) {
 			const uint32_t pos = L.pos[r];
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 		if (HAS1) { v += C.w1sq * acc1[j]; }
 		po[j] = v;
 	}
-	if (CELLS) {
+	if (has_cells) {
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			const V  v  = *reinterpret_cast<const V*>(&yb[q][ty][VX * tx]);
