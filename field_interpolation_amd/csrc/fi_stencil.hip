@@ -638,7 +638,11 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 #pragma unroll
 			for (int j = 0; j < VX; ++j) { held[j] = po[j]; }
 		} else if (active) {
+#ifdef FI_NT_STORE
+			__builtin_nontemporal_store(*reinterpret_cast<const NV*>(&out), reinterpret_cast<NV*>((y + static_cast<int64_t>(z) * P.plane) + col));
+#else
 			if (!(P.dbg & 2)) { *reinterpret_cast<V*>((y + static_cast<int64_t>(z) * P.plane) + col) = out; }
+#endif
 			dot_acc += static_cast<double>(dsum);
 		} else if (tail) {
 			store_tail(y + static_cast<int64_t>(z) * P.plane, pc, po);
@@ -832,16 +836,16 @@ __global__ void k_iota32(uint32_t* v, int64_t n)
 // neighbours, so long chunks are cheaper per plane; but the grid should cover the CUs in whole rounds --
 // `slots` workgroups run at a time (256 CUs x 4 / 3 / 2 resident workgroups, see the launch bounds).
 // Cost model: rounds(zc) * (zc + 5); a fractional last round counts in full while the grid is only a few rounds.
-int pick_chunk(int tiles_xy, int nz_own, int slots, int forced)
+int pick_chunk(int tiles_xy, int nz_own, int slots, int forced, int zc_max)
 {
 	if (forced > 0) { return forced; }
 	if (const char* env = getenv("FI_ZC")) {
 		const int v = atoi(env);
-		if (v > 0) { return v > 64 ? 64 : v; }  // s_lay holds the bounds of at most 64 + 2 layers
+		if (v > 0) { return v > zc_max ? zc_max : v; }
 	}
 	int    best = 4;
 	double best_cost = 1e300;
-	for (int zc = 4; zc <= 64; ++zc) {
+	for (int zc = 4; zc <= zc_max; ++zc) {
 		if (zc > nz_own && zc > 4) { break; }
 		const int64_t nwg = static_cast<int64_t>(tiles_xy) * ((nz_own + zc - 1) / zc);
 		const double  r   = static_cast<double>(nwg) / slots;
@@ -898,7 +902,9 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0)
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
 	const bool fused = c->cells.ncell > 0 && !getenv("FI_NO_FUSE");
 	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : (w.model_1 > 0 && w.model_2 > 0 ? FI_CELL_WAVES - 1 : FI_CELL_WAVES);
-	P->zc     = pick_chunk(P->tiles_x * P->tiles_y, nz_own, (cus > 0 ? cus : 256) * wgs_per_cu, forced_zc);
+	// the fused variant stages the list bounds of at most 64 + 2 layers in LDS (s_lay); without data cells the chunk
+	// may be as long as one round of workgroups allows (512^3: 128 planes, 1024 workgroups)
+	P->zc     = pick_chunk(P->tiles_x * P->tiles_y, nz_own, (cus > 0 ? cus : 256) * wgs_per_cu, forced_zc, fused ? 64 : 256);
 	P->chunks = (nz_own + P->zc - 1) / P->zc;
 	P->nwg    = P->tiles_x * P->tiles_y * P->chunks;
 	P->plane  = static_cast<int64_t>(P->nx) * P->ny;
