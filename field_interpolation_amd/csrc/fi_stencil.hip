@@ -267,9 +267,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	// add the 8 corner products of a cell into the accumulation planes of lattice planes slot_lo (corner z-bit
 	// 0) and slot_hi (z-bit 1); corners outside the tile -- and the lower ones when lo_ok is false -- go to
 	// the thread's dump slot (no branches)
-	auto put8 = [&](int tcx, int tcy, const T* out, int slot_lo, int slot_hi, bool lo_ok) {
+	auto put8 = [&](int tcx, int tcy, const T* out, int slot_lo, int slot_hi, bool lo_ok, bool on = true) {
 		T* const dump = &ydump[threadIdx.x];
-		const bool vx0 = tcx >= 0, vx1 = tcx + 1 < TX, vy0 = tcy >= 0, vy1 = tcy + 1 < kTY;
+		const bool vx0 = on && tcx >= 0, vx1 = on && tcx + 1 < TX, vy0 = tcy >= 0, vy1 = tcy + 1 < kTY;
 		T* const base = &yb[0][0][0][0] + tcy * TX + tcx;
 		// Plain read-add-write (LDS float atomics cost ~3 cycles per lane here).  Two phases by the corner's
 		// x-bit: inside a phase the 4 corners of a cell go to 4 different planes and the cells of a wave
@@ -312,7 +312,11 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 		T out[8];
 #pragma unroll
 		for (int i = 0; i < 8; ++i) { out[i] = a[i] * t; }
-		put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok);
+		// the second row of a two-row cell sits in the lane next to the first: same addresses, so it is added in a
+		// pass of its own (wave-uniform branch; LDS instructions of a wave execute in order)
+		const bool second = ((pos >> 8) & 0xFFu) != 0u;
+		put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok, !second);
+		if (__ballot(second) != 0ull) { put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok, second); }
 	};
 	auto load_row = [&](uint32_t r, uint32_t* pos, T* a) {
 		*pos = L.pos_row[r];
@@ -329,6 +333,12 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	// all block records
 	auto cells_scatter = [&](uint32_t rsR, uint32_t reR, uint32_t rsB, uint32_t reB, int buf_lo, int buf_hi, int slot_lo,
 	                         int slot_hi, bool lo_ok) {
+#ifdef FI_SKIP_ROWS
+		reR = rsR;
+#endif
+#ifdef FI_SKIP_BLK
+		reB = rsB;
+#endif
 		for (uint32_t r = rsR + lane; r < reR; r += 64) {
 			uint32_t pos;
 			T a[8];
@@ -536,17 +546,24 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 					store_tail(y + static_cast<int64_t>(z - 1) * P.plane, pm, po);
 				}
 			}
+#ifndef FI_E1
 			xload = load_own(z + 5);
+#endif
 			// layer z into the accumulation planes of z and z+1
 			if (layer_dense(s + 1)) {
 				const int o = (s + 1) * 4 + band;
 				cells_scatter(uni(layR[o]), uni(layR[o + 1]), uni(layB[o]), uni(layB[o + 1]), b0, b1, b0, b1, true);
 			} else if (band == (s & 3)) {
 				const int o = (s + 1) * 4;
+#ifndef FI_SKIP_ROWS
 				if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1, b0, b1, true); }
+#endif
 				cells_scatter(0u, 0u, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
 			}
 			prefetch_rows(s + 2, pf);
+#ifdef FI_E1
+			xload = load_own(z + 5);
+#endif
 		}
 
 		T acc2[VX], acc1[VX];
@@ -720,7 +737,8 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 {
 	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	const bool live = c < ncell;
-	const int  kind = (live && nrow[c] == 1u) ? 0 : 1;    // 0: single-row cell, 1: block cell
+	const uint32_t rows_c = live ? nrow[c] : 0u;
+	const int  kind = (rows_c == 1u) ? 0 : 1;             // 0: single-row cell, 1: multi-row cell (statistics)
 	{
 		// distinct cells of each kind: one atomic per wave (a single hot address serialises in L2)
 		// distinct cells of each kind (statistics): one atomic per wave, spread over 64 counter pairs -- atomics on
@@ -752,19 +770,47 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 	const bool z_ok[2] = {zz >= 0 && zz < nz_own, zz + 1 >= 0 && zz + 1 < nz_own && (zz + 1) % P.zc == 0};
 	const int  z_tk[2] = {zz >= 0 ? zz / P.zc : 0, (zz + 1) / P.zc};
 	const int  z_tl[2] = {zz >= 0 ? zz % P.zc + 1 : 0, 0};
+	// A cell with exactly two data rows joins the ROW lists with two records (row index in bits 8..15 of pos, the
+	// pair adjacent and in row order: the sort is stable and the pair's slots are neighbours), so that its rows are
+	// prefetched like every other row record; the kernel scatters the two rows of a cell in two passes.  That takes
+	// two of the cell's 8 slots per membership, so a two-row cell with more than 4 memberships (the corner of a tile
+	// AND of a chunk) stays a block record.  Block records are loaded where they are used, on the critical path of
+	// the plane step: config 4 (3 % two-row cells) 66 -> 47 us per launch.
+	int nmemb = 0;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) { nmemb += (z_ok[m >> 2] && y_ok[(m >> 1) & 1] && x_ok[m & 1]) ? 1 : 0; }
+	const bool pair     = rows_c == 2u && nmemb <= 4;
+	const int  listkind = (rows_c == 1u || pair) ? 0 : 1;  // 0: row records, 1: block record
+	uint32_t kk[8], pv[8];
+#pragma unroll
+	for (int m = 0; m < 8; ++m) { kk[m] = kNoKey; pv[m] = 0; }
+	int j = 0;
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
 		const int a = m >> 2, b = (m >> 1) & 1, d = m & 1;
-		uint32_t k = kNoKey, pp = 0;
 		if (z_ok[a] && y_ok[b] && x_ok[d]) {
 			const int     wg     = (z_tk[a] * P.tiles_y + y_ti[b]) * P.tiles_x + x_ti[d];
 			const int     band   = (y_tc[b] + 1) * 4 / (P.ty + 1);  // 4 bands of consecutive origin rows -1 .. ty-1
 			const int64_t bucket = (static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a]) * 4 + band;
-			k  = static_cast<uint32_t>(kind * nbuckets + bucket);
-			pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(y_tc[b] + 1) << 16);
+			const uint32_t k  = static_cast<uint32_t>(listkind * nbuckets + bucket);
+			const uint32_t pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(y_tc[b] + 1) << 16);
+			if (pair) {
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {  // slots 2j, 2j+1 (static indexing: the arrays stay in registers)
+					if (q == 2 * j) { kk[q] = k; pv[q] = pp; }
+					if (q == 2 * j + 1) { kk[q] = k; pv[q] = pp | (1u << 8); }
+				}
+				++j;
+			} else {
+				kk[m] = k;
+				pv[m] = pp;
+			}
 		}
-		key[c * 8 + m] = k;
-		pos[c * 8 + m] = pp;
+	}
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		key[c * 8 + m] = kk[m];
+		pos[c * 8 + m] = pv[m];
 	}
 }
 
@@ -784,8 +830,10 @@ __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_
 	const uint32_t slot = slot_sorted[i];
 	const int64_t  c    = slot >> 3;
 	if (i < n_row) {  // keys of kind 0 sort first
-		pos_row[i] = pos[slot];
-		const V* src = reinterpret_cast<const V*>(row1 + c * 8);
+		const uint32_t pp = pos[slot];
+		pos_row[i] = pp;
+		// row (pp >> 8) & 0xFF of the cell: the data rows of a cell with <= 8 rows are its factor rows (row 0 == row1)
+		const V* src = reinterpret_cast<const V*>(mrow + c * 64 + ((pp >> 8) & 0xFFu) * 8);
 		V*       dst = reinterpret_cast<V*>(coef_row + i * 8);
 #pragma unroll
 		for (int k = 0; k < 8 / VX; ++k) { dst[k] = src[k]; }
