@@ -65,6 +65,9 @@ constexpr int kThreads = 256;
 // Tile shapes (threads along x; a thread owns VX points): 32 -> 128 x 8 tiles in fp32 (512-byte runs per row: 7 %
 // faster than 64 x 16 at 512^3, equal at 256^3), 16 -> 64 x 16 for lattices a wide tile would mostly overhang
 // (64^3 levels of the cascade: half of every 128-wide tile would be idle).  Chosen per context by march_setup.
+#ifndef FI_DENSE_MIN
+#define FI_DENSE_MIN 64u  // a layer with more records than this is scattered by all four waves (a band each)
+#endif
 constexpr int kR       = 2;   // halo rows/cols kept in LDS
 
 template <typename T>
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	constexpr int NSC  = 2 * R * (kTY + 2 * R);
 	static_assert(NVEC + NSC <= kThreads, "halo slots exceed the workgroup");
 	constexpr int NLAY  = 4 * 66 + 1;  // (zc + 2) layers x 4 bands of record bounds, zc <= 64
+	constexpr bool kDensePF = sizeof(T) == 4 && HAS2 && !HAS1;  // band prefetch in dense layers (prefetch_rows): the variants with registers to spare
 
 	__shared__ __attribute__((aligned(16))) T xs[3][ROWS][W];
 	// accumulation planes of the data term: [plane ring of 3][corner y-bit][TY][TX]
@@ -445,16 +449,20 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	// cell): the other waves skip the code, which matters because the kernel is instruction-issue bound.  That
 	// wave prefetches the layer's row records 4 steps ahead.  Denser layers: every wave takes its band, direct loads.
 	auto layer_dense = [&](int layer) {
-		return (uni(layR[layer * 4 + 4]) - uni(layR[layer * 4])) + (uni(layB[layer * 4 + 4]) - uni(layB[layer * 4])) > 64u;
+		return (uni(layR[layer * 4 + 4]) - uni(layR[layer * 4])) + (uni(layB[layer * 4 + 4]) - uni(layB[layer * 4])) > FI_DENSE_MIN;
 	};
 	// Every wave issues the record loads of the next layer in every step, unconditionally (clamped index):
 	// loads that cross a step must sit in straight-line code, or the compiler's s_waitcnt bookkeeping gives up
 	// and drains the whole pipeline (vmcnt(0)) at the first use.  The three extra waves hit the same lines in L1.
 	auto prefetch_rows = [&](int layer, RowPF& pf) {  // layer index l: cell plane z_begin - 1 + l
 		const int      lc = layer <= nsteps ? layer : nsteps;
-		const uint32_t r0 = uni(layR[lc * 4]), r1 = uni(layR[lc * 4 + 4]);
+		// dense layers: the first 64 records of this wave's band (fp32 only: the fp64 variant has no registers left
+		// for a prefetch that is live across the band loop -- it would spill, and a spill reload drains the pipeline)
+		const bool     dense = layer_dense(lc);
+		const bool     mine  = kDensePF && dense;
+		const uint32_t r0 = uni(layR[lc * 4 + (mine ? band : 0)]), r1 = uni(layR[lc * 4 + (mine ? band + 1 : 4)]);
 		const uint32_t r  = r0 + lane;
-		pf.ok = layer <= nsteps && !layer_dense(lc) && r < r1;
+		pf.ok = layer <= nsteps && (kDensePF || !dense) && r < r1;
 		load_row(r < r1 ? r : r0, &pf.pos, pf.a);  // r0 <= n_row, and the arrays hold n_row + 1 records
 	};
 	{
@@ -552,7 +560,13 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 			// layer z into the accumulation planes of z and z+1
 			if (layer_dense(s + 1)) {
 				const int o = (s + 1) * 4 + band;
-				cells_scatter(uni(layR[o]), uni(layR[o + 1]), uni(layB[o]), uni(layB[o + 1]), b0, b1, b0, b1, true);
+				if (kDensePF) {
+					if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1, b0, b1, true); }
+					const uint32_t re = uni(layR[o + 1]), rs = uni(layR[o]) + 64u;  // beyond the prefetched 64: loaded here
+					cells_scatter(rs < re ? rs : re, re, uni(layB[o]), uni(layB[o + 1]), b0, b1, b0, b1, true);
+				} else {
+					cells_scatter(uni(layR[o]), uni(layR[o + 1]), uni(layB[o]), uni(layB[o + 1]), b0, b1, b0, b1, true);
+				}
 			} else if (band == (s & 3)) {
 				const int o = (s + 1) * 4;
 #ifndef FI_SKIP_ROWS
