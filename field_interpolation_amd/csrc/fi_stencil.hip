@@ -741,7 +741,6 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 //   radix sort      slots by key (stable: the lists come out in cell order, run to run identical);
 //   exclusive scan  of the counts = list bounds;
 //   k_cell_records  one thread per sorted slot copies the row / packed block into the self-contained record.
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g, int64_t ncell, int64_t nbuckets,
                                                             const uint32_t* __restrict__ cell_id,
@@ -797,7 +796,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 	const int  listkind = (rows_c == 1u || pair) ? 0 : 1;  // 0: row records, 1: block record
 	uint32_t kk[8], pv[8];
 #pragma unroll
-	for (int m = 0; m < 8; ++m) { kk[m] = kNoKey; pv[m] = 0; }
+	for (int m = 0; m < 8; ++m) { kk[m] = static_cast<uint32_t>(2 * nbuckets); pv[m] = 0; }  // unused slot: sorts last
 	int j = 0;
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
@@ -864,7 +863,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_
 
 // List bounds straight from the sorted keys (no per-bucket counters: 10^6 scattered atomics cost 0.3 ms):
 // bound[k] = first sorted slot whose key is >= k, for k = 0 .. nkeys: one binary search per key value
-// (unused slots carry 0xFFFFFFFF and sort behind every real key).
+// (unused slots carry nkeys and sort behind every real key).
 __global__ __launch_bounds__(kThreads) void k_list_bounds(int64_t nslots, int64_t nkeys, const uint32_t* __restrict__ key_sorted,
                                                            uint32_t* __restrict__ bound)
 {
@@ -1082,15 +1081,18 @@ void build_cell_lists(fi_ctx* c)
 	                   pos.as<uint32_t>(), count.as<uint32_t>());
 	hipLaunchKernelGGL(k_iota32, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
 	                   slot_in.as<uint32_t>(), nslots);
-	// unused slots carry key 0xFFFFFFFF and sort to the end: all 32 key bits take part
+	// unused slots carry key 2 * nbuckets and sort to the end; only the bits such keys have take part (256^3:
+	// 18 bits = 3 radix passes instead of 4)
+	int key_bits = 1;
+	while ((1LL << key_bits) <= 2 * nbuckets) { ++key_bits; }
 	size_t tb = 0;
 	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
 	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-	                                              static_cast<int>(nslots), 0, 32, st));
+	                                              static_cast<int>(nslots), 0, key_bits, st));
 	tmp.alloc(tb);
 	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
 	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-	                                              static_cast<int>(nslots), 0, 32, st));
+	                                              static_cast<int>(nslots), 0, key_bits, st));
 	uint32_t* bound = count.as<uint32_t>() + 128;  // [2 * nbuckets + 1]
 	hipLaunchKernelGGL(k_list_bounds, dim3(static_cast<int>((2 * nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
 	                   st, nslots, 2 * nbuckets, key_sorted.as<uint32_t>(), bound);
