@@ -137,7 +137,8 @@ struct MarchState {
 	DevBuf      coef_blk;          // T[n_blk][8][8]
 	int64_t     n_row = 0, n_blk = 0;          // records (cells on tile borders are listed more than once)
 	int64_t     cells_row = 0, cells_blk = 0;  // distinct cells of each kind
-	DevBuf      wg_cells, wg_plain;            // workgroup ids with / without any cell (ascending)
+	DevBuf      wg_cells, wg_plain;            // workgroup ids with cells (ascending) / first workgroups of the plain runs
+	DevBuf      wg_runs;                       // chunks per plain run (consecutive empty chunks of one tile)
 	int         n_wg_cells = 0, n_wg_plain = 0;
 };
 

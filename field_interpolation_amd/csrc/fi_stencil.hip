@@ -48,6 +48,10 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "fi_internal.h"
 
 namespace fi {
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done,
-                                                             const uint32_t* __restrict__ wg_list, int nlist)
+                                                             const uint32_t* __restrict__ wg_list, int nlist,
+                                                             const uint32_t* __restrict__ wg_runs)
 {
 	using V = typename VecOf<T>::V;
 	constexpr int kTXT = TXT;             // threads along x
@@ -151,6 +156,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	const int slot = (blockIdx.x % 8) * per + blockIdx.x / 8;
 	if (slot >= nrun) { return; }
 	const int wg = wg_list ? static_cast<int>(wg_list[slot]) : slot;
+	// plain launches over surface-type data: a workgroup marches over `nrun` consecutive chunks of its tile (the
+	// chunks of a split launch are short for the sake of the data workgroups)
+	const int nchunk = (!CELLS && wg_runs) ? static_cast<int>(wg_runs[slot]) : 1;
 	const int tiles_xy = P.tiles_x * P.tiles_y;
 	const int chunk    = wg / tiles_xy;
 	const int txy      = wg % tiles_xy;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	const int lx = PADX + VX * tx, ly = kR + ty;
 
 	const int z_begin = P.own_z0 + chunk * P.zc;
-	int       z_end   = z_begin + P.zc;
+	int       z_end   = z_begin + P.zc * nchunk;
 	if (z_end > P.own_z1) { z_end = P.own_z1; }
 
 	// offsets inside a plane stay 32-bit and unsigned: the plane base is wave-uniform (SGPR pair), so every
@@ -728,6 +736,10 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 		if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wsum; }
 		__syncthreads();
 		if (threadIdx.x == 0) { partial[wg] = red[0] + red[1] + red[2] + red[3]; }
+		// the slots of the other chunks of a run: the consumers sum all P.nwg partials
+		if (static_cast<int>(threadIdx.x) > 0 && static_cast<int>(threadIdx.x) < nchunk) {
+			partial[wg + static_cast<int>(threadIdx.x) * tiles_xy] = 0.0;
+		}
 	}
 }
 
@@ -987,7 +999,8 @@ MarchCoef<T> march_coef(const fi_weights& w)
 }
 
 template <typename T, bool CELLS>
-void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint32_t* wg_list = nullptr, int nlist = 0)
+void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint32_t* wg_list = nullptr, int nlist = 0,
+                        const uint32_t* wg_runs = nullptr)
 {
 	const MarchParams& P = c->march.P;
 	const MarchCoef<T> C = march_coef<T>(c->w);
@@ -1000,7 +1013,8 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 	const int  grid = ((nrun + 7) / 8) * 8;
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done, wg_list, nlist);
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done, wg_list, nlist,
+		                   wg_runs);
 	};
 	if (P.txt == 32) {
 		if (h1 && h2) {
@@ -1030,13 +1044,13 @@ void march_launch(fi_ctx* c, const T* x, T* y, double* partial)
 	const MarchState& m = c->march;
 	if (!m.fused) {
 		march_launch_cells<T, false>(c, x, y, partial);
-	} else if (m.n_wg_plain * 16 < m.P.nwg || getenv("FI_NO_SPLIT")) {  // (nearly) every workgroup holds data
+	} else if ((m.P.nwg - m.n_wg_cells) * 16 < m.P.nwg || getenv("FI_NO_SPLIT")) {  // (nearly) every workgroup holds data
 		march_launch_cells<T, true>(c, x, y, partial);
 	} else {
 		// two launches over disjoint workgroups, back to back (running the data workgroups on a side stream next to
 		// the plain ones was tried: 543 instead of 482 us at 512^3 -- the long data columns starve the plain launch)
 		march_launch_cells<T, true>(c, x, y, partial, m.wg_cells.as<uint32_t>(), m.n_wg_cells);
-		march_launch_cells<T, false>(c, x, y, partial, m.wg_plain.as<uint32_t>(), m.n_wg_plain);
+		march_launch_cells<T, false>(c, x, y, partial, m.wg_plain.as<uint32_t>(), m.n_wg_plain, m.wg_runs.as<uint32_t>());
 	}
 }
 
@@ -1146,9 +1160,66 @@ void build_cell_lists(fi_ctx* c)
 		                                         m.wg_plain.as<uint32_t>(), nsel.as<int>() + 1, nwg, st));
 		int counts[2] = {0, 0};
 		FI_HIP_TRY(hipMemcpyAsync(counts, nsel.p, sizeof(counts), hipMemcpyDeviceToHost, st));
+		std::vector<uint8_t> h_has(static_cast<size_t>(nwg));
+		FI_HIP_TRY(hipMemcpyAsync(h_has.data(), has.p, static_cast<size_t>(nwg), hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
 		m.n_wg_cells = counts[0];
 		m.n_wg_plain = counts[1];
+		// Plain workgroups as runs of consecutive empty chunks of one tile: a split launch cuts the lattice into short
+		// chunks for the sake of the data workgroups, and short chunks cost the plain ones 4 overlap planes and the
+		// pipeline fill per 8 planes (512^3 without data: 344 us at 8 planes, 212 us at 128).  Run starts in chunk-major
+		// order (neighbours in the list are neighbours in the plane); a run covers at most 128 planes.
+		{
+			const int tiles_xy = P.tiles_x * P.tiles_y;
+			int cus = 256;
+			(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+			const double slots = static_cast<double>((cus > 0 ? cus : 256) * FI_BASE_WAVES);
+			std::vector<uint32_t> first, len;
+			std::vector<uint8_t>  used(static_cast<size_t>(nwg));
+			auto build_runs = [&](int cap) {
+				first.clear();
+				len.clear();
+				std::fill(used.begin(), used.end(), 0);
+				for (int ch = 0; ch < P.chunks; ++ch) {
+					for (int t = 0; t < tiles_xy; ++t) {
+						const int w0 = ch * tiles_xy + t;
+						if (h_has[w0] || used[w0]) { continue; }
+						int n = 0;
+						while (n < cap && ch + n < P.chunks && !h_has[w0 + n * tiles_xy]) {
+							used[w0 + n * tiles_xy] = 1;
+							++n;
+						}
+						first.push_back(static_cast<uint32_t>(w0));
+						len.push_back(static_cast<uint32_t>(n));
+					}
+				}
+			};
+			// longest run: the one that minimises rounds x (planes + pipeline fill), whole rounds while there are few
+			// (the cost model of pick_chunk); the grid must still cover the CUs
+			int    best_cap = 1;
+			double best_cost = 1e300;
+			for (int cap = 1; cap * P.zc <= 128; cap *= 2) {
+				build_runs(cap);
+				const double r = static_cast<double>(first.size()) / slots;
+				const double rounds = r < 6.0 ? std::ceil(r) : r;
+				const double cost = rounds * (cap * P.zc + 5);
+				if (cost < best_cost * 0.999) {
+					best_cost = cost;
+					best_cap  = cap;
+				}
+			}
+			if (const char* env = getenv("FI_RUN_CAP")) {  // experiments
+				if (atoi(env) > 0) { best_cap = atoi(env); }
+			}
+			build_runs(best_cap);
+			m.n_wg_plain = static_cast<int>(first.size());
+			m.wg_runs.alloc(sizeof(uint32_t) * (first.size() + 1));
+			if (!first.empty()) {
+				FI_HIP_TRY(hipMemcpyAsync(m.wg_plain.p, first.data(), sizeof(uint32_t) * first.size(), hipMemcpyHostToDevice, st));
+				FI_HIP_TRY(hipMemcpyAsync(m.wg_runs.p, len.data(), sizeof(uint32_t) * len.size(), hipMemcpyHostToDevice, st));
+				FI_HIP_TRY(hipStreamSynchronize(st));  // the host vectors die here
+			}
+		}
 	}
 }
 

@@ -212,3 +212,33 @@ def test_fused_cell_blocks_dense_and_bitwise_reproducible(oracle, fi, dtype, mon
     y3 = fg2.apply_AtA(x)
     assert np.abs(y3 - ref).max() <= TOL[dtype] * scale
     assert np.abs(y3 - y1).max() <= TOL[dtype] * scale
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_surface_data_split_launches_with_merged_plain_runs(oracle, fi, dtype):
+    """Surface-type data (oriented points on a small sphere) in a lattice of many chunks: fewer than half of the
+    workgroups hold cells, so the apply is two launches -- the fused variant over the data workgroups (8-plane
+    chunks) and the plain variant over runs of consecutive empty chunks.  Operator and p.q partials against the
+    oracle's explicit AtA; run twice for bitwise equality."""
+    from util import sphere_points
+    sizes = [70, 33, 90]
+    rng = np.random.default_rng(5)
+    pos, nrm = sphere_points(rng, [21, 21, 21], 3000, noise=0.2)
+    pos = (pos + np.array([30.0, 6.0, 50.0])).astype(np.float32)     # a sphere of radius 6 in one corner region
+    x = rng.normal(size=int(np.prod(sizes)))
+    fo, fg = build_pair(oracle, fi, sizes, fi.Weights(), pos, nrm, None, None, dtype=dtype)
+    AtA, _, _ = fo.normal_equations()
+    ref = AtA @ x
+    scale = (abs(AtA) @ np.abs(x)).max()
+    y1 = fg.apply_AtA(x)
+    y2 = fg.apply_AtA(x)
+    np.testing.assert_array_equal(y1, y2)
+    assert np.abs(y1 - ref).max() <= TOL[dtype] * scale
+    # the solver consumes the kernel's p.q partials (a run of chunks writes one sum and zeros): the same recurrence
+    # as the oracle's PCG must give the same iterate
+    if dtype == "f64":
+        guess = rng.normal(size=x.size).astype(np.float32)
+        xo, ito, erro = fo.solve_pcg(guess, 25, 1e-30, use_double=True)
+        _, itg, errg = fg.solve_cg(guess, 25, 1e-30)
+        assert itg == ito == 25
+        assert rel_inf(fg.solution_f64(), xo) <= 1e-9 and abs(errg - erro) <= 1e-6 * erro
