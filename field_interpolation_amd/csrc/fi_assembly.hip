@@ -435,12 +435,16 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, c
 		idx += static_cast<int64_t>(li) * g.stride[d];
 		lp[d] = li + g.off[d] - g.coff[d];
 	}
-	T a = atb[idx], dg = diag[idx];
+	// all 2^D map look-ups first (independent loads), then the few hits in colour order
+	uint32_t cidx[NC];
+	int      cq[NC];
+#pragma unroll
 	for (int colour = 0; colour < NC; ++colour) {
 		// the incident cell whose origin has this parity: the point is its corner q
 		uint32_t key = 0, mul = 1;
 		int      q  = 0;
 		bool     ok = true;
+#pragma unroll
 		for (int d = 0; d < D; ++d) {
 			const int b = (lp[d] ^ (colour >> d)) & 1;
 			const int l = lp[d] - b;
@@ -449,9 +453,15 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, c
 			mul *= static_cast<uint32_t>(g.cn[d]);
 			q |= b << d;
 		}
-		if (!ok) { continue; }
-		const uint32_t c = map[key];
+		cidx[colour] = ok ? map[key] : 0xFFFFFFFFu;
+		cq[colour]   = q;
+	}
+	T a = atb[idx], dg = diag[idx];
+#pragma unroll
+	for (int colour = 0; colour < NC; ++colour) {
+		const uint32_t c = cidx[colour];
 		if (c == 0xFFFFFFFFu) { continue; }
+		const int q = cq[colour];
 		a += static_cast<T>(cell_rhs[static_cast<long>(q) * ncell + c]);
 		dg += blk[static_cast<long>(c) * (NC * (NC + 1) / 2) + packed_index(q, q, NC)];
 	}

@@ -31,6 +31,10 @@
 // fp32 arithmetic is evaluated operation by operation like the reference build,
 // build.sh:68 "-O2 -DNDEBUG").
 
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -1019,6 +1023,107 @@ int fio_solve_pcg(void* h, int ncols, const float* guess, int max_iterations, do
 		*err = e;
 		for (int i = 0; i < ncols; ++i) { out[i] = x[i]; }
 	}
+	return 1;
+}
+
+// "Best-effort CPU" figure of SURVEY.md 8(d), NOT the reference's algorithm: Jacobi-PCG on the normal equations
+// without ever forming AtA -- q = A^T (A p) from the compressed rows and columns of the reference's own A
+// (sparse_linear.cpp:59-70 semantics: duplicates summed), fp32 storage, fp64 dot products, OpenMP over rows /
+// columns / vector elements on `threads` cores.  Same stop rule as the GPU solver: ||r|| <= tol ||A^T b||.
+// seconds[0] = building the compressed rows and columns, seconds[1] = the iteration.
+int fio_solve_pcg_rows_omp(void* h, int ncols, const float* guess, int max_iterations, double tol, int threads,
+                           float* out, int* iters, double* err, double* seconds)
+{
+	using clock = std::chrono::steady_clock;
+	const fio::System& sys = static_cast<Field*>(h)->sys;
+	const int nrows = static_cast<int>(sys.rhs.size());
+	const int n = ncols;
+#ifdef _OPENMP
+	if (threads > 0) { omp_set_num_threads(threads); }
+#endif
+	const auto t0 = clock::now();
+	fio::Compressed<float> Acsc, Acsr;
+	if (!fio::compress<float>(sys.ent, nrows, ncols, true, false, &Acsc)) { return 0; }
+	if (!fio::compress<float>(sys.ent, nrows, ncols, false, false, &Acsr)) { return 0; }
+	std::vector<float> b(sys.rhs.begin(), sys.rhs.end());
+	std::vector<float> atb(n), inv(n), x(guess, guess + n), r(n), p(n), q(n), t(nrows);
+#pragma omp parallel for schedule(static)
+	for (int j = 0; j < n; ++j) {
+		double sb = 0, sd = 0;
+		for (int a = Acsc.ptr[j]; a < Acsc.ptr[j + 1]; ++a) {
+			sb += static_cast<double>(Acsc.val[a]) * b[Acsc.idx[a]];
+			sd += static_cast<double>(Acsc.val[a]) * Acsc.val[a];
+		}
+		atb[j] = static_cast<float>(sb);
+		inv[j] = sd != 0 ? static_cast<float>(1.0 / sd) : 1.0f;  // Eigen DiagonalPreconditioner: 1 where the diagonal is 0
+	}
+	const auto t1 = clock::now();
+	auto apply = [&](const std::vector<float>& v, std::vector<float>& y) {
+#pragma omp parallel for schedule(static)
+		for (int i = 0; i < nrows; ++i) {
+			float sum = 0;
+			for (int a = Acsr.ptr[i]; a < Acsr.ptr[i + 1]; ++a) { sum += Acsr.val[a] * v[Acsr.idx[a]]; }
+			t[i] = sum;
+		}
+#pragma omp parallel for schedule(static)
+		for (int j = 0; j < n; ++j) {
+			float sum = 0;
+			for (int a = Acsc.ptr[j]; a < Acsc.ptr[j + 1]; ++a) { sum += Acsc.val[a] * t[Acsc.idx[a]]; }
+			y[j] = sum;
+		}
+	};
+	auto dot = [&](const std::vector<float>& u, const std::vector<float>& v) {
+		double sum = 0;
+#pragma omp parallel for reduction(+ : sum) schedule(static)
+		for (int i = 0; i < n; ++i) { sum += static_cast<double>(u[i]) * v[i]; }
+		return sum;
+	};
+	if (max_iterations <= 0) { max_iterations = 2 * n; }
+	if (!(tol > 0)) { tol = std::numeric_limits<float>::epsilon(); }
+	apply(x, q);
+#pragma omp parallel for schedule(static)
+	for (int i = 0; i < n; ++i) { r[i] = atb[i] - q[i]; }
+	const double rhs_sq = dot(atb, atb);
+	int it = 0;
+	double rr = dot(r, r);
+	if (rhs_sq == 0) {
+		std::fill(x.begin(), x.end(), 0.0f);
+		rr = 0;
+	} else {
+		const double tol2 = tol * tol * rhs_sq;
+		double rz = 0;
+#pragma omp parallel for reduction(+ : rz) schedule(static)
+		for (int i = 0; i < n; ++i) {
+			p[i] = inv[i] * r[i];
+			rz += static_cast<double>(r[i]) * p[i];
+		}
+		while (rr > tol2 && it < max_iterations) {
+			apply(p, q);
+			const double pq = dot(p, q);
+			if (!(pq > 0)) { break; }
+			const float al = static_cast<float>(rz / pq);
+			double rz_new = 0, rr_new = 0;
+#pragma omp parallel for reduction(+ : rz_new, rr_new) schedule(static)
+			for (int i = 0; i < n; ++i) {
+				x[i] += al * p[i];
+				r[i] -= al * q[i];
+				rz_new += static_cast<double>(r[i]) * inv[i] * r[i];
+				rr_new += static_cast<double>(r[i]) * r[i];
+			}
+			const float be = static_cast<float>(rz_new / rz);
+			rz = rz_new;
+			rr = rr_new;
+#pragma omp parallel for schedule(static)
+			for (int i = 0; i < n; ++i) { p[i] = inv[i] * r[i] + be * p[i]; }
+			++it;
+		}
+	}
+	const auto t2 = clock::now();
+	std::copy(x.begin(), x.end(), out);
+	*iters = it;
+	*err   = rhs_sq > 0 ? std::sqrt(rr / rhs_sq) : 0.0;
+	seconds[0] = std::chrono::duration<double>(t1 - t0).count();
+	seconds[1] = std::chrono::duration<double>(t2 - t1).count();
 	return 1;
 }
 

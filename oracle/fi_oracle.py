@@ -90,6 +90,7 @@ def lib():
         L.fio_solve_exact_f64.argtypes = [vp, C.c_int, dp]
         L.fio_solve_with_guess.argtypes = [vp, C.c_int, fp, C.c_int, C.c_float, fp, ip, fp]
         L.fio_solve_pcg.argtypes = [vp, C.c_int, fp, C.c_int, C.c_double, C.c_int, dp, ip, dp]
+        L.fio_solve_pcg_rows_omp.argtypes = [vp, C.c_int, fp, C.c_int, C.c_double, C.c_int, fp, ip, dp, dp]
         L.fio_jacobi_iterations.argtypes = [vp, C.c_int, fp, C.c_int, C.c_float, fp]
         L.fio_solve_tiled_with_guess.argtypes = [vp, C.c_long, fp, C.c_int, ip, C.POINTER(SolveOptions),
                                                  fp, ip, fp]
@@ -232,6 +233,18 @@ class LatticeField:
         ok = lib().fio_solve_pcg(self._h, g.size, _f(g), max_iterations, tol, int(use_double), _d(out),
                                  C.byref(it), C.byref(err))
         return (out, it.value, err.value) if ok else None
+
+    def solve_pcg_rows_omp(self, guess, max_iterations=0, tol=0.0, threads=0):
+        """Jacobi-PCG on A^T(A x) from the compressed rows / columns of A, OpenMP on `threads` cores (0: all): the
+        "best-effort CPU" figure of bench.py -- not the reference's algorithm.  Returns (x, iterations, relative
+        residual, seconds building the compressed forms, seconds iterating)."""
+        g = _f32(guess)
+        out = np.empty_like(g)
+        it, err = C.c_int(0), C.c_double(0)
+        sec = (C.c_double * 2)()
+        ok = lib().fio_solve_pcg_rows_omp(self._h, g.size, _f(g), max_iterations, tol, threads, _f(out), C.byref(it),
+                                          C.byref(err), sec)
+        return (out, it.value, err.value, sec[0], sec[1]) if ok else None
 
     def jacobi_iterations(self, guess, num_iterations, weight):
         g = _f32(guess)

@@ -138,3 +138,20 @@ def test_error_map(oracle):
     heat = np.zeros(72)
     np.add.at(heat, cols, np.where(sq[rows] != 0, vals.astype(np.float64) ** 2 / np.maximum(sq[rows], 1e-300), 0) * err[rows])
     np.testing.assert_allclose(f.error_map(x), heat, rtol=2e-4, atol=1e-5)
+
+
+def test_rows_omp_pcg_matches_explicit_pcg():
+    """bench.py's "best-effort CPU" solver (Jacobi-PCG on A^T(A x) from compressed rows/columns, OpenMP) runs the
+    same recurrence as the oracle's PCG on the explicit AtA: same iteration count, same solution."""
+    from oracle import fi_oracle as fo
+    rng = np.random.default_rng(11)
+    sizes = [14, 12, 10]
+    f = fo.LatticeField(sizes)
+    f.add_field_constraints(fo.Weights(model_2=0.5))
+    pos = np.stack([rng.uniform(0, s - 1, 300) for s in sizes], 1).astype(np.float32)
+    f.add_value_constraints(pos, rng.normal(size=300).astype(np.float32), 1.0)
+    g = np.zeros(f.num_unknowns, np.float32)
+    xd, itd, errd = f.solve_pcg(g, 0, 1e-6, use_double=True)
+    xo, ito, erro, _, _ = f.solve_pcg_rows_omp(g, 0, 1e-6, 2)
+    assert abs(ito - itd) <= 2 and erro <= 1e-6
+    assert np.abs(xo - xd).max() <= 1e-4 * np.abs(xd).max()
