@@ -44,6 +44,23 @@ def measured_traffic(side, points, dtype):
         return None
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota, at most 16 (a GPU box gives
+    one GPU's job a 16-core share of a 256-thread host; more OpenMP threads than that only fight each other)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(side, tol):
     """Oracle ("port") on a bounded sample: config 4 scaled to side^3 with the same point density."""
     import numpy as np
@@ -64,7 +81,7 @@ def cpu_baseline(side, tol):
                       "%d iterations" % (side, npts, t1 - t0, t2 - t1, iters)}
     # SURVEY.md 8(d) "best-effort CPU": the same rows, Jacobi-PCG on A^T(A x) without forming AtA, OpenMP on every
     # host core -- not the reference's algorithm (that is the port above), reported beside it
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     t3 = time.perf_counter()
     best = f.solve_pcg_rows_omp(np.zeros(f.num_unknowns, np.float32), 0, tol, cores)
     t4 = time.perf_counter()

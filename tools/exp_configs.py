@@ -36,7 +36,8 @@ for cfg in which:
             f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
         f.assemble()
         t1 = time.perf_counter()
-        res = f.solve_cg(None, int(os.environ.get("MAXIT", "3000")), tol)
+        guess = np.zeros(f.num_unknowns, np.float32) if os.environ.get("ZERO_GUESS") else None   # a guess skips the cascade start
+        res = f.solve_cg(guess, int(os.environ.get("MAXIT", "3000")), tol)
         t2 = time.perf_counter()
         st = f.stats()
         print("config %s %s %s: levels %d iters %d (coarse %d) assemble %.1f ms (wall %.0f) solve %.1f ms (wall %.0f) rel %.2e true %.2e conv %d cells %d"
