@@ -106,6 +106,7 @@ struct CellData {
 	DevBuf  mrow;     // T[ncell][2^D][2^D] (3-D only) up to 2^D factor rows a_k with block = sum a_k a_k^T
 	DevBuf  nfac;     // uint32[ncell] number of factor rows
 	int     nb = 0;   // entries per block: 2^D(2^D+1)/2
+	bool    pack = false;  // cells of >= 3 rows are kept as packed blocks in mrow (contexts of mostly multi-row cells)
 };
 
 // Tiling of the z-marching stencil kernel (fi_stencil.hip) and, per workgroup and z-layer, the list of

@@ -50,6 +50,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "fi_internal.h"
@@ -114,8 +115,30 @@ __host__ __device__ constexpr int tri(int i, int j)  // packed upper-triangle in
 	return i * 8 - (i * (i - 1)) / 2 + (j - i);
 }
 
-template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT>
-__global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1 : FI_CELL_WAVES) : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
+// row / column of packed index e (inverse of tri)
+__host__ __device__ constexpr int tri_row(int e)
+{
+	int i = 0;
+	while (tri(i + 1, i + 1) <= e && i < 7) { ++i; }
+	return i;
+}
+__host__ __device__ constexpr int tri_col(int e) { return tri_row(e) + (e - tri(tri_row(e), tri_row(e))); }
+
+// workgroups per CU the fused variant is register-allocated for: one less with both model_1 and model_2 on, and for
+// model_1 alone in the fp32 variant for packed blocks (those variants would spill, and a spill reload drains the
+// load pipeline)
+template <typename T>
+__host__ __device__ constexpr int fused_waves(bool has1, bool has2, bool pack)
+{
+	return (has1 && (has2 || (pack && sizeof(T) == 4))) ? FI_CELL_WAVES - 1 : FI_CELL_WAVES;
+}
+
+// PACK (fused variants): the context keeps its cells of >= 3 rows as packed blocks (CellData::pack: an SDF, the
+// coarse levels of a cascade); the other variant carries the factor-row loop only (and, in fp64, the packed block
+// of cells beyond 8 rows).  Two variants because the unrolled block product is code the row-dominated contexts
+// would only pay for: config 4's finest level ran 2-4 us per launch slower with it compiled in.
+template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT, bool PACK>
+__global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)) : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done,
@@ -138,7 +161,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 	constexpr int NSC  = 2 * R * (kTY + 2 * R);
 	static_assert(NVEC + NSC <= kThreads, "halo slots exceed the workgroup");
 	constexpr int NLAY  = 4 * 66 + 1;  // (zc + 2) layers x 4 bands of record bounds, zc <= 64
-	constexpr bool kDensePF = sizeof(T) == 4 && HAS2 && !HAS1;  // band prefetch in dense layers (prefetch_rows): the variants with registers to spare
+	constexpr bool kDensePF = sizeof(T) == 4 && HAS2 && !HAS1 && (TXT == 32 || !PACK);  // band prefetch in dense layers (prefetch_rows): the variants with registers to spare
 
 	__shared__ __attribute__((aligned(16))) T xs[3][ROWS][W];
 	// accumulation planes of the data term: [plane ring of 3][corner y-bit][TY][TX]
@@ -366,20 +389,46 @@ __global__ __launch_bounds__(kThreads, CELLS ? (HAS1 && HAS2 ? FI_CELL_WAVES - 1
 			corners(tcx, tcy, buf_lo, buf_hi, xv);
 #pragma unroll
 			for (int i = 0; i < 8; ++i) { out[i] = T(0); }
+			const uint32_t ro = r * 64u;  // 32-bit element offset against the uniform base: one address register
 			const V* ap = reinterpret_cast<const V*>(multi + static_cast<int64_t>(r) * 64);
-			if (sizeof(T) == 8 && nrows == 0xFF) {  // fp64: the packed symmetric block, out = B x
-				T b[36];
+			if ((PACK || sizeof(T) == 8) && nrows == 0xFF) {  // the packed symmetric block, out = B x
+				if (PACK) {
+					// batches of 8 coefficients -- the register footprint of one factor row; all 36 at once do not fit beside
+					// the march's register rings.  The record is 144 B in fp32: the first batch brings in its lines, the others
+					// hit them in L1.
+	#pragma unroll
+					for (int batch = 0; batch < 5; ++batch) {
+						constexpr int NV8 = 8 / VX;
+						V w[NV8];
+	#pragma unroll
+						for (int v = 0; v < NV8; ++v) {
+							if (batch * 8 + v * VX < 36) { w[v] = *reinterpret_cast<const V*>(multi + (ro + static_cast<uint32_t>(batch * 8 + v * VX))); }
+						}
+	#pragma unroll
+						for (int e = 0; e < 8; ++e) {
+							if (batch * 8 + e < 36) {
+								const int i = tri_row(batch * 8 + e), j = tri_col(batch * 8 + e);  // constants once unrolled
+								const T bv = reinterpret_cast<const T*>(&w[e / VX])[e % VX];
+								out[i] += bv * xv[j];
+								if (i != j) { out[j] += bv * xv[i]; }
+							}
+						}
+						asm volatile("" ::: "memory");
+					}
+				} else {  // fp64, cells beyond 8 rows
+					T b[36];
 #pragma unroll
-				for (int k = 0; k < 36 / VX; ++k) {
-					const V  w  = ap[k];
-					const T* pw = reinterpret_cast<const T*>(&w);
+					for (int k = 0; k < 36 / VX; ++k) {
+						const V  w  = ap[k];
+						const T* pw = reinterpret_cast<const T*>(&w);
 #pragma unroll
-					for (int j = 0; j < VX; ++j) { b[k * VX + j] = pw[j]; }
-				}
+						for (int j = 0; j < VX; ++j) { b[k * VX + j] = pw[j]; }
+					}
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
+					for (int i = 0; i < 8; ++i) {
 #pragma unroll
-					for (int j = 0; j < 8; ++j) { out[i] += b[i <= j ? tri(i, j) : tri(j, i)] * xv[j]; }
+						for (int j = 0; j < 8; ++j) { out[i] += b[i <= j ? tri(i, j) : tri(j, i)] * xv[j]; }
+					}
 				}
 				put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok);
 				continue;
@@ -974,7 +1023,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0)
 	int cus = 256;
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
 	const bool fused = c->cells.ncell > 0 && !getenv("FI_NO_FUSE");
-	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : (w.model_1 > 0 && w.model_2 > 0 ? FI_CELL_WAVES - 1 : FI_CELL_WAVES);
+	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : fused_waves<T>(w.model_1 > 0, w.model_2 > 0, c->cells.pack);
 	// the fused variant stages the list bounds of at most 64 + 2 layers in LDS (s_lay); without data cells the chunk
 	// may be as long as one round of workgroups allows (512^3: 128 planes, 1024 workgroups)
 	P->zc     = pick_chunk(P->tiles_x * P->tiles_y, nz_own, (cus > 0 ? cus : 256) * wgs_per_cu, forced_zc, fused ? 64 : 256);
@@ -1016,22 +1065,23 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done, wg_list, nlist,
 		                   wg_runs);
 	};
+	const bool pack = CELLS && c->cells.pack;  // the variant that matches the context's block records
+	auto pick = [&](auto txt, auto pk) {
+		constexpr int  TXT = decltype(txt)::value;
+		constexpr bool PK  = decltype(pk)::value;
+		if (h1 && h2) {
+			launch(k_apply_march3d<T, true, true, CELLS, TXT, PK>);
+		} else if (h2) {
+			launch(k_apply_march3d<T, false, true, CELLS, TXT, PK>);
+		} else {
+			launch(k_apply_march3d<T, true, false, CELLS, TXT, PK>);
+		}
+	};
+	using std::integral_constant;
 	if (P.txt == 32) {
-		if (h1 && h2) {
-			launch(k_apply_march3d<T, true, true, CELLS, 32>);
-		} else if (h2) {
-			launch(k_apply_march3d<T, false, true, CELLS, 32>);
-		} else {
-			launch(k_apply_march3d<T, true, false, CELLS, 32>);
-		}
+		if (CELLS && pack) { pick(integral_constant<int, 32>{}, integral_constant<bool, CELLS>{}); } else { pick(integral_constant<int, 32>{}, integral_constant<bool, false>{}); }
 	} else {
-		if (h1 && h2) {
-			launch(k_apply_march3d<T, true, true, CELLS, 16>);
-		} else if (h2) {
-			launch(k_apply_march3d<T, false, true, CELLS, 16>);
-		} else {
-			launch(k_apply_march3d<T, true, false, CELLS, 16>);
-		}
+		if (CELLS && pack) { pick(integral_constant<int, 16>{}, integral_constant<bool, CELLS>{}); } else { pick(integral_constant<int, 16>{}, integral_constant<bool, false>{}); }
 	}
 	FI_HIP_TRY(hipGetLastError());
 }

@@ -32,10 +32,12 @@ def _variants(report, kernel):
 
 def test_marching_kernel_budget():
     rep = _variants(_report("fi_stencil.usage.txt"), "k_apply_march3d")
-    assert len(rep) == 24            # {fp32, fp64} x {model_1, model_2, both} x {plain, fused} x {128 x 8, 64 x 16 tiles}
+    # {fp32, fp64} x {model_1, model_2, both} x {plain, fused} x {128 x 8, 64 x 16 tiles}, the fused ones once more
+    # for contexts that keep their multi-row cells as packed blocks
+    assert len(rep) == 36
     for name, r in rep.items():
-        # (SGPR spills go to VGPR lanes, not to memory: the both-models fused variant keeps 11 lane masks there)
-        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0 and r["SGPRs Spill"] <= 16, name
+        # (SGPR spills go to VGPR lanes, not to memory: the both-models fused variant keeps 11-17 lane masks and bounds there)
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0 and r["SGPRs Spill"] <= 24, name
         assert r["AGPRs"] == 0, name
         if r["LDS Size [bytes/block]"] > 30000:           # fused variants: 3 workgroups per CU (2 with both models)
             assert r["LDS Size [bytes/block]"] * 3 <= 160 * 1024, name
@@ -44,7 +46,7 @@ def test_marching_kernel_budget():
             assert r["VGPRs"] <= 128 and r["Occupancy [waves/SIMD]"] >= 4, name
             assert r["LDS Size [bytes/block]"] * 4 <= 160 * 1024, name
     # the bench variant: fp32, model_2 only, fused -- three workgroups per CU
-    bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1ELi32E" in n]
+    bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1ELi32ELb0E" in n]
     assert len(bench) == 1 and bench[0]["VGPRs"] <= 168 and bench[0]["Occupancy [waves/SIMD]"] == 3
 
 
