@@ -40,7 +40,13 @@
 //     The owner of a lattice point collects plane z-1 one step late (after the barrier of step z, when
 //     layers z-2 and z-1 are complete), so the data path needs no barrier of its own; the stencil result
 //     of plane z-1 waits in registers for that one step.  Row records are prefetched one plane ahead by
-//     every wave.  The scatter code is branch-free (a per-thread dump slot for corners outside the tile).
+//     every wave (dense layers: each wave its band).  The scatter code is branch-free (a per-thread dump slot
+//     for corners outside the tile).  Nothing on the plane step's critical path may wait for a load it has just
+//     issued: a cell with TWO rows is listed as two row records in neighbouring lanes (scattered in two passes)
+//     so that it travels with the prefetched stream; contexts of mostly multi-row cells keep cells of >= 3 rows as
+//     packed blocks (36 coefficients in independent batches, out = B x) and run the PACK instantiation;
+//   * workgroups without any data cell run the plain variant (two launches over disjoint lists), the plain ones
+//     over runs of consecutive empty chunks of a tile;
 //   * p.q partials: fp32 products per plane, fp64 per-thread accumulation, wave64 shuffle tree, one
 //     partial per workgroup;
 //   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. (same XCD, same L2) get adjacent tiles; the
