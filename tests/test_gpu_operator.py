@@ -242,3 +242,53 @@ def test_surface_data_split_launches_with_merged_plain_runs(oracle, fi, dtype):
         _, itg, errg = fg.solve_cg(guess, 25, 1e-30)
         assert itg == ito == 25
         assert rel_inf(fg.solution_f64(), xo) <= 1e-9 and abs(errg - erro) <= 1e-6 * erro
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_gather_assembly_same_bits_as_colour_launches(fi, dtype, monkeypatch):
+    """A^T b and diag(A^T A) by the gather launch (dense cell map, cells visited in colour order) and by the 2^D
+    parity-colour scatter launches: the same sums in the same order, bit for bit (3-D and 2-D)."""
+    rng = np.random.default_rng(9)
+    for sizes, n in (([40, 36, 28], 9000), ([90, 70], 2500)):
+        pos, nrm, pw, val = random_points(rng, sizes, n)
+        got = []
+        for no_gather in (False, True):
+            if no_gather:
+                monkeypatch.setenv("FI_NO_GATHER", "1")
+            else:
+                monkeypatch.delenv("FI_NO_GATHER", raising=False)
+            f = fi.LatticeField(sizes, dtype=dtype)
+            f.add_field_constraints(fi.Weights(model_1=0.2))
+            f.add_points(1.0, fi.ValueKernel.kLinearInterpolation, 1.0, fi.GradientKernel.kCellEdges, pos, nrm, pw, values=val)
+            f.assemble()
+            got.append((f.Atb().copy(), f.diag().copy()))
+        np.testing.assert_array_equal(got[0][0], got[1][0])
+        np.testing.assert_array_equal(got[0][1], got[1][1])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_packed_blocks_and_factor_rows_agree(oracle, fi, dtype, monkeypatch):
+    """Contexts of mostly multi-row cells keep cells of >= 3 rows as packed blocks (PACK kernel variants); with
+    FI_NO_PACK the same cells go through the factor-row loop.  Both against the oracle's explicit AtA."""
+    sizes = [50, 21, 37]
+    rng = np.random.default_rng(3)
+    n = 30000                                          # ~0.8 points, i.e. ~3 rows, per cell: 1 to 20 rows per occupied cell
+    pos = np.stack([rng.uniform(-1.2, s + 0.2, n) for s in sizes], 1).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    x = rng.normal(size=int(np.prod(sizes)))
+    ys = []
+    for no_pack in (False, True):
+        if no_pack:
+            monkeypatch.setenv("FI_NO_PACK", "1")
+        else:
+            monkeypatch.delenv("FI_NO_PACK", raising=False)
+        fo, fg = build_pair(oracle, fi, sizes, fi.Weights(), pos, nrm, None, None, dtype=dtype)
+        if not ys:
+            AtA, _, _ = fo.normal_equations()
+            ref = AtA @ x
+            scale = (abs(AtA) @ np.abs(x)).max()
+        y = fg.apply_AtA(x)
+        np.testing.assert_array_equal(y, fg.apply_AtA(x))
+        assert np.abs(y - ref).max() <= TOL[dtype] * scale
+        ys.append(y)
+    assert np.abs(ys[0] - ys[1]).max() <= TOL[dtype] * scale
