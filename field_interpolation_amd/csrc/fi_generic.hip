@@ -434,6 +434,70 @@ void generic_assemble(fi_ctx* c)
 
 int generic_num_partials(const fi_ctx* c) { return c->generic.nnz > 0 ? capped_blocks(c->generic.ncols) : 0; }
 
+// The tile operator of tile_solver_square (sparse_linear.cpp:246-390) for materialised rows: entry (i, j) of A^T A
+// is kept only when unknowns i and j lie in the same ts^D tile of the lattice, i.e. every row is split into its
+// per-tile pieces:  y_i += sum_r a_ri * sum_{j in row r, tile(j) == tile(i)} a_rj x_j.  One thread per non-empty
+// column i walks the column (CSC) and, for every row it meets, that row's entries (CSR): rows are short.  The
+// pre-solver runs once per solve, not per iteration of the main CG.
+__device__ inline uint32_t tile_of(const Geom& g, uint32_t j, int ts)
+{
+	uint32_t t = 0, mul = 1;
+	for (int d = 0; d < g.ndim; ++d) {
+		const uint32_t n = static_cast<uint32_t>(g.gn[d]);
+		t += ((j % n) / static_cast<uint32_t>(ts)) * mul;
+		mul *= (n + static_cast<uint32_t>(ts) - 1) / static_cast<uint32_t>(ts);
+		j /= n;
+	}
+	return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_generic_tile(Geom g, int ts, int64_t ncols, const uint32_t* __restrict__ cols,
+                                                            const uint32_t* __restrict__ ptr,
+                                                            const uint32_t* __restrict__ row,
+                                                            const T* __restrict__ val,
+                                                            const uint32_t* __restrict__ csr_ptr,
+                                                            const uint32_t* __restrict__ csr_col,
+                                                            const T* __restrict__ csr_val, const T* __restrict__ x,
+                                                            T* __restrict__ y, double* __restrict__ partial,
+                                                            const int* __restrict__ done)
+{
+	if (done && *done) { return; }
+	double contrib = 0;
+	for (int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; c < ncols;
+	     c += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const uint32_t j  = cols[c];
+		const uint32_t tj = tile_of(g, j, ts);
+		T s = 0;
+		for (uint32_t k = ptr[c]; k < ptr[c + 1]; ++k) {
+			const uint32_t r = row[k];
+			T u = 0;
+			for (uint32_t e = csr_ptr[r]; e < csr_ptr[r + 1]; ++e) {
+				const uint32_t jj = csr_col[e];
+				if (tile_of(g, jj, ts) == tj) { u += csr_val[e] * x[jj]; }
+			}
+			s += val[k] * u;
+		}
+		y[j] += s;
+		contrib += static_cast<double>(x[j]) * static_cast<double>(s);
+	}
+	if (partial) {
+		const double s = block_sum(contrib);
+		if (threadIdx.x == 0) { partial[blockIdx.x] = s; }
+	}
+}
+
+template <typename T>
+static void generic_apply_tile_t(fi_ctx* c, const T* x, T* y, double* partial, int ts)
+{
+	GenericRows& G = c->generic;
+	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
+	hipLaunchKernelGGL((k_generic_tile<T>), dim3(capped_blocks(G.ncols)), dim3(kThreads), 0, c->stream, c->g, ts, G.ncols,
+	                   G.csc_cols.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), G.csc_row.as<uint32_t>(), G.csc_val.as<T>(),
+	                   G.csr_ptr.as<uint32_t>(), G.csr_col.as<uint32_t>(), G.csr_val.as<T>(), x, y, partial, done);
+	FI_HIP_TRY(hipGetLastError());
+}
+
 template <typename T>
 static void generic_apply_t(fi_ctx* c, const T* x, T* y, double* partial)
 {
@@ -509,6 +573,55 @@ void generic_error_map(fi_ctx* c, const void* x, void* out)
 	if (c->generic.ntrip == 0 || c->generic.nrows == 0) { return; }
 	c->dtype == FI_F64 ? generic_error_map_t<double>(c, static_cast<const double*>(x), static_cast<double*>(out))
 	                   : generic_error_map_t<float>(c, static_cast<const float*>(x), static_cast<float*>(out));
+}
+
+// tile_solver_square skips a tile that holds nothing but its 1e-6 diagonal (sparse_linear.cpp:343-346 in spirit:
+// "ent.size() == per_tile"): its unknowns keep the guess.  With rows only (no model, no cells) a tile is empty iff
+// none of its unknowns is a non-empty column.
+__global__ __launch_bounds__(kThreads) void k_tile_flags(Geom g, int ts, int64_t ncols, const uint32_t* __restrict__ cols,
+                                                          uint8_t* __restrict__ flag)
+{
+	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c < ncols) { flag[tile_of(g, cols[c], ts)] = 1; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_keep_guess_in_empty_tiles(Geom g, int ts, int64_t n,
+                                                                         const uint8_t* __restrict__ flag,
+                                                                         const T* __restrict__ guess, T* __restrict__ x)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i < n && !flag[tile_of(g, static_cast<uint32_t>(i), ts)]) { x[i] = guess[i]; }
+}
+
+void generic_keep_guess_in_empty_tiles(fi_ctx* c, int ts, const void* guess, void* x)
+{
+	GenericRows& G = c->generic;
+	int64_t ntiles = 1;
+	for (int d = 0; d < c->g.ndim; ++d) { ntiles *= (c->g.gn[d] + ts - 1) / ts; }
+	DevBuf& flag = c->scratch[25];
+	flag.alloc(static_cast<size_t>(ntiles));
+	FI_HIP_TRY(hipMemsetAsync(flag.p, 0, static_cast<size_t>(ntiles), c->stream));
+	if (G.ncols > 0) {
+		hipLaunchKernelGGL(k_tile_flags, dim3(blocks_for(G.ncols)), dim3(kThreads), 0, c->stream, c->g, ts, G.ncols,
+		                   G.csc_cols.as<uint32_t>(), flag.as<uint8_t>());
+	}
+	const int64_t n = c->g.nloc;
+	if (c->dtype == FI_F64) {
+		hipLaunchKernelGGL((k_keep_guess_in_empty_tiles<double>), dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, ts, n,
+		                   flag.as<uint8_t>(), static_cast<const double*>(guess), static_cast<double*>(x));
+	} else {
+		hipLaunchKernelGGL((k_keep_guess_in_empty_tiles<float>), dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, c->g, ts, n,
+		                   flag.as<uint8_t>(), static_cast<const float*>(guess), static_cast<float*>(x));
+	}
+	FI_HIP_TRY(hipGetLastError());
+}
+
+void generic_apply_tile(fi_ctx* c, const void* x, void* y, double* partial, int ts)
+{
+	if (c->generic.nnz == 0) { return; }
+	c->dtype == FI_F64 ? generic_apply_tile_t<double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial, ts)
+	                   : generic_apply_tile_t<float>(c, static_cast<const float*>(x), static_cast<float*>(y), partial, ts);
 }
 
 void generic_apply(fi_ctx* c, const void* x, void* y, double* partial)

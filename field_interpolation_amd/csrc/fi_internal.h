@@ -294,6 +294,8 @@ void generic_clear(fi_ctx* c);
 void generic_assemble(fi_ctx* c);                      // after assemble(): adds A^T b and diag, builds CSR/CSC
 int  generic_num_partials(const fi_ctx* c);
 void generic_apply(fi_ctx* c, const void* x, void* y, double* partial);  // y += A^T (A x)
+void generic_apply_tile(fi_ctx* c, const void* x, void* y, double* partial, int ts);  // the tile operator (fi_tile_pass)
+void generic_keep_guess_in_empty_tiles(fi_ctx* c, int ts, const void* guess, void* x);  // rows-only contexts
 void generic_error_map(fi_ctx* c, const void* x, void* out);             // out += blame of the generic rows
 
 // fi_assembly.hip

@@ -336,6 +336,7 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 		                   partial ? partial + nb_model : nullptr, done, ts);
 	}
 	if (ts > 0) {
+		generic_apply_tile(c, x, y, partial ? partial + nb_model + nb_cells : nullptr, ts);
 		FI_HIP_TRY(hipGetLastError());
 		return;
 	}
@@ -349,7 +350,9 @@ size_t elem_size(const fi_ctx* c) { return c->dtype == FI_F64 ? sizeof(double) :
 
 int apply_num_partials(const fi_ctx* c)
 {
-	if (c->tile_ts > 0) { return capped_blocks(c->g.nown) + (c->cells.ncell > 0 ? capped_blocks(c->cells.ncell) : 0); }
+	if (c->tile_ts > 0) {
+		return capped_blocks(c->g.nown) + (c->cells.ncell > 0 ? capped_blocks(c->cells.ncell) : 0) + generic_num_partials(c);
+	}
 	int nb_model = stencil_partials(c);
 	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
 	int n = nb_model + generic_num_partials(c);

@@ -1781,10 +1781,6 @@ __global__ __launch_bounds__(kThreads) void k_tile_rhs(int64_t n, const T* __res
 template <typename T>
 void tile_pass_run(RankSet& R, int tile_size)  // x of every member: the guess on entry, the tile solutions on return
 {
-	for (fi_ctx* c : R) {
-		FI_REQUIRE(c->generic.ntrip == 0 && c->generic.nnz == 0, FI_ERR_UNSUPPORTED,
-		           "the tile pre-solver works on lattice rows (fi_set_model / fi_add_points), not on fi_add_rows_coo rows");
-	}
 	CgScalars init{};
 	reset_scalars(R, init);
 	halo_exchange(R, &fi_ctx::x);
@@ -1819,7 +1815,24 @@ void tile_pass_run(RankSet& R, int tile_size)  // x of every member: the guess o
 		std::swap(c->atb.bytes, rhs.bytes);
 		restore.swapped[i] = true;
 	}
+	// contexts of materialised rows only (the drop-in's solve_tiled_with_guess): tiles without any entry keep the guess
+	std::vector<DevBuf*> kept(R.size(), nullptr);
+	for (size_t i = 0; i < R.size(); ++i) {
+		fi_ctx* c = R[i];
+		const fi_weights& w = c->w;
+		const bool rows_only = c->generic.nnz > 0 && c->cells.ncell == 0 && c->nranks == 1 && !(w.model_0 > 0) && !(w.model_1 > 0) &&
+		                       !(w.model_2 > 0) && !(w.model_3 > 0) && !(w.model_4 > 0) && !(w.gradient_smoothness > 0);
+		if (rows_only) {
+			DevBuf& g0 = c->scratch[22];
+			g0.alloc(elem_size(c) * c->g.nloc);
+			FI_HIP_TRY(hipMemcpyAsync(g0.p, c->x.p, elem_size(c) * c->g.nloc, hipMemcpyDeviceToDevice, c->stream));
+			kept[i] = &g0;
+		}
+	}
 	cg_run<T>(R, 4000, sizeof(T) == 8 ? 1e-12f : 1e-6f);  // the reference factorises: iterate to the precision's floor
+	for (size_t i = 0; i < R.size(); ++i) {
+		if (kept[i]) { generic_keep_guess_in_empty_tiles(R[i], tile_size, kept[i]->p, R[i]->x.p); }
+	}
 }
 
 template <typename T>

@@ -48,13 +48,15 @@ static_assert(sizeof(Triplet) == sizeof(fi_triplet), "Triplet must stay 12 bytes
 
 void warn(const char* what) { std::fprintf(stderr, "field_interpolation: %s: %s\n", what, fi_last_error()); }
 
-// A context that holds nothing but the caller's rows: 1-D "lattice" of num_columns unknowns, no model rows.
+// A context that holds nothing but the caller's rows: 1-D "lattice" of num_columns unknowns (or the caller's lattice,
+// which only the tile pre-solver looks at), no model rows.
 struct RowsOnGpu {
 	fi_ctx* ctx = nullptr;
-	RowsOnGpu(const LinearEquation& eq, int num_columns, int dtype)
+	RowsOnGpu(const LinearEquation& eq, int num_columns, int dtype, const std::vector<int>* lattice = nullptr)
 	{
-		const int sizes[1] = {num_columns};
-		if (num_columns < 1 || fi_ctx_create(&ctx, 1, sizes, dtype) != FI_OK) {
+		const int flat[1] = {num_columns};
+		const bool nd = lattice && !lattice->empty() && lattice->size() <= 3;
+		if (num_columns < 1 || fi_ctx_create(&ctx, nd ? static_cast<int>(lattice->size()) : 1, nd ? lattice->data() : flat, dtype) != FI_OK) {
 			warn("fi_ctx_create");
 			ctx = nullptr;
 			return;
@@ -139,14 +141,35 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 		std::fprintf(stderr, "field_interpolation: Incomplete guess.\n");
 		return {};
 	}
-	if (options.tile) {
-		// The tile pre-pass only improves the starting guess of the iterative phase.  The device version
-		// (fi_tile_pass) works on lattice rows; a materialised LinearEquation goes through the generic sparse-row
-		// path, where it is not available: the iteration starts from the caller's guess.  GpuLatticeField honours it.
-		std::fprintf(stderr, "field_interpolation: SolveOptions.tile is ignored for materialised rows (use GpuLatticeField)\n");
+	if (!options.tile) {
+		if (!options.cg) { return guess; }
+		return iterate(eq, &guess, static_cast<int>(n), FI_F32, options.max_iterations, options.error_tolerance, false);
 	}
-	if (!options.cg) { return guess; }
-	return iterate(eq, &guess, static_cast<int>(n), FI_F32, options.max_iterations, options.error_tolerance, false);
+	// tile_solver_square (sparse_linear.cpp:246-390, 415-425) on the device: fi_tile_pass solves every tile_size^D
+	// tile of the lattice with its couplings to the other tiles taken from the guess, then the iteration starts
+	// from the tile solutions (:427-440).  More than 3 lattice dimensions: no tiles to speak of here, plain iteration.
+	if (sizes.size() > 3) {
+		std::fprintf(stderr, "field_interpolation: SolveOptions.tile needs a lattice of at most 3 dimensions; ignored\n");
+		if (!options.cg) { return guess; }
+		return iterate(eq, &guess, static_cast<int>(n), FI_F32, options.max_iterations, options.error_tolerance, false);
+	}
+	RowsOnGpu gpu(eq, static_cast<int>(n), FI_F32, &sizes);
+	if (!gpu.ctx) { return {}; }
+	std::vector<float> tiled(n);
+	if (fi_tile_pass(gpu.ctx, guess.data(), options.tile_size, tiled.data(), FI_HOST) != FI_OK) {
+		warn("tile pre-solver");
+		return {};
+	}
+	if (!options.cg) { return tiled; }
+	std::vector<float> out(n);
+	int   iterations = 0;
+	float error      = 0;
+	if (fi_solve_cg(gpu.ctx, tiled.data(), options.max_iterations, options.error_tolerance, out.data(), &iterations, &error,
+	                FI_HOST) != FI_OK) {
+		warn("solver failed");
+		return {};
+	}
+	return out;
 }
 
 }  // namespace field_interpolation

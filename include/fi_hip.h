@@ -203,7 +203,9 @@ int fi_jacobi(fi_ctx* ctx, const float* guess, int num_iterations, float weight,
  * off-tile coupling twice, :327-334 -- reproduced), 1e-6 added to the tile diagonals (:296-300).  The tiles are
  * independent SPD systems; they are solved together by one CG run on the block-diagonal tile operator
  * (fp32 contexts to a relative residual of 1e-6, fp64 to 1e-12) instead of one sparse Cholesky per tile.
- * Lattice rows only (fi_set_model / fi_add_points); tile_size >= 2 (:254). */
+ * Lattice rows (fi_set_model / fi_add_points) and fi_add_rows_coo rows alike -- the rows of a materialised
+ * LinearEquation are split into their per-tile pieces on the fly; in a context of such rows only, a tile without
+ * any entry keeps the guess, as the reference skips it.  tile_size >= 2 (:254). */
 int fi_tile_pass(fi_ctx* ctx, const float* guess, int tile_size, float* out, int memory);
 
 /* Replaces generate_error_map (field_interpolation.cpp:402-429): the blame heat-map of a solution.  Every

@@ -97,6 +97,29 @@ int main()
 		fi::SolveOptions options;  // defaults: cg, tolerance 1e-3
 		auto approx = fi::solve_tiled_with_guess(field.eq, std::vector<float>(n, 0.0f), field.sizes, options);
 		require(approx.size() == n, "sdf: solve_tiled_with_guess with default SolveOptions");
+		// SolveOptions.tile on materialised rows (sparse_linear.cpp:415-425): the tile pre-solver alone moves the zero
+		// guess towards the solution, and tile + CG converges like CG alone
+		fi::SolveOptions tiles_only;
+		tiles_only.tile = true;
+		tiles_only.tile_size = 8;
+		tiles_only.cg = false;
+		auto pre = fi::solve_tiled_with_guess(field.eq, std::vector<float>(n, 0.0f), field.sizes, tiles_only);
+		require(pre.size() == n, "sdf: tile pre-solver on materialised rows returns a field");
+		{
+			double d0 = 0, d1 = 0;
+			for (size_t i = 0; i < n; ++i) {
+				d0 += static_cast<double>(exact[i]) * exact[i];
+				d1 += (static_cast<double>(pre[i]) - exact[i]) * (static_cast<double>(pre[i]) - exact[i]);
+			}
+			require(d1 < d0, "sdf: the tile solutions are closer to the solution than the zero guess");
+		}
+		fi::SolveOptions tiles_cg;
+		tiles_cg.tile = true;
+		tiles_cg.tile_size = 8;
+		tiles_cg.error_tolerance = 1e-7f;
+		tiles_cg.max_iterations = 100000;
+		auto both = fi::solve_tiled_with_guess(field.eq, std::vector<float>(n, 0.0f), field.sizes, tiles_cg);
+		require(both.size() == n && max_rel(both, exact) <= 1e-3f, "sdf: tile pre-solver + CG reaches the solution");
 		auto from_exact = fi::solve_sparse_linear_with_guess(field.eq, exact, 50, 1e-6f);
 		require(from_exact.size() == n && max_rel(from_exact, exact) <= 1e-3f, "sdf: warm start stays at the solution");
 	}

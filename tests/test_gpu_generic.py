@@ -116,3 +116,63 @@ def test_generic_errors(fi):
     g = fi.LatticeGroup([8, 8], 2)
     with pytest.raises(FiError):            # generic rows need an undivided lattice
         g.members[0].add_rows_coo(np.array([0]), np.array([0]), np.array([1.0], np.float32), np.array([0.0], np.float32))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("sizes,ts", [([20, 18], 8), ([12, 9, 10], 4), ([50], 16)])
+def test_tile_pass_on_materialised_rows(oracle, fi, dtype, sizes, ts):
+    """solve_tiled_with_guess(eq, ...) with SolveOptions.tile (sparse_linear.cpp:415-425) for rows handed over as
+    triplets (fi_add_rows_coo): the rows of a lattice problem taken from the oracle, all but one corner region of
+    the lattice, so that one tile holds no entry at all and keeps the guess (tile_solver_square skips it).  Against a
+    dense float64 re-derivation (couplings to other tiles moved to the rhs TWICE, 1e-6 on the diagonal) and the
+    oracle's per-tile Cholesky."""
+    rng = np.random.default_rng(ts + len(sizes))
+    n = int(np.prod(sizes))
+    fo = oracle.LatticeField(sizes)
+    fo.add_field_constraints(oracle.Weights(model_1=0.4, model_2=0.3))
+    pos = np.stack([rng.uniform(0, s - 1, 60) for s in sizes], 1).astype(np.float32)
+    fo.add_value_constraints(pos, rng.normal(size=60).astype(np.float32), 1.0)
+    rows, cols, vals, rhs = fo.get()
+    # drop every row that touches the last tile along every axis: that tile stays empty
+    coords = np.stack(np.unravel_index(np.arange(n), sizes[::-1])[::-1], 1)
+    last = np.all(coords // ts == (np.array(sizes) - 1) // ts, axis=1)
+    bad_rows = np.unique(rows[last[cols]])
+    keep = ~np.isin(rows, bad_rows)
+    remap = -np.ones(len(rhs), np.int64)
+    kept_rows = np.setdiff1d(np.arange(len(rhs)), bad_rows)
+    remap[kept_rows] = np.arange(len(kept_rows))
+    rows2, cols2, vals2, rhs2 = remap[rows[keep]].astype(np.int32), cols[keep], vals[keep], rhs[kept_rows]
+    import scipy.sparse as sp
+    A = sp.csr_matrix((vals2.astype(np.float64), (rows2, cols2)), shape=(len(rhs2), n))
+    M = (A.T @ A).toarray()
+    atb = A.T @ rhs2.astype(np.float64)
+    g = rng.normal(size=n).astype(np.float32)
+    tile_of = np.zeros(n, np.int64)
+    for d in range(len(sizes) - 1, -1, -1):
+        tile_of = tile_of * 64 + coords[:, d] // ts
+    expect = g.astype(np.float64).copy()
+    empty = 0
+    for t in np.unique(tile_of):
+        mine, other = np.where(tile_of == t)[0], np.where(tile_of != t)[0]
+        if not M[np.ix_(mine, mine)].any():
+            empty += 1
+            continue                                    # nothing but the 1e-6 diagonal: the tile keeps the guess
+        r = atb[mine] - 2.0 * M[np.ix_(mine, other)] @ g[other].astype(np.float64)
+        expect[mine] = np.linalg.solve(M[np.ix_(mine, mine)] + 1e-6 * np.eye(len(mine)), r)
+    assert empty >= 1
+    f = fi.LatticeField(sizes, dtype=dtype)
+    f.add_field_constraints(fi.Weights(model_2=0.0))
+    f.add_rows_coo(rows2, cols2, vals2, rhs2)
+    f.assemble()
+    x = f.tile_pass(g, ts)
+    tol = 1e-6 if dtype == "f64" else 5e-3
+    assert np.abs(x - expect).max() <= tol * np.abs(expect).max()
+    np.testing.assert_array_equal(x[last], g[last])                        # the empty tile: the guess, untouched
+    # the oracle's tile_solver_square on the same rows
+    fo2 = oracle.LatticeField(sizes)
+    for r, c, v in zip(rows2, cols2, vals2):
+        fo2.push_triplet(int(r), int(c), float(v))
+    for v in rhs2:
+        fo2.push_rhs(float(v))
+    xo, _, _ = fo2.solve_tiled_with_guess(g, sizes, oracle.SolveOptions(tile=1, tile_size=ts, cg=0))
+    assert np.abs(xo - expect).max() <= 5e-3 * np.abs(expect).max()
