@@ -226,8 +226,10 @@ def main():
         "value": value, "unit": "lattice points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5, "
-                               "Jacobi-PCG to rel. residual %g" % (side, side, depth, npts, args.tol),
+        "config": {"workload": ("config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5, "
+                                "Jacobi-PCG to rel. residual %g" % (side, side, depth, npts, args.tol)) if parallelism.startswith("slab")
+                               else ("config4: %d independent 3D %dx%dx%d lattices, %d scattered noisy value constraints each, "
+                                     "model_2=0.5, Jacobi-PCG to rel. residual %g" % (world, side, side, side, args.points, args.tol)),
                    "parallelism": parallelism, "iterations": iters, "rel_residual": rel,
                    "levels": st["num_levels"], "coarse_iterations": st["coarse_iterations"],
                    "solver": ("V-cycle PCG" if (args.multigrid and st["num_levels"] > 1) else
