@@ -764,13 +764,13 @@ void store_owned(fi_ctx* c, const DevBuf& v, float* dst, int memory)
 // tested on a single GPU against the undivided solve; it runs the same kernels as the RCCL path.
 using RankSet = std::vector<fi_ctx*>;
 
-__global__ void k_group_sum(CgScalars* const* sc, int nranks, int nvec)
+__global__ void k_group_sum(CgScalars* const* sc, int nranks, int nvec, int slot)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
 	for (int v = 0; v < nvec; ++v) {
 		double s = 0;
-		for (int r = 0; r < nranks; ++r) { s += sc[r]->sums[v]; }  // fixed order
-		for (int r = 0; r < nranks; ++r) { sc[r]->sums[v] = s; }
+		for (int r = 0; r < nranks; ++r) { s += sc[r][slot].sums[v]; }  // fixed order
+		for (int r = 0; r < nranks; ++r) { sc[r][slot].sums[v] = s; }
 	}
 }
 
@@ -820,12 +820,32 @@ void reduce_phase(RankSet& R, int nvec, CountFn count_of, StrideFn stride_of, in
 	if (R.size() > 1) {
 		fi_ctx* c0 = R[0];
 		hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, c0->stream, c0->group_scal.as<CgScalars*>(),
-		                   static_cast<int>(R.size()), nvec);
+		                   static_cast<int>(R.size()), nvec, 0);
 	} else if (R[0]->nranks > 1) {
 		allreduce_sum(R[0], R[0]->scal.as<CgScalars>()->sums, nvec);
 	}
 	if (phase >= 0) {
 		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_cg_logic, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), phase); }
+	}
+}
+
+// The same sums for the folded CG kernels of a rank set: partials -> one value per vector in scalar slot 2 of every
+// member, summed over slabs (loop-back group: a summing kernel; one slab per process: RCCL all-reduce in place).  The
+// folded kernels then take slot 2's sums as a partial list of length one and do the scalar recurrences themselves --
+// no k_cg_logic launch.  Slot 2 is written only here, between the kernels that read it.
+template <typename CountFn, typename StrideFn>
+void reduce_to_slot2(RankSet& R, int nvec, CountFn count_of, StrideFn stride_of, const double* (*partials_of)(fi_ctx*))
+{
+	for (fi_ctx* c : R) {
+		hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, partials_of(c), nvec,
+		                   stride_of(c), count_of(c), 0);
+	}
+	if (R.size() > 1) {
+		fi_ctx* c0 = R[0];
+		hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, c0->stream, c0->group_scal.as<CgScalars*>(),
+		                   static_cast<int>(R.size()), nvec, 2);
+	} else if (R[0]->nranks > 1) {
+		allreduce_sum(R[0], (R[0]->scal.as<CgScalars>() + 2)->sums, nvec);
 	}
 }
 
@@ -892,6 +912,7 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	};
 	// one context, one process: the dot-product reductions are folded into the vector kernels (3 launches per step)
 	const bool folded = R.size() == 1 && c0->nranks == 1 && !getenv("FI_NO_FOLD");
+	const bool folded_set = !folded && !getenv("FI_NO_FOLD");  // slabs: the same kernels behind a reduction over the rank set
 	int issued = 0;         // CG steps enqueued so far (the device runs step k only while it is not done)
 	int restarts_left = c0->verify_residual ? 3 : 0;
 	for (;;) {
@@ -950,6 +971,39 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 					                   nb_apply(c), c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, pr, nbf);
 					hipLaunchKernelGGL((k_cg_xp_f<T, false>), dim3(nbf), dim3(kThreads), 0, st, c->g.nown, sc + 1, sc, issued, pr, nbf,
 					                   c->r.as<T>() + o, c->dinv.as<T>() + o, c->x.as<T>() + o, c->p.as<T>() + o);
+				}
+				continue;
+			}
+			if (folded_set) {
+				// rank sets: the folded kernels on every member, fed with the dot products summed over the slabs
+				auto nbf_of = [&](fi_ctx* c) { return nbv(c) > 1024 ? 1024 : nbv(c); };
+				reduce_to_slot2(R, 1, nb_apply, zero, +[](fi_ctx* c) -> const double* { return c->partial.as<double>(); });
+				for (fi_ctx* c : R) {
+					const int64_t o   = c->g.own_first;
+					const int     nbf = nbf_of(c);
+					CgScalars*    sc  = c->scal.as<CgScalars>();
+					double*       pr  = c->partial.as<double>() + c->max_blocks;
+					if (vec_ok(c)) {
+						hipLaunchKernelGGL((k_cg_resid_f<T, true>), dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc, sc + 1, issued,
+						                   (sc + 2)->sums, 1, c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, pr, nbf);
+					} else {
+						hipLaunchKernelGGL((k_cg_resid_f<T, false>), dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc, sc + 1, issued,
+						                   (sc + 2)->sums, 1, c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, pr, nbf);
+					}
+				}
+				reduce_to_slot2(R, 2, nbf_of, nbf_of,
+				                +[](fi_ctx* c) -> const double* { return c->partial.as<double>() + c->max_blocks; });
+				for (fi_ctx* c : R) {
+					const int64_t o   = c->g.own_first;
+					const int     nbf = nbf_of(c);
+					CgScalars*    sc  = c->scal.as<CgScalars>();
+					if (vec_ok(c)) {
+						hipLaunchKernelGGL((k_cg_xp_f<T, true>), dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc + 1, sc, issued,
+						                   (sc + 2)->sums, 1, c->r.as<T>() + o, c->dinv.as<T>() + o, c->x.as<T>() + o, c->p.as<T>() + o);
+					} else {
+						hipLaunchKernelGGL((k_cg_xp_f<T, false>), dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc + 1, sc, issued,
+						                   (sc + 2)->sums, 1, c->r.as<T>() + o, c->dinv.as<T>() + o, c->x.as<T>() + o, c->p.as<T>() + o);
+					}
 				}
 				continue;
 			}
@@ -2182,7 +2236,8 @@ fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks)
 		FI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->halo = 1;
 		compute_geom(c, ndim, sizes);
-		c->scal.alloc(2 * sizeof(CgScalars));  // [0]: the state every kernel and the host look at, [1]: mid-iteration copy
+		c->scal.alloc(3 * sizeof(CgScalars));  // [0]: the state every kernel and the host look at, [1]: mid-iteration copy,
+		                                       // [2]: landing place of the dot products summed over slabs (rank sets)
 		FI_HIP_TRY(hipMemset(c->scal.p, 0, 2 * sizeof(CgScalars)));
 		FI_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->scal_host), sizeof(CgScalars), hipHostMallocDefault));
 		// default Weights (field_interpolation.hpp:75-95)
