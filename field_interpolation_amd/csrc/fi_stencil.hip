@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 	// all block records
 	auto cells_scatter = [&](uint32_t rsR, uint32_t reR, uint32_t rsB, uint32_t reB, int buf_lo, int buf_hi, int slot_lo,
 	                         int slot_hi, bool lo_ok) {
-#ifdef FI_SKIP_ROWS
+#ifdef FI_SKIP_ROWS  // timing builds of profiles/r1_ablation.md (results wrong by construction): tools/build_variant.sh
 		reR = rsR;
 #endif
 #ifdef FI_SKIP_BLK
@@ -617,9 +617,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 					store_tail(y + static_cast<int64_t>(z - 1) * P.plane, pm, po);
 				}
 			}
-#ifndef FI_E1
 			xload = load_own(z + 5);
-#endif
 			// layer z into the accumulation planes of z and z+1
 			if (layer_dense(s + 1)) {
 				const int o = (s + 1) * 4 + band;
@@ -638,9 +636,6 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 				cells_scatter(0u, 0u, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
 			}
 			prefetch_rows(s + 2, pf);
-#ifdef FI_E1
-			xload = load_own(z + 5);
-#endif
 		}
 
 		T acc2[VX], acc1[VX];
@@ -732,11 +727,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 #pragma unroll
 			for (int j = 0; j < VX; ++j) { held[j] = po[j]; }
 		} else if (active) {
-#ifdef FI_NT_STORE
-			__builtin_nontemporal_store(*reinterpret_cast<const NV*>(&out), reinterpret_cast<NV*>((y + static_cast<int64_t>(z) * P.plane) + col));
-#else
 			if (!(P.dbg & 2)) { *reinterpret_cast<V*>((y + static_cast<int64_t>(z) * P.plane) + col) = out; }
-#endif
 			dot_acc += static_cast<double>(dsum);
 		} else if (tail) {
 			store_tail(y + static_cast<int64_t>(z) * P.plane, pc, po);
