@@ -59,6 +59,29 @@ def test_field_1d_known_answer(fi):
     np.testing.assert_allclose(x, expected, rtol=0, atol=2e-7)
 
 
+def test_readme_known_answers(fi):
+    """The reference README's worked statements, on the GPU without the oracle: the 6-point example (README.md:11-40:
+    least-squares solution of its printed A and b), and "f(0) = 10, f(10) = 0 with a smoothness constraint lets the
+    solver figure out that f(20) = -10" (the straight line 10 - x)."""
+    f = fi.LatticeField([21], dtype="f64")
+    assert f.add_value_constraint([0.0], 10.0, 1.0)
+    assert f.add_value_constraint([10.0], 0.0, 1.0)
+    f.add_field_constraints(fi.Weights(model_2=0.5))
+    x = fi.solve_sparse_linear_exact(f)
+    np.testing.assert_allclose(x, 10.0 - np.arange(21), rtol=0, atol=1e-5)
+    A = np.array([[1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], [-1, 1, 0, 0, 0, 0], [0, 0, 0, 0, -1, 1],
+                  [1, -2, 1, 0, 0, 0], [0, 1, -2, 1, 0, 0], [0, 0, 1, -2, 1, 0], [0, 0, 0, 1, -2, 1]], np.float64)
+    b = np.array([4, 2, 1, -1, 0, 0, 0, 0], np.float64)
+    g = fi.LatticeField([6], dtype="f64")
+    assert g.add_value_constraint([0.0], 4.0, 1.0) and g.add_value_constraint([5.0], 2.0, 1.0)
+    assert g.add_gradient_constraint([0.0], [1.0], 1.0, fi.GradientKernel.kNearestNeighbor)
+    rows, cols = np.nonzero(A[3:4])
+    g.add_rows_coo(rows, cols, A[3, cols], b[3:4])                 # f(5) - f(4) = -1 sits on the border: a raw row
+    g.add_field_constraints(fi.Weights(model_2=1.0))
+    xg = fi.solve_sparse_linear_exact(g)
+    np.testing.assert_allclose(xg, np.linalg.lstsq(A, b, rcond=None)[0], rtol=0, atol=2e-6)
+
+
 def test_config1_1024(oracle, fi):
     """BASELINE config 1: 1-D lattice, 1024 points, 2 value + 2 gradient constraints."""
     from field_interpolation_amd import synth

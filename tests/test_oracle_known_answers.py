@@ -2,7 +2,9 @@
 
 The reference ships no tests and cannot be built here, so these are all the
 anchors there are:
-  * README.md:11-40: the 6-point worked example (8x6 matrix A and rhs b);
+  * README.md:11-40: the 6-point worked example (8x6 matrix A and rhs b); README.md "Data interpolation",
+    "Extending it to multiple dimensions", "Making it work without point normals": the rows of f(3.4) = 10 and
+    f'(3.1) = -12, the 3-D smoothness rows, and the straight line through f(0) = 10, f(10) = 0;
   * survey-time output of the reference assembly for the field_1d.cpp:20-29
     default input (resolution 12): 14 rows / 38 triplets and the float64 least-squares solution
     (cond(AtA) = 165.7);
@@ -112,3 +114,51 @@ def test_model_0_is_emitted_once_per_axis(oracle):
     f.add_field_constraints(oracle.Weights(model_0=2.0, model_2=0.0))
     _, _, diag = f.normal_equations()
     np.testing.assert_allclose(diag, 3 * 4.0)
+
+
+def test_readme_data_interpolation_rows(oracle):
+    """README.md "Data interpolation": `f(3.4) = 10` on an integer lattice becomes `0.6 f(3) + 0.4 f(4) = 10`
+    (linear-interpolation value kernel), and `f'(3.1) = -12` becomes `f(4) - f(3) = -12` (nearest-neighbour gradient
+    kernel).  fp32 weights: 3.4f - 3 = 0.4000001."""
+    f = oracle.LatticeField([8])
+    assert f.add_value_constraint([3.4], 10.0, 1.0)
+    assert f.add_gradient_constraint([3.1], [-12.0], 1.0, oracle.GRAD_NEAREST)
+    A, b = _dense(f, 8)
+    assert A.shape == (2, 8)
+    expect = np.zeros((2, 8))
+    expect[0, 3], expect[0, 4] = 0.6, 0.4
+    expect[1, 3], expect[1, 4] = -1.0, 1.0
+    np.testing.assert_allclose(A, expect, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(b, [10.0, -12.0], rtol=0, atol=1e-5)
+
+
+def test_readme_smoothness_rows_3d(oracle):
+    """README.md "Extending it to multiple dimensions": f(x,y,z) - 2 f(x+1,y,z) + f(x+2,y,z) = 0 and the same along
+    y and z: with model_2 = 1 every model row is [1, -2, 1] on three points one stride apart along one axis, rhs 0."""
+    sizes = [5, 4, 6]
+    f = oracle.LatticeField(sizes)
+    f.add_field_constraints(oracle.Weights(model_2=1.0))
+    rows, cols, vals, rhs = f.get()
+    assert not rhs.any()
+    strides = [1, sizes[0], sizes[0] * sizes[1]]
+    n_expect = sum((sizes[d] - 2) * int(np.prod(sizes)) // sizes[d] for d in range(3))
+    assert len(rhs) == n_expect
+    order = np.lexsort((cols, rows))
+    r, c, v = rows[order].reshape(-1, 3), cols[order].reshape(-1, 3), vals[order].reshape(-1, 3)
+    assert (r[:, 0] == r[:, 2]).all()
+    np.testing.assert_array_equal(v, np.tile(np.float32([1, -2, 1]), (len(r), 1)))
+    step = c[:, 1] - c[:, 0]
+    assert (c[:, 2] - c[:, 1] == step).all() and set(np.unique(step)) == set(strides)
+
+
+def test_readme_pivot_extrapolation(oracle):
+    """README.md "Making it work without point normals": with a smoothness constraint and the data f(0) = 10,
+    f(10) = 0 the solver "will be able to figure out that f(20) = -10": the least-squares solution is the straight
+    line 10 - x, whatever the weights."""
+    f = oracle.LatticeField([21])
+    assert f.add_value_constraint([0.0], 10.0, 1.0)
+    assert f.add_value_constraint([10.0], 0.0, 1.0)
+    f.add_field_constraints(oracle.Weights(model_2=0.5))
+    x = f.solve_exact()
+    np.testing.assert_allclose(x, 10.0 - np.arange(21), rtol=0, atol=2e-4)
+    assert abs(x[20] + 10.0) <= 2e-4
