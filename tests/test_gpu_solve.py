@@ -82,6 +82,25 @@ def test_readme_known_answers(fi):
     np.testing.assert_allclose(xg, np.linalg.lstsq(A, b, rcond=None)[0], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("term,degree,weight", [("model_1", 0, 1e3), ("model_2", 1, 1e3), ("model_3", 2, 1e4),
+                                                ("model_4", 3, 1e5)])
+def test_header_limit_behaviour_of_the_model_weights(fi, term, degree, weight):
+    """field_interpolation.hpp:79-85 on the GPU, without the oracle: a large model_1 averages the data, model_2 fits a
+    line, model_3 a quadratic, model_4 a cubic (fp64 CG to 1e-12; the answer is numpy's least-squares polynomial)."""
+    rng = np.random.default_rng(degree)
+    n = 40
+    at = np.sort(rng.choice(n, 12, replace=False))
+    val = rng.normal(size=12)
+    f = fi.LatticeField([n], dtype="f64")
+    for p, v in zip(at, val):
+        assert f.add_value_constraint([float(p)], float(v), 1.0)
+    f.add_field_constraints(fi.Weights(**{"model_2": 0.0, term: weight}))
+    x = fi.solve_sparse_linear_exact(f)
+    assert x is not None
+    fit = np.polyval(np.polyfit(at, val, degree), np.arange(n))
+    assert np.abs(f.solution_f64() - fit).max() <= 2e-3 * (np.abs(val).max() + np.abs(fit).max())
+
+
 def test_config1_1024(oracle, fi):
     """BASELINE config 1: 1-D lattice, 1024 points, 2 value + 2 gradient constraints."""
     from field_interpolation_amd import synth

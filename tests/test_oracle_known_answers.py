@@ -162,3 +162,33 @@ def test_readme_pivot_extrapolation(oracle):
     x = f.solve_exact()
     np.testing.assert_allclose(x, 10.0 - np.arange(21), rtol=0, atol=2e-4)
     assert abs(x[20] + 10.0) <= 2e-4
+
+
+@pytest.mark.parametrize("term,degree,weight", [("model_1", 0, 1e3), ("model_2", 1, 1e3), ("model_3", 2, 1e4),
+                                                ("model_4", 3, 1e5)])
+def test_header_limit_behaviour_of_the_model_weights(oracle, term, degree, weight):
+    """field_interpolation.hpp:79-85: a large model_1 "take[s] the average of the data", a large model_2 fits a line,
+    model_3 a quadratic, model_4 a cubic: with weight 1e3..1e5 against data weight 1 the solution is the least-squares
+    polynomial of that degree through the data (values on lattice points) to ~1e-3 of the data's range."""
+    rng = np.random.default_rng(degree)
+    n = 40
+    at = np.sort(rng.choice(n, 12, replace=False))
+    val = rng.normal(size=12)
+    f = oracle.LatticeField([n])
+    for p, v in zip(at, val):
+        assert f.add_value_constraint([float(p)], float(v), 1.0)
+    f.add_field_constraints(oracle.Weights(**{"model_2": 0.0, term: weight}))
+    x = f.solve_exact_f64()
+    fit = np.polyval(np.polyfit(at, val, degree), np.arange(n))
+    assert np.abs(x - fit).max() <= 2e-3 * (np.abs(val).max() + np.abs(fit).max())
+
+
+def test_header_model_0_pulls_the_field_to_zero(oracle):
+    """field_interpolation.hpp:78: "If this is large everything will be zero"."""
+    f = oracle.LatticeField([12, 9])
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        f.add_value_constraint([rng.uniform(0, 11), rng.uniform(0, 8)], 5.0, 1.0)
+    f.add_field_constraints(oracle.Weights(model_0=1e3, model_2=0.0))
+    x = f.solve_exact_f64()
+    assert np.abs(x).max() <= 5.0 * 1e-5
