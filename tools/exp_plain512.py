@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Scratch experiment: plain (no data) AtA apply at 512^3 / 256^3 per library variant and chunk length."""
+"""Scratch experiment: plain (no data) AtA apply at 512^3 per dtype, tile shape (FI_TXT) and chunk length (FI_ZC)."""
 import os
 import subprocess
 import sys
@@ -15,15 +15,15 @@ f.assemble()
 f.time_apply(10)
 ms = min(f.time_apply(30) for _ in range(3))
 st = f.stats()
-print("%%-6s side %%d %%s zc %%-4s: apply %%.1f us  (%%.0f GB/s algorithmic)" %% (os.environ.get("VARIANT"), side, dtype, os.environ.get("FI_ZC", "auto"), ms * 1e3, st["spmv_bytes"] / ms / 1e6), flush=True)
+print("side %%d %%s txt %%-4s zc %%-4s: apply %%.1f us  (%%.0f GB/s algorithmic)" %% (side, dtype, os.environ.get("FI_TXT", "auto"), os.environ.get("FI_ZC", "auto"), ms * 1e3, st["spmv_bytes"] / ms / 1e6), flush=True)
 ''' % ROOT
-for variant in os.environ.get("VARIANTS", "base,nt").split(","):
-    for side, dtype in [(512, "f32"), (512, "f64"), (256, "f32")]:
-        for zc in os.environ.get("ZCS", "auto,64,128").split(","):
-            env = dict(os.environ, SIDE=str(side), DTYPE=dtype, VARIANT=variant)
-            env.pop("FI_ZC", None)
+for dtype in os.environ.get("DTYPES", "f64").split(","):
+    for txt in os.environ.get("TXTS", "auto,16").split(","):
+        for zc in os.environ.get("ZCS", "auto,64,128,256").split(","):
+            env = dict(os.environ, SIDE="512", DTYPE=dtype)
+            env.pop("FI_ZC", None); env.pop("FI_TXT", None)
             if zc != "auto":
                 env["FI_ZC"] = zc
-            if variant != "base":
-                env["FI_HIP_LIB"] = os.path.join(ROOT, "exp_libs", "libfi_%s.so" % variant)
+            if txt != "auto":
+                env["FI_TXT"] = txt
             subprocess.run([sys.executable, "-c", CHILD], env=env, check=False)
