@@ -292,3 +292,39 @@ def test_packed_blocks_and_factor_rows_agree(oracle, fi, dtype, monkeypatch):
         assert np.abs(y - ref).max() <= TOL[dtype] * scale
         ys.append(y)
     assert np.abs(ys[0] - ys[1]).max() <= TOL[dtype] * scale
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_two_row_cells_on_tile_and_chunk_seams(oracle, fi, dtype, monkeypatch):
+    """Cells that hold exactly two value rows travel as record pairs in the prefetched row stream (two scatter passes);
+    on the corner of a tile AND of a chunk such a cell has 8 memberships and stays a block record.  A lattice three
+    128-wide tiles across with two points in every cell of the planes around the tile / chunk seams, and single
+    points elsewhere (so that the context is row-dominated: the non-PACK variant), against the oracle's AtA."""
+    sizes = [258, 17, 26]
+    monkeypatch.setenv("FI_ZC", "8")                        # chunk seams at z = 7|8, 15|16, 23|24
+    rng = np.random.default_rng(21)
+    cells = []
+    for cz in (6, 7, 8, 15, 22, 23):                         # cells whose corners straddle the chunk seams
+        for cy in (6, 7, 8, 14, 15):                         # ... and the 8-row tile seams
+            for cx in list(range(120, 136)) + [126, 127, 128, 255, 256]:
+                cells.append((cx, cy, cz))
+    cells = np.array(cells, np.float32)
+    two = np.repeat(cells, 2, axis=0) + rng.uniform(0.05, 0.95, (2 * len(cells), 3)).astype(np.float32)
+    one = np.stack([rng.uniform(0, s - 1, 4000) for s in sizes], 1).astype(np.float32)
+    pos = np.concatenate([two, one])
+    val = rng.normal(size=len(pos)).astype(np.float32)
+    x = rng.normal(size=int(np.prod(sizes)))
+    w = fi.Weights(model_2=0.7)
+    fo = oracle.LatticeField(sizes)
+    fo.add_field_constraints(oracle.Weights(model_2=0.7))
+    fo.add_value_constraints(pos, val, w.data_pos)
+    fg = fi.LatticeField(sizes, dtype=dtype)
+    fg.add_field_constraints(w)
+    fg.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    AtA, atb, _ = fo.normal_equations()
+    ref = AtA @ x
+    scale = (abs(AtA) @ np.abs(x)).max()
+    y1 = fg.apply_AtA(x)
+    np.testing.assert_array_equal(y1, fg.apply_AtA(x))
+    assert np.abs(y1 - ref).max() <= TOL[dtype] * scale
+    assert np.abs(fg.Atb() - atb).max() <= TOL[dtype] * np.abs(atb).max()
