@@ -476,6 +476,16 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, c
 	diag[idx] = dg;
 }
 
+// {number of runs, key of the last run, length of the last run}
+__global__ void k_rle_tail(const uint32_t* __restrict__ nruns, const uint32_t* __restrict__ uniq,
+                           const uint32_t* __restrict__ counts, uint32_t* __restrict__ out)
+{
+	const uint32_t n = nruns[0];
+	out[0] = n;
+	out[1] = n ? uniq[n - 1] : 0u;
+	out[2] = n ? counts[n - 1] : 0u;
+}
+
 inline int blocks_for(long n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
 
 template <int D>
@@ -596,13 +606,17 @@ void assemble_dim(fi_ctx* c)
 	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp2.p, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
 	                                                 counts.as<uint32_t>(), nruns.as<uint32_t>(),
 	                                                 static_cast<int>(total), st));
-	uint32_t h_runs = 0;
-	FI_HIP_TRY(hipMemcpyAsync(&h_runs, nruns.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	// the run count and the last run (the invalid rows, if any) in ONE host round trip
+	DevBuf& tail3 = c->scratch[26];
+	tail3.alloc(sizeof(uint32_t) * 3);
+	hipLaunchKernelGGL(k_rle_tail, dim3(1), dim3(1), 0, st, nruns.as<uint32_t>(), uniq.as<uint32_t>(), counts.as<uint32_t>(),
+	                   tail3.as<uint32_t>());
+	uint32_t h_tail[3] = {0, 0, 0};
+	FI_HIP_TRY(hipMemcpyAsync(h_tail, tail3.p, sizeof(h_tail), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
+	const uint32_t h_runs = h_tail[0];
 	if (h_runs == 0) { return; }
-	uint32_t h_last_key = 0, h_last_count = 0;
-	FI_HIP_TRY(hipMemcpy(&h_last_key, uniq.as<uint32_t>() + (h_runs - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
-	FI_HIP_TRY(hipMemcpy(&h_last_count, counts.as<uint32_t>() + (h_runs - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+	const uint32_t h_last_key = h_tail[1], h_last_count = h_tail[2];
 	long ncell   = h_runs;
 	long invalid_rows = 0;
 	if (h_last_key == invalid) {
@@ -673,7 +687,8 @@ void assemble_dim(fi_ctx* c)
 		}
 	}
 	FI_HIP_TRY(hipGetLastError());
-	FI_HIP_TRY(hipStreamSynchronize(st));  // temporaries die here
+	// no host round trip here: every buffer above is scratch the context owns, and whatever comes next is enqueued on
+	// the same stream
 }
 
 }  // namespace
