@@ -246,7 +246,7 @@ struct fi_ctx {
 	int        max_blocks = 0;
 
 	// assembly temporaries, kept between fi_assemble calls (hipMalloc/hipFree are slow and synchronising)
-	fi::DevBuf scratch[28];
+	fi::DevBuf scratch[32];
 
 	fi::Comm*  comm = nullptr;
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)

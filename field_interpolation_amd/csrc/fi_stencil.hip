@@ -1159,6 +1159,30 @@ void build_cell_lists(fi_ctx* c)
 	                   st, nslots, 2 * nbuckets, key_sorted.as<uint32_t>(), bound);
 	hipLaunchKernelGGL(k_split_bounds, dim3(static_cast<int>((nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
 	                   nbuckets, bound, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>());
+	// workgroups with and without cells (march_launch): classified here, read back with the totals below
+	const int nwg = P.nwg;
+	DevBuf &ids = c->scratch[27], &has = c->scratch[28], &has_not = c->scratch[29], &nsel = c->scratch[30];  // pos / slot_sorted are still live
+	ids.alloc(sizeof(uint32_t) * nwg);
+	has.alloc(nwg);
+	has_not.alloc(nwg);
+	nsel.alloc(sizeof(int) * 2);
+	m.wg_cells.alloc(sizeof(uint32_t) * nwg);
+	m.wg_plain.alloc(sizeof(uint32_t) * nwg);
+	hipLaunchKernelGGL(k_classify_wg, dim3((nwg + kThreads - 1) / kThreads), dim3(kThreads), 0, st, nwg, (P.zc + 1) * 4,
+	                   m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), ids.as<uint32_t>(), has.as<uint8_t>(),
+	                   has_not.as<uint8_t>());
+	size_t tb3 = 0;
+	FI_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
+	                                         nsel.as<int>(), nwg, st));
+	tmp.alloc(tb3);
+	FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
+	                                         nsel.as<int>(), nwg, st));
+	FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has_not.as<uint8_t>(),
+	                                         m.wg_plain.as<uint32_t>(), nsel.as<int>() + 1, nwg, st));
+	int counts[2] = {0, 0};
+	FI_HIP_TRY(hipMemcpyAsync(counts, nsel.p, sizeof(counts), hipMemcpyDeviceToHost, st));
+	std::vector<uint8_t> h_has(static_cast<size_t>(nwg));
+	FI_HIP_TRY(hipMemcpyAsync(h_has.data(), has.p, static_cast<size_t>(nwg), hipMemcpyDeviceToHost, st));
 	uint32_t totals[2] = {0, 0}, uniq[2] = {0, 0}, uniq64[128];
 	FI_HIP_TRY(hipMemcpyAsync(&totals[0], m.lay_row.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipMemcpyAsync(&totals[1], m.lay_blk.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1184,32 +1208,7 @@ void build_cell_lists(fi_ctx* c)
 		                   m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(), m.coef_blk.as<T>());
 	}
 	FI_HIP_TRY(hipGetLastError());
-	// workgroups with and without cells (march_launch)
 	{
-		const int nwg = P.nwg;
-		DevBuf &ids = c->scratch[15], &has = c->scratch[16], &has_not = c->scratch[17], &nsel = c->scratch[18];
-		ids.alloc(sizeof(uint32_t) * nwg);
-		has.alloc(nwg);
-		has_not.alloc(nwg);
-		nsel.alloc(sizeof(int) * 2);
-		m.wg_cells.alloc(sizeof(uint32_t) * nwg);
-		m.wg_plain.alloc(sizeof(uint32_t) * nwg);
-		hipLaunchKernelGGL(k_classify_wg, dim3((nwg + kThreads - 1) / kThreads), dim3(kThreads), 0, st, nwg, (P.zc + 1) * 4,
-		                   m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), ids.as<uint32_t>(), has.as<uint8_t>(),
-		                   has_not.as<uint8_t>());
-		size_t tb3 = 0;
-		FI_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
-		                                         nsel.as<int>(), nwg, st));
-		tmp.alloc(tb3);
-		FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
-		                                         nsel.as<int>(), nwg, st));
-		FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has_not.as<uint8_t>(),
-		                                         m.wg_plain.as<uint32_t>(), nsel.as<int>() + 1, nwg, st));
-		int counts[2] = {0, 0};
-		FI_HIP_TRY(hipMemcpyAsync(counts, nsel.p, sizeof(counts), hipMemcpyDeviceToHost, st));
-		std::vector<uint8_t> h_has(static_cast<size_t>(nwg));
-		FI_HIP_TRY(hipMemcpyAsync(h_has.data(), has.p, static_cast<size_t>(nwg), hipMemcpyDeviceToHost, st));
-		FI_HIP_TRY(hipStreamSynchronize(st));
 		m.n_wg_cells = counts[0];
 		m.n_wg_plain = counts[1];
 		// Plain workgroups as runs of consecutive empty chunks of one tile: a split launch cuts the lattice into short
