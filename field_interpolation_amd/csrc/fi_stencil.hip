@@ -962,10 +962,12 @@ int pick_chunk(int tiles_xy, int nz_own, int slots, int forced, int zc_max)
 		const int v = atoi(env);
 		if (v > 0) { return v > zc_max ? zc_max : v; }
 	}
-	int    best = 4;
+	// small lattices (the coarse levels of a cascade) do not fill the CUs with 4-plane chunks: down to single planes
+	// (64^3 with 1 M points: 44 us at 4 planes, 29 us at 2)
+	int    best = 1;
 	double best_cost = 1e300;
-	for (int zc = 4; zc <= zc_max; ++zc) {
-		if (zc > nz_own && zc > 4) { break; }
+	for (int zc = 1; zc <= zc_max; ++zc) {
+		if (zc > nz_own && zc > 1) { break; }
 		const int64_t nwg = static_cast<int64_t>(tiles_xy) * ((nz_own + zc - 1) / zc);
 		const double  r   = static_cast<double>(nwg) / slots;
 		const double  rounds = r < 6.0 ? static_cast<double>((nwg + slots - 1) / slots) : r;
