@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--levels", type=int, default=2, help="coarser levels for the coarse-to-fine start (0: plain Jacobi-PCG)")
     ap.add_argument("--coarse-tol", type=float, default=1e-5)
     ap.add_argument("--multigrid", action="store_true", help="V-cycle preconditioned CG instead of Jacobi-PCG")
+    ap.add_argument("--poly", type=int, default=4, help="terms of the Chebyshev polynomial preconditioner (0: Jacobi-PCG)")
+    ap.add_argument("--poly-ratio", type=float, default=10.0)
     args = ap.parse_args()
 
     import numpy as np
@@ -163,6 +165,8 @@ def main():
             field.set_levels(args.levels, args.coarse_tol)
             if args.multigrid:
                 field.set_multigrid(True)
+        if args.poly > 1 and not args.multigrid:
+            field.set_polynomial(args.poly, args.poly_ratio)
 
         def step():
             field.clear_points()

@@ -112,6 +112,13 @@ class LatticeField:
         check(_capi.lib().fi_slab_range(self._h, C.byref(lo), C.byref(hi)))
         self.slab = (lo.value, hi.value)
 
+    def point_range(self):
+        """[lo, hi) of the slowest coordinate of the data points this rank has to be given (fi_slab_point_range:
+        covers the cells touching the slab on every level set so far -- call after set_levels)."""
+        lo, hi = C.c_float(0), C.c_float(0)
+        check(_capi.lib().fi_slab_point_range(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h and _capi._LIB is not None and not getattr(self, "_borrowed", False):
@@ -271,6 +278,13 @@ class LatticeField:
         check(_capi.lib().fi_set_option(self._h, 5, 1.0 if on else 0.0))
         self._dirty = True
 
+    def set_polynomial(self, terms, ratio=None):
+        """FI_OPT_POLY_TERMS / FI_OPT_POLY_RATIO: CG preconditioned by a Chebyshev polynomial of `terms` terms
+        (0: the Jacobi diagonal).  No re-assembly needed."""
+        check(_capi.lib().fi_set_option(self._h, 6, float(terms)))
+        if ratio is not None:
+            check(_capi.lib().fi_set_option(self._h, 7, float(ratio)))
+
     def jacobi(self, guess, num_iterations, weight):
         self._ready()
         g, kg, _kg = _buf(guess)
@@ -385,6 +399,10 @@ class LatticeGroup:
     def set_mixed_precision(self, on=True):
         for m in self.members:
             m.set_mixed_precision(on)
+
+    def set_polynomial(self, terms, ratio=None):
+        for m in self.members:
+            m.set_polynomial(terms, ratio)
 
     def assemble(self):
         check(_capi.lib().fi_group_assemble(self._g))

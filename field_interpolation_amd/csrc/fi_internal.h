@@ -130,6 +130,8 @@ struct MarchState {
 	bool        valid = false;  // the marching kernel applies to this context
 	bool        fused = false;  // cell blocks are applied inside the marching kernel
 	MarchParams P{};
+	MarchParams Pplain{};  // chunking for launches of the plain (model-only) variant over the whole lattice: the
+	                       // polynomial preconditioner's steps (4 workgroups per CU, longer chunks)
 	// self-contained records per (workgroup, layer); two kinds: a cell holding a single data row (8
 	// coefficients) or a cell holding several: up to 8 factor rows in a 64-coefficient slot
 	DevBuf      lay_row, lay_blk;  // uint32[nwg*(zc+1)+1] record ranges
@@ -239,6 +241,9 @@ struct fi_ctx {
 	// multigrid work vectors of this level: V-cycle rhs / result, smoother residual and direction
 	fi::DevBuf mg_b, mg_x, mg_r, mg_d;
 	double     lambda_max = 0;    // estimate of the largest eigenvalue of Dinv * AtA on this level
+	int        poly_terms = 0;    // > 1: CG preconditioned by a Chebyshev polynomial of that many terms (cg_run_poly)
+	double     poly_ratio = 10.0; // the polynomial's interval is [hi / ratio, hi], hi = 1.1 * poly_lambda
+	double     poly_lambda = 0;   // largest eigenvalue of diag(A_model)^-1 A_model (power method, once per model)
 	int        mg_mode = 0;       // 0: Jacobi-PCG (+ cascade start when levels exist); 1: V-cycle preconditioned CG
 	fi::DevBuf partial;       // double[4 * max_blocks]
 	fi::DevBuf scal;          // CgScalars
@@ -280,6 +285,13 @@ int  stencil_partials(const fi_ctx* c);
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
 
 bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also applies the cell blocks
+// one step of the Chebyshev polynomial preconditioner / of the power method through the plain marching kernel
+// (fi_stencil.hip, ChebEpi); z / v with valid ghost planes; partials: one per workgroup of the launch
+bool stencil_cheb_available(const fi_ctx* c);
+int  stencil_cheb_partials(const fi_ctx* c);
+void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double c1,
+                       double c2, double* partial);
+void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 
 // fi_stencil2d.hip: LDS-tiled kernel for 2-D lattices (model_0/1/2), called through the stencil_* entry points
 void tile2d_prepare(fi_ctx* c);

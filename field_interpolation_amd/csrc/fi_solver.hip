@@ -725,6 +725,7 @@ void ensure_vectors(fi_ctx* c)
 	FI_HIP_TRY(hipMemsetAsync(c->q.p, 0, es * g.nloc, c->stream));
 	int nb = apply_num_partials(c);
 	if (nb < 4096) { nb = 4096; }  // also covers the plain kernels of the tile operator (fi_tile_pass)
+	if (stencil_cheb_available(c) && nb < stencil_cheb_partials(c)) { nb = stencil_cheb_partials(c); }
 	c->max_blocks = nb;
 	c->partial.alloc(sizeof(double) * 4 * nb);
 	c->vectors_ready = true;
@@ -1088,6 +1089,10 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
 }
 
+bool poly_ok(const fi_ctx* c);
+template <typename T>
+void cg_run_poly(RankSet& R, int max_iterations, float tol);
+
 // Coarse-to-fine start (the reference's own remedy for large lattices: solve a coarser lattice, upscale, use
 // as the guess -- src/sdf_field.cpp:272-288, README.md "My resolution is huge"): every coarser level is
 // solved from the interpolated solution of the level below it, to a loose tolerance; x of `c` receives the
@@ -1118,7 +1123,15 @@ void cascade_guess(RankSet& R)
 		RankSet& lc = chains[k];
 		RankSet& lf = chains[k - 1];
 		try {
-			cg_run<T>(lc, 0, static_cast<float>(root->coarse_tol));
+			for (fi_ctx* l : lc) {  // the levels solve the way the finest level does
+				l->poly_terms = root->poly_terms;
+				l->poly_ratio = root->poly_ratio;
+			}
+			if (poly_ok(lc[0])) {
+				cg_run_poly<T>(lc, 0, static_cast<float>(root->coarse_tol));
+			} else {
+				cg_run<T>(lc, 0, static_cast<float>(root->coarse_tol));
+			}
 		} catch (const Fail& f) {
 			if (f.code != FI_ERR_BREAKDOWN) { throw; }  // a coarse level without data: keep what it has
 		}
@@ -1513,6 +1526,10 @@ void vcycle(RankSet& R, Vec b, Vec x)
 {
 	const int deg = mg_degree();
 	const double ratio = mg_ratio();
+	if (getenv("FI_MG_POLY")) {  // experiment: the polynomial alone as the preconditioner, no coarse correction
+		cheb_smooth<T>(R, b, x, deg, ratio, true);
+		return;
+	}
 	if (!R[0]->coarse) {  // coarsest level: a longer polynomial over a wider band
 		cheb_smooth<T>(R, b, x, 4 * deg + 4, 10.0 * ratio, true);
 		return;
@@ -1806,6 +1823,441 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
 }
 
+
+// the polynomial preconditioner runs through the 3-D marching kernel; contexts it does not cover (1-D / 2-D lattices,
+// model_3 / model_4 / gradient_smoothness, rows given as triplets) keep the Jacobi diagonal
+bool poly_ok(const fi_ctx* c) { return c->poly_terms > 1 && stencil_cheb_available(c) && c->generic.ntrip == 0 && c->tile_ts == 0; }
+
+// ---- CG preconditioned by a Chebyshev polynomial in Dinv (A_model + diag(A_data)) ---------------------------------
+// z = M r,  M = p_d(Dinv A~) Dinv  with  A~ = the model rows + the DIAGONAL of the data rows: symmetric positive definite
+// whenever the interval's upper end bounds the spectrum of Dinv A~, which is at most max(lambda_max(m^-1 A_model), 1)
+// (m = diag(A_model); the data diagonal only lowers the Rayleigh quotients) -- a number of the lattice and the model
+// weights alone, found once by the power method (poly_lambda) and kept across assembles.  Iteration counts equal
+// those of the polynomial in the full operator (profiles/r2_ablation.md), but a step of the polynomial never reads a
+// cell record and is ONE launch of the plain marching kernel with the recurrence in its epilogue: 5 lattice passes.
+// An outer iteration of d terms = 1 full apply (2 passes + records) + k_pcg_resid (5) + (d - 1) steps (4-5 each) +
+// k_pcg_xp (5): 7 passes per operator application at d = 4 against the 12 of a Jacobi-PCG iteration, and TWO
+// reductions (p.q; r.r with r.z) per outer iteration instead of two per application.
+//
+// The scalar recurrences are folded into the vector kernels like in cg_run: k_pcg_resid reads slot 0, sums the apply's
+// p.q partials (or takes the all-reduced value from slot 2) and publishes alpha in slot 1; k_pcg_xp reads slot 1, sums
+// r.r and r.z, publishes beta, the iteration count and the stop flag in slot 0.
+
+// first half: alpha, r -= alpha q, z1 = Dinv r / theta, partials r.r and r.z1  (reads r, q, Dinv; writes r, z1)
+// phase 0 / 2 (start / restart from b - A x): r = b - q instead, and b.b on the start
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScalars* __restrict__ in, CgScalars* __restrict__ mid,
+                                                         int tag, int phase, const double* __restrict__ pq_partial, int pq_count,
+                                                         const T* __restrict__ b, const T* __restrict__ q,
+                                                         const T* __restrict__ dinv, T* __restrict__ r, T* __restrict__ z1,
+                                                         T inv_theta, double* __restrict__ prr, double* __restrict__ prz,
+                                                         double* __restrict__ pbb)
+{
+	double alpha_d = 0.0;
+	if (phase == 1) {
+		if (in->done) { return; }
+		const double pq  = sum_partials(pq_partial, pq_count);
+		const bool   bad = !(pq > 0.0) || !isfinite(pq);
+		alpha_d = in->rz / pq;
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			CgScalars s = *in;
+			s.pq    = pq;
+			s.alpha = alpha_d;
+			s.tag   = tag;
+			if (bad) { s.done = 2; }
+			*mid = s;
+		}
+		if (bad) { return; }
+	} else if (blockIdx.x == 0 && threadIdx.x == 0) {
+		CgScalars s = *in;
+		s.alpha = 0.0;
+		s.tag   = tag;
+		s.done  = 0;
+		*mid = s;
+	}
+	using V = typename Vec16<T>::V;
+	constexpr int N = VEC ? Vec16<T>::N : 1;
+	const T alpha = static_cast<T>(alpha_d);
+	double acc[3] = {0, 0, 0};
+	const int64_t nv = n / N;
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		T rv[N], qv[N], dv[N], zv[N], bv[N];
+		if (VEC) {
+			ld16_nt(qv, q, i);
+			*reinterpret_cast<V*>(dv) = reinterpret_cast<const V*>(dinv)[i];
+			if (phase == 1) { *reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i]; } else { ld16_nt(bv, b, i); }
+		} else {
+			qv[0] = q[i]; dv[0] = dinv[i];
+			if (phase == 1) { rv[0] = r[i]; } else { bv[0] = b[i]; }
+		}
+		T s0 = T(0), s1 = T(0), s2 = T(0);
+#pragma unroll
+		for (int j = 0; j < N; ++j) {
+			if (phase == 1) { rv[j] -= alpha * qv[j]; } else { rv[j] = bv[j] - qv[j]; s2 += bv[j] * bv[j]; }
+			zv[j] = inv_theta * dv[j] * rv[j];
+			s0 += rv[j] * rv[j];
+			s1 += rv[j] * zv[j];
+		}
+		if (VEC) {
+			reinterpret_cast<V*>(r)[i]  = *reinterpret_cast<V*>(rv);
+			reinterpret_cast<V*>(z1)[i] = *reinterpret_cast<V*>(zv);
+		} else {
+			r[i] = rv[0]; z1[i] = zv[0];
+		}
+		acc[0] += static_cast<double>(s0);
+		acc[1] += static_cast<double>(s1);
+		acc[2] += static_cast<double>(s2);
+	}
+	double out[3];
+	block_sum<3>(acc, out);
+	if (threadIdx.x == 0) {
+		prr[blockIdx.x] = out[0];
+		prz[blockIdx.x] = out[1];
+		if (phase == 0) { pbb[blockIdx.x] = out[2]; }
+	}
+}
+
+// second half: beta and the stop test, x += alpha p, p = z + beta p            (reads x, p, z; writes x, p)
+// phase 0: start (b.b, tolerance, p = z); phase 2: restart from the true residual (p = z, verified stop)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars* __restrict__ mid, CgScalars* __restrict__ out_sc,
+                                                      int tag, int phase, const double* __restrict__ prr, int nrr,
+                                                      const double* __restrict__ prz, int nrz, const double* __restrict__ pbb,
+                                                      int nbb, const T* __restrict__ z, T* __restrict__ x, T* __restrict__ p)
+{
+	if (mid->tag != tag) { return; }  // the first half of this iteration did not run: the solve had finished
+	if (mid->done == 2) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = *mid; }
+		return;
+	}
+	const double rr = sum_partials(prr, nrr);
+	const double rz = sum_partials(prz, nrz);
+	CgScalars s = *mid;
+	double beta_d = 0.0;
+	if (phase == 1) {
+		beta_d = rz / s.rz;
+		s.iter += 1;
+		s.done = !isfinite(rr) || !isfinite(rz) ? 2 : (!(rr > s.tol2) ? 1 : (s.iter >= s.max_iter ? 3 : 0));
+	} else {
+		if (phase == 0) {
+			s.bb   = sum_partials(pbb, nbb);
+			s.tol2 = s.tol2 * s.bb;
+			s.iter = 0;
+		} else {
+			s.restarts += 1;
+			s.true_rr = rr;
+		}
+		s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase == 2 ? 5 : 1) : (s.iter >= s.max_iter ? 3 : 0)));
+	}
+	s.rz_new = rz;
+	s.rr     = rr;
+	s.beta   = beta_d;
+	s.rz     = rz;
+	if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = s; }
+	if (s.done == 2) { return; }
+	using V = typename Vec16<T>::V;
+	constexpr int N = VEC ? Vec16<T>::N : 1;
+	const T    alpha = static_cast<T>(s.alpha);
+	const T    beta  = static_cast<T>(beta_d);
+	const bool go_on = s.done == 0;
+	const int64_t nv = n / N;
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		T xv[N], pv[N], zv[N];
+		if (phase == 1) {
+			if (VEC) {
+				ld16_nt(xv, x, i);
+				*reinterpret_cast<V*>(pv) = reinterpret_cast<const V*>(p)[i];
+			} else {
+				xv[0] = x[i]; pv[0] = p[i];
+			}
+#pragma unroll
+			for (int j = 0; j < N; ++j) { xv[j] += alpha * pv[j]; }
+			if (VEC) { st16_nt(x, i, xv); } else { x[i] = xv[0]; }
+		} else {
+#pragma unroll
+			for (int j = 0; j < N; ++j) { pv[j] = T(0); }
+		}
+		if (go_on) {
+			if (VEC) { ld16_nt(zv, z, i); } else { zv[0] = z[i]; }
+#pragma unroll
+			for (int j = 0; j < N; ++j) { pv[j] = zv[j] + beta * pv[j]; }
+			if (VEC) { reinterpret_cast<V*>(p)[i] = *reinterpret_cast<V*>(pv); } else { p[i] = pv[0]; }
+		}
+	}
+}
+
+// sums of up to three partial lists of different lengths into sums[0..2] of a scalar slot (rank sets: the values
+// then cross the slabs by k_group_sum / the all-reduce)
+__global__ __launch_bounds__(kThreads) void k_reduce3(CgScalars* sc, const double* __restrict__ pa, int na,
+                                                       const double* __restrict__ pb, int nb, const double* __restrict__ pc,
+                                                       int nc)
+{
+	const double a = sum_partials(pa, na);
+	const double b = pb ? sum_partials(pb, nb) : 0.0;
+	const double c = pc ? sum_partials(pc, nc) : 0.0;
+	if (threadIdx.x == 0) {
+		sc->sums[0] = a;
+		sc->sums[1] = b;
+		sc->sums[2] = c;
+	}
+}
+
+template <typename T>
+void ensure_poly_vectors(fi_ctx* c)
+{
+	ensure_vectors(c);
+	const size_t bytes = sizeof(T) * c->g.nloc;
+	const bool fresh = c->mg_x.bytes < bytes || c->mg_d.bytes < bytes;
+	c->mg_x.alloc(bytes);
+	c->mg_d.alloc(bytes);
+	if (fresh) {  // ghost planes outside the lattice are never written: keep them finite
+		FI_HIP_TRY(hipMemsetAsync(c->mg_x.p, 0, bytes, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->mg_d.p, 0, bytes, c->stream));
+	}
+}
+
+// largest eigenvalue of diag(A_model)^-1 A_model by the power method (16 steps through the marching kernel's epilogue,
+// unnormalised: growth <= 4^16): a property of the lattice and the model weights, kept until fi_set_model
+template <typename T>
+void estimate_poly_lambda(RankSet& R)
+{
+	for (fi_ctx* c : R) { ensure_poly_vectors<T>(c); }
+	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	for (fi_ctx* c : R) {
+		CgScalars clear{};
+		FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, c->stream));
+		hipLaunchKernelGGL((k_seed<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, global_first(c),
+		                   c->mg_x.as<T>() + c->g.own_first);
+	}
+	const int steps = 16;
+	double sums[2] = {0, 0};
+	DevBuf fi_ctx::*cur = &fi_ctx::mg_x, fi_ctx::*nxt = &fi_ctx::mg_d;
+	for (int k = 0; k < steps; ++k) {
+		halo_exchange(R, cur);
+		for (fi_ctx* c : R) { stencil_power_step(c, (c->*cur).p, (c->*nxt).p, c->partial.as<double>()); }
+		if (k >= steps - 2) {
+			for (fi_ctx* c : R) {
+				hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, c->partial.as<double>(),
+				                   stencil_cheb_partials(c), static_cast<const double*>(nullptr), 0, static_cast<const double*>(nullptr), 0);
+			}
+			if (R.size() > 1) {
+				hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, R[0]->stream, R[0]->group_scal.as<CgScalars*>(),
+				                   static_cast<int>(R.size()), 1, 2);
+			} else if (R[0]->nranks > 1) {
+				allreduce_sum(R[0], (R[0]->scal.as<CgScalars>() + 2)->sums, 1);
+			}
+			fi_ctx* c0 = R[0];
+			FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, c0->scal.as<CgScalars>() + 2, sizeof(CgScalars), hipMemcpyDeviceToHost, c0->stream));
+			FI_HIP_TRY(hipStreamSynchronize(c0->stream));
+			sums[k - (steps - 2)] = c0->scal_host->sums[0];
+		}
+		std::swap(cur, nxt);
+	}
+	const double lambda = (sums[0] > 0 && sums[1] > 0 && std::isfinite(sums[1])) ? std::sqrt(sums[1] / sums[0]) : 4.0;
+	for (fi_ctx* c : R) { c->poly_lambda = lambda; }
+}
+
+template <typename T>
+void cg_run_poly(RankSet& R, int max_iterations, float tol)
+{
+	fi_ctx* c0 = R[0];
+	hipStream_t st = c0->stream;
+	const int terms = c0->poly_terms;
+	if (max_iterations <= 0) {
+		const int64_t dflt = 2 * static_cast<int64_t>(c0->g.gn[0]) * c0->g.gn[1] * c0->g.gn[2];
+		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
+	}
+	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
+	for (fi_ctx* c : R) { ensure_poly_vectors<T>(c); }
+	if (!(c0->poly_lambda > 0)) { estimate_poly_lambda<T>(R); }
+
+	hipEvent_t e0, e1;
+	FI_HIP_TRY(hipEventCreate(&e0));
+	FI_HIP_TRY(hipEventCreate(&e1));
+	FI_HIP_TRY(hipEventRecord(e0, st));
+
+	// Chebyshev interval and recurrence constants (the same polynomial as cheb_smooth)
+	const double lam = c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0;
+	const double hi = 1.1 * lam, lo = hi / (c0->poly_ratio > 1.0 ? c0->poly_ratio : 10.0);
+	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	std::vector<double> c1s, c2s;
+	{
+		double rho = 1.0 / sigma;
+		for (int k = 1; k < terms; ++k) {
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			c1s.push_back(rho_new * rho);
+			c2s.push_back(2.0 * rho_new / delta);
+			rho = rho_new;
+		}
+	}
+
+	CgScalars init{};
+	init.tol2     = tolerance * tolerance;
+	init.max_iter = max_iterations;
+	init.rz       = 1.0;
+	reset_scalars(R, init);
+
+	auto nbf_of   = [](fi_ctx* c) { const int b = stream_blocks(c->g.nown); return b > 1024 ? 1024 : b; };
+	auto vec_ok = [](fi_ctx* c) {
+		constexpr int N = Vec16<T>::N;
+		return (c->g.own_first % N == 0) && (c->g.nown % N == 0);
+	};
+	const bool single = R.size() == 1 && c0->nranks == 1;
+	// partial regions of every member: [0] apply p.q, [1] r.r, [2] r.z, [3] b.b
+	auto region = [](fi_ctx* c, int k) { return c->partial.as<double>() + static_cast<size_t>(k) * c->max_blocks; };
+	auto slot2 = [](fi_ctx* c) { return (c->scal.as<CgScalars>() + 2)->sums; };
+	auto cross = [&](int nvec) {  // sums[0..nvec) of slot 2 over the slabs
+		if (R.size() > 1) {
+			hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, st, c0->group_scal.as<CgScalars*>(), static_cast<int>(R.size()), nvec, 2);
+		} else if (c0->nranks > 1) {
+			allreduce_sum(c0, slot2(c0), nvec);
+		}
+	};
+	const Vec ZA = &fi_ctx::mg_x, ZB = &fi_ctx::mg_d;
+
+	int tag = 0;
+	// one pass of the recurrence: phase 1 = a CG step (the apply of p has been launched), 0 / 2 = start / restart (the
+	// apply of x has been launched)
+	auto half_steps = [&](int phase) {
+		++tag;
+		if (!single && phase == 1) {
+			for (fi_ctx* c : R) {
+				hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, region(c, 0),
+				                   apply_num_partials(c), static_cast<const double*>(nullptr), 0, static_cast<const double*>(nullptr), 0);
+			}
+			cross(1);
+		}
+		for (fi_ctx* c : R) {
+			const int64_t o = c->g.own_first;
+			const int     nbf = nbf_of(c);
+			CgScalars*    sc = c->scal.as<CgScalars>();
+			const double* pq = single ? region(c, 0) : slot2(c);
+			const int     npq = single ? apply_num_partials(c) : 1;
+			auto go = [&](auto kernel) {
+				hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc, sc + 1, tag, phase, pq, npq,
+				                   c->atb.as<T>() + o, c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, vown<T>(c, ZA),
+				                   static_cast<T>(1.0 / theta), region(c, 1), region(c, 2), region(c, 3));
+			};
+			if (vec_ok(c)) { go(k_pcg_resid<T, true>); } else { go(k_pcg_resid<T, false>); }
+		}
+		// the polynomial: z_{k+1} from z_k (ZA / ZB alternate; the result ends in `zfin`)
+		Vec zin = ZA, zout = ZB;
+		for (int k = 1; k < terms; ++k) {
+			halo_exchange(R, zin);
+			for (fi_ctx* c : R) {
+				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1],
+				                  c2s[k - 1], region(c, 2));
+			}
+			std::swap(zin, zout);
+		}
+		const Vec zfin = zin;
+		if (!single) {
+			for (fi_ctx* c : R) {
+				hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, region(c, 1), nbf_of(c),
+				                   region(c, 2), terms > 1 ? stencil_cheb_partials(c) : nbf_of(c),
+				                   phase == 0 ? region(c, 3) : static_cast<const double*>(nullptr), nbf_of(c));
+			}
+			cross(phase == 0 ? 3 : 2);
+		}
+		for (fi_ctx* c : R) {
+			const int64_t o = c->g.own_first;
+			const int     nbf = nbf_of(c);
+			CgScalars*    sc = c->scal.as<CgScalars>();
+			const int     nrz = terms > 1 ? stencil_cheb_partials(c) : nbf;
+			auto go = [&](auto kernel) {
+				if (single) {
+					hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc + 1, sc, tag, phase, region(c, 1), nbf,
+					                   region(c, 2), nrz, region(c, 3), nbf, vown<T>(c, zfin), c->x.as<T>() + o, c->p.as<T>() + o);
+				} else {
+					hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc + 1, sc, tag, phase, slot2(c), 1,
+					                   slot2(c) + 1, 1, slot2(c) + 2, 1, vown<T>(c, zfin), c->x.as<T>() + o, c->p.as<T>() + o);
+				}
+			};
+			if (vec_ok(c)) { go(k_pcg_xp<T, true>); } else { go(k_pcg_xp<T, false>); }
+		}
+	};
+	auto start = [&](int phase) {  // r = b - A x, z = M r, p = z
+		halo_exchange(R, &fi_ctx::x);
+		for (fi_ctx* c : R) { apply_AtA(c, c->x.p, c->q.p, nullptr); }
+		half_steps(phase);
+	};
+	start(0);
+
+	int samples = 0;
+	while (static_cast<int>(c0->ev.size()) < 2 * kMaxSamples) {
+		hipEvent_t e;
+		FI_HIP_TRY(hipEventCreate(&e));
+		c0->ev.push_back(e);
+	}
+	double limit_s = 600.0;
+	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
+	const auto wall0 = std::chrono::steady_clock::now();
+	bool timed_out = false;
+	CgScalars* sc0 = c0->scal.as<CgScalars>();
+	int restarts_left = c0->verify_residual ? 3 : 0;
+	const int burst = terms >= 4 ? 4 : 8;  // outer iterations between two looks at the stop flag
+	int issued = 0;
+	for (;;) {
+		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		if (c0->scal_host->done) {
+			if (c0->scal_host->done != 1 || restarts_left <= 0) { break; }
+			--restarts_left;  // the recurrence met the tolerance: check b - A x, go on from it if it misses
+			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), 0); }
+			start(2);
+			continue;
+		}
+		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
+			timed_out = true;
+			break;
+		}
+		for (int k = 0; k < burst; ++k) {
+			++issued;
+			halo_exchange(R, &fi_ctx::p);
+			const bool sample = samples < kMaxSamples && (issued & 1) == 1;
+			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
+			for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, region(c, 0)); }
+			if (sample) {
+				FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples + 1], st));
+				++samples;
+			}
+			half_steps(1);
+		}
+		FI_HIP_TRY(hipGetLastError());
+	}
+	FI_HIP_TRY(hipEventRecord(e1, st));
+	FI_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+
+	const CgScalars h = *c0->scal_host;
+	int used = samples;
+	if ((h.iter + 1) / 2 < used) { used = (h.iter + 1) / 2; }  // sample k belongs to outer iteration 2k + 1
+	double sum_ms = 0;
+	for (int k = 0; k < used; ++k) {
+		float t = 0;
+		FI_HIP_TRY(hipEventElapsedTime(&t, c0->ev[2 * k], c0->ev[2 * k + 1]));
+		sum_ms += t;
+	}
+	for (fi_ctx* c : R) {
+		c->stats.spmv_samples = used;
+		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
+		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		c->stats.solve_ms     = ms;
+		c->stats.iterations   = h.iter;
+		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
+		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+		c->stats.restarts     = h.restarts;
+		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
+		if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
+	}
+	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
+}
+
 template <typename T>
 void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
                 float* rel_residual, int memory)
@@ -1826,6 +2278,8 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	}
 	if (c->mg_mode == 1 && (c->coarse || (c->twin && c->twin->coarse))) {
 		cg_run_mg<T>(R, max_iterations, tol);
+	} else if (poly_ok(c)) {
+		cg_run_poly<T>(R, max_iterations, tol);
 	} else {
 		cg_run<T>(R, max_iterations, tol);
 	}
@@ -2367,6 +2821,20 @@ int fi_slab_range(const fi_ctx* c, int* lo, int* hi)
 	FI_API_END
 }
 
+int fi_slab_point_range(const fi_ctx* c, float* lo, float* hi)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	// Level l halves the lattice l times (coarse plane k sits on fine plane k * 2^l; this rank keeps coarse planes
+	// ceil(slab_lo / 2^l) .. ceil(slab_hi / 2^l) - 1), and a rank needs every cell that touches an owned plane of
+	// that level plus one cell of margin for the nearest-neighbour kernels: 2 cells of 2^l fine planes below, 1 above.
+	const int L = c->levels_wanted > 0 ? c->levels_wanted : 0;
+	const float cell = static_cast<float>(1 << (L < 20 ? L : 20));
+	if (lo) { *lo = static_cast<float>(c->slab_lo) - 2.0f * cell; }
+	if (hi) { *hi = static_cast<float>(c->slab_hi) + cell; }
+	FI_API_END
+}
+
 int fi_set_model(fi_ctx* c, const fi_weights* w)
 {
 	FI_API_BEGIN
@@ -2375,6 +2843,10 @@ int fi_set_model(fi_ctx* c, const fi_weights* w)
 	c->w         = *w;
 	c->model_set = true;
 	c->assembled = false;
+	for (fi_ctx* l = c; l; l = l->coarse) { l->poly_lambda = 0; }  // the polynomial preconditioner's bound belongs to the model
+	if (c->twin) {
+		for (fi_ctx* l = c->twin; l; l = l->coarse) { l->poly_lambda = 0; }
+	}
 	FI_API_END
 }
 
@@ -2561,6 +3033,14 @@ int fi_set_option(fi_ctx* c, int option, double value)
 		FI_REQUIRE(value == 0.0 || c->dtype == FI_F64, FI_ERR_INVALID, "FI_OPT_MIXED_PRECISION needs an FI_F64 context");
 		c->mixed = value != 0.0 ? 1 : 0;
 		c->assembled = false;
+		break;
+	case FI_OPT_POLY_TERMS:
+		FI_REQUIRE(value >= 0 && value <= 32, FI_ERR_INVALID, "FI_OPT_POLY_TERMS must be 0..32");
+		c->poly_terms = static_cast<int>(value);
+		break;
+	case FI_OPT_POLY_RATIO:
+		FI_REQUIRE(value > 1.0, FI_ERR_INVALID, "FI_OPT_POLY_RATIO must be above 1");
+		c->poly_ratio = value;
 		break;
 	default: FI_REQUIRE(false, FI_ERR_INVALID, "unknown option %d", option);
 	}
@@ -2861,6 +3341,9 @@ int fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float
 	if (c0->mg_mode == 1 && (c0->coarse || (c0->twin && c0->twin->coarse))) {
 		g->dtype == FI_F64 ? fi::cg_run_mg<double>(g->members, max_iterations, tol)
 		                   : fi::cg_run_mg<float>(g->members, max_iterations, tol);
+	} else if (fi::poly_ok(c0)) {
+		g->dtype == FI_F64 ? fi::cg_run_poly<double>(g->members, max_iterations, tol)
+		                   : fi::cg_run_poly<float>(g->members, max_iterations, tol);
 	} else {
 		g->dtype == FI_F64 ? fi::cg_run<double>(g->members, max_iterations, tol) : fi::cg_run<float>(g->members, max_iterations, tol);
 	}

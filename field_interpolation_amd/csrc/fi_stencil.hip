@@ -69,6 +69,16 @@ constexpr int kThreads = 256;
 #ifndef FI_BASE_WAVES
 #define FI_BASE_WAVES 4  // waves per SIMD the model-only variant is register-allocated for
 #endif
+// Depth of the register rings of the loads with a short lead: a ring of R sets gives a lead of R steps (the set a step
+// has consumed is refilled at once with the data of R steps on).  Measured (profiles/r2_ablation.md): rings of 2 or 3
+// sets, with 3 or 2 workgroups per CU, are no faster than single sets -- the step is a chain of dependent LDS round
+// trips and memory-issue stalls, not a wait for one late load.
+#ifndef FI_HALO_RING
+#define FI_HALO_RING 1
+#endif
+#ifndef FI_ROW_RING
+#define FI_ROW_RING 1
+#endif
 #ifndef FI_CELL_WAVES
 #define FI_CELL_WAVES 3  // waves per SIMD the fused (data cell) variant is register-allocated for (one less with both
                          // model_1 and model_2 on: that variant would spill, and a spill reload drains the load pipeline)
@@ -94,11 +104,35 @@ struct VecOf<double> {
 	static constexpr int VX = 2;
 };
 
+#ifdef FI_STAMPS  // timing builds: in-kernel time stamps of one workgroup's march (tools/exp_stamps.py)
+__device__ unsigned long long g_stamp[64 * 8 * 4];
+#endif
+
 template <typename T>
 struct MarchCoef {
 	T w0x3;  // 3 * model_0^2
 	T w1sq;  // model_1^2
 	T w2sq;  // model_2^2
+};
+
+// Epilogue of the plain variant for one step of the Chebyshev polynomial preconditioner (fi_solver.hip, cg_run_poly):
+// the kernel applies the MODEL rows to z (tile + halo as ever) and, instead of storing q = A z, forms for its own points
+//     s      = Dinv (q - m z) + z                      = Dinv (A_model + diag(A_data)) z,  m = the model diagonal
+//     z_new  = a z - c1 z_prev + c2 (Dinv r - s)        (three-term Chebyshev recurrence, a = 1 + c1; the step from
+//                                                        z_prev = 0 passes z itself with c1 = 0)
+// and the partials of r . z_new.  mode 1 is one step of the power method for the smoother bound, on the MODEL
+// operator alone (data only lowers the Rayleigh quotients of Dinv (A_model + diag)): z_new = (A_model z) / m, partials
+// of z_new . z_new.  The data rows enter the preconditioner through their diagonal only -- as good a
+// preconditioner as the polynomial in the full operator (profiles/r2_ablation.md: equal iteration counts) -- so a step
+// never reads a cell record: 5 lattice passes (z, z_prev, r, Dinv in; z_new out) in one launch.
+template <typename T>
+struct ChebEpi {
+	const T* zprev;
+	const T* r;
+	const T* dinv;
+	T*       znew;
+	T        a, c1, c2;
+	int      mode;  // 0: Chebyshev step, 1: power-method step
 };
 
 struct CellLists {
@@ -143,14 +177,16 @@ __host__ __device__ constexpr int fused_waves(bool has1, bool has2, bool pack)
 // coarse levels of a cascade); the other variant carries the factor-row loop only (and, in fp64, the packed block
 // of cells beyond 8 rows).  Two variants because the unrolled block product is code the row-dominated contexts
 // would only pay for: config 4's finest level ran 2-4 us per launch slower with it compiled in.
-template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT, bool PACK>
-__global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)) : FI_BASE_WAVES) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
+template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT, bool PACK, bool EPI = false>
+__global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)) : (EPI && HAS1 && HAS2 && sizeof(T) == 4 ? FI_BASE_WAVES - 1 : FI_BASE_WAVES)) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done,
                                                              const uint32_t* __restrict__ wg_list, int nlist,
-                                                             const uint32_t* __restrict__ wg_runs)
+                                                             const uint32_t* __restrict__ wg_runs,
+                                                             ChebEpi<T> E = ChebEpi<T>{})
 {
+	static_assert(!(EPI && CELLS), "the Chebyshev epilogue belongs to the plain variant");
 	using V = typename VecOf<T>::V;
 	constexpr int kTXT = TXT;             // threads along x
 	constexpr int kTY  = kThreads / TXT;  // tile rows (= threads along y)
@@ -175,8 +211,24 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 	__shared__ T ydump[CELLS ? kThreads : 1];  // write-only target of corner products that fall outside the tile
 	__shared__ uint32_t s_lay[2][CELLS ? NLAY : 1];  // record bounds of this workgroup's (layer, band) lists
 	__shared__ double red[kThreads / 64];
+#ifdef FI_STAMPS
+	__shared__ unsigned long long s_stamp[4][64 * 8];
+#define FI_STAMP(stepno, k)                                                                                  \
+	do {                                                                                                     \
+		if ((threadIdx.x & 63) == 0 && (stepno) < 64) {                                                      \
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+			s_stamp[threadIdx.x >> 6][(stepno) * 8 + (k)] = __builtin_amdgcn_s_memtime();                     \
+		}                                                                                                    \
+	} while (0)
+#else
+#define FI_STAMP(stepno, k) do { } while (0)
+#endif
 
 	if (done && *done) { return; }
+#ifdef FI_STAMPS
+	for (int i = threadIdx.x; i < 4 * 64 * 8; i += kThreads) { s_stamp[i / 512][i % 512] = 0ull; }
+	__syncthreads();
+#endif
 
 	// XCD-aware tile order: consecutive tiles on one XCD.  With a list, the launch covers only the listed
 	// workgroups (the ones with / without data cells: march_launch).
@@ -286,7 +338,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 	};
 	auto load_halo = [&](int lz, HaloRegs& h) {
 		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
+#ifdef FI_TIMING_BUILD  // timing builds only (tools/build_variant.sh -DFI_TIMING_BUILD): results wrong by construction
 		if (P.dbg & 1) { return; }
+#endif
 		h.vec = *reinterpret_cast<const NV*>(xp + hvg);
 		h.sc  = xp[hsg];
 	};
@@ -374,12 +428,6 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 	// all block records
 	auto cells_scatter = [&](uint32_t rsR, uint32_t reR, uint32_t rsB, uint32_t reB, int buf_lo, int buf_hi, int slot_lo,
 	                         int slot_hi, bool lo_ok) {
-#ifdef FI_SKIP_ROWS  // timing builds of profiles/r1_ablation.md (results wrong by construction): tools/build_variant.sh
-		reR = rsR;
-#endif
-#ifdef FI_SKIP_BLK
-		reB = rsB;
-#endif
 		for (uint32_t r = rsR + lane; r < reR; r += 64) {
 			uint32_t pos;
 			T a[8];
@@ -471,6 +519,32 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 		*s1 = zero;
 	};
 
+	// ---- Chebyshev epilogue (EPI): the x/y part of the model diagonal of the thread's points, and the operand loads
+	T mxy[EPI ? VX : 1];
+	if (EPI) {
+		T ay = T(0), by = T(0);
+		if (HAS2) { ay = (c2y[0] ? T(1) : T(0)) + (c2y[1] ? T(4) : T(0)) + (c2y[2] ? T(1) : T(0)); }
+		if (HAS1) { by = (c1y[0] ? T(1) : T(0)) + (c1y[1] ? T(1) : T(0)); }
+#pragma unroll
+		for (int j = 0; j < VX; ++j) {
+			T m = C.w0x3;
+			if (HAS2) { m += C.w2sq * ((m2x[j] ? T(1) : T(0)) + (m2x[j + 1] ? T(4) : T(0)) + (m2x[j + 2] ? T(1) : T(0)) + ay); }
+			if (HAS1) { m += C.w1sq * ((m1x[j] ? T(1) : T(0)) + (m1x[j + 1] ? T(1) : T(0)) + by); }
+			mxy[j] = m;
+		}
+	}
+	struct EpiRegs {
+		V zp, rv, dv;
+	};
+	// operands of plane lz (clamped like every load that crosses a step): issued right behind the epilogue that
+	// consumed the previous set, used one step later
+	auto load_epi = [&](int lz, EpiRegs& e) {
+		const int64_t o = static_cast<int64_t>(clamp_plane(lz)) * P.plane + xoff;
+		e.zp = *reinterpret_cast<const V*>(E.zprev + o);  // never null: the host passes z itself with c1 = 0 on the first step
+		e.rv = *reinterpret_cast<const V*>(E.r + o);
+		e.dv = *reinterpret_cast<const V*>(E.dinv + o);
+	};
+
 	// ---- prologue ---------------------------------------------------------------------------------
 	// Software pipeline, all ring indices relative to the step number s = z - z_begin:
 	//   own x values: plane s lives in register slot X[s % 6]; step s reads slots s, s+1, s+2 and issues the
@@ -491,9 +565,13 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 	V X3 = load_own(z_begin + 3), X4 = load_own(z_begin + 4), X5 = V{};
 	// ring of 2: plane s in H[s % 2]; step s stages plane s+1 and loads plane s+2.  The fused variant is short of
 	// registers: there H1 alone carries every plane from z_begin+1 on (the load follows the LDS store of the same step)
-	HaloRegs H0{}, H1{};
+	constexpr int HR = FI_HALO_RING, PR = CELLS ? FI_ROW_RING : 1;
+	static_assert(6 % HR == 0 && 6 % PR == 0, "ring depths must divide the 6 instantiations of the step");
+	// halo sets: step k (mod 6) consumes set (k + 1) % HR -- plane z_begin + k + 1 -- and refills it with plane + HR
+	HaloRegs H0{}, Hr[HR];
 	load_halo(z_begin, H0);
-	load_halo(z_begin + 1, H1);
+#pragma unroll
+	for (int k = 0; k < HR; ++k) { load_halo(z_begin + k + 1, Hr[(k + 1) % HR]); }
 	if (CELLS) {  // issued after the plane loads so that the two latencies overlap
 		for (int i = threadIdx.x; i < 4 * (P.zc + 1) + 1; i += kThreads) {
 			const int64_t o = static_cast<int64_t>(wg) * (P.zc + 1) * 4 + i;
@@ -506,8 +584,11 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 #pragma unroll
 	for (int j = 0; j < VX; ++j) { held[j] = T(0); U0[j] = T(0); D0[j] = T(0); }
 	const int nsteps = z_end - z_begin;
-	RowPF PF0;
-	PF0.ok = false;
+	EpiRegs EP{};
+	if (EPI) { load_epi(z_begin, EP); }
+	RowPF PFr[PR];  // record sets: step k consumes set (k + 1) % PR -- layer k + 1 -- and refills it with layer + PR
+#pragma unroll
+	for (int k = 0; k < PR; ++k) { PFr[k].ok = false; }
 	// A layer with at most 64 records is scattered by ONE wave (wave s % 4 at step s, all 4 bands, one lane per
 	// cell): the other waves skip the code, which matters because the kernel is instruction-issue bound.  That
 	// wave prefetches the layer's row records 4 steps ahead.  Denser layers: every wave takes its band, direct loads.
@@ -518,6 +599,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 	// loads that cross a step must sit in straight-line code, or the compiler's s_waitcnt bookkeeping gives up
 	// and drains the whole pipeline (vmcnt(0)) at the first use.  The three extra waves hit the same lines in L1.
 	auto prefetch_rows = [&](int layer, RowPF& pf) {  // layer index l: cell plane z_begin - 1 + l
+#ifdef FI_TIMING_BUILD
+		if (P.dbg & 16) { pf.ok = false; return; }
+#endif
 		const int      lc = layer <= nsteps ? layer : nsteps;
 		// dense layers: the first 64 records of this wave's band (fp32 only: the fp64 variant has no registers left
 		// for a prefetch that is live across the band loop -- it would spill, and a spill reload drains the pipeline)
@@ -526,6 +610,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 		const uint32_t r0 = uni(layR[lc * 4 + (mine ? band : 0)]), r1 = uni(layR[lc * 4 + (mine ? band + 1 : 4)]);
 		const uint32_t r  = r0 + lane;
 		pf.ok = layer <= nsteps && (kDensePF || !dense) && r < r1;
+#ifdef FI_TIMING_BUILD
+		if ((P.dbg & 32) && band != 0) { load_row(r0, &pf.pos, pf.a); return; }
+#endif
 		load_row(r < r1 ? r : r0, &pf.pos, pf.a);  // r0 <= n_row, and the arrays hold n_row + 1 records
 	};
 	{
@@ -552,7 +639,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 #pragma unroll
 				for (int q = 0; q < 6; ++q) { *reinterpret_cast<V*>(&yb[q >> 1][q & 1][ty][VX * tx]) = zero; }
 			}
-			prefetch_rows(1, PF0);
+#pragma unroll
+			for (int k = 0; k < PR; ++k) { prefetch_rows(k + 1, PFr[(k + 1) % PR]); }
 			if (layR[4] > layR[0] || layB[4] > layB[0]) {  // workgroup-uniform
 				HaloRegs hprev{};
 				load_halo(z_begin - 1, hprev);
@@ -579,15 +667,18 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 		dot_acc += static_cast<double>(part);
 	};
 
-	auto step = [&](int s, const V& xc, const V& xp1, const V& xp2, V& xload, const HaloRegs& h_use, HaloRegs& h_load,
+	auto step = [&](int s, const V& xc, const V& xp1, const V& xp2, V& xload, HaloRegs& h,
 	                RowPF& pf,
 	                const T* uA, const T* uB, T* uC, const T* dA, T* dC) {
 		const int z = z_begin + s;
-		// stage plane z+1 into the LDS ring (needed by the cells of layer z) and prefetch ahead
-		write_plane((s + 1) % 3, xp1, h_use);
-		load_halo(z + 2, h_load);
+		FI_STAMP(s, 0);
+		// stage plane z+1 into the LDS ring (needed by the cells of layer z) and refill its halo set HR planes ahead
+		write_plane((s + 1) % 3, xp1, h);
+		FI_STAMP(s, 1);
+		load_halo(z + 1 + HR, h);
 		if (!CELLS) { xload = load_own(z + 5); }
 		__syncthreads();
+		FI_STAMP(s, 2);
 
 		const int gzc = z + P.zoff;
 		const int b0 = s % 3, b1 = (s + 1) % 3;
@@ -618,6 +709,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 				}
 			}
 			xload = load_own(z + 5);
+			FI_STAMP(s, 3);
 			// layer z into the accumulation planes of z and z+1
 			if (layer_dense(s + 1)) {
 				const int o = (s + 1) * 4 + band;
@@ -630,14 +722,14 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 				}
 			} else if (band == (s & 3)) {
 				const int o = (s + 1) * 4;
-#ifndef FI_SKIP_ROWS
 				if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1, b0, b1, true); }
-#endif
 				cells_scatter(0u, 0u, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
 			}
-			prefetch_rows(s + 2, pf);
+			FI_STAMP(s, 4);
+			prefetch_rows(s + 1 + PR, pf);
 		}
 
+		FI_STAMP(s, 5);
 		T acc2[VX], acc1[VX];
 #pragma unroll
 		for (int j = 0; j < VX; ++j) { acc2[j] = T(0); acc1[j] = T(0); }
@@ -723,11 +815,51 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 			po[j] = v;
 			dsum += pc[j] * v;
 		}
+		FI_STAMP(s, 6);
 		if (CELLS) {  // completed at the next step, when the data sums of this plane are final
 #pragma unroll
 			for (int j = 0; j < VX; ++j) { held[j] = po[j]; }
+		} else if (EPI) {
+			// model diagonal along z (wave-uniform) on top of the thread's x/y part
+			T mz = T(0);
+			if (HAS2) {
+				const int g = gzc;
+				mz += C.w2sq * (((g - 2 >= 0 && g < P.gz) ? T(1) : T(0)) + ((g - 1 >= 0 && g + 1 < P.gz) ? T(4) : T(0)) +
+				                ((g + 2 < P.gz) ? T(1) : T(0)));
+			}
+			if (HAS1) { mz += C.w1sq * (((gzc - 1 >= 0) ? T(1) : T(0)) + ((gzc + 1 < P.gz) ? T(1) : T(0))); }
+			const T* zp = reinterpret_cast<const T*>(&EP.zp);
+			const T* rv = reinterpret_cast<const T*>(&EP.rv);
+			const T* dv = reinterpret_cast<const T*>(&EP.dv);
+			V zn;
+			T* pz = reinterpret_cast<T*>(&zn);
+			T  rz = T(0);
+			if (E.mode == 1) {
+#pragma unroll
+				for (int j = 0; j < VX; ++j) {
+					pz[j] = po[j] / (mxy[j] + mz);
+					rz += pz[j] * pz[j];
+				}
+			} else {
+#pragma unroll
+				for (int j = 0; j < VX; ++j) {
+					const T sv = dv[j] * (po[j] - (mxy[j] + mz) * pc[j]) + pc[j];
+					pz[j] = E.a * pc[j] - E.c1 * zp[j] + E.c2 * (dv[j] * rv[j] - sv);
+					rz += rv[j] * pz[j];
+				}
+			}
+			if (active) {
+				*reinterpret_cast<V*>((E.znew + static_cast<int64_t>(z) * P.plane) + col) = zn;
+				dot_acc += static_cast<double>(rz);
+			} else if (tail) {
+				store_tail(E.znew + static_cast<int64_t>(z) * P.plane, E.mode == 1 ? pz : rv, pz);
+			}
+			load_epi(z + 1, EP);
 		} else if (active) {
-			if (!(P.dbg & 2)) { *reinterpret_cast<V*>((y + static_cast<int64_t>(z) * P.plane) + col) = out; }
+#ifdef FI_TIMING_BUILD
+			if (!(P.dbg & 2))
+#endif
+			{ *reinterpret_cast<V*>((y + static_cast<int64_t>(z) * P.plane) + col) = out; }
 			dot_acc += static_cast<double>(dsum);
 		} else if (tail) {
 			store_tail(y + static_cast<int64_t>(z) * P.plane, pc, po);
@@ -735,17 +867,17 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 	};
 
 	for (int s0 = 0; s0 < nsteps; s0 += 6) {
-		step(s0, X0, X1, X2, X5, H1, CELLS ? H1 : H0, PF0, U1, U2, U0, D1, D0);
+		step(s0, X0, X1, X2, X5, Hr[1 % HR], PFr[1 % PR], U1, U2, U0, D1, D0);
 		if (s0 + 1 >= nsteps) { break; }
-		step(s0 + 1, X1, X2, X3, X0, CELLS ? H1 : H0, H1, PF0, U2, U0, U1, D0, D1);
+		step(s0 + 1, X1, X2, X3, X0, Hr[2 % HR], PFr[2 % PR], U2, U0, U1, D0, D1);
 		if (s0 + 2 >= nsteps) { break; }
-		step(s0 + 2, X2, X3, X4, X1, H1, CELLS ? H1 : H0, PF0, U0, U1, U2, D1, D0);
+		step(s0 + 2, X2, X3, X4, X1, Hr[3 % HR], PFr[3 % PR], U0, U1, U2, D1, D0);
 		if (s0 + 3 >= nsteps) { break; }
-		step(s0 + 3, X3, X4, X5, X2, CELLS ? H1 : H0, H1, PF0, U1, U2, U0, D0, D1);
+		step(s0 + 3, X3, X4, X5, X2, Hr[4 % HR], PFr[4 % PR], U1, U2, U0, D0, D1);
 		if (s0 + 4 >= nsteps) { break; }
-		step(s0 + 4, X4, X5, X0, X3, H1, CELLS ? H1 : H0, PF0, U2, U0, U1, D1, D0);
+		step(s0 + 4, X4, X5, X0, X3, Hr[5 % HR], PFr[5 % PR], U2, U0, U1, D1, D0);
 		if (s0 + 5 >= nsteps) { break; }
-		step(s0 + 5, X5, X0, X1, X4, CELLS ? H1 : H0, H1, PF0, U0, U1, U2, D0, D1);
+		step(s0 + 5, X5, X0, X1, X4, Hr[6 % HR], PFr[6 % PR], U0, U1, U2, D0, D1);
 	}
 	if (CELLS) {  // the last plane of the chunk: x(z_end-1) sits in ring slot (nsteps-1) % 6
 		__syncthreads();
@@ -777,6 +909,12 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 		}
 	}
 
+#ifdef FI_STAMPS
+	__syncthreads();
+	if (wg == (P.dbg >> 8)) {
+		for (int i = threadIdx.x; i < 4 * 64 * 8; i += kThreads) { g_stamp[i] = s_stamp[i / 512][i % 512]; }
+	}
+#endif
 	if (partial) {
 		const double wsum = wave_sum(dot_acc);
 		if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wsum; }
@@ -981,7 +1119,7 @@ int pick_chunk(int tiles_xy, int nz_own, int slots, int forced, int zc_max)
 }
 
 template <typename T>
-bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0)
+bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain = false)
 {
 	const Geom& g = c->g;
 	constexpr int VX = VecOf<T>::VX;
@@ -1021,7 +1159,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0)
 	const int nz_own = P->own_z1 - P->own_z0;
 	int cus = 256;
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-	const bool fused = c->cells.ncell > 0 && !getenv("FI_NO_FUSE");
+	const bool fused = !plain && c->cells.ncell > 0 && !getenv("FI_NO_FUSE");
 	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : fused_waves<T>(w.model_1 > 0, w.model_2 > 0, c->cells.pack);
 	// the fused variant stages the list bounds of at most 64 + 2 layers in LDS (s_lay); without data cells the chunk
 	// may be as long as one round of workgroups allows (512^3: 128 planes, 1024 workgroups)
@@ -1029,7 +1167,10 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0)
 	P->chunks = (nz_own + P->zc - 1) / P->zc;
 	P->nwg    = P->tiles_x * P->tiles_y * P->chunks;
 	P->plane  = static_cast<int64_t>(P->nx) * P->ny;
+	P->dbg    = 0;
+#if defined(FI_TIMING_BUILD) || defined(FI_STAMPS)
 	P->dbg    = getenv("FI_DBG") ? atoi(getenv("FI_DBG")) : 0;
+#endif
 	return true;
 }
 
@@ -1062,7 +1203,7 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
 	auto launch = [&](auto kernel) {
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done, wg_list, nlist,
-		                   wg_runs);
+		                   wg_runs, ChebEpi<T>{});
 	};
 	const bool pack = CELLS && c->cells.pack;  // the variant that matches the context's block records
 	auto pick = [&](auto txt, auto pk) {
@@ -1082,6 +1223,35 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 	} else {
 		if (CELLS && pack) { pick(integral_constant<int, 16>{}, integral_constant<bool, CELLS>{}); } else { pick(integral_constant<int, 16>{}, integral_constant<bool, false>{}); }
 	}
+	FI_HIP_TRY(hipGetLastError());
+}
+
+// One Chebyshev step of the polynomial preconditioner: the plain variant with the epilogue, over the whole lattice
+// (its own chunking: MarchState::Pplain).  partial: r . z_new per workgroup.
+template <typename T>
+void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partial)
+{
+	const MarchParams& P = c->march.Pplain;
+	const MarchCoef<T> C = march_coef<T>(c->w);
+	CellLists L{};
+	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
+	const int  grid = ((P.nwg + 7) / 8) * 8;
+	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, z, static_cast<T*>(nullptr), partial, done,
+		                   static_cast<const uint32_t*>(nullptr), 0, static_cast<const uint32_t*>(nullptr), E);
+	};
+	auto pick = [&](auto txt) {
+		constexpr int TXT = decltype(txt)::value;
+		if (h1 && h2) {
+			launch(k_apply_march3d<T, true, true, false, TXT, false, true>);
+		} else if (h2) {
+			launch(k_apply_march3d<T, false, true, false, TXT, false, true>);
+		} else {
+			launch(k_apply_march3d<T, true, false, false, TXT, false, true>);
+		}
+	};
+	if (P.txt == 32) { pick(std::integral_constant<int, 32>{}); } else { pick(std::integral_constant<int, 16>{}); }
 	FI_HIP_TRY(hipGetLastError());
 }
 
@@ -1279,6 +1449,9 @@ void stencil_prepare(fi_ctx* c)
 	m.valid = c->dtype == FI_F64 ? march_setup<double>(c, &m.P) : march_setup<float>(c, &m.P);
 	m.fused = false;
 	m.n_row = m.n_blk = 0;
+	if (m.valid) {  // chunking of whole-lattice launches of the plain variant (polynomial preconditioner)
+		c->dtype == FI_F64 ? march_setup<double>(c, &m.Pplain, 0, true) : march_setup<float>(c, &m.Pplain, 0, true);
+	}
 	c->tile2.valid = c->tile2.fused = false;
 	if (c->g.ndim == 2) { tile2d_prepare(c); }
 	if (!m.valid) { return; }
@@ -1299,6 +1472,47 @@ void stencil_prepare(fi_ctx* c)
 int stencil_partials(const fi_ctx* c) { return c->march.valid ? c->march.P.nwg : tile2d_partials(c); }
 
 bool cells_fused(const fi_ctx* c) { return (c->march.valid && c->march.fused) || (c->tile2.valid && c->tile2.fused); }
+
+#ifdef FI_STAMPS
+}  // namespace fi
+extern "C" int fi_debug_stamps(unsigned long long* out)
+{
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(fi::g_stamp), sizeof(unsigned long long) * 64 * 8 * 4) == hipSuccess ? 0 : 1;
+}
+namespace fi {
+#endif
+
+// Chebyshev step through the marching kernel (see ChebEpi); false when the kernel does not apply to this context.
+bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid; }
+int  stencil_cheb_partials(const fi_ctx* c) { return c->march.Pplain.nwg; }
+void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double c1,
+                       double c2, double* partial)
+{
+	// zprev == nullptr: the step from z_prev = 0
+	if (c->dtype == FI_F64) {
+		ChebEpi<double> E{static_cast<const double*>(zprev ? zprev : z), static_cast<const double*>(r),
+		                  static_cast<const double*>(dinv), static_cast<double*>(znew), 1.0 + c1, zprev ? c1 : 0.0, c2, 0};
+		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial);
+	} else {
+		ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r),
+		                 static_cast<const float*>(dinv), static_cast<float*>(znew), static_cast<float>(1.0 + c1),
+		                 static_cast<float>(zprev ? c1 : 0.0), static_cast<float>(c2), 0};
+		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial);
+	}
+}
+// v_new = (A_model v) / diag(A_model), partials of v_new . v_new (power method on the model operator)
+void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
+{
+	if (c->dtype == FI_F64) {
+		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), static_cast<const double*>(v),
+		                  static_cast<double*>(vnew), 0, 0, 0, 1};
+		march_launch_epi<double>(c, static_cast<const double*>(v), E, partial);
+	} else {
+		ChebEpi<float> E{static_cast<const float*>(v), static_cast<const float*>(v), static_cast<const float*>(v),
+		                 static_cast<float*>(vnew), 0, 0, 0, 1};
+		march_launch_epi<float>(c, static_cast<const float*>(v), E, partial);
+	}
+}
 
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial)
 {

@@ -4,7 +4,7 @@ The reference is single-process; these helpers exist becau
 into contiguous slabs of its slowest axis, one per rank:
   slab_range      which planes a rank owns            (same arithmetic as fi_slab_partition in libfi_hip)
   halo_width      ghost planes per side               (same rule as fi_halo_width)
-  points_of_slab  data points a rank has to see       (cells touching its slab: origin plane in [lo-1, hi-1])
+  points_of_slab  data points a rank has to see       (cells touching its slab on every level: fi_slab_point_range)
   init_comm       RCCL bootstrap: rank 0 makes the unique id, torch.distributed broadcasts it
 Nothing here touches the GPU except init_comm.
 """
@@ -28,11 +28,21 @@ def halo_width(weights):
     return max(reach, 1)
 
 
-def points_of_slab(positions, ndim, lo, hi):
-    """Boolean mask of the points whose cell (origin floor(pos) along the slowest axis) touches planes
-    [lo, hi): origin in [lo-1, hi-1].  One extra cell of margin keeps nearest-neighbour rows too."""
+def point_range(lo, hi, levels=0):
+    """[zlo, zhi) of the slowest coordinate of the points a rank owning planes [lo, hi) has to see (the rule of
+    fi_slab_point_range): a cell of coarse level l spans 2^l fine planes and the rank's coarse replicas are built from
+    its own points, so the margin grows with the level count -- two cells of the coarsest level below (cell origin
+    floor(pos) one plane under the slab, plus one cell for the nearest-neighbour kernels), one above."""
+    cell = float(1 << max(int(levels), 0))
+    return lo - 2.0 * cell, hi + cell
+
+
+def points_of_slab(positions, ndim, lo, hi, levels=0):
+    """Boolean mask of the points a rank owning planes [lo, hi) of the slowest axis has to upload, for a context
+    with `levels` coarser levels (FI_OPT_LEVELS)."""
     z = np.asarray(positions, np.float32).reshape(-1, ndim)[:, ndim - 1]
-    return (z >= lo - 2.0) & (z < hi + 1.0)
+    zlo, zhi = point_range(lo, hi, levels)
+    return (z >= zlo) & (z < zhi)
 
 
 def init_comm(field, device=None):

@@ -113,6 +113,12 @@ int fi_ctx_destroy(fi_ctx* ctx);
 
 /* Owned range [lo, hi) of the slowest axis for this rank. */
 int fi_slab_range(const fi_ctx* ctx, int* lo, int* hi);
+/* Data points this rank has to be given: those whose coordinate z along the slowest axis lies in [*lo, *hi).  The
+ * range covers every cell that touches the slab on the finest level AND on each of the FI_OPT_LEVELS coarser levels
+ * set so far (a coarse cell of level l spans 2^l fine planes, and the coarse replicas are assembled from the rank's
+ * own points): call it after fi_set_option(FI_OPT_LEVELS).  Points outside the range are never needed; points inside
+ * it that touch no owned plane are dropped by the library. */
+int fi_slab_point_range(const fi_ctx* ctx, float* lo, float* hi);
 /* The partition rule itself (pure host arithmetic, no GPU): planes [lo, hi) of `planes` for `rank`. */
 int fi_slab_partition(int planes, int rank, int nranks, int* lo, int* hi);
 /* Ghost planes a slab keeps on each side: the reach of the widest enabled model stencil (model_k -> k),
@@ -192,6 +198,14 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * pure fp64 solve, about 0.7x the time.  The SDF configurations need fp64 residuals: in fp32 alone b - A x stalls
  * near 1e-4 (kappa ~ side^4).  With guess == NULL the coarse-to-fine start also runs on the replica. */
 #define FI_OPT_MIXED_PRECISION 5
+/* FI_OPT_POLY_TERMS (default 0 = the Jacobi diagonal, Eigen's DiagonalPreconditioner as in sparse_linear.cpp:199): with
+ * d >= 2, CG is preconditioned by a Chebyshev polynomial of d terms in Dinv (A_model + diag(A_data)) over the interval
+ * [hi / FI_OPT_POLY_RATIO, hi] (default ratio 10; hi = 1.1 x the largest eigenvalue of the Jacobi-scaled model operator,
+ * found once per model by the power method).  Same stop rule, same answers; about the same number of operator
+ * applications as Jacobi-PCG but d - 1 of every d run as ONE 5-pass launch without cell records, and dot products
+ * are reduced twice per d applications.  3-D lattices with model_0 / model_1 / model_2; other contexts ignore it. */
+#define FI_OPT_POLY_TERMS 6
+#define FI_OPT_POLY_RATIO 7
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */

@@ -1,0 +1,139 @@
+"""CG preconditioned by the Chebyshev polynomial (FI_OPT_POLY_TERMS; fi_solver.hip cg_run_poly, the epilogue of the plain
+marching kernel in fi_stencil.hip).  The preconditioner changes the path to the solution, not the solution: the same
+stop rule (sparse_linear.cpp:199-206 semantics, ||r|| <= tol ||Atb||), the same answers.
+
+  * fp64, every term count, several model-weight combinations and lattice shapes (rows that are not a multiple of the
+    16-byte group, tiles that overhang, lattices smaller than a tile): the solution equals the oracle's float64 direct
+    solution to 1e-7 relative (BASELINE tolerance 1e-5) and the verified residual meets the tolerance;
+  * the polynomial in the model rows + the data DIAGONAL must stay positive definite on data-heavy problems (many rows
+    per cell, large data weights) -- CG would break down otherwise;
+  * operator applications: about as many as Jacobi-PCG takes iterations (the point of the method is cheaper ones);
+  * slabs (loop-back group): the decomposed solve takes the same outer iterations and gives the same solution;
+  * cascade start with the polynomial on every level;
+  * contexts the marching kernel does not cover ignore the option.
+"""
+import numpy as np
+import pytest
+
+from util import build_pair, random_points, rel_inf, sphere_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fi():
+    import field_interpolation_amd as fi
+    from field_interpolation_amd import _capi
+    assert _capi.device_count() >= 1, "no HIP device visible"
+    return fi
+
+
+@pytest.mark.parametrize("terms", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("sizes,kw", [([14, 12, 13], dict()),
+                                      ([18, 9, 10], dict(model_2=0.0, model_1=0.7)),
+                                      ([9, 17, 12], dict(model_0=0.2, model_1=0.4, model_2=0.9)),
+                                      ([21, 8, 8], dict(model_0=0.05, model_2=0.5))])
+def test_solution_equals_direct_solution(oracle, fi, sizes, kw, terms):
+    rng = np.random.default_rng(terms + sizes[0])
+    pos, nrm = sphere_points(rng, sizes, 300)
+    fo, fg = build_pair(oracle, fi, sizes, fi.Weights(**kw), pos, nrm, None, None, dtype="f64")
+    x_ref = fo.solve_exact_f64()
+    assert x_ref is not None
+    fg.assemble()
+    x0, it0, _ = fg.solve_cg(None, 0, 1e-12)
+    fg.set_polynomial(terms)
+    x, it, rel = fg.solve_cg(None, 0, 1e-12)
+    assert x is not None and rel <= 1e-12 and fg.true_residual() <= 1.01e-12
+    assert rel_inf(fg.solution_f64(), x_ref) <= 1e-7
+    # operator applications: terms per outer iteration; within 2x of the Jacobi-PCG count (usually 1.0-1.5x; long
+    # polynomials over the default interval [hi / 10, hi] pay more: 8 terms 2.0-2.5x)
+    assert it * terms <= (2.0 if terms <= 5 else 3.0) * it0 + 2 * terms, (it, it0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+def test_value_constraints_odd_shapes(oracle, fi, dtype, tol):
+    """Scattered value constraints (config-4 kind) on lattices whose rows are not a multiple of the 16-byte group."""
+    for sizes in ([13, 11, 10], [34, 9, 9], [130, 5, 6]):
+        rng = np.random.default_rng(sizes[0])
+        pos, nrm, pw, val = random_points(rng, sizes, 400, margin=0.5)
+        w = fi.Weights(model_2=0.5, data_gradient=0.0)
+        fo, fg = build_pair(oracle, fi, sizes, w, pos, None, pw, val, dtype=dtype)
+        x_ref = fo.solve_exact_f64()
+        fg.assemble()
+        fg.set_polynomial(4)
+        x, it, rel = fg.solve_cg(None, 0, tol)
+        assert x is not None and rel <= tol and fg.true_residual() <= 3 * tol
+        if dtype == "f64":
+            assert rel_inf(fg.solution_f64(), x_ref) <= 1e-5
+
+
+def test_data_heavy_problem_keeps_the_preconditioner_positive(oracle, fi):
+    """Thousands of rows per cell and large data weights: the data diagonal dominates the model diagonal."""
+    sizes = [10, 9, 8]
+    rng = np.random.default_rng(5)
+    pos, nrm, pw, val = random_points(rng, sizes, 20000, margin=0.2, with_edge_cases=False)
+    w = fi.Weights(model_2=0.05, data_pos=7.0, data_gradient=0.0)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, None, None, val, dtype="f64")
+    x_ref = fo.solve_exact_f64()
+    fg.assemble()
+    for terms in (2, 3, 4, 6):
+        fg.set_polynomial(terms)
+        x, it, rel = fg.solve_cg(None, 0, 1e-11)
+        assert x is not None and rel <= 1e-11
+        assert rel_inf(fg.solution_f64(), x_ref) <= 1e-7
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_slabs_equal_undivided(fi, dtype, nranks):
+    sizes = [16, 12, 24]
+    rng = np.random.default_rng(nranks)
+    pos, nrm = sphere_points(rng, sizes, 250)
+    w = fi.Weights()
+    one = fi.LatticeField(sizes, dtype=dtype)
+    grp = fi.LatticeGroup(sizes, nranks, dtype=dtype)
+    for f in (one, grp):
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        f.assemble()
+        f.set_polynomial(4)
+    tol = 1e-9 if dtype == "f64" else 1e-4
+    x1, it1, rel1 = one.solve_cg(None, 0, tol)
+    xg, itg, relg = grp.solve_cg(None, 0, tol)
+    assert abs(itg - it1) <= max(2, it1 // 25), (itg, it1)
+    assert relg <= tol and rel1 <= tol
+    assert grp.true_residual() <= tol * 1.01
+    assert rel_inf(grp.solution_f64(), one.solution_f64()) <= (1e-6 if dtype == "f64" else 2e-2)
+
+
+def test_cascade_start_with_polynomial_levels(fi):
+    from field_interpolation_amd import synth
+    sizes, w, pos, val = synth.config4(side=64, num_points=15625, seed=3)
+    f = fi.LatticeField(sizes, dtype="f32")
+    f.add_field_constraints(w)
+    f.set_levels(2, 1e-5)
+    f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    f.assemble()
+    x0, it0, rel0 = f.solve_cg(None, 0, 1e-5)
+    st0 = f.stats()
+    f.set_polynomial(4)
+    x1, it1, rel1 = f.solve_cg(None, 0, 1e-5)
+    st1 = f.stats()
+    assert rel1 <= 1e-5 and f.true_residual() <= 1.5e-5
+    assert st1["num_levels"] == 3 and st1["coarse_iterations"] > 0
+    assert it1 * 4 <= 2.0 * it0 + 8 and st1["coarse_iterations"] < st0["coarse_iterations"]
+    assert np.abs(x1 - x0).max() <= 2e-3 * np.abs(x0).max()      # two fp32 solves to a 1e-5 residual
+
+
+def test_contexts_without_the_marching_kernel_ignore_the_option(oracle, fi):
+    """2-D lattices and model_3 rows run the Jacobi-preconditioned recurrence whatever the option says."""
+    for sizes, kw in (([30, 28], dict()), ([10, 9, 8], dict(model_3=0.3))):
+        rng = np.random.default_rng(1)
+        pos, nrm = sphere_points(rng, sizes, 120)
+        fo, fg = build_pair(oracle, fi, sizes, fi.Weights(**kw), pos, nrm, None, None, dtype="f64")
+        fg.assemble()
+        x0, it0, _ = fg.solve_cg(None, 0, 1e-10)
+        fg.set_polynomial(4)
+        x1, it1, _ = fg.solve_cg(None, 0, 1e-10)
+        assert it1 == it0
+        np.testing.assert_array_equal(x0, x1)
