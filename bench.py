@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- solved lattice points / second on MI355X (BASELINE.json metric).
 
-One "step" = one full pass of the hot path on a synthetic lattice problem whose inputs already sit in
-HBM: data-constraint assembly (fi_add_points + fi_assemble) + Jacobi-PCG to ||r|| <= tol*||Atb||
-(fi_solve_cg).  Workload (config.workload): BASELINE.json config 4 -- a 256^3 lattice, 1M scattered noisy
-value constraints, model_2 = 0.5 -- on one GPU; with --gpus N the lattice is 256 x 256 x (256*N) with
-N*1M points of the same density, one 256^3 slab per GPU (weak scaling), halo planes and dot products
-over RCCL.
+One "step" = one full pass of the hot path on a synthetic lattice problem whose inputs already sit in HBM:
+data-constraint assembly (fi_clear_points + fi_add_points + fi_assemble) + the iterative solve to
+||Atb - AtA x|| <= tol * ||Atb|| (fi_solve_cg).
+
+Workloads (--config, named in config.workload; SURVEY.md 8(d) recipes, field_interpolation_amd/synth.py):
+  4 (default, the configuration BASELINE.json's metric is quoted on): 3-D 256^3 lattice, 1 M scattered noisy value
+    constraints, model_2 = 0.5, tol 1e-5, fp32; coarse-to-fine start + CG preconditioned by a Chebyshev polynomial
+  5: 3-D 512^3 SDF from 5 M oriented points, tol 1e-6: fp64 CG with the V-cycle preconditioner in fp32 (mixed)
+  3: 2-D 4096^2 SDF from 200 k oriented points, tol 1e-5: the same solver
+  2: 2-D 1024^2, 10 k noisy value constraints, model_2 = 10, tol 1e-5: the same solver
+--gpus N (launched by torch.distributed.run, one rank per GPU): ONE lattice, one slab of its slowest axis per rank, halo
+planes and dot products over RCCL.  --scaling weak (default): the slab per GPU is fixed -- config 4 becomes
+256 x 256 x (256 N) with N x 1 M points of the same density; --scaling strong: the lattice of the configuration itself,
+split N ways (the form BASELINE configs 4 and 5 state).  If the slab exchange cannot be set up the run FAILS (exit 3)
+unless --allow-replicas is given; the line then says "replicasN" and its value is not the metric.
 
 Prints ONE JSON line on rank 0 (see the task contract), including
-  "roofline"     achieved HBM GB/s of the AtA-apply kernel: algorithmic bytes / mean
-                 launch duration measured with HIP events inside the timed region (fi_stats.spmv_ms_avg);
-  "cpu_baseline" the C++ oracle (restatement of the reference's triplets -> AtA -> BiCGSTAB path, fp32,
-                 one thread) timed on a bounded sample of the same workload (rank 0, N = 1 only);
+  "roofline"       the dominant kernel of the timed region (largest share of GPU time): algorithmic bytes per launch
+                    / mean launch duration measured with HIP events on the solver stream inside
+                   the timed region; for the default solver that is the Chebyshev step of the preconditioner
+                   (k_apply_march3d<..., EPI>: the model-operator apply with the polynomial recurrence in its epilogue)
+  "roofline_apply" the same for the full operator apply with fused data cells (the CG SpMV the north-star names)
+  "solution_rel_err" ||x - x64||_inf / ||x64||_inf against an fp64 solve of the same inputs to 1e-10 (outside the timed
+                   region; N = 1 only)
+  "cpu_baseline"   the C++ oracle (restatement of the reference's triplets -> AtA -> BiCGSTAB path, fp32, one thread)
+                   timed on a bounded sample of the same workload (rank 0, N = 1, config 4 only)
   "cpu_best_effort" the same rows solved by a matrix-free Jacobi-PCG with OpenMP on all host cores
-                 (not the reference's algorithm, a second CPU figure beside the port).
 """
 import argparse
 import json
@@ -29,14 +42,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def measured_traffic(side, points, dtype):
-    """HBM bytes per launch of the AtA-apply kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE and
-    WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_traffic.py).  Counters cannot be
-    read from inside this process, so the figure is the committed measurement of exactly this workload
-    (profiles/r1_traffic_apply_c4.json); any other workload reports null."""
-    if (side, points, dtype) != (256, 1_000_000, "f32"):
+def measured_traffic(kind, config, side, points, dtype):
+    """HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
+    x2 read correction; tools/pmc_traffic.py).  Counters cannot be read from inside this process, so the figure is the
+    committed measurement of exactly this workload (profiles/r2_traffic_*.json); any other workload reports null."""
+    if (config, side, points, dtype) != (4, 256, 1_000_000, "f32"):
         return None
-    path = os.path.join(ROOT, "profiles", "r1_traffic_apply_c4.json")
+    path = os.path.join(ROOT, "profiles", "r2_traffic_%s_c4.json" % kind)
     try:
         with open(path) as f:
             return json.load(f)["traffic_bytes"]
@@ -94,21 +106,75 @@ def cpu_baseline(side, tol):
     return port, extra
 
 
+def workload(args, world):
+    """-> dict(sizes, weights, positions, normals, values, tol, dtype, solver settings, text)"""
+    from field_interpolation_amd import synth
+    cfg = args.config
+    weak = args.scaling == "weak" and world > 1
+    if cfg == 4:
+        side = args.side or 256
+        depth = side * world if weak else side
+        npts = args.points or int(round(1_000_000 * (side / 256.0) ** 3))
+        npts = npts * world if weak else npts
+        sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3, depth=depth)
+        return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or 1e-5, dtype=args.dtype or "f32",
+                    levels=2 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-5,
+                    multigrid=args.multigrid, mixed=False, poly=0 if args.multigrid else args.poly, points=npts,
+                    text="config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5" % (
+                        sizes[0], sizes[1], sizes[2], npts))
+    if cfg == 5:
+        side = args.side or 512
+        npts = args.points or int(round(5_000_000 * (side / 512.0) ** 2))
+        if weak:
+            raise SystemExit("config 5 is a fixed lattice: use --scaling strong")
+        sizes, w, pos, nrm = synth.config5(side=side, num_points=npts, seed=4)
+        return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or 1e-6, dtype=args.dtype or "f64",
+                    levels=6 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-4,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts,
+                    text="config5: 3D %d^3 SDF from %d oriented points (sdf_from_points, default Weights)" % (side, npts))
+    if cfg == 3:
+        side = args.side or 4096
+        pps = (args.points or 200_000) // 2
+        if weak:
+            raise SystemExit("config 3 is a fixed lattice: use --scaling strong")
+        sizes, w, pos, nrm = synth.config3(side=side, points_per_shape=pps, seed=2)
+        return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or 1e-5, dtype=args.dtype or "f64",
+                    levels=7 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-4,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps,
+                    text="config3: 2D %dx%d SDF from %d oriented points (triangle + inverted circle)" % (side, side, 2 * pps))
+    if cfg == 2:
+        side = args.side or 1024
+        npts = args.points or 10_000
+        if weak:
+            raise SystemExit("config 2 is a fixed lattice: use --scaling strong")
+        sizes, w, pos, val = synth.config2(side=side, num_points=npts, seed=1)
+        return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or 1e-5, dtype=args.dtype or "f64",
+                    levels=7 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-4,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts,
+                    text="config2: 2D %dx%d lattice, %d noisy value constraints, model_2=10" % (side, side, npts))
+    raise SystemExit("--config must be 2, 3, 4 or 5 (config 1 is the CPU-runnable 1-D case: tests/)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--side", type=int, default=256)
-    ap.add_argument("--points", type=int, default=1_000_000, help="data points per 256^3-equivalent slab")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--tol", type=float, default=1e-5)
+    ap.add_argument("--config", type=int, default=4, help="BASELINE.json configuration: 2, 3, 4 (default) or 5")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--allow-replicas", action="store_true",
+                    help="if the slab exchange cannot be set up, run N independent replicas instead of failing")
+    ap.add_argument("--side", type=int, default=0, help="lattice side (default: the configuration's)")
+    ap.add_argument("--points", type=int, default=0, help="data points (default: the configuration's, scaled with the side)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
+    ap.add_argument("--tol", type=float, default=0.0)
     ap.add_argument("--cpu-side", type=int, default=112, help="lattice side of the CPU baseline sample (0: skip)")
-    ap.add_argument("--levels", type=int, default=2, help="coarser levels for the coarse-to-fine start (0: plain Jacobi-PCG)")
-    ap.add_argument("--coarse-tol", type=float, default=1e-5)
-    ap.add_argument("--multigrid", action="store_true", help="V-cycle preconditioned CG instead of Jacobi-PCG")
+    ap.add_argument("--levels", type=int, default=None, help="coarser levels (config 4: coarse-to-fine start; 0: none)")
+    ap.add_argument("--coarse-tol", type=float, default=0.0)
+    ap.add_argument("--multigrid", action="store_true", help="config 4: V-cycle preconditioned CG")
     ap.add_argument("--poly", type=int, default=4, help="terms of the Chebyshev polynomial preconditioner (0: Jacobi-PCG)")
-    ap.add_argument("--poly-ratio", type=float, default=10.0)
+    ap.add_argument("--poly-ratio", type=float, default=30.0)
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the fp64 comparison solve (solution_rel_err)")
     args = ap.parse_args()
 
     import numpy as np
@@ -116,7 +182,6 @@ def main():
 
     import field_interpolation_amd as fi
     from field_interpolation_amd import dist as fdist
-    from field_interpolation_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,7 +190,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     dist = None
-    # FI_BENCH_ONE_DEVICE=1 (functional test on a 1-GPU box only): every rank uses cuda:0, torch talks gloo
+    # FI_BENCH_ONE_DEVICE=1 (functional test on a 1-GPU box only): every rank uses cuda:0, torch talks gloo and the
+    # slab exchange goes through the host-staged test transport (fi_comm_init_host) instead of RCCL
     one_device = os.environ.get("FI_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
@@ -138,45 +204,62 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    side = args.side
-    depth = side * world
-    npts = args.points * world
+    def agree(ok, what):
+        """All ranks learn whether every rank got through `what`; nobody enters the next collective otherwise."""
+        if dist is None:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=("cpu" if one_device else dev))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    wl = workload(args, world)
+    ndim = len(wl["sizes"])
 
     def build(slabs):
-        """slabs: ONE lattice of 256 x 256 x (256 * world), a slab per rank, halo planes and dot products over RCCL.
-        not slabs (only if the communicator cannot be set up): every rank solves its own 256^3 replica."""
+        """slabs: ONE lattice, a slab per rank, halo planes and dot products over RCCL.  not slabs (--allow-replicas, only
+        if the communicator cannot be set up): every rank solves its own copy of the single-GPU workload."""
+        note = None
         if slabs:
-            sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3, depth=depth)
-            field = fi.LatticeField(sizes, dtype=args.dtype, rank=rank, nranks=world)
+            field = fi.LatticeField(wl["sizes"], dtype=wl["dtype"], rank=rank, nranks=world)
             if world > 1:
-                fdist.init_comm(field, dev)      # RCCL unique id from rank 0, broadcast by torch.distributed
+                try:
+                    fdist.init_comm(field, dev, host_staged=one_device)
+                except Exception as e:          # noqa: BLE001 -- reported below, by every rank together
+                    note = "%s: %s" % (type(e).__name__, e)
+                if not agree(note is None, "communicator"):
+                    raise RuntimeError(note or "communicator set-up failed on another rank")
         else:
-            sizes, w, pos, val = synth.config4(side=side, num_points=args.points, seed=3 + rank)
-            field = fi.LatticeField(sizes, dtype=args.dtype)
-        lo, hi = field.slab
-        # each rank uploads the points whose cells touch its slab (the library drops the rest anyway)
-        keep = fdist.points_of_slab(pos, 3, lo, hi)
-        d_pos = torch.from_numpy(np.ascontiguousarray(pos[keep])).to(dev)
-        d_val = torch.from_numpy(np.ascontiguousarray(val[keep])).to(dev)
+            field = fi.LatticeField(wl["sizes"], dtype=wl["dtype"])
+        field.add_field_constraints(wl["w"])
+        if wl["levels"] > 0:
+            field.set_levels(wl["levels"], wl["coarse_tol"])
+            if wl["multigrid"]:
+                field.set_multigrid(True)
+                if wl["mixed"]:
+                    field.set_mixed_precision(True)
+        if wl["poly"] > 1:
+            field.set_polynomial(wl["poly"], args.poly_ratio)
+        # each rank uploads the points whose cells touch its slab on any level (the library drops the rest anyway)
+        zlo, zhi = field.point_range()
+        z = wl["pos"].reshape(-1, ndim)[:, ndim - 1]
+        keep = (z >= zlo) & (z < zhi) if (slabs and world > 1) else np.ones(len(z), bool)
+        d_pos = torch.from_numpy(np.ascontiguousarray(wl["pos"][keep])).to(dev)
+        d_nrm = torch.from_numpy(np.ascontiguousarray(wl["nrm"][keep])).to(dev) if wl["nrm"] is not None else None
+        d_val = torch.from_numpy(np.ascontiguousarray(wl["val"][keep])).to(dev) if wl["val"] is not None else None
         d_out = torch.empty(field.num_owned, dtype=torch.float32, device=dev)   # the solution stays in HBM
         torch.cuda.synchronize()
-        field.add_field_constraints(w)
-        if args.levels > 0:
-            field.set_levels(args.levels, args.coarse_tol)
-            if args.multigrid:
-                field.set_multigrid(True)
-        if args.poly > 1 and not args.multigrid:
-            field.set_polynomial(args.poly, args.poly_ratio)
+        w = wl["w"]
 
         def step():
             field.clear_points()
-            field.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, d_pos, None, None, values=d_val)
+            field.add_points(w.data_pos, w.value_kernel, w.data_gradient if d_nrm is not None else 0.0, w.gradient_kernel,
+                             d_pos, d_nrm, None, values=d_val)
             field.assemble()
-            out = field.solve_cg(None, 0, args.tol, out=d_out)
+            out = field.solve_cg(None, 0, wl["tol"], out=d_out)
             if out is None:
                 raise RuntimeError("CG breakdown")
             return out
-        return field, step
+        return field, step, d_out
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,33 +268,51 @@ def main():
         torch.cuda.synchronize()
 
     parallelism, note = "slab%d" % world, None
+    field = step = d_out = None
     try:
-        field, step = build(True)
-        for _ in range(args.warmup):
-            step()
-        ok = 1
+        field, step, d_out = build(True)
+        ok = True
     except Exception as e:          # noqa: BLE001 -- any failure of the exchange path is reported, not hidden
         if world == 1:
             raise
-        ok, note = 0, "%s: %s" % (type(e).__name__, e)
-    if world > 1:
-        flag = torch.tensor([ok], dtype=torch.int32, device=("cpu" if one_device else dev))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:   # some rank could not run the slab exchange: independent replicas, said so in the line
-            parallelism = "replicas%d (slab exchange failed: %s)" % (world, note or "on another rank")
-            field, step = build(False)
-            for _ in range(args.warmup):
+        ok, note = False, "%s: %s" % (type(e).__name__, e)
+    if ok:
+        for _ in range(args.warmup):
+            try:
                 step()
-    spmv_ms, spmv_n, asm_ms, solve_ms = 0.0, 0, 0.0, 0.0
+            except Exception as e:  # noqa: BLE001
+                if world == 1:
+                    raise
+                ok, note = False, "%s: %s" % (type(e).__name__, e)
+            if not agree(ok, "warm-up step"):   # after every step: a rank that failed must not leave the others in a collective
+                ok = False
+                break
+    if not ok:
+        if not args.allow_replicas:
+            if rank == 0:
+                print("bench.py: the slab exchange failed (%s); no metric measured (--allow-replicas runs independent "
+                      "replicas instead)" % (note or "on another rank"), file=sys.stderr, flush=True)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
+        parallelism = "replicas%d (slab exchange failed: %s)" % (world, note or "on another rank")
+        field, step, d_out = build(False)
+        for _ in range(args.warmup):
+            step()
+
+    acc = {"spmv_ms": 0.0, "spmv_n": 0, "prec_ms": 0.0, "prec_n": 0, "asm_ms": 0.0, "solve_ms": 0.0, "applies": 0}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, iters, rel = step()
         st = field.stats()
-        spmv_ms += st["spmv_ms_avg"] * st["spmv_samples"]
-        spmv_n += st["spmv_samples"]
-        asm_ms += st["assemble_ms"]
-        solve_ms += st["solve_ms"]
+        acc["spmv_ms"] += st["spmv_ms_avg"] * st["spmv_samples"]
+        acc["spmv_n"] += st["spmv_samples"]
+        acc["prec_ms"] += st["prec_ms_avg"] * st["prec_samples"]
+        acc["prec_n"] += st["prec_samples"]
+        acc["asm_ms"] += st["assemble_ms"]
+        acc["solve_ms"] += st["solve_ms"]
+        acc["applies"] += st["operator_applies"]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -221,33 +322,77 @@ def main():
     st = field.stats()
     true_rel = field.true_residual()
 
-    n_global = side * side * depth
+    replicas = not parallelism.startswith("slab")
+    n_global = int(np.prod(wl["sizes"])) * (world if replicas else 1)
     value = n_global * args.steps / elapsed
-    spmv_avg_ms = spmv_ms / max(spmv_n, 1)
-    achieved = st["spmv_bytes"] / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+    spmv_avg_ms = acc["spmv_ms"] / max(acc["spmv_n"], 1)
+    prec_avg_ms = acc["prec_ms"] / max(acc["prec_n"], 1)
+
+    def roof(kernel, bytes_, ms, n, traffic):
+        achieved = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": kernel, "launch_ms": ms, "algorithmic_bytes": bytes_, "samples": n}
+
+    def tr(kind):
+        return measured_traffic(kind, args.config, wl["sizes"][0], wl["points"], wl["dtype"]) if world == 1 else None
+
+    apply_name = ("k_apply_march3d: AtA apply, matrix-free stencil + fused data cells (finest level)" if ndim == 3 else
+                  "k_apply_tile2d: AtA apply, matrix-free stencil + fused data cells (finest level)")
+    roof_apply = roof(apply_name, st["spmv_bytes"], spmv_avg_ms, acc["spmv_n"], tr("apply"))
+    # the dominant kernel of the timed region: the Chebyshev step when the polynomial preconditioner runs (terms - 1
+    # launches per outer iteration against one full apply), else the apply
+    if acc["prec_n"] > 0 and wl["poly"] > 2:
+        roof_main = roof("k_apply_march3d<EPI>: Chebyshev step of the polynomial preconditioner = model-operator apply + "
+                         "three-term recurrence in the epilogue, 5 lattice passes (finest level)",
+                         st["prec_bytes"], prec_avg_ms, acc["prec_n"], tr("cheb"))
+    else:
+        roof_main = roof_apply
+    solver = ("V-cycle PCG" + (" (fp64 CG, fp32 V-cycle)" if wl["mixed"] else "") if (wl["multigrid"] and st["num_levels"] > 1) else
+              ("CG preconditioned by a %d-term Chebyshev polynomial" % wl["poly"] if wl["poly"] > 1 else "Jacobi-PCG")
+              + (" from a coarse-to-fine cascade" if st["num_levels"] > 1 else ""))
     line = {
-        "metric": "solved lattice points/sec (assembly+CG to tol=%g)" % args.tol,
+        "metric": "solved lattice points/sec (assembly+CG to tol=%g)" % wl["tol"],
         "value": value, "unit": "lattice points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5, "
-                                "Jacobi-PCG to rel. residual %g" % (side, side, depth, npts, args.tol)) if parallelism.startswith("slab")
-                               else ("config4: %d independent 3D %dx%dx%d lattices, %d scattered noisy value constraints each, "
-                                     "model_2=0.5, Jacobi-PCG to rel. residual %g" % (world, side, side, side, args.points, args.tol)),
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": args.scaling if world > 1 else "weak",
+        "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
+        "config": {"workload": wl["text"] + ", %s to rel. residual %g" % (solver, wl["tol"]) + (
+                       "; %d independent copies, one per GPU" % world if replicas else (
+                           "; one lattice, %d slabs (%s scaling)" % (world, args.scaling) if world > 1 else "")),
                    "parallelism": parallelism, "iterations": iters, "rel_residual": rel,
-                   "levels": st["num_levels"], "coarse_iterations": st["coarse_iterations"],
-                   "solver": ("V-cycle PCG" if (args.multigrid and st["num_levels"] > 1) else
-                              "Jacobi-PCG" + (" from a coarse-to-fine cascade" if st["num_levels"] > 1 else "")),
-                   "true_rel_residual": true_rel, "assemble_ms": asm_ms / args.steps,
-                   "solve_ms": solve_ms / args.steps, "occupied_cells": st["num_cells"],
+                   "levels": st["num_levels"], "coarse_iterations": st["coarse_iterations"], "solver": solver,
+                   "operator_applies": acc["applies"] // max(args.steps, 1),
+                   "true_rel_residual": true_rel, "assemble_ms": acc["asm_ms"] / args.steps,
+                   "solve_ms": acc["solve_ms"] / args.steps, "occupied_cells": st["num_cells"],
                    "data_rows": st["num_data_rows"]},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(side, args.points, args.dtype) if world == 1 else None,
-                     "kernel": "k_apply_march3d: AtA apply, matrix-free stencil + fused data cells (finest level)", "launch_ms": spmv_avg_ms,
-                     "algorithmic_bytes": st["spmv_bytes"], "samples": spmv_n},
+        "roofline": roof_main,
+        "roofline_apply": roof_apply,
     }
-    if rank == 0 and world == 1 and args.cpu_side > 0:
-        line["cpu_baseline"], best_effort = cpu_baseline(args.cpu_side, args.tol)
+    if world == 1 and not args.no_accuracy:
+        # the same inputs solved in fp64 to 1e-10 (V-cycle PCG where levels are available), outside the timed region
+        x_run = d_out.cpu().numpy().astype(np.float64)
+        ref = fi.LatticeField(wl["sizes"], dtype="f64")
+        ref.add_field_constraints(wl["w"])
+        if args.config == 4:
+            ref.set_levels(max(wl["levels"], 2), 1e-6)
+            ref.set_polynomial(4, args.poly_ratio)
+        else:
+            ref.set_levels(max(wl["levels"], 4), 1e-4)
+            ref.set_multigrid(True)
+            ref.set_mixed_precision(True)
+        w = wl["w"]
+        ref.add_points(w.data_pos, w.value_kernel, w.data_gradient if wl["nrm"] is not None else 0.0, w.gradient_kernel,
+                       wl["pos"], wl["nrm"], None, values=wl["val"])
+        ref.assemble()
+        out = ref.solve_cg(None, 0, 1e-10)
+        if out is not None:
+            x64 = ref.solution_f64()
+            line["solution_rel_err"] = float(np.abs(x_run - x64).max() / np.abs(x64).max())
+            line["config"]["solution_check"] = ("||x - x64||_inf / ||x64||_inf against an fp64 solve of the same inputs to "
+                                                "rel. residual %.1e (%d iterations)" % (ref.true_residual(), out[1]))
+        del ref
+    if rank == 0 and world == 1 and args.cpu_side > 0 and args.config == 4:
+        line["cpu_baseline"], best_effort = cpu_baseline(args.cpu_side, wl["tol"])
         if best_effort:
             line["cpu_best_effort"] = best_effort
     if rank == 0:

@@ -10,12 +10,12 @@ FI_OK = 0
 FI_HOST, FI_DEVICE = 0, 1
 FI_F32, FI_F64 = 0, 1
 ERR_NAMES = {1: "FI_ERR_INVALID", 2: "FI_ERR_HIP", 3: "FI_ERR_STATE", 4: "FI_ERR_COMM",
-             5: "FI_ERR_UNSUPPORTED", 6: "FI_ERR_BREAKDOWN"}
+             5: "FI_ERR_UNSUPPORTED", 6: "FI_ERR_BREAKDOWN", 7: "FI_ERR_TIMEOUT"}
 
 # every symbol include/fi_hip.h declares
 SYMBOLS = [
     "fi_last_error", "fi_device_count", "fi_ctx_create", "fi_ctx_create_slab", "fi_ctx_destroy",
-    "fi_slab_range", "fi_slab_point_range", "fi_slab_partition", "fi_halo_width", "fi_comm_unique_id", "fi_comm_init", "fi_comm_self_test", "fi_set_model", "fi_add_points",
+    "fi_slab_range", "fi_slab_point_range", "fi_slab_partition", "fi_halo_width", "fi_comm_unique_id", "fi_comm_init", "fi_comm_init_host", "fi_comm_self_test", "fi_set_model", "fi_add_points",
     "fi_add_rows_coo", "fi_assemble", "fi_clear_points", "fi_set_option", "fi_solve_cg", "fi_jacobi", "fi_tile_pass", "fi_error_map",
     "fi_get_solution_f64", "fi_true_residual", "fi_apply_AtA_f64", "fi_get_Atb_f64", "fi_get_diag_f64",
     "fi_get_stats", "fi_time_apply", "fi_upscale_field",
@@ -46,7 +46,9 @@ class FiStats(C.Structure):
                 ("rel_residual", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
                 ("spmv_ms_avg", C.c_double), ("spmv_samples", C.c_int), ("spmv_bytes", C.c_double),
                 ("restarts", C.c_int), ("verified_residual", C.c_double),
-                ("num_levels", C.c_int), ("coarse_iterations", C.c_int)]
+                ("num_levels", C.c_int), ("coarse_iterations", C.c_int),
+                ("prec_ms_avg", C.c_double), ("prec_samples", C.c_int), ("prec_bytes", C.c_double),
+                ("operator_applies", C.c_int)]
 
 
 class FiError(RuntimeError):
@@ -78,6 +80,7 @@ def lib():
     L.fi_halo_width.argtypes = [C.POINTER(FiWeights), ip]
     L.fi_comm_unique_id.argtypes = [vp]
     L.fi_comm_init.argtypes = [vp, vp]
+    L.fi_comm_init_host.argtypes = [vp, C.c_char_p, C.c_int]
     L.fi_set_model.argtypes = [vp, C.POINTER(FiWeights)]
     L.fi_add_points.argtypes = [vp, C.c_long, fp, fp, fp, fp, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int]
     L.fi_add_rows_coo.argtypes = [vp, C.c_long, C.c_long, vp, fp, C.c_int]

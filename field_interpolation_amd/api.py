@@ -221,6 +221,10 @@ class LatticeField:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(_capi.lib().fi_comm_init(self._h, buf))
 
+    def comm_init_host(self, name, create):
+        """fi_comm_init_host: the host-staged TEST transport for ranks that share one GPU."""
+        check(_capi.lib().fi_comm_init_host(self._h, name.encode(), 1 if create else 0))
+
     # ---- assemble / solve --------------------------------------------------------------------
     def assemble(self):
         """as_sparse_matrix_float + make_square + A^T b (sparse_linear.cpp:59-70,105-113,120) on the GPU."""

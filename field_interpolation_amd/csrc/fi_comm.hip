@@ -11,7 +11,14 @@
 // binds to whichever librccl.so.1 the process already holds, e.g. the one torch.distributed loaded).
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <string>
 #include <vector>
 #include <rccl/rccl.h>
 
@@ -19,8 +26,32 @@
 
 namespace fi {
 
+// Test transport (fi_comm_init_host): the same two operations carried through a POSIX shared-memory segment by
+// host copies, for ranks that share ONE GPU (RCCL refuses two ranks on one device).  It lets the real per-process
+// orchestration -- rank bootstrap, point filtering, per-rank assembly, rank-set solvers, bench.py --gpus N -- run on a
+// single-GPU machine; only the RCCL wire itself stays untested there.  Not a production path: every exchange
+// synchronises the stream and both ranks' hosts.
+struct HostShm {
+	uint32_t              magic;
+	uint32_t              nranks;
+	uint64_t              slot_bytes;
+	std::atomic<uint32_t> arrived;
+	std::atomic<uint32_t> generation;
+	std::atomic<uint32_t> failed;  // a rank that gives up (timeout, HIP error) releases everybody else
+};
+struct HostComm {
+	std::string name;
+	int         fd = -1;
+	size_t      bytes = 0;
+	char*       base = nullptr;
+	bool        owner = false;
+	HostShm*    hdr() const { return reinterpret_cast<HostShm*>(base); }
+	char*       slot(int r) const { return base + 4096 + static_cast<size_t>(r) * hdr()->slot_bytes; }
+};
+
 struct Comm {
 	ncclComm_t comm = nullptr;
+	HostComm*  host = nullptr;
 };
 
 const char* rccl_error_string(ncclResult_t r);
@@ -44,26 +75,29 @@ Rccl& rccl()
 {
 	static Rccl r;
 	if (r.handle) { return r; }
+	// resolved into a local table first: a missing symbol must not leave a half-filled table behind a set handle
+	Rccl t;
 	const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 	for (const char* n : names) {
-		r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-		if (r.handle) { break; }
+		t.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+		if (t.handle) { break; }
 	}
-	FI_REQUIRE(r.handle != nullptr, FI_ERR_COMM, "cannot load librccl: %s", dlerror());
+	FI_REQUIRE(t.handle != nullptr, FI_ERR_COMM, "cannot load librccl: %s", dlerror());
 	auto sym = [&](const char* name) {
-		void* p = dlsym(r.handle, name);
+		void* p = dlsym(t.handle, name);
 		FI_REQUIRE(p != nullptr, FI_ERR_COMM, "librccl lacks %s", name);
 		return p;
 	};
-	r.GetUniqueId    = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-	r.CommInitRank   = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-	r.CommDestroy    = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-	r.AllReduce      = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
-	r.Send           = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
-	r.Recv           = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
-	r.GroupStart     = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-	r.GroupEnd       = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-	r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+	t.GetUniqueId    = reinterpret_cast<decltype(t.GetUniqueId)>(sym("ncclGetUniqueId"));
+	t.CommInitRank   = reinterpret_cast<decltype(t.CommInitRank)>(sym("ncclCommInitRank"));
+	t.CommDestroy    = reinterpret_cast<decltype(t.CommDestroy)>(sym("ncclCommDestroy"));
+	t.AllReduce      = reinterpret_cast<decltype(t.AllReduce)>(sym("ncclAllReduce"));
+	t.Send           = reinterpret_cast<decltype(t.Send)>(sym("ncclSend"));
+	t.Recv           = reinterpret_cast<decltype(t.Recv)>(sym("ncclRecv"));
+	t.GroupStart     = reinterpret_cast<decltype(t.GroupStart)>(sym("ncclGroupStart"));
+	t.GroupEnd       = reinterpret_cast<decltype(t.GroupEnd)>(sym("ncclGroupEnd"));
+	t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(sym("ncclGetErrorString"));
+	r = t;
 	return r;
 }
 
@@ -84,23 +118,119 @@ namespace {
 
 }  // namespace
 
+namespace {
+
+constexpr uint32_t kHostMagic = 0x46494853u;  // "FIHS"
+
+void host_close(HostComm* h)
+{
+	if (!h) { return; }
+	if (h->base) { (void)munmap(h->base, h->bytes); }
+	if (h->fd >= 0) { (void)close(h->fd); }
+	if (h->owner) { (void)shm_unlink(h->name.c_str()); }
+	delete h;
+}
+
+// all ranks meet here; a rank that has given up releases the others with an error instead of a hang
+void host_barrier(HostComm* h)
+{
+	HostShm* s = h->hdr();
+	const uint32_t gen = s->generation.load(std::memory_order_acquire);
+	if (s->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == s->nranks) {
+		s->arrived.store(0, std::memory_order_relaxed);
+		s->generation.fetch_add(1, std::memory_order_release);
+		return;
+	}
+	const auto t0 = std::chrono::steady_clock::now();
+	while (s->generation.load(std::memory_order_acquire) == gen) {
+		if (s->failed.load(std::memory_order_acquire)) {
+			set_error("host-staged exchange: another rank failed");
+			throw Fail{FI_ERR_COMM};
+		}
+		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+			s->failed.store(1, std::memory_order_release);
+			set_error("host-staged exchange: no partner within 120 s");
+			throw Fail{FI_ERR_COMM};
+		}
+		usleep(20);
+	}
+}
+
+void host_allreduce(fi_ctx* c, double* dev, int count)
+{
+	HostComm* h = c->comm->host;
+	FI_REQUIRE(count > 0 && count <= 8, FI_ERR_INVALID, "host-staged all-reduce of %d values", count);
+	double* mine = reinterpret_cast<double*>(h->slot(c->rank));
+	FI_HIP_TRY(hipMemcpyAsync(mine, dev, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	host_barrier(h);
+	double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (int r = 0; r < c->nranks; ++r) {  // rank order: every rank forms the same bits
+		const double* v = reinterpret_cast<const double*>(h->slot(r));
+		for (int k = 0; k < count; ++k) { sum[k] += v[k]; }
+	}
+	host_barrier(h);  // everybody has read: the slots may be rewritten
+	FI_HIP_TRY(hipMemcpyAsync(dev, sum, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+}
+
+void host_exchange(fi_ctx* c, void* v)
+{
+	HostComm* h = c->comm->host;
+	const Geom&  g     = c->g;
+	const int    L     = g.ndim - 1;
+	const int    H     = c->halo;
+	const size_t es    = elem_size(c);
+	const size_t plane = static_cast<size_t>(g.stride[L]);
+	const size_t bytes = es * plane * H;
+	FI_REQUIRE(64 + 2 * bytes <= h->hdr()->slot_bytes, FI_ERR_COMM, "host-staged exchange: halo larger than the slot");
+	char* base = static_cast<char*>(v);
+	// slot layout: [64 B of sums][planes for the lower neighbour][planes for the upper neighbour]
+	char* mine = h->slot(c->rank) + 64;
+	if (c->rank > 0) { FI_HIP_TRY(hipMemcpyAsync(mine, base + es * plane * g.own_lo[L], bytes, hipMemcpyDeviceToHost, c->stream)); }
+	if (c->rank + 1 < c->nranks) {
+		FI_HIP_TRY(hipMemcpyAsync(mine + bytes, base + es * plane * (g.own_hi[L] - H), bytes, hipMemcpyDeviceToHost, c->stream));
+	}
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	host_barrier(h);
+	if (c->rank > 0) {  // the lower neighbour's planes for its upper neighbour -> my lower ghost planes
+		FI_HIP_TRY(hipMemcpyAsync(base, h->slot(c->rank - 1) + 64 + bytes, bytes, hipMemcpyHostToDevice, c->stream));
+	}
+	if (c->rank + 1 < c->nranks) {
+		FI_HIP_TRY(hipMemcpyAsync(base + es * plane * g.own_hi[L], h->slot(c->rank + 1) + 64, bytes, hipMemcpyHostToDevice, c->stream));
+	}
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	host_barrier(h);
+}
+
+}  // namespace
+
 void comm_destroy(Comm* cm)
 {
 	if (!cm) { return; }
 	if (cm->comm) { (void)rccl().CommDestroy(cm->comm); }
+	host_close(cm->host);
 	delete cm;
 }
 
 void allreduce_sum(fi_ctx* c, double* dev, int count)
 {
-	FI_REQUIRE(c->comm && c->comm->comm, FI_ERR_STATE, "slab context without fi_comm_init");
+	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+	if (c->comm->host) {
+		host_allreduce(c, dev, count);
+		return;
+	}
 	FI_NCCL_TRY(rccl().AllReduce(dev, dev, static_cast<size_t>(count), ncclFloat64, ncclSum, c->comm->comm, c->stream));
 }
 
 void exchange_halo(fi_ctx* c, void* v)
 {
 	if (c->nranks <= 1) { return; }
-	FI_REQUIRE(c->comm && c->comm->comm, FI_ERR_STATE, "slab context without fi_comm_init");
+	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+	if (c->comm->host) {
+		host_exchange(c, v);
+		return;
+	}
 	const Geom&  g     = c->g;
 	const int    L     = g.ndim - 1;
 	const int    H     = c->halo;
@@ -198,8 +328,57 @@ int fi_comm_init(fi_ctx* c, const void* unique_id128)
 		ncclUniqueId id;
 		memcpy(&id, unique_id128, sizeof(id));
 		if (!c->comm) { c->comm = new fi::Comm(); }
+		if (c->comm->comm) {  // a second call replaces the communicator
+			(void)fi::rccl().CommDestroy(c->comm->comm);
+			c->comm->comm = nullptr;
+		}
 		FI_NCCL_TRY(fi::rccl().CommInitRank(&c->comm->comm, c->nranks, id, c->rank));
 	} catch (const fi::Fail& f) {
+		return f.code;
+	}
+	return FI_OK;
+}
+
+int fi_comm_init_host(fi_ctx* c, const char* name, int create)
+{
+	fi::HostComm* h = nullptr;
+	try {
+		FI_REQUIRE(c != nullptr && name != nullptr && name[0] == '/', FI_ERR_INVALID, "bad argument (the name starts with '/')");
+		FI_REQUIRE(c->nranks > 1, FI_ERR_STATE, "fi_comm_init_host on a single-rank context");
+		// slot: 64 bytes of sums + the ghost planes for both neighbours at the finest level in fp64 with the widest halo
+		// any model needs (model_4: 4 planes; the model may be set after the communicator) -- coarser levels and fp32
+		// replicas are smaller
+		const fi::Geom& g = c->g;
+		const size_t plane = static_cast<size_t>(g.stride[g.ndim - 1]);
+		const size_t slot = ((64 + 2 * plane * 4 * sizeof(double)) + 4095) / 4096 * 4096;
+		h = new fi::HostComm();
+		h->name  = name;
+		h->bytes = 4096 + slot * static_cast<size_t>(c->nranks);
+		h->owner = create != 0;
+		h->fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+		FI_REQUIRE(h->fd >= 0, FI_ERR_COMM, "shm_open(%s) failed", name);
+		if (create) { FI_REQUIRE(ftruncate(h->fd, static_cast<off_t>(h->bytes)) == 0, FI_ERR_COMM, "ftruncate(%s) failed", name); }
+		void* m = mmap(nullptr, h->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, h->fd, 0);
+		FI_REQUIRE(m != MAP_FAILED, FI_ERR_COMM, "mmap(%s) failed", name);
+		h->base = static_cast<char*>(m);
+		fi::HostShm* s = h->hdr();
+		if (create) {
+			s->nranks     = static_cast<uint32_t>(c->nranks);
+			s->slot_bytes = slot;
+			s->arrived.store(0);
+			s->generation.store(0);
+			s->failed.store(0);
+			std::atomic_thread_fence(std::memory_order_release);
+			s->magic = fi::kHostMagic;
+		} else {
+			FI_REQUIRE(s->magic == fi::kHostMagic && s->nranks == static_cast<uint32_t>(c->nranks) && s->slot_bytes == slot,
+			           FI_ERR_COMM, "host segment %s does not match this decomposition", name);
+		}
+		if (!c->comm) { c->comm = new fi::Comm(); }
+		fi::host_close(c->comm->host);
+		c->comm->host = h;
+	} catch (const fi::Fail& f) {
+		fi::host_close(h);
 		return f.code;
 	}
 	return FI_OK;

@@ -264,7 +264,8 @@ struct fi_ctx {
 	int        tile_ts = 0;          // > 0 while fi_tile_pass runs: apply_AtA applies the tile operator of that tile size
 	int        verify_residual = 1;  // check b - A x when the recurrence converges, restart CG if it misses
 	fi_stats   stats{};
-	std::vector<hipEvent_t> ev;  // sampled events around AtA applies
+	std::vector<hipEvent_t> ev;       // sampled events around AtA applies
+	std::vector<hipEvent_t> ev_prec;  // ... around Chebyshev steps of the polynomial preconditioner
 };
 
 namespace fi {

@@ -482,6 +482,8 @@ __device__ inline void cg_logic(CgScalars* sc, int phase)
 	}
 }
 
+__global__ void k_noop(int) {}
+
 __global__ void k_set_done(CgScalars* sc, int value)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) { sc->done = value; }
@@ -874,6 +876,23 @@ void reset_scalars(RankSet& R, const CgScalars& init)
 	}
 }
 
+// The wall-clock guard of a solve reads every rank's OWN clock.  With one slab per process the ranks must leave the
+// loop in the same poll round -- a rank that went on alone would enqueue halo exchanges and all-reduces that have no
+// partner and hang in them -- so the flag is all-reduced at every look (slot 2, sums[3]: no reduction of the drivers
+// uses more than three sums).  Every other stop condition comes from all-reduced device scalars and is agreed anyway.
+bool timed_out_anywhere(RankSet& R, bool mine)
+{
+	fi_ctx* c0 = R[0];
+	if (!(R.size() == 1 && c0->nranks > 1)) { return mine; }
+	double* flag = (c0->scal.as<CgScalars>() + 2)->sums + 3;
+	double  v = mine ? 1.0 : 0.0;
+	FI_HIP_TRY(hipMemcpyAsync(flag, &v, sizeof(double), hipMemcpyHostToDevice, c0->stream));
+	allreduce_sum(c0, flag, 1);
+	FI_HIP_TRY(hipMemcpyAsync(&v, flag, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c0->stream));
+	return v > 0.0;
+}
+
 // Jacobi-PCG over a rank set; x of every member holds the guess on entry and the solution on return.
 template <typename T>
 void cg_run(RankSet& R, int max_iterations, float tol)
@@ -957,7 +976,7 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 			reduce_phase(R, 2, nbv, nbv, kPhaseRestart);
 			continue;
 		}
-		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
+		if (timed_out_anywhere(R, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s)) {
 			timed_out = true;
 			break;
 		}
@@ -1074,6 +1093,10 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		c->stats.spmv_samples = used;
 		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		c->stats.prec_samples = 0;
+		c->stats.prec_ms_avg  = 0.0;
+		c->stats.prec_bytes   = 0.0;
+		c->stats.operator_applies = h.iter + 1 + h.restarts;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
 		// with the verified stop on, "converged" means b - A x itself met the tolerance (done == 5); a recurrence
@@ -1087,6 +1110,8 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		}
 	}
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
+	FI_REQUIRE(!timed_out, FI_ERR_TIMEOUT, "solve stopped by the wall-clock guard (FI_SOLVE_TIMEOUT_S = %g s) after %d iterations, "
+	           "relative residual %g", limit_s, h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0);
 }
 
 bool poly_ok(const fi_ctx* c);
@@ -1770,7 +1795,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			restart();
 			continue;
 		}
-		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
+		if (timed_out_anywhere(R, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s)) {
 			timed_out = true;
 			break;
 		}
@@ -1812,6 +1837,10 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		c->stats.spmv_samples = used;
 		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		c->stats.prec_samples = 0;
+		c->stats.prec_ms_avg  = 0.0;
+		c->stats.prec_bytes   = 0.0;
+		c->stats.operator_applies = h.iter + 1 + h.restarts;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
@@ -1821,6 +1850,8 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
 	}
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
+	FI_REQUIRE(!timed_out, FI_ERR_TIMEOUT, "solve stopped by the wall-clock guard (FI_SOLVE_TIMEOUT_S = %g s) after %d iterations, "
+	           "relative residual %g", limit_s, h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0);
 }
 
 
@@ -1845,6 +1876,22 @@ bool poly_ok(const fi_ctx* c) { return c->poly_terms > 1 && stencil_cheb_availab
 
 // first half: alpha, r -= alpha q, z1 = Dinv r / theta, partials r.r and r.z1  (reads r, q, Dinv; writes r, z1)
 // phase 0 / 2 (start / restart from b - A x): r = b - q instead, and b.b on the start
+// streams of the polynomial-PCG vector kernels: plain or non-temporal 16-byte accesses (FI_PCG_NT; measured, see
+// profiles/r2_ablation.md)
+#ifndef FI_PCG_NT
+#define FI_PCG_NT 1
+#endif
+template <typename T>
+__device__ inline void pld16(T* dst, const T* base, int64_t i)
+{
+	if (FI_PCG_NT) { ld16_nt(dst, base, i); } else { *reinterpret_cast<typename Vec16<T>::V*>(dst) = reinterpret_cast<const typename Vec16<T>::V*>(base)[i]; }
+}
+template <typename T>
+__device__ inline void pst16(T* base, int64_t i, const T* src)
+{
+	if (FI_PCG_NT) { st16_nt(base, i, src); } else { reinterpret_cast<typename Vec16<T>::V*>(base)[i] = *reinterpret_cast<const typename Vec16<T>::V*>(src); }
+}
+
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScalars* __restrict__ in, CgScalars* __restrict__ mid,
                                                          int tag, int phase, const double* __restrict__ pq_partial, int pq_count,
@@ -1884,9 +1931,9 @@ __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScala
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
 		T rv[N], qv[N], dv[N], zv[N], bv[N];
 		if (VEC) {
-			ld16_nt(qv, q, i);
+			pld16(qv, q, i);
 			*reinterpret_cast<V*>(dv) = reinterpret_cast<const V*>(dinv)[i];
-			if (phase == 1) { *reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i]; } else { ld16_nt(bv, b, i); }
+			if (phase == 1) { *reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i]; } else { pld16(bv, b, i); }
 		} else {
 			qv[0] = q[i]; dv[0] = dinv[i];
 			if (phase == 1) { rv[0] = r[i]; } else { bv[0] = b[i]; }
@@ -1918,6 +1965,9 @@ __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScala
 	}
 }
 
+#ifdef FI_XP_STAMPS
+__device__ unsigned long long g_xp_stamp[8];
+#endif
 // second half: beta and the stop test, x += alpha p, p = z + beta p            (reads x, p, z; writes x, p)
 // phase 0: start (b.b, tolerance, p = z); phase 2: restart from the true residual (p = z, verified stop)
 template <typename T, bool VEC>
@@ -1926,13 +1976,25 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
                                                       const double* __restrict__ prz, int nrz, const double* __restrict__ pbb,
                                                       int nbb, const T* __restrict__ z, T* __restrict__ x, T* __restrict__ p)
 {
+#ifdef FI_XP_STAMPS
+	const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+#endif
 	if (mid->tag != tag) { return; }  // the first half of this iteration did not run: the solve had finished
 	if (mid->done == 2) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = *mid; }
 		return;
 	}
+#ifdef FI_XP_STAMPS
+	const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
 	const double rr = sum_partials(prr, nrr);
+#ifdef FI_XP_STAMPS
+	const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+#endif
 	const double rz = sum_partials(prz, nrz);
+#ifdef FI_XP_STAMPS
+	const unsigned long long t_c = __builtin_amdgcn_s_memtime();
+#endif
 	CgScalars s = *mid;
 	double beta_d = 0.0;
 	if (phase == 1) {
@@ -1962,31 +2024,58 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
 	const T    beta  = static_cast<T>(beta_d);
 	const bool go_on = s.done == 0;
 	const int64_t nv = n / N;
+	// all three streams are loaded before anything is stored (a load placed behind the store of x costs a second
+	// memory round trip per sweep: the kernel ran latency-bound, 69 instead of 53 us at 256^3)
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
 		T xv[N], pv[N], zv[N];
-		if (phase == 1) {
-			if (VEC) {
-				ld16_nt(xv, x, i);
+		if (VEC) {
+			pld16(zv, z, i);
+			if (phase == 1) {
+				pld16(xv, x, i);
 				*reinterpret_cast<V*>(pv) = reinterpret_cast<const V*>(p)[i];
-			} else {
-				xv[0] = x[i]; pv[0] = p[i];
 			}
+		} else {
+			zv[0] = z[i];
+			if (phase == 1) { xv[0] = x[i]; pv[0] = p[i]; }
+		}
+		if (phase == 1) {
 #pragma unroll
-			for (int j = 0; j < N; ++j) { xv[j] += alpha * pv[j]; }
-			if (VEC) { st16_nt(x, i, xv); } else { x[i] = xv[0]; }
+			for (int j = 0; j < N; ++j) {
+				xv[j] += alpha * pv[j];
+				pv[j] = zv[j] + beta * pv[j];
+			}
+			if (VEC) { pst16(x, i, xv); } else { x[i] = xv[0]; }
 		} else {
 #pragma unroll
-			for (int j = 0; j < N; ++j) { pv[j] = T(0); }
+			for (int j = 0; j < N; ++j) { pv[j] = zv[j]; }
 		}
 		if (go_on) {
-			if (VEC) { ld16_nt(zv, z, i); } else { zv[0] = z[i]; }
-#pragma unroll
-			for (int j = 0; j < N; ++j) { pv[j] = zv[j] + beta * pv[j]; }
 			if (VEC) { reinterpret_cast<V*>(p)[i] = *reinterpret_cast<V*>(pv); } else { p[i] = pv[0]; }
 		}
 	}
+#ifdef FI_XP_STAMPS
+	if (threadIdx.x == 0 && n < 300000) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const unsigned long long t_out = __builtin_amdgcn_s_memtime();
+		if (blockIdx.x == 0) { g_xp_stamp[0] = t_a - t_in; g_xp_stamp[1] = t_b - t_a; g_xp_stamp[2] = t_c - t_b; g_xp_stamp[3] = t_out - t_c; }
+		atomicMin(&g_xp_stamp[4], t_in);
+		atomicMax(&g_xp_stamp[5], t_in);
+		atomicMax(&g_xp_stamp[6], t_out);
+		if (tag == 30) { g_xp_stamp[4] = ~0ull; g_xp_stamp[5] = 0; g_xp_stamp[6] = 0; }
+	}
+#endif
 }
+#ifdef FI_XP_STAMPS
+}  // namespace
+}  // namespace fi
+extern "C" int fi_debug_xp_stamps(unsigned long long* out)
+{
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(fi::g_xp_stamp), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
+}
+namespace fi {
+namespace {
+#endif
 
 // sums of up to three partial lists of different lengths into sums[0..2] of a scalar slot (rank sets: the values
 // then cross the slabs by k_group_sum / the all-reduce)
@@ -2118,6 +2207,14 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	const Vec ZA = &fi_ctx::mg_x, ZB = &fi_ctx::mg_d;
 
 	int tag = 0;
+	int psamples = 0;  // timed Chebyshev steps
+	std::vector<int> ptags;
+	std::vector<hipEvent_t>& pev = c0->ev_prec;
+	while (static_cast<int>(pev.size()) < 2 * kMaxSamples) {
+		hipEvent_t e;
+		FI_HIP_TRY(hipEventCreate(&e));
+		pev.push_back(e);
+	}
 	// one pass of the recurrence: phase 1 = a CG step (the apply of p has been launched), 0 / 2 = start / restart (the
 	// apply of x has been launched)
 	auto half_steps = [&](int phase) {
@@ -2146,9 +2243,19 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		Vec zin = ZA, zout = ZB;
 		for (int k = 1; k < terms; ++k) {
 			halo_exchange(R, zin);
+			// every 4th pass times its last step (5 lattice passes when the polynomial has 3 terms or more)
+			const bool sample = phase == 1 && k == terms - 1 && psamples < kMaxSamples && (tag & 3) == 1;
+			if (sample) {
+				FI_HIP_TRY(hipEventRecord(pev[2 * psamples], st));
+				ptags.push_back(tag);
+			}
 			for (fi_ctx* c : R) {
 				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1],
 				                  c2s[k - 1], region(c, 2));
+			}
+			if (sample) {
+				FI_HIP_TRY(hipEventRecord(pev[2 * psamples + 1], st));
+				++psamples;
 			}
 			std::swap(zin, zout);
 		}
@@ -2161,6 +2268,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			}
 			cross(phase == 0 ? 3 : 2);
 		}
+		if (getenv("FI_DUMMY")) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st, 0); }  // experiment
 		for (fi_ctx* c : R) {
 			const int64_t o = c->g.own_first;
 			const int     nbf = nbf_of(c);
@@ -2209,7 +2317,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			start(2);
 			continue;
 		}
-		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s) {
+		if (timed_out_anywhere(R, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s)) {
 			timed_out = true;
 			break;
 		}
@@ -2243,10 +2351,24 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		FI_HIP_TRY(hipEventElapsedTime(&t, c0->ev[2 * k], c0->ev[2 * k + 1]));
 		sum_ms += t;
 	}
+	// the timed steps of passes that ran (pass t is outer iteration t - 1; passes past the stop exited at once)
+	int pused = 0;
+	double psum = 0;
+	for (int k = 0; k < psamples; ++k) {
+		if (ptags[k] - 1 > h.iter) { break; }  // pass `tag` is CG step tag - 1 (or earlier, after restarts): it ran
+		float t = 0;
+		FI_HIP_TRY(hipEventElapsedTime(&t, pev[2 * k], pev[2 * k + 1]));
+		psum += t;
+		++pused;
+	}
 	for (fi_ctx* c : R) {
 		c->stats.spmv_samples = used;
 		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		c->stats.prec_samples = pused;
+		c->stats.prec_ms_avg  = pused ? psum / pused : 0.0;
+		c->stats.prec_bytes   = static_cast<double>(sizeof(T)) * (terms > 2 ? 5.0 : 4.0) * static_cast<double>(c->g.nown);
+		c->stats.operator_applies = (h.iter + 1 + h.restarts) * terms;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
@@ -2256,6 +2378,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
 	}
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
+	FI_REQUIRE(!timed_out, FI_ERR_TIMEOUT, "solve stopped by the wall-clock guard (FI_SOLVE_TIMEOUT_S = %g s) after %d iterations, "
+	           "relative residual %g", limit_s, h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0);
 }
 
 template <typename T>
@@ -2787,6 +2911,7 @@ int fi_ctx_destroy(fi_ctx* c)
 	c->pending.clear();
 	c->pending_pool.clear();
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
+	for (auto e : c->ev_prec) { (void)hipEventDestroy(e); }
 	if (c->comm && c->owns_comm) { fi::comm_destroy(c->comm); }
 	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
 	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }

@@ -45,20 +45,59 @@ def points_of_slab(positions, ndim, lo, hi, levels=0):
     return (z >= zlo) & (z < zhi)
 
 
-def init_comm(field, device=None):
-    """Create the RCCL communicator of a slab LatticeField: the 128-byte unique id made by rank 0 travels
-    through torch.distributed (any backend), then every rank calls fi_comm_init."""
+_HOST_SEGMENTS = 0
+
+
+def init_comm(field, device=None, host_staged=False):
+    """Create the communicator of a slab LatticeField.  RCCL: the 128-byte unique id made by rank 0 travels through
+    torch.distributed (any backend) together with a status byte, so that a failure on rank 0 raises on EVERY rank
+    instead of leaving the others in the broadcast; then every rank calls fi_comm_init.  host_staged (tests on a
+    one-GPU machine, where RCCL refuses two ranks on one device): the shared-memory test transport of
+    fi_comm_init_host -- rank 0 creates the segment, the others attach after a barrier.
+    A failure of fi_comm_init itself on some rank is the caller's to agree on (bench.py does) before the next collective."""
     import ctypes
+    import os
     import torch
     import torch.distributed as dist
     from . import _capi
     if field.nranks == 1:
         return
+    rank0 = dist.get_rank() == 0
+    if host_staged:
+        global _HOST_SEGMENTS
+        _HOST_SEGMENTS += 1                             # every rank makes the same sequence of communicators
+        name = "/fi_host_%s_%d_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), _HOST_SEGMENTS)
+        t = torch.zeros(1, dtype=torch.int32)
+        err = None
+        if rank0:
+            try:
+                try:
+                    os.unlink("/dev/shm" + name)       # a segment left behind by a killed run
+                except OSError:
+                    pass
+                field.comm_init_host(name, True)
+            except Exception as e:                      # noqa: BLE001 -- told to every rank below
+                err = e
+                t[0] = 1
+        dist.broadcast(t, 0)                            # also the barrier: the segment exists before anybody attaches
+        if int(t[0]) != 0:
+            raise RuntimeError("rank 0 could not create the host segment: %s" % (err or "see rank 0"))
+        if not rank0:
+            field.comm_init_host(name, False)
+        return
     buf = ctypes.create_string_buffer(128)
-    if dist.get_rank() == 0:
-        _capi.check(_capi.lib().fi_comm_unique_id(buf))
-    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    status = 0
+    err = None
+    if rank0:
+        try:
+            _capi.check(_capi.lib().fi_comm_unique_id(buf))
+        except Exception as e:                          # noqa: BLE001 -- told to every rank below
+            status, err = 1, e
+    t = torch.frombuffer(bytearray(bytes([status]) + buf.raw), dtype=torch.uint8).clone()
     if device is not None and dist.get_backend() == "nccl":
         t = t.to(device)
     dist.broadcast(t, 0)
-    field.comm_init(bytes(t.cpu().numpy().tobytes()))
+    raw = bytes(t.cpu().numpy().tobytes())
+    if raw[0] != 0:
+        raise RuntimeError("rank 0 could not create the RCCL unique id: %s" % (err or "see rank 0"))
+    field.comm_init(raw[1:129])

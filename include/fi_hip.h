@@ -31,6 +31,8 @@ extern "C" {
 #define FI_ERR_COMM 4         /* RCCL failure */
 #define FI_ERR_UNSUPPORTED 5  /* valid in the reference, not available in this mode */
 #define FI_ERR_BREAKDOWN 6    /* solver breakdown (non-finite or non-positive curvature): reference returns {} */
+#define FI_ERR_TIMEOUT 7      /* the wall-clock guard of a solve (FI_SOLVE_TIMEOUT_S, default 600 s) stopped it; over slabs
+                                 all ranks stop in the same round.  The iterate is kept in the context. */
 
 #define FI_HOST 0
 #define FI_DEVICE 1
@@ -93,6 +95,10 @@ typedef struct fi_stats {
 	double verified_residual;  /* ||b - A x||/||b|| at the last such evaluation (-1: none) */
 	int    num_levels;         /* 1 + coarser levels built by the last fi_assemble */
 	int    coarse_iterations;  /* CG iterations spent on coarser levels by the last solve (cascade start) */
+	double prec_ms_avg;        /* mean duration of the sampled Chebyshev-step launches of the polynomial preconditioner */
+	int    prec_samples;
+	double prec_bytes;         /* algorithmic bytes of one such launch: 5 lattice passes (4 on the first step of a polynomial) */
+	int    operator_applies;   /* full operator applications + preconditioner steps of the last solve (finest level) */
 } fi_stats;
 
 const char* fi_last_error(void);
@@ -135,6 +141,12 @@ int fi_comm_self_test(int device, long count);
  * fi_comm_init.  Halo planes of the CG search direction and the dot products then travel over xGMI. */
 int fi_comm_unique_id(void* out128);
 int fi_comm_init(fi_ctx* ctx, const void* unique_id128);
+/* TEST transport for ranks that share one GPU (RCCL refuses two ranks on one device): the halo planes and the dot
+ * products travel through the POSIX shared-memory segment `name` ("/...") by host copies, behind the same two internal
+ * operations (exchange_halo, allreduce_sum) the RCCL path implements.  Rank 0 passes create = 1 BEFORE the other ranks
+ * attach (the launcher orders the calls).  Everything above the wire -- slab geometry, per-rank assembly, the rank-set
+ * solvers, bench.py --gpus N -- then runs for real on a single-GPU machine.  Slow by construction; never the product path. */
+int fi_comm_init_host(fi_ctx* ctx, const char* name, int create);
 
 /* ---- assembly -------------------------------------------------------------------------------
  * fi_set_model replaces add_field_constraints(field, weights) (field_interpolation.cpp:326-341):

@@ -165,3 +165,31 @@ def test_points_of_slab_keeps_every_touching_cell():
         cz = np.floor(pos[:, 2])
         must = (cz >= lo - 1) & (cz <= hi - 1)
         assert not (must & ~keep).any()
+
+
+def test_points_of_slab_covers_the_cells_of_every_coarse_level():
+    """A rank's coarser levels are assembled from its own points (positions / 2^l): the margin must cover every cell of
+    level l that touches the rank's coarse planes ceil(lo / 2^l) .. ceil(hi / 2^l) - 1 (build_levels' rule), plus one
+    cell for the nearest-neighbour kernels -- the round-1 margin (2 fine cells) lost cells of level 2 and deeper."""
+    from field_interpolation_amd import dist as fdist
+    rng = np.random.default_rng(1)
+    planes = 512
+    pos = rng.uniform(-3, planes + 2, size=(20000, 3)).astype(np.float32)
+    z = pos[:, 2].astype(np.float64)
+    for nranks in (2, 3, 8):
+        for levels in (0, 1, 2, 3, 5):
+            for rank in range(nranks):
+                lo, hi = fdist.slab_range(planes, rank, nranks)
+                keep = fdist.points_of_slab(pos, 3, lo, hi, levels)
+                clo, chi = lo, hi
+                for lev in range(levels + 1):
+                    if lev > 0:
+                        clo, chi = (clo + 1) // 2, (chi + 1) // 2
+                    cz = np.floor(z / 2.0 ** lev)                 # cell origin on level lev
+                    rz = np.round(z / 2.0 ** lev)                 # nearest-neighbour row on level lev
+                    must = ((cz >= clo - 1) & (cz <= chi - 1)) | ((rz >= clo) & (rz <= chi - 1))
+                    assert not (must & ~keep).any(), (nranks, levels, rank, lev)
+            # and the margins stay small: the ranks together upload each point a bounded number of times
+            total = sum(int(fdist.points_of_slab(pos, 3, *fdist.slab_range(planes, r, nranks), levels).sum())
+                        for r in range(nranks))
+            assert total <= len(pos) * (1.0 + 3.0 * nranks * 2.0 ** levels / planes) + 1

@@ -1,0 +1,66 @@
+"""Two ranks, two processes, ONE GPU: everything of the multi-GPU path except the RCCL wire.
+
+torch.distributed.run starts two workers before either touches the GPU; each builds its slab context (fi_ctx_create_slab),
+joins the host-staged test transport (fi_comm_init_host: halo planes and dot products through shared memory -- RCCL
+refuses two ranks on one device), uploads only the points fi_slab_point_range asks for, assembles its slab with its
+coarser levels and runs the rank-set solvers.  Rank 0 compares with the undivided solve of the same inputs.  Then the
+real bench orchestration: bench.py --gpus 2 in both scaling modes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(args, timeout=600):
+    env = dict(os.environ, FI_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_processes_equal_the_undivided_solve():
+    r = _torchrun([os.path.join(ROOT, "tests", "two_rank_worker.py")])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULTS ")]
+    assert line, r.stdout[-3000:] + r.stderr[-3000:]
+    results = json.loads(line[-1][len("RESULTS "):])
+    assert len(results) == 4
+    for res in results:
+        it = res["iterations"]
+        assert it[0] == it[1], res                                  # both ranks stop in the same iteration
+        assert abs(it[0] - res["iterations_one"]) <= max(3, res["iterations_one"] // 10), res
+        assert max(res["rel"]) <= res["tol"] and max(res["true_rel"]) <= 1.5 * res["tol"], res
+        assert res["true_rel"][0] == res["true_rel"][1], res        # the residual is a sum over both slabs
+        # every rank filtered its points: nobody uploaded everything, together they cover the cloud
+        assert max(res["points_kept"]) < res["points"] and sum(res["points_kept"]) >= res["points"], res
+        # the solutions agree to what the tolerance allows (kappa * tol; fp64 cases are tight)
+        assert res["max_diff"] <= (5e-2 if res["tol"] >= 1e-6 else 1e-4), res
+        if res["coarse_iterations_one"]:
+            # the slabs' coarse operators are the undivided ones (fi_slab_point_range covers the coarse cells)
+            assert abs(res["coarse_iterations"][0] - res["coarse_iterations_one"]) <= max(3, res["coarse_iterations_one"] // 10), res
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu(scaling):
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--side", "64", "--cpu-side", "0",
+                   "--scaling", scaling])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling
+    assert line["config"]["parallelism"] == "slab2"
+    assert line["config"]["true_rel_residual"] <= 1.5e-5
+    assert ("64x64x128" if scaling == "weak" else "64x64x64") in line["config"]["workload"]
+    assert line["value"] > 0

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Worker of tests/test_gpu_two_ranks.py, started by torch.distributed.run with two ranks on ONE GPU: the real
+one-process-per-slab orchestration (rank bootstrap, fi_slab_point_range filtering of the points, per-rank assembly with
+coarser levels, rank-set solvers) with the halo planes and dot products carried by the host-staged test transport
+(fi_comm_init_host) instead of RCCL.  Rank 0 also solves the undivided problem and compares."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch
+import torch.distributed as dist
+
+dist.init_process_group("gloo")     # before any GPU call
+rank, world = dist.get_rank(), dist.get_world_size()
+
+import field_interpolation_amd as fi                      # noqa: E402
+from field_interpolation_amd import dist as fdist         # noqa: E402
+from field_interpolation_amd import synth                 # noqa: E402
+from util import sphere_points                            # noqa: E402
+
+torch.cuda.set_device(0)
+
+
+def run(name, sizes, w, pos, nrm, val, dtype, tol, levels=0, poly=0, multigrid=False, mixed=False):
+    def configure(f):
+        f.add_field_constraints(w)
+        if levels:
+            f.set_levels(levels, 1e-6 if dtype == "f64" else 1e-5)
+            if multigrid:
+                f.set_multigrid(True)
+                if mixed:
+                    f.set_mixed_precision(True)
+        if poly:
+            f.set_polynomial(poly)
+
+    f = fi.LatticeField(sizes, dtype=dtype, rank=rank, nranks=world)
+    fdist.init_comm(f, None, host_staged=True)
+    configure(f)
+    zlo, zhi = f.point_range()
+    D = len(sizes)
+    z = pos.reshape(-1, D)[:, D - 1]
+    keep = (z >= zlo) & (z < zhi)
+    gw = w.data_gradient if nrm is not None else 0.0
+    f.add_points(w.data_pos, w.value_kernel, gw, w.gradient_kernel, pos[keep], None if nrm is None else nrm[keep], None,
+                 values=None if val is None else val[keep])
+    f.assemble()
+    x, it, rel = f.solve_cg(None, 0, tol)
+    true_rel = f.true_residual()           # a collective over the slabs as well
+    st = f.stats()
+    parts = [None] * world
+    dist.gather_object((x, it, rel, true_rel, st["coarse_iterations"], int(keep.sum())), parts if rank == 0 else None, dst=0)
+    out = None
+    if rank == 0:
+        xs = np.concatenate([p[0] for p in parts])
+        one = fi.LatticeField(sizes, dtype=dtype)
+        configure(one)
+        one.add_points(w.data_pos, w.value_kernel, gw, w.gradient_kernel, pos, nrm, None, values=val)
+        one.assemble()
+        x1, it1, rel1 = one.solve_cg(None, 0, tol)
+        st1 = one.stats()
+        out = {"case": name, "iterations": [p[1] for p in parts], "iterations_one": it1, "rel": [p[2] for p in parts],
+               "true_rel": [p[3] for p in parts], "coarse_iterations": [p[4] for p in parts],
+               "coarse_iterations_one": st1["coarse_iterations"], "points_kept": [p[5] for p in parts], "points": len(pos),
+               "max_diff": float(np.abs(xs - x1).max() / np.abs(x1).max()), "tol": tol}
+        del one
+    del f
+    dist.barrier()
+    return out
+
+
+results = []
+sizes, w, pos, val = synth.config4(side=48, num_points=6591, seed=3)
+results.append(run("config4 48^3 cascade(2 levels) + polynomial PCG f32", sizes, w, pos, None, val, "f32", 1e-5, levels=2, poly=4))
+results.append(run("config4 48^3 Jacobi-PCG f64", sizes, w, pos, None, val, "f64", 1e-9))
+results.append(run("config4 48^3 cascade(2 levels) + Jacobi-PCG f64", sizes, w, pos, None, val, "f64", 1e-9, levels=2))
+rng = np.random.default_rng(7)
+sizes = [40, 36, 48]
+spos, snrm = sphere_points(rng, sizes, 3000)
+results.append(run("SDF 40x36x48 V-cycle PCG f64 mixed (3 levels)", sizes, fi.Weights(), spos, snrm, None, "f64", 1e-8, levels=2,
+                   multigrid=True, mixed=True))
+if rank == 0:
+    print("RESULTS " + json.dumps(results), flush=True)
+dist.destroy_process_group()
