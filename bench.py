@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="data points (default: the configuration's, scaled with the side)")
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--tol", type=float, default=0.0)
-    ap.add_argument("--cpu-side", type=int, default=112, help="lattice side of the CPU baseline sample (0: skip)")
+    ap.add_argument("--cpu-side", type=int, default=160, help="lattice side of the CPU baseline sample (0: skip)")
     ap.add_argument("--levels", type=int, default=None, help="coarser levels (config 4: coarse-to-fine start; 0: none)")
     ap.add_argument("--coarse-tol", type=float, default=0.0)
     ap.add_argument("--multigrid", action="store_true", help="config 4: V-cycle preconditioned CG")

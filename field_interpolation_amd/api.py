@@ -512,10 +512,16 @@ def solve_tiled_with_guess(field, guess, sizes, options):
 def solve_sparse_linear_exact(field, num_columns=None, tolerance=1e-12, max_iterations=0):
     """Stands in for solve_sparse_linear_exact (sparse_linear.cpp:154-184): the reference factorises AtA
     (sparse Cholesky, double).  On the GPU the same system is iterated to `tolerance` in fp64; create the
-    field with dtype="f64" for this.  Returns None if CG breaks down (the reference returns {} when the
-    factorisation fails, e.g. for a singular AtA)."""
+    field with dtype="f64" for this.  Returns None where the reference returns {}: an unknown without any equation (the
+    zero pivot that stops the factorisation) or a solver breakdown.  A well-posed system whose attainable residual
+    (about eps * kappa) stays above `tolerance` returns its best iterate with a warning -- the factorisation would
+    still answer."""
+    import warnings
     if field.dtype != "f64":
         raise ValueError("solve_sparse_linear_exact needs a dtype='f64' field")
+    field._ready()
+    if not (field.diag() > 0).all():
+        return None
     if max_iterations <= 0:
         # CG in floating point can need several times N steps on these kappa ~ side^4 systems
         max_iterations = max(2000, 20 * field.num_unknowns)
@@ -524,7 +530,7 @@ def solve_sparse_linear_exact(field, num_columns=None, tolerance=1e-12, max_iter
         return None
     x, it, rel = res
     if not (rel <= tolerance * 1.0001):
-        return None
+        warnings.warn("solve_sparse_linear_exact: relative residual %g after %d iterations (asked for %g)" % (rel, it, tolerance))
     return x
 
 

@@ -3,9 +3,11 @@
 // The reference builds Eigen matrices here (sparse_linear.cpp:59-113) and calls SimplicialLLT / BiCGSTAB.
 // This file uploads the triplets as generic sparse rows (fi_add_rows_coo) and iterates A^T A x = A^T b on
 // the GPU: Jacobi-preconditioned CG with the reference's stop rule; "exact"/"fast" iterate to a tight
-// tolerance in fp64 / fp32.  Failure conventions follow the reference: log + empty vector.
+// tolerance in fp64.  Failure conventions follow the reference: log + empty vector.  Device contexts are cached per
+// lattice shape between the stateless calls.
 #include "field_interpolation/sparse_linear.hpp"
 
+#include <climits>
 #include <cstdio>
 #include <ostream>
 
@@ -48,36 +50,101 @@ static_assert(sizeof(Triplet) == sizeof(fi_triplet), "Triplet must stay 12 bytes
 
 void warn(const char* what) { std::fprintf(stderr, "field_interpolation: %s: %s\n", what, fi_last_error()); }
 
-// A context that holds nothing but the caller's rows: 1-D "lattice" of num_columns unknowns (or the caller's lattice,
-// which only the tile pre-solver looks at), no model rows.
+// Device contexts are kept between calls, keyed by (lattice shape, precision): the reference API is stateless and
+// its per-frame caller (src/bipolar_2d.cpp:730: a 128^2 warm-started solve every frame) would otherwise pay context
+// creation -- stream, hipMalloc of every vector, the sort buffers -- on each call (SURVEY.md 8(b) allows exactly this
+// cache).  A handful of shapes, least recently used first out; one cache per thread, like the contexts themselves.
+struct CachedCtx {
+	std::vector<int> shape;
+	int              dtype = 0;
+	fi_ctx*          ctx = nullptr;
+	unsigned long    used = 0;
+};
+struct CtxCache {
+	std::vector<CachedCtx> slots;
+	unsigned long          clock = 0;
+	~CtxCache()
+	{
+		for (CachedCtx& s : slots) { fi_ctx_destroy(s.ctx); }
+	}
+	fi_ctx* get(const std::vector<int>& shape, int dtype)
+	{
+		++clock;
+		for (CachedCtx& s : slots) {
+			if (s.dtype == dtype && s.shape == shape) {
+				s.used = clock;
+				return s.ctx;
+			}
+		}
+		fi_ctx* ctx = nullptr;
+		if (fi_ctx_create(&ctx, static_cast<int>(shape.size()), shape.data(), dtype) != FI_OK) {
+			warn("fi_ctx_create");
+			return nullptr;
+		}
+		if (slots.size() >= 6) {
+			size_t old = 0;
+			for (size_t i = 1; i < slots.size(); ++i) {
+				if (slots[i].used < slots[old].used) { old = i; }
+			}
+			fi_ctx_destroy(slots[old].ctx);
+			slots.erase(slots.begin() + static_cast<long>(old));
+		}
+		slots.push_back(CachedCtx{shape, dtype, ctx, clock});
+		return ctx;
+	}
+	void drop(fi_ctx* ctx)  // a context that failed is not reused
+	{
+		for (size_t i = 0; i < slots.size(); ++i) {
+			if (slots[i].ctx == ctx) {
+				fi_ctx_destroy(ctx);
+				slots.erase(slots.begin() + static_cast<long>(i));
+				return;
+			}
+		}
+	}
+};
+CtxCache& cache()
+{
+	static thread_local CtxCache c;
+	return c;
+}
+
+// The caller's rows on the device: a context that holds nothing else -- a 1-D "lattice" of num_columns unknowns (or the
+// caller's lattice, which only the tile pre-solver looks at), no model rows.
 struct RowsOnGpu {
 	fi_ctx* ctx = nullptr;
 	RowsOnGpu(const LinearEquation& eq, int num_columns, int dtype, const std::vector<int>* lattice = nullptr)
 	{
-		const int flat[1] = {num_columns};
+		if (num_columns < 1) { return; }
 		const bool nd = lattice && !lattice->empty() && lattice->size() <= 3;
-		if (num_columns < 1 || fi_ctx_create(&ctx, nd ? static_cast<int>(lattice->size()) : 1, nd ? lattice->data() : flat, dtype) != FI_OK) {
-			warn("fi_ctx_create");
-			ctx = nullptr;
-			return;
-		}
+		const std::vector<int> shape = nd ? *lattice : std::vector<int>{num_columns};
+		ctx = cache().get(shape, dtype);
+		if (!ctx) { return; }
 		const fi_weights none = {1, 1, 0, 0, 0, 0, 0, 0, FI_VALUE_LINEAR_INTERPOLATION, FI_GRADIENT_CELL_EDGES};
-		const bool ok = fi_set_model(ctx, &none) == FI_OK &&
+		const bool ok = fi_clear_points(ctx) == FI_OK && fi_set_model(ctx, &none) == FI_OK &&
 		                fi_add_rows_coo(ctx, static_cast<long>(eq.rhs.size()), static_cast<long>(eq.triplets.size()),
 		                                reinterpret_cast<const fi_triplet*>(eq.triplets.data()), eq.rhs.data(), FI_HOST) == FI_OK &&
 		                fi_assemble(ctx) == FI_OK;
 		if (!ok) {
 			warn("assembling the linear equation");
-			fi_ctx_destroy(ctx);
+			cache().drop(ctx);
 			ctx = nullptr;
 		}
 	}
-	~RowsOnGpu() { fi_ctx_destroy(ctx); }
 	RowsOnGpu(const RowsOnGpu&) = delete;
 };
 
+// Eigen::BiCGSTAB applies the operator twice per iteration, the CG used here once: a caller's iteration budget
+// (src/bipolar_2d.cpp:328: solve_sparse_linear_with_guess(eq, last, 100, 0)) buys the same number of operator
+// applications -- two CG steps per requested BiCGSTAB step.  0 keeps meaning "the solver's default".
+int cg_budget(int bicgstab_iterations)
+{
+	if (bicgstab_iterations <= 0) { return 0; }
+	return bicgstab_iterations > INT_MAX / 2 ? INT_MAX : 2 * bicgstab_iterations;
+}
+
 std::vector<float> iterate(const LinearEquation& eq, const std::vector<float>* guess, int num_columns, int dtype,
-                           int max_iterations, float tolerance, bool must_converge)
+                           int max_iterations, float tolerance)
 {
 	RowsOnGpu gpu(eq, num_columns, dtype);
 	if (!gpu.ctx) { return {}; }
@@ -89,33 +156,66 @@ std::vector<float> iterate(const LinearEquation& eq, const std::vector<float>* g
 		warn("solver failed");  // the reference: LOG_F(WARNING, "solver.solve failed"); return {};
 		return {};
 	}
-	if (must_converge && !(error <= tolerance * 1.0001f)) {
-		std::fprintf(stderr, "field_interpolation: solver did not converge (residual %g after %d iterations)\n", error,
-		             iterations);
+	return out;
+}
+
+// solve_sparse_linear_exact / _fast: the reference factorises A^T A (SimplicialLLT) and returns {} when the
+// factorisation fails (sparse_linear.cpp:137-149, 169-172).  Here the normal equations are iterated in fp64:
+//   * an unknown without any equation (a zero on the diagonal of A^T A -- the zero pivot that stops LLT) -> {} like the
+//     reference; so does a solver breakdown (non-finite values, non-positive curvature);
+//   * otherwise the best iterate is returned.  A well-posed but ill-conditioned system (kappa of A^T A grows like
+//     side^4..8 for model_2..4 lattices with few data) may not reach the requested relative residual in floating
+//     point -- the attainable one is about eps * kappa -- and the factorisation the reference runs would still answer:
+//     the iterate is returned with a warning instead of {}.
+std::vector<float> solve_direct_like(const LinearEquation& eq, int num_columns, float tolerance)
+{
+	RowsOnGpu gpu(eq, num_columns, FI_F64);
+	if (!gpu.ctx) { return {}; }
+	{
+		std::vector<double> diag(static_cast<size_t>(num_columns));
+		if (fi_get_diag_f64(gpu.ctx, diag.data()) != FI_OK) {
+			warn("fi_get_diag_f64");
+			return {};
+		}
+		for (double d : diag) {
+			if (!(d > 0.0)) {
+				std::fprintf(stderr, "field_interpolation: singular system (an unknown without equations): LLT would fail\n");
+				return {};
+			}
+		}
+	}
+	std::vector<float> out(static_cast<size_t>(num_columns));
+	int   iterations = 0;
+	float error      = 0;
+	const int budget = num_columns > (1 << 24) ? (1 << 30) : 50 * num_columns + 1000;
+	if (fi_solve_cg(gpu.ctx, nullptr, budget, tolerance, out.data(), &iterations, &error, FI_HOST) != FI_OK) {
+		warn("solver failed");
 		return {};
+	}
+	if (!(error <= tolerance * 1.0001f)) {
+		std::fprintf(stderr, "field_interpolation: iterative stand-in for the factorisation stopped at relative residual %g "
+		                     "after %d iterations (asked for %g); returning that iterate\n", error, iterations, tolerance);
 	}
 	return out;
 }
 
 }  // namespace
 
-// The reference factorises A^T A (SimplicialLLT, double) and returns {} when that fails, e.g. for a singular
-// system.  Here: fp64 CG to 1e-12; a system CG cannot drive there (singular / inconsistent) returns {}.
 std::vector<float> solve_sparse_linear_exact(const LinearEquation& eq, int num_columns)
 {
-	return iterate(eq, nullptr, num_columns, FI_F64, 50 * num_columns + 1000, 1e-12f, true);
+	return solve_direct_like(eq, num_columns, 1e-12f);
 }
 
 // SimplicialLLT in float in the reference: same system, fp32 accuracy.
 std::vector<float> solve_sparse_linear_fast(const LinearEquation& eq, int num_columns)
 {
-	return iterate(eq, nullptr, num_columns, FI_F64, 50 * num_columns + 1000, 1e-7f, true);
+	return solve_direct_like(eq, num_columns, 1e-7f);
 }
 
 std::vector<float> solve_sparse_linear_with_guess(const LinearEquation& eq, const std::vector<float>& guess,
                                                   int max_iterations, float error_tolerance)
 {
-	return iterate(eq, &guess, static_cast<int>(guess.size()), FI_F32, max_iterations, error_tolerance, false);
+	return iterate(eq, &guess, static_cast<int>(guess.size()), FI_F32, cg_budget(max_iterations), error_tolerance);
 }
 
 std::vector<float> jacobi_iterations(const LinearEquation& eq, const std::vector<float>& guess, const int num_iterations,
@@ -143,7 +243,7 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 	}
 	if (!options.tile) {
 		if (!options.cg) { return guess; }
-		return iterate(eq, &guess, static_cast<int>(n), FI_F32, options.max_iterations, options.error_tolerance, false);
+		return iterate(eq, &guess, static_cast<int>(n), FI_F32, cg_budget(options.max_iterations), options.error_tolerance);
 	}
 	// tile_solver_square (sparse_linear.cpp:246-390, 415-425) on the device: fi_tile_pass solves every tile_size^D
 	// tile of the lattice with its couplings to the other tiles taken from the guess, then the iteration starts
@@ -151,7 +251,7 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 	if (sizes.size() > 3) {
 		std::fprintf(stderr, "field_interpolation: SolveOptions.tile needs a lattice of at most 3 dimensions; ignored\n");
 		if (!options.cg) { return guess; }
-		return iterate(eq, &guess, static_cast<int>(n), FI_F32, options.max_iterations, options.error_tolerance, false);
+		return iterate(eq, &guess, static_cast<int>(n), FI_F32, cg_budget(options.max_iterations), options.error_tolerance);
 	}
 	RowsOnGpu gpu(eq, static_cast<int>(n), FI_F32, &sizes);
 	if (!gpu.ctx) { return {}; }
@@ -164,8 +264,8 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 	std::vector<float> out(n);
 	int   iterations = 0;
 	float error      = 0;
-	if (fi_solve_cg(gpu.ctx, tiled.data(), options.max_iterations, options.error_tolerance, out.data(), &iterations, &error,
-	                FI_HOST) != FI_OK) {
+	if (fi_solve_cg(gpu.ctx, tiled.data(), cg_budget(options.max_iterations), options.error_tolerance, out.data(), &iterations,
+	                &error, FI_HOST) != FI_OK) {
 		warn("solver failed");
 		return {};
 	}

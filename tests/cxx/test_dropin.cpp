@@ -5,12 +5,18 @@
 //   2. src/sdf_field.cpp:212-304 style: sdf_from_points + solve_sparse_linear_exact (rows through the generic
 //      GPU path) against GpuLatticeField (matrix-free GPU path) on the same input;
 //   3. failure conventions: wrong guess length -> {}, singular system -> {}, num_iterations <= 0 -> guess;
-//   4. jacobi_iterations: legacy rows vs fast path; generate_error_map, upscale_field, operator<<.
+//   4. jacobi_iterations: legacy rows vs fast path; generate_error_map, upscale_field, operator<<;
+//   5. the per-frame call pattern of src/bipolar_2d.cpp:323-332 on a 128^2 system: the iteration budget rule (two CG
+//      steps per requested BiCGSTAB step), the singular-system {} convention, and the latency of warm calls (the
+//      device context is cached per lattice shape).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
 #include <vector>
+
+#include <fi_hip.h>
 
 #include <field_interpolation/field_interpolation.hpp>
 #include <field_interpolation/gpu_field.hpp>
@@ -177,6 +183,73 @@ int main()
 		auto big = fi::upscale_field(exact.data(), sizes, {47, 39});
 		require(big.size() == 47u * 39u && std::fabs(big[0] - exact[0]) < 1e-6f && std::fabs(big.back() - exact.back()) < 1e-6f,
 		        "upscale_field keeps the corners");
+	}
+	// ---- 5. per-frame solves: budget, singular systems, latency --------------------------------------------
+	{
+		const std::vector<int> s128{128, 128};
+		std::vector<float> pos, nrm;
+		for (int i = 0; i < 600; ++i) {
+			const float a = 6.2831853f * i / 600.0f;
+			pos.push_back(63.5f + 40.0f * std::cos(a) + 0.2f * std::sin(23.0f * i));
+			pos.push_back(63.5f + 40.0f * std::sin(a) + 0.2f * std::cos(19.0f * i));
+			nrm.push_back(std::cos(a));
+			nrm.push_back(std::sin(a));
+		}
+		const fi::LatticeField f128 = fi::sdf_from_points(s128, fi::Weights(), 600, pos.data(), nrm.data(), nullptr);
+		const size_t n128 = 128 * 128;
+		const std::vector<float> zero(n128, 0.0f);
+		// budget: solve_sparse_linear_with_guess(eq, guess, k, 0) runs 2k CG steps (one operator application each, like
+		// the 2 per BiCGSTAB step of the reference): the same iterate as 2k steps through the C ABI
+		auto x50 = fi::solve_sparse_linear_with_guess(f128.eq, zero, 50, 0.0f);
+		require(x50.size() == n128, "bipolar pattern: solve_sparse_linear_with_guess(eq, guess, 50, 0) returns an iterate");
+		{
+			fi_ctx* ctx = nullptr;
+			const int shape[1] = {static_cast<int>(n128)};
+			const fi_weights none = {1, 1, 0, 0, 0, 0, 0, 0, FI_VALUE_LINEAR_INTERPOLATION, FI_GRADIENT_CELL_EDGES};
+			std::vector<float> x100(n128), x50cg(n128);
+			int it = 0;
+			float err = 0;
+			const bool ok = fi_ctx_create(&ctx, 1, shape, FI_F32) == FI_OK && fi_set_model(ctx, &none) == FI_OK &&
+			                fi_add_rows_coo(ctx, static_cast<long>(f128.eq.rhs.size()), static_cast<long>(f128.eq.triplets.size()),
+			                                reinterpret_cast<const fi_triplet*>(f128.eq.triplets.data()), f128.eq.rhs.data(), FI_HOST) == FI_OK &&
+			                fi_assemble(ctx) == FI_OK &&
+			                fi_solve_cg(ctx, zero.data(), 100, 0.0f, x100.data(), &it, &err, FI_HOST) == FI_OK;
+			require(ok && it == 100, "C ABI: 100 CG steps on the same rows");
+			const bool ok2 = fi_solve_cg(ctx, zero.data(), 50, 0.0f, x50cg.data(), &it, &err, FI_HOST) == FI_OK;
+			fi_ctx_destroy(ctx);
+			require(ok2 && max_rel(x50, x100) <= 1e-6f, "budget rule: 50 requested BiCGSTAB steps == 100 CG steps");
+			require(max_rel(x50cg, x100) > 1e-4f, "... and not 50 CG steps");
+		}
+		// singular system: an unknown no equation touches is the zero pivot that stops SimplicialLLT -> {} (sparse_linear.cpp:169-172)
+		{
+			fi::LinearEquation eq;
+			fi::add_equation(&eq, fi::Weight{1.0f}, fi::Rhs{1.0f}, {{0, 1.0f}, {1, 1.0f}});
+			fi::add_equation(&eq, fi::Weight{1.0f}, fi::Rhs{0.0f}, {{0, 1.0f}, {1, -1.0f}});
+			require(fi::solve_sparse_linear_exact(eq, 2).size() == 2, "exact: a regular 2 x 2 system is solved");
+			require(fi::solve_sparse_linear_exact(eq, 3).empty(), "exact: an unknown without equations -> {} like the failed factorisation");
+			require(fi::solve_sparse_linear_fast(eq, 3).empty(), "fast: the same");
+			// a consistent system of rank 1 with positive diagonals: the factorisation's outcome is rounding luck in the
+			// reference; here the least-squares iterate comes back
+			fi::LinearEquation r1;
+			fi::add_equation(&r1, fi::Weight{1.0f}, fi::Rhs{2.0f}, {{0, 1.0f}, {1, 1.0f}});
+			auto ls = fi::solve_sparse_linear_exact(r1, 2);
+			require(ls.size() == 2 && std::fabs(ls[0] + ls[1] - 2.0f) <= 1e-5f, "exact: a consistent rank-deficient system returns a least-squares solution");
+		}
+		// latency of warm calls (contexts cached per shape): the per-frame pattern of bipolar_2d.cpp:323-332
+		{
+			using clock = std::chrono::steady_clock;
+			std::vector<float> last = fi::solve_sparse_linear_with_guess(f128.eq, zero, 100, 0.0f);  // first call: creates the context
+			const int reps = 20;
+			auto t0 = clock::now();
+			for (int r = 0; r < reps; ++r) { last = fi::solve_sparse_linear_with_guess(f128.eq, last, 100, 0.0f); }
+			const double ms_cg = std::chrono::duration<double, std::milli>(clock::now() - t0).count() / reps;
+			t0 = clock::now();
+			for (int r = 0; r < reps; ++r) { last = fi::jacobi_iterations(f128.eq, last, 100, 0.5f); }
+			const double ms_jac = std::chrono::duration<double, std::milli>(clock::now() - t0).count() / reps;
+			std::printf("latency 128^2 (%zu rows, %zu triplets), warm-started, context cached: solve_sparse_linear_with_guess(eq, last, 100, 0) "
+			            "%.2f ms/call; jacobi_iterations(eq, last, 100, 0.5) %.2f ms/call\n", f128.eq.rhs.size(), f128.eq.triplets.size(), ms_cg, ms_jac);
+			require(last.size() == n128 && ms_cg < 200.0 && ms_jac < 200.0, "per-frame calls stay interactive");
+		}
 	}
 	std::printf("all drop-in checks passed\n");
 	return 0;

@@ -1,0 +1,101 @@
+"""P4 parity at a config-shaped mid size: the GPU solve against the ORACLE's CG driven to the same tight
+tolerance in fp64 -- not against the GPU's own fp64 solve.
+
+  * config 4 at 96^3 (52 734 scattered noisy value constraints, the bench density): oracle fp64 Jacobi-PCG on the explicit
+    AtA of the reference's rows to 1e-10 (its residual re-checked with fio_apply_normal_f64), GPU fp64 to 1e-10 through
+    Jacobi-PCG, through the polynomial preconditioner from the coarse-to-fine start, and through V-cycle PCG:
+    ||dx||_inf / ||x||_inf <= 1e-5 (BASELINE tolerance; observed ~1e-8);
+  * the bench's own precision mode beside it (fp32, residual 1e-5): its error is what kappa allows, reported and bounded;
+  * a config-5-shaped SDF (48^3, 43 945 oriented points, default Weights) through the mixed-precision V-cycle path
+    against the oracle's fp64 PCG (about 6 000 iterations on the CPU).
+"""
+import numpy as np
+import pytest
+
+from util import rel_inf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fi():
+    import field_interpolation_amd as fi
+    from field_interpolation_amd import _capi
+    assert _capi.device_count() >= 1, "no HIP device visible"
+    return fi
+
+
+def _oracle_solution(fo, tol=1e-10, max_it=40000):
+    res = fo.solve_pcg(np.zeros(fo.num_unknowns, np.float32), max_it, tol, True)
+    assert res is not None
+    x, it, rel = res
+    AtA, atb, _ = fo.normal_equations()
+    x = np.asarray(x, np.float64)
+    true_rel = np.linalg.norm(atb - fo.apply_normal(x)) / np.linalg.norm(atb)
+    assert true_rel <= 2 * tol, true_rel                     # the oracle's own iterate, checked through A^T (A x)
+    return x, it
+
+
+def test_config4_at_96_cubed(oracle, fi, capsys):
+    from field_interpolation_amd import synth
+    side = 96
+    npts = int(round(1e6 * (side / 256.0) ** 3))
+    sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3)
+    fo = oracle.LatticeField(sizes)
+    fo.add_field_constraints(oracle.Weights(model_2=w.model_2))
+    fo.add_value_constraints(pos, val, w.data_pos)
+    x_ref, it_ref = _oracle_solution(fo)
+
+    def gpu(dtype, tol, levels=0, poly=0, mg=False):
+        f = fi.LatticeField(sizes, dtype=dtype)
+        f.add_field_constraints(w)
+        if levels:
+            f.set_levels(levels, 1e-6)
+            if mg:
+                f.set_multigrid(True)
+        if poly:
+            f.set_polynomial(poly, 30.0)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, tol)
+        assert x is not None and rel <= tol
+        return f.solution_f64(), it, f.true_residual()
+
+    x_j, it_j, tr_j = gpu("f64", 1e-10)
+    assert abs(it_j - it_ref) <= max(5, it_ref // 20), (it_j, it_ref)      # the same recurrence on both sides
+    assert tr_j <= 1.01e-10 and rel_inf(x_j, x_ref) <= 1e-5
+    assert rel_inf(x_j, x_ref) <= 1e-7                                      # what fp64 delivers
+    x_p, it_p, tr_p = gpu("f64", 1e-10, levels=2, poly=4)
+    assert tr_p <= 1.01e-10 and rel_inf(x_p, x_ref) <= 1e-7
+    x_m, it_m, tr_m = gpu("f64", 1e-10, levels=3, mg=True)
+    assert tr_m <= 1.01e-10 and rel_inf(x_m, x_ref) <= 1e-7
+    # the bench's precision mode: fp32, cascade start + 4-term polynomial, residual 1e-5
+    x_b, it_b, tr_b = gpu("f32", 1e-5, levels=2, poly=4)
+    err_b = rel_inf(x_b, x_ref)
+    with capsys.disabled():
+        print("\n[P4 config 4 at 96^3] oracle fp64 PCG %d it; GPU fp64 Jacobi-PCG %d it, err %.1e; cascade + polynomial %d outer it, "
+              "err %.1e; V-cycle PCG %d it, err %.1e; bench mode (fp32, 1e-5): %d outer it, true residual %.1e, field err %.1e"
+              % (it_ref, it_j, rel_inf(x_j, x_ref), it_p, rel_inf(x_p, x_ref), it_m, rel_inf(x_m, x_ref), it_b, tr_b, err_b))
+    assert tr_b <= 1.5e-5 and err_b <= 2e-2
+
+
+def test_config5_shape_at_48_cubed(oracle, fi, capsys):
+    from field_interpolation_amd import synth
+    side = 48
+    npts = int(round(5e6 * (side / 512.0) ** 2))
+    sizes, w, pos, nrm = synth.config5(side=side, num_points=npts, seed=4)
+    fo = oracle.sdf_from_points(sizes, oracle.Weights(), pos, nrm)
+    x_ref, it_ref = _oracle_solution(fo)
+    f = fi.LatticeField(sizes, dtype="f64")
+    f.add_field_constraints(w)
+    f.set_levels(2, 1e-4)
+    f.set_multigrid(True)
+    f.set_mixed_precision(True)
+    f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    f.assemble()
+    x, it, rel = f.solve_cg(None, 0, 1e-10)
+    assert x is not None and rel <= 1e-10 and f.true_residual() <= 1.01e-10
+    err = rel_inf(f.solution_f64(), x_ref)
+    with capsys.disabled():
+        print("\n[P4 config-5 shape at 48^3] oracle fp64 PCG %d it; GPU mixed V-cycle PCG %d it, field err %.1e" % (it_ref, it, err))
+    assert err <= 1e-5

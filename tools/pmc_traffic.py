@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-launch HBM traffic of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB units).
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <out.json>
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <out.json> [share]
+(launches whose counter is below `share` (default 0.5) of the largest are dropped: early exits on the stop flag, coarser
+levels, and -- with 0.9 -- the 4-pass first step of a Chebyshev polynomial beside its 5-pass steps)
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly half the bytes of a wide (16 B/lane)
 coalesced stream; WRITE_SIZE is exact.  Both the raw and the doubled read figure are recorded; `traffic`
 uses the doubled reads because the kernel's plane loads are 16 B/lane streams."""
@@ -10,15 +12,21 @@ import json
 import sys
 
 
+SHARE = 0.5
+
+
 def avg(path, counter, needle):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
             if needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    big = [v for v in vals if v > 0.5 * max(vals)]          # drop the launches that exited on the done flag
+    big = [v for v in vals if v > SHARE * max(vals)]        # drop the launches that exited on the done flag
     return sum(big) / len(big), len(big)
 
 
 def main():
+    global SHARE
     fetch_csv, write_csv, needle, out = sys.argv[1:5]
+    if len(sys.argv) > 5:
+        SHARE = float(sys.argv[5])
     f, nf = avg(fetch_csv, "FETCH_SIZE", needle)
     w, nw = avg(write_csv, "WRITE_SIZE", needle)
     res = {"kernel": needle, "launches": [nf, nw], "fetch_size_kb_raw": f, "write_size_kb": w,
