@@ -174,7 +174,7 @@ void host_allreduce(fi_ctx* c, double* dev, int count)
 	FI_HIP_TRY(hipStreamSynchronize(c->stream));
 }
 
-void host_exchange(fi_ctx* c, void* v)
+void host_exchange(fi_ctx* c, void* v, hipStream_t stream)
 {
 	HostComm* h = c->comm->host;
 	const Geom&  g     = c->g;
@@ -187,19 +187,19 @@ void host_exchange(fi_ctx* c, void* v)
 	char* base = static_cast<char*>(v);
 	// slot layout: [64 B of sums][planes for the lower neighbour][planes for the upper neighbour]
 	char* mine = h->slot(c->rank) + 64;
-	if (c->rank > 0) { FI_HIP_TRY(hipMemcpyAsync(mine, base + es * plane * g.own_lo[L], bytes, hipMemcpyDeviceToHost, c->stream)); }
+	if (c->rank > 0) { FI_HIP_TRY(hipMemcpyAsync(mine, base + es * plane * g.own_lo[L], bytes, hipMemcpyDeviceToHost, stream)); }
 	if (c->rank + 1 < c->nranks) {
-		FI_HIP_TRY(hipMemcpyAsync(mine + bytes, base + es * plane * (g.own_hi[L] - H), bytes, hipMemcpyDeviceToHost, c->stream));
+		FI_HIP_TRY(hipMemcpyAsync(mine + bytes, base + es * plane * (g.own_hi[L] - H), bytes, hipMemcpyDeviceToHost, stream));
 	}
-	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(stream));
 	host_barrier(h);
 	if (c->rank > 0) {  // the lower neighbour's planes for its upper neighbour -> my lower ghost planes
-		FI_HIP_TRY(hipMemcpyAsync(base, h->slot(c->rank - 1) + 64 + bytes, bytes, hipMemcpyHostToDevice, c->stream));
+		FI_HIP_TRY(hipMemcpyAsync(base, h->slot(c->rank - 1) + 64 + bytes, bytes, hipMemcpyHostToDevice, stream));
 	}
 	if (c->rank + 1 < c->nranks) {
-		FI_HIP_TRY(hipMemcpyAsync(base + es * plane * g.own_hi[L], h->slot(c->rank + 1) + 64, bytes, hipMemcpyHostToDevice, c->stream));
+		FI_HIP_TRY(hipMemcpyAsync(base + es * plane * g.own_hi[L], h->slot(c->rank + 1) + 64, bytes, hipMemcpyHostToDevice, stream));
 	}
-	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(stream));
 	host_barrier(h);
 }
 
@@ -223,12 +223,14 @@ void allreduce_sum(fi_ctx* c, double* dev, int count)
 	FI_NCCL_TRY(rccl().AllReduce(dev, dev, static_cast<size_t>(count), ncclFloat64, ncclSum, c->comm->comm, c->stream));
 }
 
-void exchange_halo(fi_ctx* c, void* v)
+void exchange_halo(fi_ctx* c, void* v) { exchange_halo_on(c, v, c->stream); }
+
+void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream)
 {
 	if (c->nranks <= 1) { return; }
 	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
 	if (c->comm->host) {
-		host_exchange(c, v);
+		host_exchange(c, v, stream);
 		return;
 	}
 	const Geom&  g     = c->g;
@@ -246,12 +248,12 @@ void exchange_halo(fi_ctx* c, void* v)
 	Rccl& r = rccl();
 	FI_NCCL_TRY(r.GroupStart());
 	if (c->rank > 0) {
-		FI_NCCL_TRY(r.Send(first_owned, count, dt, c->rank - 1, c->comm->comm, c->stream));
-		FI_NCCL_TRY(r.Recv(lower_ghost, count, dt, c->rank - 1, c->comm->comm, c->stream));
+		FI_NCCL_TRY(r.Send(first_owned, count, dt, c->rank - 1, c->comm->comm, stream));
+		FI_NCCL_TRY(r.Recv(lower_ghost, count, dt, c->rank - 1, c->comm->comm, stream));
 	}
 	if (c->rank + 1 < c->nranks) {
-		FI_NCCL_TRY(r.Send(last_owned, count, dt, c->rank + 1, c->comm->comm, c->stream));
-		FI_NCCL_TRY(r.Recv(upper_ghost, count, dt, c->rank + 1, c->comm->comm, c->stream));
+		FI_NCCL_TRY(r.Send(last_owned, count, dt, c->rank + 1, c->comm->comm, stream));
+		FI_NCCL_TRY(r.Recv(upper_ghost, count, dt, c->rank + 1, c->comm->comm, stream));
 	}
 	FI_NCCL_TRY(r.GroupEnd());
 }

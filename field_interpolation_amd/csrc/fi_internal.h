@@ -143,6 +143,10 @@ struct MarchState {
 	DevBuf      wg_cells, wg_plain;            // workgroup ids with cells (ascending) / first workgroups of the plain runs
 	DevBuf      wg_runs;                       // chunks per plain run (consecutive empty chunks of one tile)
 	int         n_wg_cells = 0, n_wg_plain = 0;
+	// slabs: workgroups of the first and last z-chunk (they read ghost planes) and all the others, for P and for
+	// Pplain -- the interior launch runs while the ghost planes are still on the wire (apply_overlapped)
+	DevBuf      wg_edge, wg_inner, wgp_edge, wgp_inner;
+	int         n_edge = 0, n_inner = 0, np_edge = 0, np_inner = 0;
 };
 
 // Tiling of the 2-D tile kernel (fi_stencil2d.hip): one workgroup per TX x 16 tile of the owned rows.
@@ -254,6 +258,8 @@ struct fi_ctx {
 	fi::DevBuf scratch[32];
 
 	fi::Comm*  comm = nullptr;
+	hipStream_t comm_stream = nullptr;   // slabs over RCCL: the halo exchange runs here beside the interior launch
+	hipEvent_t  ev_ready = nullptr, ev_halo = nullptr;
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
 	bool       owns_stream = true;
 	bool       owns_comm = true;     // coarser levels share the RCCL communicator of the finest level
@@ -279,11 +285,15 @@ int  apply_num_partials(const fi_ctx* c);
 double apply_algorithmic_bytes(const fi_ctx* c);
 void error_map(fi_ctx* c, const void* x, void* out);                 // generate_error_map; x with valid ghost planes
 void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.hip
+void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream);       // the same on another stream
 
 // fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
 void stencil_prepare(fi_ctx* c);   // after assemble(): tiling + per-workgroup cell lists
 int  stencil_partials(const fi_ctx* c);
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
+// part 1: the workgroups that read no ghost plane, part 2: the others (first and last z-chunk); false when the context's
+// apply is not one launch over all workgroups (then the caller exchanges first and applies in one go)
+bool stencil_apply_part(fi_ctx* c, const void* x, void* y, double* partial, int part);
 
 bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also applies the cell blocks
 // one step of the Chebyshev polynomial preconditioner / of the power method through the plain marching kernel
@@ -291,7 +301,7 @@ bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also a
 bool stencil_cheb_available(const fi_ctx* c);
 int  stencil_cheb_partials(const fi_ctx* c);
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double c1,
-                       double c2, double* partial);
+                       double c2, double* partial, int part = 0);
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 
 // fi_stencil2d.hip: LDS-tiled kernel for 2-D lattices (model_0/1/2), called through the stencil_* entry points

@@ -821,6 +821,52 @@ void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec)
 	}
 }
 
+// ---- one slab per process: the exchange of the ghost planes overlaps the interior of the apply -------------------
+// The ghost planes of `v` travel on the context's communication stream (RCCL grouped send / recv) while the workgroups
+// of the marching kernel that read none of them run on the solver stream; the first and last z-chunk follow when
+// the planes have arrived.  Returns false (nothing launched) where the apply is not one marching launch over all
+// workgroups -- the caller then exchanges first and applies in one go.
+bool overlap_possible(const fi_ctx* c)
+{
+	return c->nranks > 1 && c->march.valid && c->march.n_inner > 0 && c->generic.ntrip == 0 && c->tile_ts == 0 &&
+	       (c->cells.ncell == 0 || cells_fused(c)) && !getenv("FI_NO_OVERLAP");
+}
+void exchange_begin(fi_ctx* c, void* v)
+{
+	if (!c->comm_stream) {
+		FI_HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+		FI_HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+		FI_HIP_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+	}
+	FI_HIP_TRY(hipEventRecord(c->ev_ready, c->stream));            // v is complete behind everything enqueued so far
+	FI_HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+	exchange_halo_on(c, v, c->comm_stream);
+	FI_HIP_TRY(hipEventRecord(c->ev_halo, c->comm_stream));
+}
+void exchange_wait(fi_ctx* c) { FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0)); }
+
+// y = AtA x with the halo exchange of x, for every member of a rank set
+void apply_exchanged(RankSet& R, DevBuf fi_ctx::*in, DevBuf fi_ctx::*out, double* (*partials_of)(fi_ctx*))
+{
+	fi_ctx* c0 = R[0];
+	if (R.size() == 1 && overlap_possible(c0)) {
+		fi_ctx* c = c0;
+		double* part = partials_of ? partials_of(c) : nullptr;
+		exchange_begin(c, (c->*in).p);
+		if (stencil_apply_part(c, (c->*in).p, (c->*out).p, part, 1)) {
+			exchange_wait(c);
+			stencil_apply_part(c, (c->*in).p, (c->*out).p, part, 2);
+			FI_HIP_TRY(hipGetLastError());
+			return;
+		}
+		exchange_wait(c);
+		apply_AtA(c, (c->*in).p, (c->*out).p, part);
+		return;
+	}
+	halo_exchange(R, in);
+	for (fi_ctx* c : R) { apply_AtA(c, (c->*in).p, (c->*out).p, partials_of ? partials_of(c) : nullptr); }
+}
+
 // partial sums -> sums[] on every rank, summed over ranks, then the scalar recurrences of `phase`
 // (phase < 0: no recurrences).  `count_of(c)` partials per vector, vectors `stride_of(c)` apart.
 template <typename CountFn, typename StrideFn>
@@ -982,11 +1028,10 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		}
 		for (int k = 0; k < kCheckEvery; ++k) {
 			++issued;
-			halo_exchange(R, &fi_ctx::p);
 			// every 4th apply is timed: an event record is a barrier packet of its own in the queue
 			const bool sample = samples < kMaxSamples && (issued & 3) == 1;
 			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
-			for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>()); }
+			apply_exchanged(R, &fi_ctx::p, &fi_ctx::q, +[](fi_ctx* c) -> double* { return c->partial.as<double>(); });
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples + 1], st));
 				++samples;
@@ -2242,16 +2287,23 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		// the polynomial: z_{k+1} from z_k (ZA / ZB alternate; the result ends in `zfin`)
 		Vec zin = ZA, zout = ZB;
 		for (int k = 1; k < terms; ++k) {
-			halo_exchange(R, zin);
 			// every 4th pass times its last step (5 lattice passes when the polynomial has 3 terms or more)
 			const bool sample = phase == 1 && k == terms - 1 && psamples < kMaxSamples && (tag & 3) == 1;
+			const bool overlap = R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
+			if (overlap) { exchange_begin(c0, (c0->*zin).p); } else { halo_exchange(R, zin); }
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(pev[2 * psamples], st));
 				ptags.push_back(tag);
 			}
 			for (fi_ctx* c : R) {
-				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1],
-				                  c2s[k - 1], region(c, 2));
+				const void* zp = k == 1 ? nullptr : (c->*zout).p;
+				if (overlap) {  // the workgroups that read no ghost plane, then the first and last z-chunk
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 1);
+					exchange_wait(c);
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 2);
+				} else {
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2));
+				}
 			}
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(pev[2 * psamples + 1], st));
@@ -2287,8 +2339,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		}
 	};
 	auto start = [&](int phase) {  // r = b - A x, z = M r, p = z
-		halo_exchange(R, &fi_ctx::x);
-		for (fi_ctx* c : R) { apply_AtA(c, c->x.p, c->q.p, nullptr); }
+		apply_exchanged(R, &fi_ctx::x, &fi_ctx::q, nullptr);
 		half_steps(phase);
 	};
 	start(0);
@@ -2323,10 +2374,9 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		}
 		for (int k = 0; k < burst; ++k) {
 			++issued;
-			halo_exchange(R, &fi_ctx::p);
 			const bool sample = samples < kMaxSamples && (issued & 1) == 1;
 			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
-			for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, region(c, 0)); }
+			apply_exchanged(R, &fi_ctx::p, &fi_ctx::q, +[](fi_ctx* c) -> double* { return c->partial.as<double>(); });
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples + 1], st));
 				++samples;
@@ -2912,6 +2962,11 @@ int fi_ctx_destroy(fi_ctx* c)
 	c->pending_pool.clear();
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
 	for (auto e : c->ev_prec) { (void)hipEventDestroy(e); }
+	if (c->comm_stream) {
+		(void)hipStreamDestroy(c->comm_stream);
+		(void)hipEventDestroy(c->ev_ready);
+		(void)hipEventDestroy(c->ev_halo);
+	}
 	if (c->comm && c->owns_comm) { fi::comm_destroy(c->comm); }
 	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
 	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }

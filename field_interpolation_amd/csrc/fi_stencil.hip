@@ -1229,17 +1229,22 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 // One Chebyshev step of the polynomial preconditioner: the plain variant with the epilogue, over the whole lattice
 // (its own chunking: MarchState::Pplain).  partial: r . z_new per workgroup.
 template <typename T>
-void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partial)
+void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partial, int part = 0)
 {
 	const MarchParams& P = c->march.Pplain;
 	const MarchCoef<T> C = march_coef<T>(c->w);
 	CellLists L{};
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
-	const int  grid = ((P.nwg + 7) / 8) * 8;
+	// part 1 / 2: the workgroups that read no ghost plane / the first and last z-chunk (slabs: the exchange of the ghost
+	// planes overlaps the interior launch)
+	const uint32_t* list = part == 1 ? c->march.wgp_inner.as<uint32_t>() : (part == 2 ? c->march.wgp_edge.as<uint32_t>() : nullptr);
+	const int nlist = part == 1 ? c->march.np_inner : (part == 2 ? c->march.np_edge : 0);
+	if (part != 0 && nlist <= 0) { return; }
+	const int  grid = (((part ? nlist : P.nwg) + 7) / 8) * 8;
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
 	auto launch = [&](auto kernel) {
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, z, static_cast<T*>(nullptr), partial, done,
-		                   static_cast<const uint32_t*>(nullptr), 0, static_cast<const uint32_t*>(nullptr), E);
+		                   list, nlist, static_cast<const uint32_t*>(nullptr), E);
 	};
 	auto pick = [&](auto txt) {
 		constexpr int TXT = decltype(txt)::value;
@@ -1443,6 +1448,8 @@ void build_cell_lists(fi_ctx* c)
 
 }  // namespace
 
+void stencil_prepare_slab_lists(fi_ctx* c);
+
 void stencil_prepare(fi_ctx* c)
 {
 	MarchState& m = c->march;
@@ -1452,6 +1459,7 @@ void stencil_prepare(fi_ctx* c)
 	if (m.valid) {  // chunking of whole-lattice launches of the plain variant (polynomial preconditioner)
 		c->dtype == FI_F64 ? march_setup<double>(c, &m.Pplain, 0, true) : march_setup<float>(c, &m.Pplain, 0, true);
 	}
+	m.n_edge = m.n_inner = m.np_edge = m.np_inner = 0;
 	c->tile2.valid = c->tile2.fused = false;
 	if (c->g.ndim == 2) { tile2d_prepare(c); }
 	if (!m.valid) { return; }
@@ -1466,6 +1474,37 @@ void stencil_prepare(fi_ctx* c)
 			c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
 		}
 	}
+	stencil_prepare_slab_lists(c);
+}
+
+// Slabs: the workgroups of the first and last z-chunk read ghost planes, the others do not.
+void build_edge_lists(fi_ctx* c, const MarchParams& P, DevBuf& edge, DevBuf& inner, int* n_edge, int* n_inner)
+{
+	const int tiles_xy = P.tiles_x * P.tiles_y;
+	const int nz_own = P.own_z1 - P.own_z0;
+	const int reach = c->halo > 1 ? c->halo : 1;  // planes a chunk reads beyond its own (short chunks: several chunks deep)
+	std::vector<uint32_t> e, in;
+	for (int ch = 0; ch < P.chunks; ++ch) {
+		const int z0 = ch * P.zc, z1 = (ch + 1) * P.zc < nz_own ? (ch + 1) * P.zc : nz_own;
+		const bool ghost = z0 < reach || nz_own - z1 < reach;
+		std::vector<uint32_t>& dst = ghost ? e : in;
+		for (int t = 0; t < tiles_xy; ++t) { dst.push_back(static_cast<uint32_t>(ch * tiles_xy + t)); }
+	}
+	*n_edge  = static_cast<int>(e.size());
+	*n_inner = static_cast<int>(in.size());
+	edge.alloc(sizeof(uint32_t) * (e.size() + 1));
+	inner.alloc(sizeof(uint32_t) * (in.size() + 1));
+	if (!e.empty()) { FI_HIP_TRY(hipMemcpyAsync(edge.p, e.data(), sizeof(uint32_t) * e.size(), hipMemcpyHostToDevice, c->stream)); }
+	if (!in.empty()) { FI_HIP_TRY(hipMemcpyAsync(inner.p, in.data(), sizeof(uint32_t) * in.size(), hipMemcpyHostToDevice, c->stream)); }
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors die here
+}
+
+void stencil_prepare_slab_lists(fi_ctx* c)
+{
+	MarchState& m = c->march;
+	if (!m.valid || c->nranks <= 1) { return; }
+	build_edge_lists(c, m.P, m.wg_edge, m.wg_inner, &m.n_edge, &m.n_inner);
+	build_edge_lists(c, m.Pplain, m.wgp_edge, m.wgp_inner, &m.np_edge, &m.np_inner);
 }
 
 // Number of p.q partials the stencil kernel writes, or 0 when the generic kernel must run.
@@ -1486,18 +1525,18 @@ namespace fi {
 bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid; }
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.Pplain.nwg; }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double c1,
-                       double c2, double* partial)
+                       double c2, double* partial, int part)
 {
 	// zprev == nullptr: the step from z_prev = 0
 	if (c->dtype == FI_F64) {
 		ChebEpi<double> E{static_cast<const double*>(zprev ? zprev : z), static_cast<const double*>(r),
 		                  static_cast<const double*>(dinv), static_cast<double*>(znew), 1.0 + c1, zprev ? c1 : 0.0, c2, 0};
-		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial);
+		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part);
 	} else {
 		ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r),
 		                 static_cast<const float*>(dinv), static_cast<float*>(znew), static_cast<float>(1.0 + c1),
 		                 static_cast<float>(zprev ? c1 : 0.0), static_cast<float>(c2), 0};
-		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial);
+		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part);
 	}
 }
 // v_new = (A_model v) / diag(A_model), partials of v_new . v_new (power method on the model operator)
@@ -1512,6 +1551,30 @@ void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 		                 static_cast<float*>(vnew), 0, 0, 0, 1};
 		march_launch_epi<float>(c, static_cast<const float*>(v), E, partial);
 	}
+}
+
+bool stencil_apply_part(fi_ctx* c, const void* x, void* y, double* partial, int part)
+{
+	const MarchState& m = c->march;
+	if (c->tile2.valid || !m.valid || c->nranks <= 1 || m.n_inner <= 0) { return false; }
+	const bool all_fused = m.fused && ((m.P.nwg - m.n_wg_cells) * 16 < m.P.nwg || getenv("FI_NO_SPLIT"));
+	if (m.fused && !all_fused) { return false; }  // surface data: two launches over cell / plain lists already
+	const uint32_t* list = part == 1 ? m.wg_inner.as<uint32_t>() : m.wg_edge.as<uint32_t>();
+	const int nlist = part == 1 ? m.n_inner : m.n_edge;
+	if (c->dtype == FI_F64) {
+		if (m.fused) {
+			march_launch_cells<double, true>(c, static_cast<const double*>(x), static_cast<double*>(y), partial, list, nlist);
+		} else {
+			march_launch_cells<double, false>(c, static_cast<const double*>(x), static_cast<double*>(y), partial, list, nlist);
+		}
+	} else {
+		if (m.fused) {
+			march_launch_cells<float, true>(c, static_cast<const float*>(x), static_cast<float*>(y), partial, list, nlist);
+		} else {
+			march_launch_cells<float, false>(c, static_cast<const float*>(x), static_cast<float*>(y), partial, list, nlist);
+		}
+	}
+	return true;
 }
 
 bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial)

@@ -24,20 +24,29 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(args, timeout=600):
-    env = dict(os.environ, FI_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+def _torchrun(args, timeout=600, **extra_env):
+    env = dict(os.environ, FI_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_two_processes_equal_the_undivided_solve():
-    r = _torchrun([os.path.join(ROOT, "tests", "two_rank_worker.py")])
+def _worker_results(**extra_env):
+    r = _torchrun([os.path.join(ROOT, "tests", "two_rank_worker.py")], **extra_env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULTS ")]
     assert line, r.stdout[-3000:] + r.stderr[-3000:]
-    results = json.loads(line[-1][len("RESULTS "):])
+    return json.loads(line[-1][len("RESULTS "):])
+
+
+def test_two_processes_equal_the_undivided_solve():
+    results = _worker_results()
     assert len(results) == 4
+    # the exchange of the ghost planes on the communication stream beside the interior launch (the default) must not
+    # change a bit: the same run with the exchange in front of a single launch gives identical solutions
+    plain = _worker_results(FI_NO_OVERLAP="1")
+    for a, b in zip(results, plain):
+        assert a["iterations"] == b["iterations"] and a["checksum"] == b["checksum"], (a, b)
     for res in results:
         it = res["iterations"]
         assert it[0] == it[1], res                                  # both ranks stop in the same iteration

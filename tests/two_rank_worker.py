@@ -67,7 +67,8 @@ def run(name, sizes, w, pos, nrm, val, dtype, tol, levels=0, poly=0, multigrid=F
         out = {"case": name, "iterations": [p[1] for p in parts], "iterations_one": it1, "rel": [p[2] for p in parts],
                "true_rel": [p[3] for p in parts], "coarse_iterations": [p[4] for p in parts],
                "coarse_iterations_one": st1["coarse_iterations"], "points_kept": [p[5] for p in parts], "points": len(pos),
-               "max_diff": float(np.abs(xs - x1).max() / np.abs(x1).max()), "tol": tol}
+               "max_diff": float(np.abs(xs - x1).max() / np.abs(x1).max()), "tol": tol,
+               "checksum": [float(np.sum(xs.astype(np.float64))), float(np.sum(np.abs(xs.astype(np.float64))))]}
         del one
     del f
     dist.barrier()
