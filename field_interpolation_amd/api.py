@@ -189,6 +189,12 @@ class LatticeField:
                         np.atleast_1d(np.asarray(gradient, np.float32)), None)
         return True
 
+    def add_border_prior(self, weight):
+        """The border prior of the reference's SDF application (src/sdf_field.cpp:218-246): every border lattice point
+        gets the row [1] * weight = (distance to the nearest data point added so far) * weight.  After add_points."""
+        check(_capi.lib().fi_add_border_prior(self._h, float(weight)))
+        self._dirty = True
+
     def add_points(self, value_weight, value_kernel, gradient_weight, gradient_kernel, positions, normals=None,
                    point_weights=None, values=None):
         """add_points (field_interpolation.cpp:343-371); `values` (optional) generalises the fixed 0 target."""
@@ -391,6 +397,10 @@ class LatticeGroup:
     def add_points(self, *a, **kw):
         for m in self.members:          # every rank sees every point and keeps the cells touching its slab
             m.add_points(*a, **kw)
+
+    def add_border_prior(self, weight):
+        for m in self.members:
+            m.add_border_prior(weight)
 
     def set_levels(self, levels, coarse_tolerance=None):
         for m in self.members:

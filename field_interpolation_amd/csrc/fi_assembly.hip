@@ -636,7 +636,7 @@ void assemble_dim(fi_ctx* c)
 
 	c->cells.ncell = ncell;
 	// two or more data rows per occupied cell on average: multi-row cells as packed blocks (finish_cell)
-	c->cells.pack = (total - invalid_rows) >= 2 * ncell && !getenv("FI_NO_PACK");
+	c->cells.pack = (total - invalid_rows) >= 2 * ncell && !test_switch("FI_NO_PACK");
 	const uint32_t pack_min = c->cells.pack ? 3u : static_cast<uint32_t>(NC) + 1u;
 	c->cells.cell_id.alloc(sizeof(uint32_t) * ncell);
 	c->cells.blk.alloc(sizeof(T) * NB * ncell);
@@ -670,7 +670,7 @@ void assemble_dim(fi_ctx* c)
 	FI_HIP_TRY(hipGetLastError());
 	int64_t ncells_ext = 1;
 	for (int d = 0; d < D; ++d) { ncells_ext *= g.cn[d]; }
-	if (static_cast<int64_t>(ncell) * 64 >= ncells_ext && ncells_ext < (1LL << 32) && !getenv("FI_NO_GATHER")) {
+	if (static_cast<int64_t>(ncell) * 64 >= ncells_ext && ncells_ext < (1LL << 32) && !test_switch("FI_NO_GATHER")) {
 		DevBuf& map = c->scratch[24];
 		map.alloc(sizeof(uint32_t) * ncells_ext);
 		FI_HIP_TRY(hipMemsetAsync(map.p, 0xFF, sizeof(uint32_t) * ncells_ext, st));
@@ -692,6 +692,137 @@ void assemble_dim(fi_ctx* c)
 }
 
 }  // namespace
+
+// ---- border prior (the reference application: src/sdf_field.cpp:218-246) ------------------------------------------
+// Every lattice point on the border of the lattice gets the value row [1] * w = d * w, d = the distance to the nearest
+// data point -- "far from the surface the field is positive and about the distance".  The reference loops over the
+// border points and, for each, over all points (O(border x points), fp32: dx*dx + dy*dy, min, sqrt).  Here: the border
+// points are enumerated in lattice order by a stream compaction of the index range (no lattice-sized buffer), one
+// thread per border point walks the point batches in LDS tiles of 256 positions with the same fp32 arithmetic, and
+// the rows enter the assembly as a batch of nearest-neighbour value constraints AT the lattice points
+// (field_interpolation.cpp:82-107 with a zero gradient gives exactly the row [1] * w, rhs value * w).
+namespace {
+
+struct BorderPred {
+	int n[3];
+	int ndim;
+	__host__ __device__ bool operator()(const uint32_t& i) const
+	{
+		uint32_t r = i;
+		bool border = false;
+		for (int d = 0; d < ndim; ++d) {
+			const int cd = static_cast<int>(r % static_cast<uint32_t>(n[d]));
+			r /= static_cast<uint32_t>(n[d]);
+			border = border || cd == 0 || cd == n[d] - 1;
+		}
+		return border;
+	}
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void k_border_min_dist(int64_t nb, const uint32_t* __restrict__ idx, BorderPred g, long npts,
+                                                          const float* __restrict__ pos, float* __restrict__ d2)
+{
+	__shared__ float tile[256 * D];
+	const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+	float x[D];
+	{
+		uint32_t r = b < nb ? idx[b] : 0u;
+		for (int d = 0; d < D; ++d) {
+			x[d] = static_cast<float>(r % static_cast<uint32_t>(g.n[d]));
+			r /= static_cast<uint32_t>(g.n[d]);
+		}
+	}
+	float best = b < nb ? d2[b] : 0.0f;
+	for (long base = 0; base < npts; base += 256) {
+		const long m = npts - base < 256 ? npts - base : 256;
+		__syncthreads();
+		for (long k = threadIdx.x; k < m * D; k += 256) { tile[k] = pos[base * D + k]; }
+		__syncthreads();
+		for (long k = 0; k < m; ++k) {
+			float s = 0.0f;
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+				const float dd = tile[k * D + d] - x[d];   // pos - lattice coordinate, as the reference
+				s = s + dd * dd;
+			}
+			best = s < best ? s : best;
+		}
+	}
+	if (b < nb) { d2[b] = best; }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_border_finish(int64_t nb, const uint32_t* __restrict__ idx, BorderPred g,
+                                                        const float* __restrict__ d2, float* __restrict__ pos,
+                                                        float* __restrict__ val)
+{
+	const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+	if (b >= nb) { return; }
+	uint32_t r = idx[b];
+	for (int d = 0; d < D; ++d) {
+		pos[b * D + d] = static_cast<float>(r % static_cast<uint32_t>(g.n[d]));
+		r /= static_cast<uint32_t>(g.n[d]);
+	}
+	val[b] = sqrtf(d2[b]);
+}
+
+__global__ void k_fill_f32(int64_t n, float v, float* out)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n) { out[i] = v; }
+}
+
+}  // namespace
+
+// -> number of border points; their coordinates and the nearest-point distances in pos / val (device buffers)
+int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val)
+{
+	const Geom& g = c->g;
+	const int D = g.ndim;
+	int64_t total = 1;
+	for (int d = 0; d < D; ++d) { total *= g.gn[d]; }
+	FI_REQUIRE(total < (1LL << 32), FI_ERR_UNSUPPORTED, "border prior: lattice too large for 32-bit point indices");
+	BorderPred pred{{g.gn[0], D > 1 ? g.gn[1] : 1, D > 2 ? g.gn[2] : 1}, D};
+	int64_t inner = 1;
+	for (int d = 0; d < D; ++d) { inner *= g.gn[d] > 2 ? g.gn[d] - 2 : 0; }
+	const int64_t nb_expected = total - inner;
+	DevBuf idx, count, tmp, d2;
+	idx.alloc(sizeof(uint32_t) * (nb_expected + 1));
+	count.alloc(sizeof(int));
+	hipStream_t st = c->stream;
+	hipcub::CountingInputIterator<uint32_t> all(0u);
+	size_t tb = 0;
+	FI_HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, all, idx.as<uint32_t>(), count.as<int>(), static_cast<int>(total), pred, st));
+	tmp.alloc(tb);
+	FI_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, all, idx.as<uint32_t>(), count.as<int>(), static_cast<int>(total), pred, st));
+	int nb = 0;
+	FI_HIP_TRY(hipMemcpyAsync(&nb, count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipStreamSynchronize(st));
+	FI_REQUIRE(nb == nb_expected, FI_ERR_HIP, "border prior: %d border points selected, %lld expected", nb,
+	           static_cast<long long>(nb_expected));
+	d2.alloc(sizeof(float) * nb);
+	pos.alloc(sizeof(float) * nb * D);
+	val.alloc(sizeof(float) * nb);
+	const int blocks = static_cast<int>((nb + 255) / 256);
+	hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), INFINITY, d2.as<float>());
+	for (const PointBatch* b : c->batches) {
+		if (b->n <= 0) { continue; }
+		switch (D) {
+		case 1: hipLaunchKernelGGL(k_border_min_dist<1>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, b->n, b->pos.as<float>(), d2.as<float>()); break;
+		case 2: hipLaunchKernelGGL(k_border_min_dist<2>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, b->n, b->pos.as<float>(), d2.as<float>()); break;
+		default: hipLaunchKernelGGL(k_border_min_dist<3>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, b->n, b->pos.as<float>(), d2.as<float>()); break;
+		}
+	}
+	switch (D) {
+	case 1: hipLaunchKernelGGL(k_border_finish<1>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, d2.as<float>(), pos.as<float>(), val.as<float>()); break;
+	case 2: hipLaunchKernelGGL(k_border_finish<2>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, d2.as<float>(), pos.as<float>(), val.as<float>()); break;
+	default: hipLaunchKernelGGL(k_border_finish<3>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, d2.as<float>(), pos.as<float>(), val.as<float>()); break;
+	}
+	FI_HIP_TRY(hipGetLastError());
+	FI_HIP_TRY(hipStreamSynchronize(st));  // the temporaries die here
+	return nb;
+}
 
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val, float vw,
                      int vk, float gw, int gk, float pos_scale, float nrm_scale)

@@ -286,9 +286,19 @@ int fi_comm_self_test(int device, long count)
 		fi::Rccl& r = fi::rccl();
 		ncclUniqueId id;
 		FI_NCCL_TRY(r.GetUniqueId(&id));
-		ncclComm_t comm = nullptr;
+		struct Guard {  // the communicator and the stream go away on every path out of here
+			fi::Rccl&   r;
+			ncclComm_t  comm = nullptr;
+			hipStream_t st = nullptr;
+			~Guard()
+			{
+				if (comm) { (void)r.CommDestroy(comm); }
+				if (st) { (void)hipStreamDestroy(st); }
+			}
+		} guard{r};
+		ncclComm_t& comm = guard.comm;
 		FI_NCCL_TRY(r.CommInitRank(&comm, 1, id, 0));
-		hipStream_t st = nullptr;
+		hipStream_t& st = guard.st;
 		FI_HIP_TRY(hipStreamCreate(&st));
 		fi::DevBuf src, dst, sums;
 		src.alloc(sizeof(float) * count);
@@ -309,8 +319,6 @@ int fi_comm_self_test(int device, long count)
 		FI_HIP_TRY(hipMemcpyAsync(back.data(), dst.p, sizeof(float) * count, hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipMemcpyAsync(hb, sums.p, sizeof(hb), hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
-		(void)r.CommDestroy(comm);
-		(void)hipStreamDestroy(st);
 		for (long i = 0; i < count; ++i) {
 			FI_REQUIRE(back[i] == h[i], FI_ERR_COMM, "self send/recv: element %ld differs", i);
 		}

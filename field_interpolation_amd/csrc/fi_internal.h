@@ -5,12 +5,26 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../include/fi_hip.h"
 
 namespace fi {
+
+// ---- environment switches ------------------------------------------------------------------------------
+// test_switch: alternative code paths the test-suite compares with each other (FI_NO_FUSE, FI_NO_MARCH, FI_NO_TILE2D,
+// FI_NO_GATHER, FI_NO_PACK, FI_NO_OVERLAP, FI_ZC) -- every one of them computes the same answers; present in the shipped
+// library.  tuning_switch: experiment knobs of the ablations in profiles/ (chunk shapes, smoother degrees, launch
+// structure) and the FI_DBG timing modes whose results are wrong by construction: compiled in only with
+// -DFI_TIMING_BUILD (tools/build_variant.sh); the shipped library never reads them.
+inline const char* test_switch(const char* name) { return getenv(name); }
+#ifdef FI_TIMING_BUILD
+inline const char* tuning_switch(const char* name) { return getenv(name); }
+#else
+inline const char* tuning_switch(const char*) { return nullptr; }
+#endif
 
 // ---- error plumbing: nothing throws or aborts across the C ABI ------------------------------------
 void set_error(const char* fmt, ...);
@@ -326,6 +340,12 @@ void generic_error_map(fi_ctx* c, const void* x, void* out);             // out 
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val,
                      float vw, int vk, float gw, int gk, float pos_scale = 1.0f, float nrm_scale = 1.0f);
 void assemble(fi_ctx* c);
+// border prior (src/sdf_field.cpp:218-246): coordinates of the lattice's border points and their distance to the nearest
+// data point added so far, as device buffers; returns their number
+int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val);
+// fi_solver.hip: a batch of points whose arrays already sit in HBM (kept for the coarser levels, rows emitted)
+void add_points_device(fi_ctx* c, long n, const float* p, const float* g, const float* w, const float* v, float value_weight,
+                       int value_kernel, float gradient_weight, int gradient_kernel);
 
 // fi_comm.cpp
 void comm_destroy(Comm* cm);

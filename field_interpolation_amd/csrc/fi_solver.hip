@@ -829,7 +829,7 @@ void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec)
 bool overlap_possible(const fi_ctx* c)
 {
 	return c->nranks > 1 && c->march.valid && c->march.n_inner > 0 && c->generic.ntrip == 0 && c->tile_ts == 0 &&
-	       (c->cells.ncell == 0 || cells_fused(c)) && !getenv("FI_NO_OVERLAP");
+	       (c->cells.ncell == 0 || cells_fused(c)) && !test_switch("FI_NO_OVERLAP");
 }
 void exchange_begin(fi_ctx* c, void* v)
 {
@@ -994,8 +994,8 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		return (c->g.own_first % N == 0) && (c->g.nown % N == 0);
 	};
 	// one context, one process: the dot-product reductions are folded into the vector kernels (3 launches per step)
-	const bool folded = R.size() == 1 && c0->nranks == 1 && !getenv("FI_NO_FOLD");
-	const bool folded_set = !folded && !getenv("FI_NO_FOLD");  // slabs: the same kernels behind a reduction over the rank set
+	const bool folded = R.size() == 1 && c0->nranks == 1 && !tuning_switch("FI_NO_FOLD");
+	const bool folded_set = !folded && !tuning_switch("FI_NO_FOLD");  // slabs: the same kernels behind a reduction over the rank set
 	int issued = 0;         // CG steps enqueued so far (the device runs step k only while it is not done)
 	int restarts_left = c0->verify_residual ? 3 : 0;
 	for (;;) {
@@ -1463,8 +1463,8 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 	}
 }
 
-int mg_degree() { const char* e = getenv("FI_MG_DEGREE"); return e && atoi(e) > 0 ? atoi(e) : 4; }  // config 3 / 5: degree 2 -> 4 halves the solve time
-double mg_ratio() { const char* e = getenv("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : 10.0; }
+int mg_degree() { const char* e = tuning_switch("FI_MG_DEGREE"); return e && atoi(e) > 0 ? atoi(e) : 4; }  // config 3 / 5: degree 2 -> 4 halves the solve time
+double mg_ratio() { const char* e = tuning_switch("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : 10.0; }
 
 template <typename T>
 void mg_alloc(fi_ctx* c)
@@ -1596,7 +1596,7 @@ void vcycle(RankSet& R, Vec b, Vec x)
 {
 	const int deg = mg_degree();
 	const double ratio = mg_ratio();
-	if (getenv("FI_MG_POLY")) {  // experiment: the polynomial alone as the preconditioner, no coarse correction
+	if (tuning_switch("FI_MG_POLY")) {  // experiment: the polynomial alone as the preconditioner, no coarse correction
 		cheb_smooth<T>(R, b, x, deg, ratio, true);
 		return;
 	}
@@ -1672,7 +1672,7 @@ void mg_prepare(RankSet& R, bool clear_finest)
 			l = coarse_of(l);
 		}
 		for (fi_ctx* c : R) { c->lambda_max = c->coarse->lambda_max; }
-		if (getenv("FI_MG_FINE_POWER")) { estimate_lambda<T>(R); }
+		if (tuning_switch("FI_MG_FINE_POWER")) { estimate_lambda<T>(R); }
 	}
 }
 
@@ -2320,7 +2320,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			}
 			cross(phase == 0 ? 3 : 2);
 		}
-		if (getenv("FI_DUMMY")) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st, 0); }  // experiment
+		if (tuning_switch("FI_DUMMY")) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st, 0); }  // experiment
 		for (fi_ctx* c : R) {
 			const int64_t o = c->g.own_first;
 			const int     nbf = nbf_of(c);
@@ -3066,6 +3066,19 @@ int fi_add_points(fi_ctx* c, long n, const float* positions, const float* normal
 		w = up(dpw, point_weights, static_cast<size_t>(n));
 		v = up(dval, values, static_cast<size_t>(n));
 	}
+	fi::add_points_device(c, n, p, g, w, v, value_weight, value_kernel, gradient_weight, gradient_kernel);
+	c->assembled = false;
+	FI_API_END
+}
+
+}  // extern "C"
+
+namespace fi {
+// positions / normals / weights / values already on the device
+void add_points_device(fi_ctx* c, long n, const float* p, const float* g, const float* w, const float* v, float value_weight,
+                       int value_kernel, float gradient_weight, int gradient_kernel)
+{
+	const int D = c->g.ndim;
 	{   // keep the points on the device: coarser levels of a multilevel solve are assembled from them
 		fi::PointBatch* b = nullptr;
 		if (!c->batches_pool.empty()) {
@@ -3098,6 +3111,27 @@ int fi_add_points(fi_ctx* c, long n, const float* positions, const float* normal
 	// ... and the 3-point-wide rows of GradientKernel::kLinearInterpolation as generic sparse rows
 	if (lin && gradient_weight != 0.0f) { fi::generic_add_gradient_linear(c, n, p, g, w, gradient_weight); }
 	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+}
+}  // namespace fi
+
+extern "C" {
+
+int fi_add_border_prior(fi_ctx* c, float weight)
+{
+	FI_API_BEGIN
+	fi::check_ctx(c);
+	fi::bind_device(c);
+	if (weight == 0.0f) { return FI_OK; }  // add_equation skips zero weights (sparse_linear.cpp:36)
+	FI_REQUIRE(!c->batches.empty(), FI_ERR_STATE, "fi_add_border_prior needs the data points: call it after fi_add_points");
+	fi::DevBuf pos, val, zero;
+	const int64_t nb = fi::border_prior_points(c, pos, val);
+	if (nb > 0) {
+		zero.alloc(sizeof(float) * nb * c->g.ndim);
+		FI_HIP_TRY(hipMemsetAsync(zero.p, 0, sizeof(float) * nb * c->g.ndim, c->stream));
+		// the row [1] * w, rhs d * w at the lattice point itself: a nearest-neighbour value constraint with a zero gradient
+		fi::add_points_device(c, static_cast<long>(nb), pos.as<float>(), zero.as<float>(), nullptr, val.as<float>(), weight,
+		                      FI_VALUE_NEAREST_NEIGHBOR, 0.0f, FI_GRADIENT_NEAREST_NEIGHBOR);
+	}
 	c->assembled = false;
 	FI_API_END
 }

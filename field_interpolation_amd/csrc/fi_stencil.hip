@@ -1096,7 +1096,7 @@ __global__ void k_iota32(uint32_t* v, int64_t n)
 int pick_chunk(int tiles_xy, int nz_own, int slots, int forced, int zc_max)
 {
 	if (forced > 0) { return forced; }
-	if (const char* env = getenv("FI_ZC")) {
+	if (const char* env = test_switch("FI_ZC")) {
 		const int v = atoi(env);
 		if (v > 0) { return v > zc_max ? zc_max : v; }
 	}
@@ -1123,7 +1123,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 {
 	const Geom& g = c->g;
 	constexpr int VX = VecOf<T>::VX;
-	if (getenv("FI_NO_MARCH")) { return false; }
+	if (test_switch("FI_NO_MARCH")) { return false; }
 	if (g.ndim != 3) { return false; }
 	if (g.gn[0] < VX) { return false; }  // rows shorter than one 16-byte group: the plain kernel
 	const fi_weights& w = c->w;
@@ -1147,7 +1147,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 				P->txt = txt;
 			}
 		}
-		if (const char* env = getenv("FI_TXT")) {
+		if (const char* env = tuning_switch("FI_TXT")) {
 			if (atoi(env) == 16 || atoi(env) == 32) { P->txt = atoi(env); }
 		}
 	}
@@ -1159,7 +1159,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 	const int nz_own = P->own_z1 - P->own_z0;
 	int cus = 256;
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-	const bool fused = !plain && c->cells.ncell > 0 && !getenv("FI_NO_FUSE");
+	const bool fused = !plain && c->cells.ncell > 0 && !test_switch("FI_NO_FUSE");
 	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : fused_waves<T>(w.model_1 > 0, w.model_2 > 0, c->cells.pack);
 	// the fused variant stages the list bounds of at most 64 + 2 layers in LDS (s_lay); without data cells the chunk
 	// may be as long as one round of workgroups allows (512^3: 128 planes, 1024 workgroups)
@@ -1169,7 +1169,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 	P->plane  = static_cast<int64_t>(P->nx) * P->ny;
 	P->dbg    = 0;
 #if defined(FI_TIMING_BUILD) || defined(FI_STAMPS)
-	P->dbg    = getenv("FI_DBG") ? atoi(getenv("FI_DBG")) : 0;
+	P->dbg    = tuning_switch("FI_DBG") ? atoi(tuning_switch("FI_DBG")) : 0;
 #endif
 	return true;
 }
@@ -1268,7 +1268,7 @@ void march_launch(fi_ctx* c, const T* x, T* y, double* partial)
 	const MarchState& m = c->march;
 	if (!m.fused) {
 		march_launch_cells<T, false>(c, x, y, partial);
-	} else if ((m.P.nwg - m.n_wg_cells) * 16 < m.P.nwg || getenv("FI_NO_SPLIT")) {  // (nearly) every workgroup holds data
+	} else if ((m.P.nwg - m.n_wg_cells) * 16 < m.P.nwg || tuning_switch("FI_NO_SPLIT")) {  // (nearly) every workgroup holds data
 		march_launch_cells<T, true>(c, x, y, partial);
 	} else {
 		// two launches over disjoint workgroups, back to back (running the data workgroups on a side stream next to
@@ -1431,7 +1431,7 @@ void build_cell_lists(fi_ctx* c)
 					best_cap  = cap;
 				}
 			}
-			if (const char* env = getenv("FI_RUN_CAP")) {  // experiments
+			if (const char* env = tuning_switch("FI_RUN_CAP")) {  // experiments
 				if (atoi(env) > 0) { best_cap = atoi(env); }
 			}
 			build_runs(best_cap);
@@ -1463,13 +1463,13 @@ void stencil_prepare(fi_ctx* c)
 	c->tile2.valid = c->tile2.fused = false;
 	if (c->g.ndim == 2) { tile2d_prepare(c); }
 	if (!m.valid) { return; }
-	if (c->cells.ncell > 0 && !getenv("FI_NO_FUSE")) {
+	if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE")) {
 		c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
 		m.fused = true;
 		// Surface-type data: fewer than half of the workgroups hold cells, and those are long latency-bound columns
 		// (march_launch runs them in a launch of their own).  Short chunks turn them into 4-8 times as many
 		// workgroups: 512^3 SDF data 476 -> 398 us, 256^3 98 -> 62 us.  The lists are rebuilt for the new chunking.
-		if (m.n_wg_cells * 2 < m.P.nwg && m.P.zc > 8 && !getenv("FI_ZC") && !getenv("FI_NO_SPLIT")) {
+		if (m.n_wg_cells * 2 < m.P.nwg && m.P.zc > 8 && !test_switch("FI_ZC") && !tuning_switch("FI_NO_SPLIT")) {
 			c->dtype == FI_F64 ? march_setup<double>(c, &m.P, 8) : march_setup<float>(c, &m.P, 8);
 			c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
 		}
@@ -1557,7 +1557,7 @@ bool stencil_apply_part(fi_ctx* c, const void* x, void* y, double* partial, int 
 {
 	const MarchState& m = c->march;
 	if (c->tile2.valid || !m.valid || c->nranks <= 1 || m.n_inner <= 0) { return false; }
-	const bool all_fused = m.fused && ((m.P.nwg - m.n_wg_cells) * 16 < m.P.nwg || getenv("FI_NO_SPLIT"));
+	const bool all_fused = m.fused && ((m.P.nwg - m.n_wg_cells) * 16 < m.P.nwg || tuning_switch("FI_NO_SPLIT"));
 	if (m.fused && !all_fused) { return false; }  // surface data: two launches over cell / plain lists already
 	const uint32_t* list = part == 1 ? m.wg_inner.as<uint32_t>() : m.wg_edge.as<uint32_t>();
 	const int nlist = part == 1 ? m.n_inner : m.n_edge;

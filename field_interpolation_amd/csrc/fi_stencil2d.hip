@@ -343,7 +343,7 @@ bool tile2_setup(const fi_ctx* c, Tile2Params* P)
 	const Geom& g = c->g;
 	constexpr int VX = VecOf<T>::VX;
 	constexpr int TX = kTXT * VX;
-	if (getenv("FI_NO_TILE2D")) { return false; }
+	if (test_switch("FI_NO_TILE2D")) { return false; }
 	if (g.ndim != 2 || g.gn[0] < VX) { return false; }
 	const fi_weights& w = c->w;
 	if (w.model_3 > 0 || w.model_4 > 0 || w.gradient_smoothness > 0) { return false; }
@@ -445,7 +445,7 @@ void tile2d_prepare(fi_ctx* c)
 	m.fused = false;
 	m.nrec  = 0;
 	if (!m.valid) { return; }
-	if (c->cells.ncell > 0 && !getenv("FI_NO_FUSE")) {
+	if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE")) {
 		c->dtype == FI_F64 ? build_lists2<double>(c) : build_lists2<float>(c);
 		m.fused = true;
 	}

@@ -63,6 +63,17 @@ void GpuLatticeField::add_points(float value_weight, ValueKernel value_kernel, f
 	dirty_ = true;
 }
 
+bool GpuLatticeField::add_border_prior(float weight)
+{
+	if (weight == 0) { return false; }
+	if (fi_add_border_prior(ctx_, weight) != FI_OK) {
+		warn("add_border_prior");
+		return false;
+	}
+	dirty_ = true;
+	return true;
+}
+
 bool GpuLatticeField::add_value_constraint(const float pos[], float value, float weight)
 {
 	if (weight == 0) { return false; }

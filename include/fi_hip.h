@@ -167,6 +167,13 @@ int fi_add_points(fi_ctx* ctx, long n, const float* positions, const float* norm
                   const float* values, float value_weight, int value_kernel, float gradient_weight,
                   int gradient_kernel, int memory);
 
+/* The border prior of the reference's SDF application (src/sdf_field.cpp:218-246, generate_sdf_field with
+ * boundary_weight > 0): every lattice point on the border of the lattice gets the row [1] * weight = d * weight, d = its
+ * distance to the nearest data point given to fi_add_points so far (fp32: sum of squared coordinate differences, min,
+ * sqrt -- the reference's arithmetic).  Brute force O(border x points) like the reference, on the device; the rows join the
+ * data rows (and the coarser levels).  Call it after fi_add_points, before fi_assemble.  weight == 0 adds nothing. */
+int fi_add_border_prior(fi_ctx* ctx, float weight);
+
 /* Generic rows: replaces handing an arbitrary `LinearEquation` (sparse_linear.hpp:18-22) to the solvers,
  * as src/bipolar_2d.cpp:177-302 and src/line_2d.cpp:49-104 do.  Duplicate (row, col) entries are summed
  * (sparse_linear.hpp:43).  Row indices are local to this call (0..nrows-1). */

@@ -38,6 +38,9 @@ public:
 	bool add_gradient_constraint(const float pos[], const float gradient[], float weight, GradientKernel kernel);
 	void add_points(float value_weight, ValueKernel value_kernel, float gradient_weight, GradientKernel gradient_kernel,
 	                int num_points, const float positions[], const float* normals, const float* point_weights);
+	// The border prior of the reference's SDF application (src/sdf_field.cpp:218-246: options.boundary_weight): every
+	// border lattice point is pulled towards its distance to the nearest point added so far.  After add_points.
+	bool add_border_prior(float weight);
 
 	// solve_sparse_linear_with_guess / solve_tiled_with_guess / jacobi_iterations of the reference.
 	// An empty result means failure (wrong guess length, solver breakdown), as in the reference.

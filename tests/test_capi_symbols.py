@@ -70,3 +70,16 @@ def test_cxx_dropin_exports_the_reference_api():
                 "field_interpolation::solve_tiled_with_guess", "field_interpolation::upscale_field",
                 "field_interpolation::generate_error_map", "field_interpolation::GpuLatticeField::solve"):
         assert sym in out, sym
+
+
+def test_shipped_library_has_no_timing_hooks():
+    """The FI_DBG timing modes (results wrong by construction) and the ablation knobs exist only in timing builds
+    (-DFI_TIMING_BUILD, tools/build_variant.sh): the shipped library does not even contain their names."""
+    import os
+    from field_interpolation_amd import _capi
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in (b"FI_DBG", b"FI_TXT", b"FI_RUN_CAP", b"FI_NO_SPLIT", b"FI_NO_FOLD", b"FI_MG_DEGREE", b"FI_MG_RATIO", b"FI_MG_POLY",
+                 b"FI_DUMMY"):
+        assert name not in blob, name
+    for name in (b"FI_NO_FUSE", b"FI_NO_MARCH", b"FI_ZC", b"FI_SOLVE_TIMEOUT_S"):      # the switches the tests use are there
+        assert name in blob, name

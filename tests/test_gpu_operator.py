@@ -4,7 +4,7 @@ triplets.  Tolerances: fp64 contexts 1e-12 (relative to the largest entry), fp32
 import numpy as np
 import pytest
 
-from util import build_pair, random_points, rel_inf
+from util import build_pair, random_points, rel_inf, sphere_points
 
 pytestmark = pytest.mark.gpu
 
@@ -328,3 +328,38 @@ def test_two_row_cells_on_tile_and_chunk_seams(oracle, fi, dtype, monkeypatch):
     np.testing.assert_array_equal(y1, fg.apply_AtA(x))
     assert np.abs(y1 - ref).max() <= TOL[dtype] * scale
     assert np.abs(fg.Atb() - atb).max() <= TOL[dtype] * np.abs(atb).max()
+
+
+@pytest.mark.parametrize("sizes,dtype", [([30, 26], "f64"), ([30, 26], "f32"), ([12, 10, 9], "f64"), ([40], "f64")])
+def test_border_prior_equals_the_reference_rows(oracle, fi, sizes, dtype):
+    """src/sdf_field.cpp:218-246: every border lattice point gets add_equation(Weight{w}, Rhs{d}, {{index, 1.0f}}) with
+    d = sqrt(min over the points of the squared fp32 coordinate differences).  The oracle side restates that loop with
+    numpy in fp32; the device side is fi_add_border_prior (stream compaction + tiled brute force + nearest-neighbour
+    value rows)."""
+    rng = np.random.default_rng(len(sizes))
+    pos, nrm = sphere_points(rng, sizes, 150) if len(sizes) > 1 else (rng.uniform(5, 30, size=(6, 1)).astype(np.float32), None)
+    w = fi.Weights()
+    bw = 0.7
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, None, None, dtype=dtype)
+    # the reference loop (fp32 arithmetic, lattice order)
+    D = len(sizes)
+    coords = np.stack(np.meshgrid(*[np.arange(s) for s in sizes], indexing="ij"), axis=-1).reshape(-1, D)
+    lin = sum(coords[:, d] * int(np.prod(sizes[:d])) for d in range(D))
+    border = np.any((coords == 0) | (coords == np.array(sizes) - 1), axis=1)
+    order = np.argsort(lin[border])
+    bc, bl = coords[border][order], lin[border][order]
+    for c, index in zip(bc, bl):
+        dd = pos.astype(np.float32) - c.astype(np.float32)
+        s = np.zeros(len(pos), np.float32)
+        for d in range(D):
+            s = (s + dd[:, d] * dd[:, d]).astype(np.float32)
+        fo.add_equation(bw, float(np.sqrt(np.float32(s.min()))), [(int(index), 1.0)])
+    fg.add_border_prior(bw)
+    fg.assemble()
+    AtA, atb, diag = fo.normal_equations()
+    tol = 1e-12 if dtype == "f64" else 2e-6
+    assert rel_inf(fg.Atb(), atb) <= tol
+    assert rel_inf(fg.diag(), diag) <= tol
+    x = rng.normal(size=int(np.prod(sizes)))
+    assert rel_inf(fg.apply_AtA(x), AtA @ x) <= tol
+    assert fg.stats()["num_data_rows"] == fo.num_rows - _model_rows(oracle, sizes, w)
