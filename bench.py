@@ -118,7 +118,7 @@ def workload(args, world):
         npts = npts * world if weak else npts
         sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3, depth=depth)
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or 1e-5, dtype=args.dtype or "f32",
-                    levels=2 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-5,
+                    levels=(3 if args.multigrid else 1) if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-5,
                     multigrid=args.multigrid, mixed=False, poly=0 if args.multigrid else args.poly, points=npts,
                     text="config4: 3D %dx%dx%d lattice, %d scattered noisy value constraints, model_2=0.5" % (
                         sizes[0], sizes[1], sizes[2], npts))
@@ -374,7 +374,7 @@ def main():
         ref = fi.LatticeField(wl["sizes"], dtype="f64")
         ref.add_field_constraints(wl["w"])
         if args.config == 4:
-            ref.set_levels(max(wl["levels"], 2), 1e-6)
+            ref.set_levels(max(wl["levels"], 1), 1e-6)
             ref.set_polynomial(4, args.poly_ratio)
         else:
             ref.set_levels(max(wl["levels"], 4), 1e-4)

@@ -482,8 +482,6 @@ __device__ inline void cg_logic(CgScalars* sc, int phase)
 	}
 }
 
-__global__ void k_noop(int) {}
-
 __global__ void k_set_done(CgScalars* sc, int value)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) { sc->done = value; }
@@ -2010,9 +2008,6 @@ __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScala
 	}
 }
 
-#ifdef FI_XP_STAMPS
-__device__ unsigned long long g_xp_stamp[8];
-#endif
 // second half: beta and the stop test, x += alpha p, p = z + beta p            (reads x, p, z; writes x, p)
 // phase 0: start (b.b, tolerance, p = z); phase 2: restart from the true residual (p = z, verified stop)
 template <typename T, bool VEC>
@@ -2021,25 +2016,13 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
                                                       const double* __restrict__ prz, int nrz, const double* __restrict__ pbb,
                                                       int nbb, const T* __restrict__ z, T* __restrict__ x, T* __restrict__ p)
 {
-#ifdef FI_XP_STAMPS
-	const unsigned long long t_in = __builtin_amdgcn_s_memtime();
-#endif
 	if (mid->tag != tag) { return; }  // the first half of this iteration did not run: the solve had finished
 	if (mid->done == 2) {
 		if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = *mid; }
 		return;
 	}
-#ifdef FI_XP_STAMPS
-	const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-#endif
 	const double rr = sum_partials(prr, nrr);
-#ifdef FI_XP_STAMPS
-	const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-#endif
 	const double rz = sum_partials(prz, nrz);
-#ifdef FI_XP_STAMPS
-	const unsigned long long t_c = __builtin_amdgcn_s_memtime();
-#endif
 	CgScalars s = *mid;
 	double beta_d = 0.0;
 	if (phase == 1) {
@@ -2051,11 +2034,11 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
 			s.bb   = sum_partials(pbb, nbb);
 			s.tol2 = s.tol2 * s.bb;
 			s.iter = 0;
-		} else {
+		} else if (phase == 2) {
 			s.restarts += 1;
 			s.true_rr = rr;
 		}
-		s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase == 2 ? 5 : 1) : (s.iter >= s.max_iter ? 3 : 0)));
+		s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase >= 2 ? 5 : 1) : (s.iter >= s.max_iter ? 3 : 0)));
 	}
 	s.rz_new = rz;
 	s.rr     = rr;
@@ -2099,28 +2082,24 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
 			if (VEC) { reinterpret_cast<V*>(p)[i] = *reinterpret_cast<V*>(pv); } else { p[i] = pv[0]; }
 		}
 	}
-#ifdef FI_XP_STAMPS
-	if (threadIdx.x == 0 && n < 300000) {
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		const unsigned long long t_out = __builtin_amdgcn_s_memtime();
-		if (blockIdx.x == 0) { g_xp_stamp[0] = t_a - t_in; g_xp_stamp[1] = t_b - t_a; g_xp_stamp[2] = t_c - t_b; g_xp_stamp[3] = t_out - t_c; }
-		atomicMin(&g_xp_stamp[4], t_in);
-		atomicMax(&g_xp_stamp[5], t_in);
-		atomicMax(&g_xp_stamp[6], t_out);
-		if (tag == 30) { g_xp_stamp[4] = ~0ull; g_xp_stamp[5] = 0; g_xp_stamp[6] = 0; }
-	}
-#endif
 }
-#ifdef FI_XP_STAMPS
-}  // namespace
-}  // namespace fi
-extern "C" int fi_debug_xp_stamps(unsigned long long* out)
+
+// verified stop: r = b - A x has been formed by k_pcg_resid (phase 2); decide whether it meets the tolerance before
+// the polynomial is spent on it (the usual outcome: it does, and the solve ends here)
+__global__ __launch_bounds__(kThreads) void k_pcg_verify(CgScalars* __restrict__ mid, CgScalars* __restrict__ out_sc,
+                                                          const double* __restrict__ prr, int nrr)
 {
-	return hipMemcpyFromSymbol(out, HIP_SYMBOL(fi::g_xp_stamp), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : 1;
+	const double rr = sum_partials(prr, nrr);
+	if (threadIdx.x != 0) { return; }
+	CgScalars s = *mid;
+	s.restarts += 1;
+	s.true_rr = rr;
+	s.rr      = rr;
+	s.done    = !isfinite(rr) ? 2 : (!(rr > s.tol2) ? 5 : (s.iter >= s.max_iter ? 3 : 0));
+	*out_sc = s;
+	s.done  = 0;
+	*mid    = s;  // the restart that may follow (k_pcg_xp, phase 3) continues from this record
 }
-namespace fi {
-namespace {
-#endif
 
 // sums of up to three partial lists of different lengths into sums[0..2] of a scalar slot (rank sets: the values
 // then cross the slabs by k_group_sum / the all-reduce)
@@ -2262,7 +2241,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	}
 	// one pass of the recurrence: phase 1 = a CG step (the apply of p has been launched), 0 / 2 = start / restart (the
 	// apply of x has been launched)
-	auto half_steps = [&](int phase) {
+	auto first_half = [&](int phase) {  // alpha, r, z1 (phase 0 / 2 / 3: r = b - A x)
 		++tag;
 		if (!single && phase == 1) {
 			for (fi_ctx* c : R) {
@@ -2284,6 +2263,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			};
 			if (vec_ok(c)) { go(k_pcg_resid<T, true>); } else { go(k_pcg_resid<T, false>); }
 		}
+	};
+	auto second_half = [&](int phase) {  // the polynomial, beta and the stop test, x and p
 		// the polynomial: z_{k+1} from z_k (ZA / ZB alternate; the result ends in `zfin`)
 		Vec zin = ZA, zout = ZB;
 		for (int k = 1; k < terms; ++k) {
@@ -2320,7 +2301,6 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			}
 			cross(phase == 0 ? 3 : 2);
 		}
-		if (tuning_switch("FI_DUMMY")) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st, 0); }  // experiment
 		for (fi_ctx* c : R) {
 			const int64_t o = c->g.own_first;
 			const int     nbf = nbf_of(c);
@@ -2337,6 +2317,10 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			};
 			if (vec_ok(c)) { go(k_pcg_xp<T, true>); } else { go(k_pcg_xp<T, false>); }
 		}
+	};
+	auto half_steps = [&](int phase) {
+		first_half(phase);
+		second_half(phase);
 	};
 	auto start = [&](int phase) {  // r = b - A x, z = M r, p = z
 		apply_exchanged(R, &fi_ctx::x, &fi_ctx::q, nullptr);
@@ -2357,6 +2341,9 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	CgScalars* sc0 = c0->scal.as<CgScalars>();
 	int restarts_left = c0->verify_residual ? 3 : 0;
 	const int burst = terms >= 4 ? 4 : 8;  // outer iterations between two looks at the stop flag
+	// the first look comes when the context's previous solve had finished (the per-frame / re-assembled problem of a
+	// caller changes little): every look is a host round trip of ~35 us
+	int next_burst = c0->last_outer_iterations > 0 ? (c0->last_outer_iterations < 64 ? c0->last_outer_iterations : 64) : burst;
 	int issued = 0;
 	for (;;) {
 		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
@@ -2365,14 +2352,33 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			if (c0->scal_host->done != 1 || restarts_left <= 0) { break; }
 			--restarts_left;  // the recurrence met the tolerance: check b - A x, go on from it if it misses
 			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), 0); }
-			start(2);
+			apply_exchanged(R, &fi_ctx::x, &fi_ctx::q, nullptr);
+			first_half(2);  // r = b - A x, z1, partials of r.r
+			if (!single) {
+				for (fi_ctx* c : R) {
+					hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, region(c, 1), nbf_of(c),
+					                   static_cast<const double*>(nullptr), 0, static_cast<const double*>(nullptr), 0);
+				}
+				cross(1);
+			}
+			for (fi_ctx* c : R) {
+				CgScalars* sc = c->scal.as<CgScalars>();
+				hipLaunchKernelGGL(k_pcg_verify, dim3(1), dim3(kThreads), 0, c->stream, sc + 1, sc, single ? region(c, 1) : slot2(c),
+				                   single ? nbf_of(c) : 1);
+			}
+			FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+			FI_HIP_TRY(hipStreamSynchronize(st));
+			if (c0->scal_host->done) { break; }   // verified (5), out of iterations (3) or not finite (2)
+			second_half(3);  // the true residual misses the tolerance: CG goes on from it (z = M r, p = z)
 			continue;
 		}
 		if (timed_out_anywhere(R, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s)) {
 			timed_out = true;
 			break;
 		}
-		for (int k = 0; k < burst; ++k) {
+		const int nb = next_burst;
+		next_burst = burst > 2 ? 2 : burst;  // after the first look the solve is close to its end
+		for (int k = 0; k < nb; ++k) {
 			++issued;
 			const bool sample = samples < kMaxSamples && (issued & 1) == 1;
 			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
@@ -2418,7 +2424,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		c->stats.prec_samples = pused;
 		c->stats.prec_ms_avg  = pused ? psum / pused : 0.0;
 		c->stats.prec_bytes   = static_cast<double>(sizeof(T)) * (terms > 2 ? 5.0 : 4.0) * static_cast<double>(c->g.nown);
-		c->stats.operator_applies = (h.iter + 1 + h.restarts) * terms;
+		c->stats.operator_applies = (h.iter + 1) * terms + h.restarts;
+		c->last_outer_iterations = h.iter;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
