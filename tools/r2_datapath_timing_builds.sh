@@ -1,4 +1,5 @@
 #!/bin/bash
+# timing builds of the fused apply (results wrong by construction): tools/build_variant.sh tdense -DFI_TIMING_BUILD -DFI_DENSE_MIN=0u ; ... tsparse -DFI_TIMING_BUILD -DFI_DENSE_MIN=100000u
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r2_exp4
 mkdir -p $O; rm -f $O/log.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+# in-kernel stamps of one workgroup of the apply: build first with  tools/build_variant.sh stamps -DFI_STAMPS -DFI_TIMING_BUILD
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r2_exp6
 mkdir -p $O
