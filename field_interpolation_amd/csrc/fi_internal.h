@@ -318,6 +318,11 @@ int  stencil_cheb_partials(const fi_ctx* c);
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double c1,
                        double c2, double* partial, int part = 0);
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
+// z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (dinv == nullptr: z_new = r - A z) in one pass of the
+// marching kernel(s) over the lattice; z with valid ghost planes
+bool stencil_full_epi_available(const fi_ctx* c);
+void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double a,
+                       double c1, double c2);
 
 // fi_stencil2d.hip: LDS-tiled kernel for 2-D lattices (model_0/1/2), called through the stencil_* entry points
 void tile2d_prepare(fi_ctx* c);

@@ -115,16 +115,22 @@ struct MarchCoef {
 	T w2sq;  // model_2^2
 };
 
-// Epilogue of the plain variant for one step of the Chebyshev polynomial preconditioner (fi_solver.hip, cg_run_poly):
-// the kernel applies the MODEL rows to z (tile + halo as ever) and, instead of storing q = A z, forms for its own points
-//     s      = Dinv (q - m z) + z                      = Dinv (A_model + diag(A_data)) z,  m = the model diagonal
-//     z_new  = a z - c1 z_prev + c2 (Dinv r - s)        (three-term Chebyshev recurrence, a = 1 + c1; the step from
-//                                                        z_prev = 0 passes z itself with c1 = 0)
-// and the partials of r . z_new.  mode 1 is one step of the power method for the smoother bound, on the MODEL
-// operator alone (data only lowers the Rayleigh quotients of Dinv (A_model + diag)): z_new = (A_model z) / m, partials
-// of z_new . z_new.  The data rows enter the preconditioner through their diagonal only -- as good a
-// preconditioner as the polynomial in the full operator (profiles/r2_ablation.md: equal iteration counts) -- so a step
-// never reads a cell record: 5 lattice passes (z, z_prev, r, Dinv in; z_new out) in one launch.
+// Epilogue for one step of a Chebyshev recurrence: instead of storing q = A z the kernel forms, for its own points,
+//     mode 0 (plain variant; polynomial preconditioner of fi_solver.hip, cg_run_poly):
+//         s     = Dinv (q - m z) + z                   = Dinv (A_model + diag(A_data)) z,  m = the model diagonal
+//         z_new = a z - c1 z_prev + c2 (Dinv r - s)    (three-term recurrence, a = 1 + c1; the step from z_prev = 0
+//                                                       passes z itself with c1 = 0)
+//       and the partials of r . z_new.  The data rows enter that preconditioner through their diagonal only -- as good
+//       a preconditioner as the polynomial in the full operator (profiles/r2_ablation.md: equal iteration counts) -- so
+//       a step never reads a cell record: 5 lattice passes (z, z_prev, r, Dinv in; z_new out) in one launch;
+//     mode 1 (plain variant): one step of the power method for that polynomial's bound, on the MODEL operator alone
+//       (data only lowers the Rayleigh quotients of Dinv (A_model + diag)): z_new = (A_model z) / m, partials of
+//       z_new . z_new;
+//     mode 2 (every variant; smoother of the V-cycle, fi_solver.hip cheb_smooth): the same recurrence on the FULL
+//       operator, q = A z with the data cells: z_new = a z - c1 z_prev + c2 Dinv (r - q);
+//     mode 3 (every variant): the residual z_new = r - q.
+// The fused (data cell) variant completes a plane one step late and runs its epilogue there; with the operands of the
+// epilogue it is register-allocated for two workgroups per CU (at three it would spill ~190 VGPRs).
 template <typename T>
 struct ChebEpi {
 	const T* zprev;
@@ -132,7 +138,7 @@ struct ChebEpi {
 	const T* dinv;
 	T*       znew;
 	T        a, c1, c2;
-	int      mode;  // 0: Chebyshev step, 1: power-method step
+	int      mode;
 };
 
 struct CellLists {
@@ -178,7 +184,7 @@ __host__ __device__ constexpr int fused_waves(bool has1, bool has2, bool pack)
 // of cells beyond 8 rows).  Two variants because the unrolled block product is code the row-dominated contexts
 // would only pay for: config 4's finest level ran 2-4 us per launch slower with it compiled in.
 template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT, bool PACK, bool EPI = false>
-__global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)) : (EPI && HAS1 && HAS2 && sizeof(T) == 4 ? FI_BASE_WAVES - 1 : FI_BASE_WAVES)) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
+__global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, HAS2, PACK)) : (EPI && HAS1 && HAS2 && sizeof(T) == 4 ? FI_BASE_WAVES - 1 : FI_BASE_WAVES)) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
                                                              const int* __restrict__ done,
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
                                                              const uint32_t* __restrict__ wg_runs,
                                                              ChebEpi<T> E = ChebEpi<T>{})
 {
-	static_assert(!(EPI && CELLS), "the Chebyshev epilogue belongs to the plain variant");
+	static_assert(!(EPI && CELLS && sizeof(T) == 8), "the fused variant carries the epilogue in fp32 only");
 	using V = typename VecOf<T>::V;
 	constexpr int kTXT = TXT;             // threads along x
 	constexpr int kTY  = kThreads / TXT;  // tile rows (= threads along y)
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 
 	// ---- Chebyshev epilogue (EPI): the x/y part of the model diagonal of the thread's points, and the operand loads
 	T mxy[EPI ? VX : 1];
-	if (EPI) {
+	if (EPI && !CELLS) {
 		T ay = T(0), by = T(0);
 		if (HAS2) { ay = (c2y[0] ? T(1) : T(0)) + (c2y[1] ? T(4) : T(0)) + (c2y[2] ? T(1) : T(0)); }
 		if (HAS1) { by = (c1y[0] ? T(1) : T(0)) + (c1y[1] ? T(1) : T(0)); }
@@ -543,6 +549,24 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 		e.zp = *reinterpret_cast<const V*>(E.zprev + o);  // never null: the host passes z itself with c1 = 0 on the first step
 		e.rv = *reinterpret_cast<const V*>(E.r + o);
 		e.dv = *reinterpret_cast<const V*>(E.dinv + o);
+	};
+
+	// modes 2 / 3 for one completed plane: zc = the plane's z values, q = A z (full operator)
+	auto epi_full = [&](const EpiRegs& e, const T* zc, const T* q, T* pz) -> T {
+		const T* zp = reinterpret_cast<const T*>(&e.zp);
+		const T* rv = reinterpret_cast<const T*>(&e.rv);
+		const T* dv = reinterpret_cast<const T*>(&e.dv);
+		T rz = T(0);
+		if (E.mode == 3) {
+#pragma unroll
+			for (int j = 0; j < VX; ++j) { pz[j] = rv[j] - q[j]; }
+		} else {
+#pragma unroll
+			for (int j = 0; j < VX; ++j) { pz[j] = E.a * zc[j] - E.c1 * zp[j] + E.c2 * (dv[j] * (rv[j] - q[j])); }
+		}
+#pragma unroll
+		for (int j = 0; j < VX; ++j) { rz += rv[j] * pz[j]; }
+		return rz;
 	};
 
 	// ---- prologue ---------------------------------------------------------------------------------
@@ -701,7 +725,18 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 					po[j] = held[j] + data[j];
 					dsum += pm[j] * po[j];
 				}
-				if (active) {
+				if (EPI) {
+					V zn;
+					T* pz = reinterpret_cast<T*>(&zn);
+					const T rz = epi_full(EP, pm, po, pz);
+					if (active) {
+						*reinterpret_cast<V*>((E.znew + static_cast<int64_t>(z - 1) * P.plane) + col) = zn;
+						dot_acc += static_cast<double>(rz);
+					} else if (tail) {
+						store_tail(E.znew + static_cast<int64_t>(z - 1) * P.plane, reinterpret_cast<const T*>(&EP.rv), pz);
+					}
+					load_epi(z, EP);
+				} else if (active) {
 					*reinterpret_cast<V*>((y + static_cast<int64_t>(z - 1) * P.plane) + col) = out;
 					dot_acc += static_cast<double>(dsum);
 				} else if (tail) {
@@ -834,7 +869,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 			V zn;
 			T* pz = reinterpret_cast<T*>(&zn);
 			T  rz = T(0);
-			if (E.mode == 1) {
+			if (E.mode >= 2) {  // a workgroup without data cells: the model rows are the full operator here
+				rz = epi_full(EP, pc, po, pz);
+			} else if (E.mode == 1) {
 #pragma unroll
 				for (int j = 0; j < VX; ++j) {
 					pz[j] = po[j] / (mxy[j] + mz);
@@ -901,7 +938,17 @@ __global__ __launch_bounds__(kThreads, CELLS ? (fused_waves<T>(HAS1, HAS2, PACK)
 			po[j] = held[j] + data[j];
 			dsum += pm[j] * po[j];
 		}
-		if (active) {
+		if (EPI) {
+			V zn;
+			T* pz = reinterpret_cast<T*>(&zn);
+			const T rz = epi_full(EP, pm, po, pz);
+			if (active) {
+				*reinterpret_cast<V*>((E.znew + static_cast<int64_t>(z_end - 1) * P.plane) + col) = zn;
+				dot_acc += static_cast<double>(rz);
+			} else if (tail) {
+				store_tail(E.znew + static_cast<int64_t>(z_end - 1) * P.plane, reinterpret_cast<const T*>(&EP.rv), pz);
+			}
+		} else if (active) {
 			*reinterpret_cast<V*>((y + static_cast<int64_t>(z_end - 1) * P.plane) + col) = out;
 			dot_acc += static_cast<double>(dsum);
 		} else if (tail) {
@@ -1189,7 +1236,7 @@ MarchCoef<T> march_coef(const fi_weights& w)
 
 template <typename T, bool CELLS>
 void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint32_t* wg_list = nullptr, int nlist = 0,
-                        const uint32_t* wg_runs = nullptr)
+                        const uint32_t* wg_runs = nullptr, const ChebEpi<T>* epi = nullptr)
 {
 	const MarchParams& P = c->march.P;
 	const MarchCoef<T> C = march_coef<T>(c->w);
@@ -1203,26 +1250,34 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
 	auto launch = [&](auto kernel) {
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, x, y, partial, done, wg_list, nlist,
-		                   wg_runs, ChebEpi<T>{});
+		                   wg_runs, epi ? *epi : ChebEpi<T>{});
 	};
 	const bool pack = CELLS && c->cells.pack;  // the variant that matches the context's block records
-	auto pick = [&](auto txt, auto pk) {
+	auto pick = [&](auto txt, auto pk, auto ep) {
 		constexpr int  TXT = decltype(txt)::value;
 		constexpr bool PK  = decltype(pk)::value;
-		if (h1 && h2) {
-			launch(k_apply_march3d<T, true, true, CELLS, TXT, PK>);
-		} else if (h2) {
-			launch(k_apply_march3d<T, false, true, CELLS, TXT, PK>);
+		constexpr bool EP  = decltype(ep)::value;
+		if constexpr (EP && CELLS && sizeof(T) == 8) {
+			FI_REQUIRE(false, FI_ERR_UNSUPPORTED, "the fused epilogue exists in fp32 only");  // callers check stencil_full_epi_available
 		} else {
-			launch(k_apply_march3d<T, true, false, CELLS, TXT, PK>);
+			if (h1 && h2) {
+				launch(k_apply_march3d<T, true, true, CELLS, TXT, PK, EP>);
+			} else if (h2) {
+				launch(k_apply_march3d<T, false, true, CELLS, TXT, PK, EP>);
+			} else {
+				launch(k_apply_march3d<T, true, false, CELLS, TXT, PK, EP>);
+			}
 		}
 	};
 	using std::integral_constant;
-	if (P.txt == 32) {
-		if (CELLS && pack) { pick(integral_constant<int, 32>{}, integral_constant<bool, CELLS>{}); } else { pick(integral_constant<int, 32>{}, integral_constant<bool, false>{}); }
-	} else {
-		if (CELLS && pack) { pick(integral_constant<int, 16>{}, integral_constant<bool, CELLS>{}); } else { pick(integral_constant<int, 16>{}, integral_constant<bool, false>{}); }
-	}
+	auto pick_shape = [&](auto ep) {
+		if (P.txt == 32) {
+			if (CELLS && pack) { pick(integral_constant<int, 32>{}, integral_constant<bool, CELLS>{}, ep); } else { pick(integral_constant<int, 32>{}, integral_constant<bool, false>{}, ep); }
+		} else {
+			if (CELLS && pack) { pick(integral_constant<int, 16>{}, integral_constant<bool, CELLS>{}, ep); } else { pick(integral_constant<int, 16>{}, integral_constant<bool, false>{}, ep); }
+		}
+	};
+	if (epi) { pick_shape(integral_constant<bool, true>{}); } else { pick_shape(integral_constant<bool, false>{}); }
 	FI_HIP_TRY(hipGetLastError());
 }
 
@@ -1263,18 +1318,18 @@ void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partia
 // Surface-type data (an SDF from oriented points) leaves most workgroups without a single cell: those run the
 // plain variant (4 workgroups per CU, none of the data path's per-plane work), the others the fused one.
 template <typename T>
-void march_launch(fi_ctx* c, const T* x, T* y, double* partial)
+void march_launch(fi_ctx* c, const T* x, T* y, double* partial, const ChebEpi<T>* epi = nullptr)
 {
 	const MarchState& m = c->march;
 	if (!m.fused) {
-		march_launch_cells<T, false>(c, x, y, partial);
+		march_launch_cells<T, false>(c, x, y, partial, nullptr, 0, nullptr, epi);
 	} else if ((m.P.nwg - m.n_wg_cells) * 16 < m.P.nwg || tuning_switch("FI_NO_SPLIT")) {  // (nearly) every workgroup holds data
-		march_launch_cells<T, true>(c, x, y, partial);
+		march_launch_cells<T, true>(c, x, y, partial, nullptr, 0, nullptr, epi);
 	} else {
 		// two launches over disjoint workgroups, back to back (running the data workgroups on a side stream next to
 		// the plain ones was tried: 543 instead of 482 us at 512^3 -- the long data columns starve the plain launch)
-		march_launch_cells<T, true>(c, x, y, partial, m.wg_cells.as<uint32_t>(), m.n_wg_cells);
-		march_launch_cells<T, false>(c, x, y, partial, m.wg_plain.as<uint32_t>(), m.n_wg_plain, m.wg_runs.as<uint32_t>());
+		march_launch_cells<T, true>(c, x, y, partial, m.wg_cells.as<uint32_t>(), m.n_wg_cells, nullptr, epi);
+		march_launch_cells<T, false>(c, x, y, partial, m.wg_plain.as<uint32_t>(), m.n_wg_plain, m.wg_runs.as<uint32_t>(), epi);
 	}
 }
 
@@ -1551,6 +1606,24 @@ void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 		                 static_cast<float*>(vnew), 0, 0, 0, 1};
 		march_launch_epi<float>(c, static_cast<const float*>(v), E, partial);
 	}
+}
+
+// The recurrence step / residual on the FULL operator in one pass over the lattice (ChebEpi modes 2 and 3): the launches
+// of stencil_apply with the epilogue.  fp32 contexts whose data cells (if any) are fused into the marching kernel.
+bool stencil_full_epi_available(const fi_ctx* c)
+{
+	return c->march.valid && !c->tile2.valid && c->dtype == FI_F32 && (c->cells.ncell == 0 || c->march.fused);
+}
+void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double a,
+                       double c1, double c2)
+{
+	FI_REQUIRE(stencil_full_epi_available(c), FI_ERR_UNSUPPORTED, "no fused recurrence step for this context");
+	const float* zf = static_cast<const float*>(z);
+	// a null operand is never used with its coefficient: any readable vector stands in
+	ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r),
+	                 static_cast<const float*>(dinv ? dinv : r), static_cast<float*>(znew), static_cast<float>(a),
+	                 static_cast<float>(zprev ? c1 : 0.0), static_cast<float>(c2), dinv ? 2 : 3};
+	march_launch<float>(c, zf, nullptr, nullptr, &E);
 }
 
 bool stencil_apply_part(fi_ctx* c, const void* x, void* y, double* partial, int part)

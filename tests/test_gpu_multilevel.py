@@ -175,3 +175,31 @@ def test_mixed_precision_reassembly_reuses_the_replica(fi):
     f.assemble()
     x, it, rel = f.solve_cg(None, 0, 1e-9)
     assert rel <= 1e-9 and rel_inf(f.solution_f64(), x_last) <= 1e-5
+
+
+@pytest.mark.parametrize("sizes,kw", [([48, 40, 44], None), ([40, 44, 36], {"model_1": 0.3}), ([36, 40, 41], {"model_1": 0.4, "model_2": 0.0})])
+def test_fused_smoother_equals_the_unfused_one(fi, sizes, kw, monkeypatch):
+    """fp32 V-cycles smooth through the marching kernel's epilogue (one launch per Chebyshev step, three-term form in
+    the iterates); FI_NO_FUSED_SMOOTHER keeps apply + vector kernel (the form of the fp64 and 2-D paths).  Same
+    polynomial: same iteration count (rounding may move it by one) and the same solution."""
+    rng = np.random.default_rng(12)
+    pos, nrm = sphere_points(rng, sizes, 2500)
+    w = fi.Weights(**(kw or {}))
+    out = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("FI_NO_FUSED_SMOOTHER", "1")
+        else:
+            monkeypatch.delenv("FI_NO_FUSED_SMOOTHER", raising=False)
+        f = fi.LatticeField(sizes, dtype="f32")
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        f.set_levels(2)
+        f.set_multigrid(True)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-5)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.2e-5
+        out.append((x.copy(), it))
+    monkeypatch.delenv("FI_NO_FUSED_SMOOTHER", raising=False)
+    assert abs(out[0][1] - out[1][1]) <= 1
+    assert rel_inf(out[0][0], out[1][0]) <= 2e-4      # two fp32 solves to a 1e-5 residual

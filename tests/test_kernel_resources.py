@@ -34,12 +34,14 @@ def test_marching_kernel_budget():
     rep = _variants(_report("fi_stencil.usage.txt"), "k_apply_march3d")
     # {fp32, fp64} x {model_1, model_2, both} x {plain, fused} x {128 x 8, 64 x 16 tiles}, the fused ones once more
     # for contexts that keep their multi-row cells as packed blocks, the plain ones once more with the Chebyshev
-    # epilogue of the polynomial preconditioner (template flag EPI, the last one of the mangled name)
-    assert len(rep) == 48
+    # epilogue of the polynomial preconditioner (template flag EPI, the last one of the mangled name), and the fp32
+    # fused ones once more with the epilogue of the V-cycle's smoother (register-allocated for 2 workgroups per CU)
+    assert len(rep) == 60
     for name, r in rep.items():
         epi = "ELb1EEEv" in name
-        # (SGPR spills go to VGPR lanes, not to memory: the both-models variants keep 11-19 lane masks and bounds there)
-        assert r["SGPRs Spill"] <= 24 and r["AGPRs"] == 0, name
+        # (SGPR spills go to VGPR lanes, not to memory: the both-models variants keep 11-19 lane masks and bounds there,
+        # the fused ones with the smoother's epilogue up to 40)
+        assert r["SGPRs Spill"] <= (40 if epi and r["LDS Size [bytes/block]"] > 30000 else 24) and r["AGPRs"] == 0, name
         # the fp64 model_2 fused variant spills 4 VGPRs since the round-2 changes of the step's interface (round 1: none)
         relaxed = "march3dIdLb0ELb1ELb1E" in name and "ELb0ELb0EEEv" in name
         assert r["VGPRs Spill"] <= (4 if relaxed else 0) and r["ScratchSize [bytes/lane]"] <= (20 if relaxed else 0), name
