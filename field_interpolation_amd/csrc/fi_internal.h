@@ -217,6 +217,7 @@ struct Comm;  // RCCL state (fi_comm.cpp)
 struct CgScalars {  // lives in device memory; kernels read/write it, the host polls it
 	double rz, rz_new, pq, rr, bb, tol2, alpha, beta, true_rr;
 	double sums[4];
+	double tscale;  // mixed precision: the scale the fp32 copy of the current residual was divided by
 	int    iter, done, max_iter, restarts;
 	int    tag, pad_;  // second slot only (single-rank fused CG): the iteration whose first half filled it
 };

@@ -1474,6 +1474,16 @@ __global__ __launch_bounds__(kThreads) void k_seed(int64_t n, int64_t first, T* 
 	}
 }
 
+// mixed precision: r32 = r / s and z = s * z32 with s = ||r|| / ||b|| from the device-resident scalars (the V-cycle
+// is linear, the scaling only keeps its fp32 operands near the size of b while r shrinks by ten decades).  The scale in
+// use is CgScalars::tscale: the residual norm of the PREVIOUS step inside the loop (k_mg_step_mixed writes r32 before
+// the new norm exists), of the current one after a restart.
+__device__ inline double mixed_scale(const CgScalars* sc)
+{
+	return (sc->rr > 0.0 && sc->bb > 0.0) ? sqrt(sc->rr / sc->bb) : 1.0;
+}
+__device__ inline double twin_scale(const CgScalars* sc) { return sc->tscale > 0.0 ? sc->tscale : 1.0; }
+
 // CG with a preconditioner: r -= alpha q, x += alpha p (p is still the direction of this step), partial r.r
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, const CgScalars* __restrict__ sc, const T* __restrict__ p,
@@ -1522,6 +1532,56 @@ __global__ __launch_bounds__(kThreads) void k_mg_direction(int64_t n, const CgSc
 	}
 }
 
+// Mixed precision (CG in fp64, V-cycle on the fp32 replica): the fp32 copy of the residual leaves k_mg_step with the
+// update itself, and the fp64 copy of z = V(r) is never formed -- r.z and the new direction read the fp32 result.
+// Per step 3 fp64 lattice passes less than k_mg_step + k_to_twin + k_from_twin + k_dot + k_mg_direction.
+__global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgScalars* __restrict__ sc,
+                                                             const double* __restrict__ p, const double* __restrict__ q,
+                                                             double* __restrict__ x, double* __restrict__ r,
+                                                             float* __restrict__ r32, double* __restrict__ partial)
+{
+	if (sc->done) { return; }
+	const double alpha = sc->alpha;
+	const double inv = 1.0 / mixed_scale(sc);  // sc->rr is still the previous norm: k_mg_logic(kMgResid) records this scale
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += alpha * p[i];
+		const double ri = r[i] - alpha * q[i];
+		r[i]   = ri;
+		r32[i] = static_cast<float>(ri * inv);
+		acc[0] += ri * ri;
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+// partial of r . (s z32)
+__global__ __launch_bounds__(kThreads) void k_dot_mixed(int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ r,
+                                                         const float* __restrict__ z32, double* __restrict__ partial)
+{
+	const double s = twin_scale(sc);
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		acc[0] += r[i] * (s * static_cast<double>(z32[i]));
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+// p = s z32 + beta p
+__global__ __launch_bounds__(kThreads) void k_mg_direction_mixed(int64_t n, const CgScalars* __restrict__ sc,
+                                                                  const float* __restrict__ z32, double* __restrict__ p, int first)
+{
+	const double beta = first ? 0.0 : sc->beta;
+	const double s = twin_scale(sc);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		p[i] = s * static_cast<double>(z32[i]) + beta * p[i];
+	}
+}
+
 // scalar steps of the preconditioned recurrence (single block, thread 0)
 enum MgPhase { kMgInitRz = 10, kMgAlpha = 11, kMgResid = 12, kMgBeta = 13, kMgInitRr = 14 };
 __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const double* __restrict__ partial, int count,
@@ -1539,6 +1599,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 		sc->rr = s;
 		sc->true_rr = s;
 		if (sc->bb == 0.0) { sc->bb = sc->sums[2]; sc->tol2 *= sc->bb; }
+		sc->tscale = mixed_scale(sc);
 		sc->done = 0;
 		if (sc->bb == 0.0) {
 			sc->done = 4;
@@ -1555,6 +1616,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 		if (!(s > 0.0) || !isfinite(s)) { sc->done = 2; }
 		break;
 	case kMgResid:
+		sc->tscale = mixed_scale(sc);  // of the norm k_mg_step_mixed scaled its fp32 residual by
 		sc->rr = s;
 		sc->iter += 1;
 		if (!isfinite(s)) {
@@ -1852,56 +1914,40 @@ void mg_prepare(RankSet& R, bool clear_finest)
 	}
 }
 
-// mixed precision: r32 = r / s and z = s * z32 with s = ||r|| / ||b|| from the device-resident scalars (the V-cycle
-// is linear, the scaling only keeps its fp32 operands near the size of b while r shrinks by ten decades)
-__device__ inline double mixed_scale(const CgScalars* sc)
-{
-	return (sc->rr > 0.0 && sc->bb > 0.0) ? sqrt(sc->rr / sc->bb) : 1.0;
-}
 __global__ __launch_bounds__(kThreads) void k_to_twin(int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ r,
                                                        float* __restrict__ r32)
 {
-	const double inv = 1.0 / mixed_scale(sc);
+	const double inv = 1.0 / twin_scale(sc);
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
 		r32[i] = static_cast<float>(r[i] * inv);
 	}
 }
-__global__ __launch_bounds__(kThreads) void k_from_twin(int64_t n, const CgScalars* __restrict__ sc, const float* __restrict__ z32,
-                                                         double* __restrict__ z)
-{
-	const double s = mixed_scale(sc);
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
-	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		z[i] = s * static_cast<double>(z32[i]);
-	}
-}
 
+// z = V(r).  Mixed precision (Tw: the fp32 replicas): the V-cycle reads the replica's r and leaves z in the replica's
+// mg_x, scaled by CgScalars::tscale -- `have_r32`: k_mg_step_mixed has already written the fp32 residual; the fp64 copy
+// of z is not formed (k_dot_mixed / k_mg_direction_mixed read the fp32 one).
 template <typename T>
-void precondition(RankSet& R, RankSet& Tw, Vec r, Vec z)
+void precondition(RankSet& R, RankSet& Tw, Vec r, Vec z, bool have_r32)
 {
 	vcycle<T>(R, r, z);
 }
 template <>
-void precondition<double>(RankSet& R, RankSet& Tw, Vec r, Vec z)
+void precondition<double>(RankSet& R, RankSet& Tw, Vec r, Vec z, bool have_r32)
 {
 	if (Tw.empty()) {
 		vcycle<double>(R, r, z);
 		return;
 	}
-	for (size_t i = 0; i < R.size(); ++i) {
-		fi_ctx* c = R[i];
-		fi_ctx* t = Tw[i];
-		hipLaunchKernelGGL(k_to_twin, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
-		                   c->scal.as<CgScalars>(), vown<double>(c, r), vown<float>(t, &fi_ctx::r));
+	if (!have_r32) {
+		for (size_t i = 0; i < R.size(); ++i) {
+			fi_ctx* c = R[i];
+			fi_ctx* t = Tw[i];
+			hipLaunchKernelGGL(k_to_twin, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   c->scal.as<CgScalars>(), vown<double>(c, r), vown<float>(t, &fi_ctx::r));
+		}
 	}
 	vcycle<float>(Tw, &fi_ctx::r, &fi_ctx::mg_x);
-	for (size_t i = 0; i < R.size(); ++i) {
-		fi_ctx* c = R[i];
-		fi_ctx* t = Tw[i];
-		hipLaunchKernelGGL(k_from_twin, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
-		                   c->scal.as<CgScalars>(), vown<float>(t, &fi_ctx::mg_x), vown<double>(c, z));
-	}
 }
 
 // coarse-to-fine start on the fp32 replicas of FI_F64 contexts (mixed precision), widened into x
@@ -1941,7 +1987,6 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	RankSet Tw;
 	if (sizeof(T) == 8 && c0->twin && c0->twin->coarse) {
 		for (fi_ctx* c : R) { Tw.push_back(c->twin); }
-		for (fi_ctx* c : R) { mg_alloc<T>(c); }
 		mg_prepare<float>(Tw, true);
 	} else {
 		mg_prepare<T>(R, false);
@@ -1969,13 +2014,37 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		c0->ev.push_back(e);
 	}
 	int samples = 0;
+	const bool mixed = !Tw.empty();
 	auto dot = [&](Vec a, Vec b) {
 		for (fi_ctx* c : R) {
 			hipLaunchKernelGGL((k_dot<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, a), vown<T>(c, b),
 			                   c->partial.as<double>());
 		}
 	};
+	auto dot_rz = [&]() {  // partials of r . z
+		if constexpr (std::is_same<T, double>::value) {
+			if (mixed) {
+				for (size_t i = 0; i < R.size(); ++i) {
+					fi_ctx* c = R[i];
+					hipLaunchKernelGGL(k_dot_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+					                   vown<double>(c, Rv), vown<float>(Tw[i], &fi_ctx::mg_x), c->partial.as<double>());
+				}
+				return;
+			}
+		}
+		dot(Rv, Z);
+	};
 	auto direction = [&](int first) {
+		if constexpr (std::is_same<T, double>::value) {
+			if (mixed) {
+				for (size_t i = 0; i < R.size(); ++i) {
+					fi_ctx* c = R[i];
+					hipLaunchKernelGGL(k_mg_direction_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+					                   c->scal.as<CgScalars>(), vown<float>(Tw[i], &fi_ctx::mg_x), vown<double>(c, P), first);
+				}
+				return;
+			}
+		}
 		for (fi_ctx* c : R) {
 			hipLaunchKernelGGL((k_mg_direction<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
 			                   c->scal.as<CgScalars>(), vown<T>(c, Z), vown<T>(c, P), first);
@@ -1993,8 +2062,8 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
 		dot(Rv, Rv);
 		mg_reduce(R, nbv, kMgInitRr);
-		precondition<T>(R, Tw, Rv, Z);
-		dot(Rv, Z);
+		precondition<T>(R, Tw, Rv, Z, false);
+		dot_rz();
 		mg_reduce(R, nbv, kMgInitRz);
 		direction(1);
 	};
@@ -2029,13 +2098,27 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			++samples;
 		}
 		mg_reduce(R, nb_apply, kMgAlpha);
-		for (fi_ctx* c : R) {
-			hipLaunchKernelGGL((k_mg_step<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
-			                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>());
+		bool stepped = false;
+		if constexpr (std::is_same<T, double>::value) {
+			if (mixed) {
+				for (size_t i = 0; i < R.size(); ++i) {
+					fi_ctx* c = R[i];
+					hipLaunchKernelGGL(k_mg_step_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+					                   vown<double>(c, P), vown<double>(c, Q), vown<double>(c, X), vown<double>(c, Rv),
+					                   vown<float>(Tw[i], &fi_ctx::r), c->partial.as<double>());
+				}
+				stepped = true;
+			}
+		}
+		if (!stepped) {
+			for (fi_ctx* c : R) {
+				hipLaunchKernelGGL((k_mg_step<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+				                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>());
+			}
 		}
 		mg_reduce(R, nbv, kMgResid);
-		precondition<T>(R, Tw, Rv, Z);  // wasted when this step just converged; one V-cycle at most
-		dot(Rv, Z);
+		precondition<T>(R, Tw, Rv, Z, stepped);  // wasted when this step just converged; one V-cycle at most
+		dot_rz();
 		mg_reduce(R, nbv, kMgBeta);
 		direction(0);
 		FI_HIP_TRY(hipGetLastError());
