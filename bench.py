@@ -343,7 +343,7 @@ def main():
     # launches per outer iteration against one full apply), else the apply
     if acc["prec_n"] > 0 and wl["poly"] > 2:
         roof_main = roof("k_apply_march3d<EPI>: Chebyshev step of the polynomial preconditioner = model-operator apply + "
-                         "three-term recurrence in the epilogue, 5 lattice passes (finest level)",
+                         "three-term recurrence in the epilogue: z, z_prev, r in, z_new out + a bfloat16 scaling (finest level)",
                          st["prec_bytes"], prec_avg_ms, acc["prec_n"], tr("cheb"))
     else:
         roof_main = roof_apply

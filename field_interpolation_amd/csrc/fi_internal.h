@@ -255,6 +255,7 @@ struct fi_ctx {
 
 	// operator pieces (T arrays over local storage)
 	fi::DevBuf atb, diag, dinv;
+	fi::DevBuf dinv16;  // dinv truncated to bfloat16 (k_invert_diag): the scaling of the epilogue recurrences
 	// solver vectors
 	fi::DevBuf x, r, p, q;
 	// multigrid work vectors of this level: V-cycle rhs / result, smoother residual and direction
@@ -316,13 +317,13 @@ bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also a
 // (fi_stencil.hip, ChebEpi); z / v with valid ghost planes; partials: one per workgroup of the launch
 bool stencil_cheb_available(const fi_ctx* c);
 int  stencil_cheb_partials(const fi_ctx* c);
-void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double c1,
-                       double c2, double* partial, int part = 0);
+void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
+                       double* partial, int part = 0);
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
-// z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (dinv == nullptr: z_new = r - A z) in one pass of the
-// marching kernel(s) over the lattice; z with valid ghost planes
+// z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the
+// marching kernel(s) over the lattice; z with valid ghost planes.  Dinv is the context's bfloat16 copy (dinv16).
 bool stencil_full_epi_available(const fi_ctx* c);
-void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double a,
+void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a,
                        double c1, double c2);
 
 // fi_stencil2d.hip: LDS-tiled kernel for 2-D lattices (model_0/1/2), called through the stencil_* entry points

@@ -254,13 +254,19 @@ __global__ __launch_bounds__(kThreads) void k_model_diag(Geom g, ModelCoef<T> mc
 }
 
 // Eigen::DiagonalPreconditioner semantics: 1/diag, or 1 where diag == 0.
+// d16: the same scaling cut to bfloat16 (truncated: never above 1/diag), read by the recurrences that run in the
+// marching kernel's epilogue -- any fixed positive diagonal is a valid scaling there, and this one is half (a quarter in
+// fp64) of a lattice pass per step.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_invert_diag(int64_t n, const T* __restrict__ diag, T* __restrict__ dinv)
+__global__ __launch_bounds__(kThreads) void k_invert_diag(int64_t n, const T* __restrict__ diag, T* __restrict__ dinv,
+                                                           unsigned short* __restrict__ d16)
 {
 	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	if (i < n) {
 		const T d = diag[i];
-		dinv[i]   = (d != T(0)) ? T(1) / d : T(1);
+		const T v = (d != T(0)) ? T(1) / d : T(1);
+		dinv[i]   = v;
+		d16[i]    = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
 	}
 }
 
@@ -308,8 +314,9 @@ void prepare_dim(fi_ctx* c)
 	hipLaunchKernelGGL((k_model_diag<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g, mc,
 	                   c->diag.as<T>());
 	c->dinv.alloc(sizeof(T) * g.nloc);
+	c->dinv16.alloc(sizeof(unsigned short) * g.nloc);
 	hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc,
-	                   c->diag.as<T>(), c->dinv.as<T>());
+	                   c->diag.as<T>(), c->dinv.as<T>(), c->dinv16.as<unsigned short>());
 	FI_HIP_TRY(hipGetLastError());
 }
 

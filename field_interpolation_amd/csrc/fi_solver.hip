@@ -1433,6 +1433,17 @@ __global__ __launch_bounds__(kThreads) void k_cheb_first(int64_t n, const T* __r
 	}
 }
 
+// the same with the bfloat16 scaling of the fused smoother (one polynomial: every step scales by the same diagonal)
+__global__ __launch_bounds__(kThreads) void k_cheb_first16(int64_t n, const float* __restrict__ b,
+                                                            const unsigned short* __restrict__ dinv16, float* __restrict__ d,
+                                                            float alpha)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		d[i] = alpha * __uint_as_float(static_cast<unsigned int>(dinv16[i]) << 16) * b[i];
+	}
+}
+
 // r = b - q
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_sub(int64_t n, const T* __restrict__ b, const T* __restrict__ q,
@@ -1752,7 +1763,7 @@ void cheb_smooth_fused(RankSet& R, Vec b, Vec x, int degree, double ratio, bool 
 		const int next = prev < 0 ? (cur + 1) % 3 : 3 - cur - prev;
 		halo_exchange(R, ring[cur]);
 		for (fi_ctx* c : R) {
-			stencil_full_step(c, (c->*ring[cur]).p, prev < 0 ? nullptr : (c->*ring[prev]).p, (c->*b).p, c->dinv.p,
+			stencil_full_step(c, (c->*ring[cur]).p, prev < 0 ? nullptr : (c->*ring[prev]).p, (c->*b).p, false,
 			                  (c->*ring[next]).p, a, c1, c2);
 		}
 		prev = cur;
@@ -1761,8 +1772,9 @@ void cheb_smooth_fused(RankSet& R, Vec b, Vec x, int degree, double ratio, bool 
 	bool have_prev = false;  // x_{k-1} is a vector (not the zero start)
 	if (from_zero) {
 		for (fi_ctx* c : R) {  // x_1 = Dinv b / theta
-			hipLaunchKernelGGL((k_cheb_first<float>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
-			                   vown<float>(c, b), vown<float>(c, &fi_ctx::dinv), vown<float>(c, x), static_cast<float>(1.0 / theta));
+			hipLaunchKernelGGL(k_cheb_first16, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   vown<float>(c, b), c->dinv16.as<unsigned short>() + c->g.own_first, vown<float>(c, x),
+			                   static_cast<float>(1.0 / theta));
 		}
 	} else {
 		step(1.0, 0.0, 1.0 / theta);  // x_1 = x_0 + Dinv (b - A x_0) / theta
@@ -1843,7 +1855,7 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	cheb_smooth<T>(R, b, x, deg, ratio, true);
 	if (std::is_same<T, float>::value && smooth_fused_ok(R)) {  // mg_r = b - A x in one launch
 		halo_exchange(R, x);
-		for (fi_ctx* c : R) { stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, nullptr, c->mg_r.p, 0.0, 0.0, 0.0); }
+		for (fi_ctx* c : R) { stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, true, c->mg_r.p, 0.0, 0.0, 0.0); }
 	} else {
 		apply_all(R, x, &fi_ctx::q, false);
 		for (fi_ctx* c : R) {
@@ -2200,7 +2212,7 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScalars* __restrict__ in, CgScalars* __restrict__ mid,
                                                          int tag, int phase, const double* __restrict__ pq_partial, int pq_count,
                                                          const T* __restrict__ b, const T* __restrict__ q,
-                                                         const T* __restrict__ dinv, T* __restrict__ r, T* __restrict__ z1,
+                                                         const unsigned short* __restrict__ dinv, T* __restrict__ r, T* __restrict__ z1,
                                                          T inv_theta, double* __restrict__ prr, double* __restrict__ prz,
                                                          double* __restrict__ pbb)
 {
@@ -2234,14 +2246,18 @@ __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScala
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < nv;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
 		T rv[N], qv[N], dv[N], zv[N], bv[N];
+		typedef unsigned short D16 __attribute__((ext_vector_type(N)));  // the bfloat16 scaling the polynomial's steps use
+		D16 d16;
 		if (VEC) {
 			pld16(qv, q, i);
-			*reinterpret_cast<V*>(dv) = reinterpret_cast<const V*>(dinv)[i];
+			d16 = reinterpret_cast<const D16*>(dinv)[i];
 			if (phase == 1) { *reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i]; } else { pld16(bv, b, i); }
 		} else {
-			qv[0] = q[i]; dv[0] = dinv[i];
+			qv[0] = q[i]; d16[0] = dinv[i];
 			if (phase == 1) { rv[0] = r[i]; } else { bv[0] = b[i]; }
 		}
+#pragma unroll
+		for (int j = 0; j < N; ++j) { dv[j] = static_cast<T>(__uint_as_float(static_cast<unsigned int>(d16[j]) << 16)); }
 		T s0 = T(0), s1 = T(0), s2 = T(0);
 #pragma unroll
 		for (int j = 0; j < N; ++j) {
@@ -2519,7 +2535,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			const int     npq = single ? apply_num_partials(c) : 1;
 			auto go = [&](auto kernel) {
 				hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc, sc + 1, tag, phase, pq, npq,
-				                   c->atb.as<T>() + o, c->q.as<T>() + o, c->dinv.as<T>() + o, c->r.as<T>() + o, vown<T>(c, ZA),
+				                   c->atb.as<T>() + o, c->q.as<T>() + o, c->dinv16.as<unsigned short>() + o, c->r.as<T>() + o, vown<T>(c, ZA),
 				                   static_cast<T>(1.0 / theta), region(c, 1), region(c, 2), region(c, 3));
 			};
 			if (vec_ok(c)) { go(k_pcg_resid<T, true>); } else { go(k_pcg_resid<T, false>); }
@@ -2540,11 +2556,11 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			for (fi_ctx* c : R) {
 				const void* zp = k == 1 ? nullptr : (c->*zout).p;
 				if (overlap) {  // the workgroups that read no ghost plane, then the first and last z-chunk
-					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 1);
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 1);
 					exchange_wait(c);
-					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 2);
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 2);
 				} else {
-					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, c->dinv.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2));
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2));
 				}
 			}
 			if (sample) {
@@ -2684,7 +2700,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
 		c->stats.prec_samples = pused;
 		c->stats.prec_ms_avg  = pused ? psum / pused : 0.0;
-		c->stats.prec_bytes   = static_cast<double>(sizeof(T)) * (terms > 2 ? 5.0 : 4.0) * static_cast<double>(c->g.nown);
+		// a sampled step reads z, z_prev (none on the first step), r and the bfloat16 scaling, and writes z_new
+		c->stats.prec_bytes   = (static_cast<double>(sizeof(T)) * (terms > 2 ? 4.0 : 3.0) + 2.0) * static_cast<double>(c->g.nown);
 		c->stats.operator_applies = (h.iter + 1) * terms + h.restarts;
 		c->last_outer_iterations = h.iter;
 		c->stats.solve_ms     = ms;

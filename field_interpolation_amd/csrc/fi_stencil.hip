@@ -135,7 +135,7 @@ template <typename T>
 struct ChebEpi {
 	const T* zprev;
 	const T* r;
-	const T* dinv;
+	const unsigned short* dinv;  // bfloat16 (fi_ctx::dinv16)
 	T*       znew;
 	T        a, c1, c2;
 	int      mode;
@@ -539,8 +539,13 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 			mxy[j] = m;
 		}
 	}
+	typedef unsigned short DV16 __attribute__((ext_vector_type(VX)));  // VX bfloat16 values: 8 / 4 bytes
 	struct EpiRegs {
-		V zp, rv, dv;
+		V    zp, rv;
+		DV16 dv;
+	};
+	auto dinv_of = [](const DV16& d, int j) -> T {
+		return static_cast<T>(__uint_as_float(static_cast<unsigned int>(d[j]) << 16));
 	};
 	// operands of plane lz (clamped like every load that crosses a step): issued right behind the epilogue that
 	// consumed the previous set, used one step later
@@ -548,14 +553,16 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		const int64_t o = static_cast<int64_t>(clamp_plane(lz)) * P.plane + xoff;
 		e.zp = *reinterpret_cast<const V*>(E.zprev + o);  // never null: the host passes z itself with c1 = 0 on the first step
 		e.rv = *reinterpret_cast<const V*>(E.r + o);
-		e.dv = *reinterpret_cast<const V*>(E.dinv + o);
+		e.dv = *reinterpret_cast<const DV16*>(E.dinv + o);
 	};
 
 	// modes 2 / 3 for one completed plane: zc = the plane's z values, q = A z (full operator)
 	auto epi_full = [&](const EpiRegs& e, const T* zc, const T* q, T* pz) -> T {
 		const T* zp = reinterpret_cast<const T*>(&e.zp);
 		const T* rv = reinterpret_cast<const T*>(&e.rv);
-		const T* dv = reinterpret_cast<const T*>(&e.dv);
+		T dv[VX];
+#pragma unroll
+		for (int j = 0; j < VX; ++j) { dv[j] = dinv_of(e.dv, j); }
 		T rz = T(0);
 		if (E.mode == 3) {
 #pragma unroll
@@ -865,7 +872,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 			if (HAS1) { mz += C.w1sq * (((gzc - 1 >= 0) ? T(1) : T(0)) + ((gzc + 1 < P.gz) ? T(1) : T(0))); }
 			const T* zp = reinterpret_cast<const T*>(&EP.zp);
 			const T* rv = reinterpret_cast<const T*>(&EP.rv);
-			const T* dv = reinterpret_cast<const T*>(&EP.dv);
+			T dv[VX];
+#pragma unroll
+			for (int j = 0; j < VX; ++j) { dv[j] = dinv_of(EP.dv, j); }
 			V zn;
 			T* pz = reinterpret_cast<T*>(&zn);
 			T  rz = T(0);
@@ -1579,31 +1588,31 @@ namespace fi {
 // Chebyshev step through the marching kernel (see ChebEpi); false when the kernel does not apply to this context.
 bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid; }
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.Pplain.nwg; }
-void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double c1,
-                       double c2, double* partial, int part)
+void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
+                       double* partial, int part)
 {
 	// zprev == nullptr: the step from z_prev = 0
+	const unsigned short* d16 = c->dinv16.as<unsigned short>();
 	if (c->dtype == FI_F64) {
-		ChebEpi<double> E{static_cast<const double*>(zprev ? zprev : z), static_cast<const double*>(r),
-		                  static_cast<const double*>(dinv), static_cast<double*>(znew), 1.0 + c1, zprev ? c1 : 0.0, c2, 0};
+		ChebEpi<double> E{static_cast<const double*>(zprev ? zprev : z), static_cast<const double*>(r), d16,
+		                  static_cast<double*>(znew), 1.0 + c1, zprev ? c1 : 0.0, c2, 0};
 		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part);
 	} else {
-		ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r),
-		                 static_cast<const float*>(dinv), static_cast<float*>(znew), static_cast<float>(1.0 + c1),
-		                 static_cast<float>(zprev ? c1 : 0.0), static_cast<float>(c2), 0};
+		ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r), d16,
+		                 static_cast<float*>(znew), static_cast<float>(1.0 + c1), static_cast<float>(zprev ? c1 : 0.0),
+		                 static_cast<float>(c2), 0};
 		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part);
 	}
 }
 // v_new = (A_model v) / diag(A_model), partials of v_new . v_new (power method on the model operator)
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 {
+	const unsigned short* d16 = c->dinv16.as<unsigned short>();  // loaded, not used
 	if (c->dtype == FI_F64) {
-		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), static_cast<const double*>(v),
-		                  static_cast<double*>(vnew), 0, 0, 0, 1};
+		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), d16, static_cast<double*>(vnew), 0, 0, 0, 1};
 		march_launch_epi<double>(c, static_cast<const double*>(v), E, partial);
 	} else {
-		ChebEpi<float> E{static_cast<const float*>(v), static_cast<const float*>(v), static_cast<const float*>(v),
-		                 static_cast<float*>(vnew), 0, 0, 0, 1};
+		ChebEpi<float> E{static_cast<const float*>(v), static_cast<const float*>(v), d16, static_cast<float*>(vnew), 0, 0, 0, 1};
 		march_launch_epi<float>(c, static_cast<const float*>(v), E, partial);
 	}
 }
@@ -1614,15 +1623,15 @@ bool stencil_full_epi_available(const fi_ctx* c)
 {
 	return c->march.valid && !c->tile2.valid && c->dtype == FI_F32 && (c->cells.ncell == 0 || c->march.fused);
 }
-void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, const void* dinv, void* znew, double a,
+void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a,
                        double c1, double c2)
 {
 	FI_REQUIRE(stencil_full_epi_available(c), FI_ERR_UNSUPPORTED, "no fused recurrence step for this context");
 	const float* zf = static_cast<const float*>(z);
-	// a null operand is never used with its coefficient: any readable vector stands in
-	ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r),
-	                 static_cast<const float*>(dinv ? dinv : r), static_cast<float*>(znew), static_cast<float>(a),
-	                 static_cast<float>(zprev ? c1 : 0.0), static_cast<float>(c2), dinv ? 2 : 3};
+	// a null z_prev is never used with its coefficient: z stands in
+	ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r), c->dinv16.as<unsigned short>(),
+	                 static_cast<float*>(znew), static_cast<float>(a), static_cast<float>(zprev ? c1 : 0.0),
+	                 static_cast<float>(c2), residual ? 3 : 2};
 	march_launch<float>(c, zf, nullptr, nullptr, &E);
 }
 
