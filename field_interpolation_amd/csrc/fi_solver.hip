@@ -2555,12 +2555,14 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			}
 			for (fi_ctx* c : R) {
 				const void* zp = k == 1 ? nullptr : (c->*zout).p;
+				// the second step's z_prev is z_0 = Dinv r / theta: recomputed from r and Dinv, which the step reads anyway
+				const double zs = k == 2 ? 1.0 / theta : 0.0;
 				if (overlap) {  // the workgroups that read no ghost plane, then the first and last z-chunk
-					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 1);
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 1, zs);
 					exchange_wait(c);
-					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 2);
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 2, zs);
 				} else {
-					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2));
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 0, zs);
 				}
 			}
 			if (sample) {

@@ -139,6 +139,8 @@ struct ChebEpi {
 	T*       znew;
 	T        a, c1, c2;
 	int      mode;
+	T        zp_scale;  // mode 0, non-zero: z_prev = zp_scale * Dinv * (the vector passed as zprev) -- the polynomial's second
+	                    // step passes r here: its z_prev is z_0 = Dinv r / theta, which then needs no lattice pass of its own
 };
 
 struct CellLists {
@@ -890,7 +892,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 #pragma unroll
 				for (int j = 0; j < VX; ++j) {
 					const T sv = dv[j] * (po[j] - (mxy[j] + mz) * pc[j]) + pc[j];
-					pz[j] = E.a * pc[j] - E.c1 * zp[j] + E.c2 * (dv[j] * rv[j] - sv);
+					const T zq = E.zp_scale != T(0) ? E.zp_scale * dv[j] * zp[j] : zp[j];
+					pz[j] = E.a * pc[j] - E.c1 * zq + E.c2 * (dv[j] * rv[j] - sv);
 					rz += rv[j] * pz[j];
 				}
 			}
@@ -1589,18 +1592,21 @@ namespace fi {
 bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid; }
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.Pplain.nwg; }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part)
+                       double* partial, int part, double zprev_scale)
 {
-	// zprev == nullptr: the step from z_prev = 0
+	// zprev == nullptr: the step from z_prev = 0 (z itself stands in under a zero coefficient);
+	// zprev_scale != 0: z_prev = zprev_scale * Dinv r, read through r's own cache lines
 	const unsigned short* d16 = c->dinv16.as<unsigned short>();
+	const void* zp = zprev_scale != 0.0 ? r : (zprev ? zprev : z);
+	const bool  has_prev = zprev_scale != 0.0 || zprev;
 	if (c->dtype == FI_F64) {
-		ChebEpi<double> E{static_cast<const double*>(zprev ? zprev : z), static_cast<const double*>(r), d16,
-		                  static_cast<double*>(znew), 1.0 + c1, zprev ? c1 : 0.0, c2, 0};
+		ChebEpi<double> E{static_cast<const double*>(zp), static_cast<const double*>(r), d16, static_cast<double*>(znew), 1.0 + c1,
+		                  has_prev ? c1 : 0.0, c2, 0, zprev_scale};
 		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part);
 	} else {
-		ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r), d16,
-		                 static_cast<float*>(znew), static_cast<float>(1.0 + c1), static_cast<float>(zprev ? c1 : 0.0),
-		                 static_cast<float>(c2), 0};
+		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
+		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
+		                 static_cast<float>(zprev_scale)};
 		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part);
 	}
 }
@@ -1609,10 +1615,10 @@ void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 {
 	const unsigned short* d16 = c->dinv16.as<unsigned short>();  // loaded, not used
 	if (c->dtype == FI_F64) {
-		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), d16, static_cast<double*>(vnew), 0, 0, 0, 1};
+		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), d16, static_cast<double*>(vnew), 0, 0, 0, 1, 0};
 		march_launch_epi<double>(c, static_cast<const double*>(v), E, partial);
 	} else {
-		ChebEpi<float> E{static_cast<const float*>(v), static_cast<const float*>(v), d16, static_cast<float*>(vnew), 0, 0, 0, 1};
+		ChebEpi<float> E{static_cast<const float*>(v), static_cast<const float*>(v), d16, static_cast<float*>(vnew), 0, 0, 0, 1, 0};
 		march_launch_epi<float>(c, static_cast<const float*>(v), E, partial);
 	}
 }
@@ -1631,7 +1637,7 @@ void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	// a null z_prev is never used with its coefficient: z stands in
 	ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r), c->dinv16.as<unsigned short>(),
 	                 static_cast<float*>(znew), static_cast<float>(a), static_cast<float>(zprev ? c1 : 0.0),
-	                 static_cast<float>(c2), residual ? 3 : 2};
+	                 static_cast<float>(c2), residual ? 3 : 2, 0.0f};
 	march_launch<float>(c, zf, nullptr, nullptr, &E);
 }
 
