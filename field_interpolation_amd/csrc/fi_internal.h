@@ -318,7 +318,7 @@ bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also a
 bool stencil_cheb_available(const fi_ctx* c);
 int  stencil_cheb_partials(const fi_ctx* c);
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part = 0, double zprev_scale = 0.0);
+                       double* partial, int part = 0, double zprev_scale = 0.0, double pro_scale = 0.0);
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 // z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the
 // marching kernel(s) over the lattice; z with valid ghost planes.  Dinv is the context's bfloat16 copy (dinv16).

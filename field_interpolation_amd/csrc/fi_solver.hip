@@ -2247,13 +2247,15 @@ __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScala
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
 		T rv[N], qv[N], dv[N], zv[N], bv[N];
 		typedef unsigned short D16 __attribute__((ext_vector_type(N)));  // the bfloat16 scaling the polynomial's steps use
-		D16 d16;
+		D16 d16 = D16{};
+		const bool want_z = z1 != nullptr;  // null: the first step of the polynomial forms z1 itself while it loads r
 		if (VEC) {
 			pld16(qv, q, i);
-			d16 = reinterpret_cast<const D16*>(dinv)[i];
+			if (want_z) { d16 = reinterpret_cast<const D16*>(dinv)[i]; }
 			if (phase == 1) { *reinterpret_cast<V*>(rv) = reinterpret_cast<const V*>(r)[i]; } else { pld16(bv, b, i); }
 		} else {
-			qv[0] = q[i]; d16[0] = dinv[i];
+			qv[0] = q[i];
+			if (want_z) { d16[0] = dinv[i]; }
 			if (phase == 1) { rv[0] = r[i]; } else { bv[0] = b[i]; }
 		}
 #pragma unroll
@@ -2267,10 +2269,11 @@ __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScala
 			s1 += rv[j] * zv[j];
 		}
 		if (VEC) {
-			reinterpret_cast<V*>(r)[i]  = *reinterpret_cast<V*>(rv);
-			reinterpret_cast<V*>(z1)[i] = *reinterpret_cast<V*>(zv);
+			reinterpret_cast<V*>(r)[i] = *reinterpret_cast<V*>(rv);
+			if (want_z) { reinterpret_cast<V*>(z1)[i] = *reinterpret_cast<V*>(zv); }
 		} else {
-			r[i] = rv[0]; z1[i] = zv[0];
+			r[i] = rv[0];
+			if (want_z) { z1[i] = zv[0]; }
 		}
 		acc[0] += static_cast<double>(s0);
 		acc[1] += static_cast<double>(s1);
@@ -2495,6 +2498,10 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		return (c->g.own_first % N == 0) && (c->g.nown % N == 0);
 	};
 	const bool single = R.size() == 1 && c0->nranks == 1;
+	// undivided lattice, 3 terms or more: the first step of the polynomial reads r and the scaling and forms z_0 as it
+	// loads them (fi_stencil.hip, PRO) -- k_pcg_resid then stores no z_0, and step 2 recomputes it as its z_prev.  (Slabs
+	// keep z_0: the scaling's ghost planes are not the neighbour's values.)
+	const bool z0_on_load = single && terms > 2 && !test_switch("FI_NO_Z0_ON_LOAD");
 	// partial regions of every member: [0] apply p.q, [1] r.r, [2] r.z, [3] b.b
 	auto region = [](fi_ctx* c, int k) { return c->partial.as<double>() + static_cast<size_t>(k) * c->max_blocks; };
 	auto slot2 = [](fi_ctx* c) { return (c->scal.as<CgScalars>() + 2)->sums; };
@@ -2535,7 +2542,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			const int     npq = single ? apply_num_partials(c) : 1;
 			auto go = [&](auto kernel) {
 				hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc, sc + 1, tag, phase, pq, npq,
-				                   c->atb.as<T>() + o, c->q.as<T>() + o, c->dinv16.as<unsigned short>() + o, c->r.as<T>() + o, vown<T>(c, ZA),
+				                   c->atb.as<T>() + o, c->q.as<T>() + o, c->dinv16.as<unsigned short>() + o, c->r.as<T>() + o,
+				                   z0_on_load ? static_cast<T*>(nullptr) : vown<T>(c, ZA),
 				                   static_cast<T>(1.0 / theta), region(c, 1), region(c, 2), region(c, 3));
 			};
 			if (vec_ok(c)) { go(k_pcg_resid<T, true>); } else { go(k_pcg_resid<T, false>); }
@@ -2548,7 +2556,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			// every 4th pass times its last step (5 lattice passes when the polynomial has 3 terms or more)
 			const bool sample = phase == 1 && k == terms - 1 && psamples < kMaxSamples && (tag & 3) == 1;
 			const bool overlap = R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
-			if (overlap) { exchange_begin(c0, (c0->*zin).p); } else { halo_exchange(R, zin); }
+			const bool pro = z0_on_load && k == 1;  // single rank: no ghost planes to exchange
+			if (overlap) { exchange_begin(c0, (c0->*zin).p); } else if (!pro) { halo_exchange(R, zin); }
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(pev[2 * psamples], st));
 				ptags.push_back(tag);
@@ -2557,6 +2566,10 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 				const void* zp = k == 1 ? nullptr : (c->*zout).p;
 				// the second step's z_prev is z_0 = Dinv r / theta: recomputed from r and Dinv, which the step reads anyway
 				const double zs = k == 2 ? 1.0 / theta : 0.0;
+				if (pro) {
+					stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 0, 0.0, 1.0 / theta);
+					continue;
+				}
 				if (overlap) {  // the workgroups that read no ghost plane, then the first and last z-chunk
 					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 1, zs);
 					exchange_wait(c);

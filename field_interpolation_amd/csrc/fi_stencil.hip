@@ -139,6 +139,8 @@ struct ChebEpi {
 	T*       znew;
 	T        a, c1, c2;
 	int      mode;
+	T        pro_scale;  // PRO variant (the polynomial's FIRST step): the kernel's input vector is r and the operand of the
+	                     // stencil is formed on load, z_0 = pro_scale * Dinv * r -- z_0 is never stored (z_prev = 0 there)
 	T        zp_scale;  // mode 0, non-zero: z_prev = zp_scale * Dinv * (the vector passed as zprev) -- the polynomial's second
 	                    // step passes r here: its z_prev is z_0 = Dinv r / theta, which then needs no lattice pass of its own
 };
@@ -185,7 +187,7 @@ __host__ __device__ constexpr int fused_waves(bool has1, bool has2, bool pack)
 // coarse levels of a cascade); the other variant carries the factor-row loop only (and, in fp64, the packed block
 // of cells beyond 8 rows).  Two variants because the unrolled block product is code the row-dominated contexts
 // would only pay for: config 4's finest level ran 2-4 us per launch slower with it compiled in.
-template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT, bool PACK, bool EPI = false>
+template <typename T, bool HAS1, bool HAS2, bool CELLS, int TXT, bool PACK, bool EPI = false, bool PRO = false>
 __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, HAS2, PACK)) : (EPI && HAS1 && HAS2 && sizeof(T) == 4 ? FI_BASE_WAVES - 1 : FI_BASE_WAVES)) void k_apply_march3d(MarchParams P, MarchCoef<T> C, CellLists L,
                                                              const T* __restrict__ x, T* __restrict__ y,
                                                              double* __restrict__ partial,
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
                                                              ChebEpi<T> E = ChebEpi<T>{})
 {
 	static_assert(!(EPI && CELLS && sizeof(T) == 8), "the fused variant carries the epilogue in fp32 only");
+	static_assert(!PRO || (EPI && !CELLS), "the input formed on load belongs to the plain variant with the epilogue");
 	using V = typename VecOf<T>::V;
 	constexpr int kTXT = TXT;             // threads along x
 	constexpr int kTY  = kThreads / TXT;  // tile rows (= threads along y)
@@ -274,9 +277,15 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 
 	// ---- per-thread constants: halo slots and x/y boundary masks --------------------------------
 	typedef T NV __attribute__((ext_vector_type(VX)));
+	typedef unsigned short DV16 __attribute__((ext_vector_type(VX)));  // VX bfloat16 values: 8 / 4 bytes
+	auto dinv_of = [](const DV16& d, int j) -> T {
+		return static_cast<T>(__uint_as_float(static_cast<unsigned int>(d[j]) << 16));
+	};
 	struct HaloRegs {
 		NV vec;
 		T  sc;
+		DV16           dvec;  // PRO: the scaling of the same points
+		unsigned short dsc;
 	};
 	const bool hv_on = threadIdx.x < NVEC;
 	const bool hs_on = threadIdx.x >= NVEC && threadIdx.x < NVEC + NSC;
@@ -351,12 +360,34 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 #endif
 		h.vec = *reinterpret_cast<const NV*>(xp + hvg);
 		h.sc  = xp[hsg];
+		if (PRO) {
+			const unsigned short* dp = E.dinv + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
+			h.dvec = *reinterpret_cast<const DV16*>(dp + hvg);
+			h.dsc  = dp[hsg];
+		}
+	};
+	// PRO: the scaling of the thread's own points of plane lz, and the operand formed from a loaded pair
+	auto load_own_d = [&](int lz) -> DV16 {
+		return *reinterpret_cast<const DV16*>(E.dinv + static_cast<int64_t>(clamp_plane(lz)) * P.plane + xoff);
+	};
+	auto form_own = [&](V& v, const DV16& d) {
+		T* pv = reinterpret_cast<T*>(&v);
+#pragma unroll
+		for (int j = 0; j < VX; ++j) { pv[j] = E.pro_scale * dinv_of(d, j) * pv[j]; }
 	};
 	auto write_plane = [&](int buf, const V& own, const HaloRegs& h) {
 		T* base = &xs[buf][0][0];
 		*reinterpret_cast<V*>(&xs[buf][ly][lx]) = own;
-		if (hv_on) { *reinterpret_cast<NV*>(base + h_lds) = h.vec; }
-		if (hs_on) { base[h_lds] = h.sc; }
+		if (PRO) {
+			NV hv;
+#pragma unroll
+			for (int j = 0; j < VX; ++j) { hv[j] = E.pro_scale * dinv_of(h.dvec, j) * h.vec[j]; }
+			if (hv_on) { *reinterpret_cast<NV*>(base + h_lds) = hv; }
+			if (hs_on) { base[h_lds] = E.pro_scale * static_cast<T>(__uint_as_float(static_cast<unsigned int>(h.dsc) << 16)) * h.sc; }
+		} else {
+			if (hv_on) { *reinterpret_cast<NV*>(base + h_lds) = h.vec; }
+			if (hs_on) { base[h_lds] = h.sc; }
+		}
 	};
 
 	// ---- data cells of one layer: corner products into the 8 corner planes ------------------------------
@@ -541,13 +572,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 			mxy[j] = m;
 		}
 	}
-	typedef unsigned short DV16 __attribute__((ext_vector_type(VX)));  // VX bfloat16 values: 8 / 4 bytes
 	struct EpiRegs {
 		V    zp, rv;
 		DV16 dv;
-	};
-	auto dinv_of = [](const DV16& d, int j) -> T {
-		return static_cast<T>(__uint_as_float(static_cast<unsigned int>(d[j]) << 16));
 	};
 	// operands of plane lz (clamped like every load that crosses a step): issued right behind the epilogue that
 	// consumed the previous set, used one step later
@@ -596,6 +623,15 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	};
 	V X0 = load_own(z_begin), X1 = load_own(z_begin + 1), X2 = load_own(z_begin + 2);
 	V X3 = load_own(z_begin + 3), X4 = load_own(z_begin + 4), X5 = V{};
+	// PRO: the scaling of the same planes, slot for slot; a slot is turned into the operand (form_own) two steps before
+	// it becomes the centre plane -- when it is first needed, as x(z+2) of the z stencil -- slots 0 and 1 here
+	DV16 Q0{}, Q1{}, Q2{}, Q3{}, Q4{}, Q5{};
+	if (PRO) {
+		Q0 = load_own_d(z_begin); Q1 = load_own_d(z_begin + 1); Q2 = load_own_d(z_begin + 2);
+		Q3 = load_own_d(z_begin + 3); Q4 = load_own_d(z_begin + 4);
+		form_own(X0, Q0);
+		form_own(X1, Q1);
+	}
 	// ring of 2: plane s in H[s % 2]; step s stages plane s+1 and loads plane s+2.  The fused variant is short of
 	// registers: there H1 alone carries every plane from z_begin+1 on (the load follows the LDS store of the same step)
 	constexpr int HR = FI_HALO_RING, PR = CELLS ? FI_ROW_RING : 1;
@@ -618,7 +654,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	for (int j = 0; j < VX; ++j) { held[j] = T(0); U0[j] = T(0); D0[j] = T(0); }
 	const int nsteps = z_end - z_begin;
 	EpiRegs EP{};
-	if (EPI) { load_epi(z_begin, EP); }
+	if (EPI && !PRO) { load_epi(z_begin, EP); }
 	RowPF PFr[PR];  // record sets: step k consumes set (k + 1) % PR -- layer k + 1 -- and refills it with layer + PR
 #pragma unroll
 	for (int k = 0; k < PR; ++k) { PFr[k].ok = false; }
@@ -649,7 +685,11 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		load_row(r < r1 ? r : r0, &pf.pos, pf.a);  // r0 <= n_row, and the arrays hold n_row + 1 records
 	};
 	{
-		const V xa = load_own(z_begin - 2), xb = load_own(z_begin - 1);
+		V xa = load_own(z_begin - 2), xb = load_own(z_begin - 1);
+		if (PRO) {
+			form_own(xa, load_own_d(z_begin - 2));
+			form_own(xb, load_own_d(z_begin - 1));
+		}
 		const T* pa = reinterpret_cast<const T*>(&xa);
 		const T* pb = reinterpret_cast<const T*>(&xb);
 		const T* pc = reinterpret_cast<const T*>(&X0);
@@ -700,16 +740,19 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		dot_acc += static_cast<double>(part);
 	};
 
-	auto step = [&](int s, const V& xc, const V& xp1, const V& xp2, V& xload, HaloRegs& h,
+	auto step = [&](int s, const V& xc, const V& xp1, V& xp2, V& xload, HaloRegs& h,
 	                RowPF& pf,
-	                const T* uA, const T* uB, T* uC, const T* dA, T* dC) {
+	                const T* uA, const T* uB, T* uC, const T* dA, T* dC,
+	                const DV16& qc, const DV16& q2, DV16& qload) {
 		const int z = z_begin + s;
+		if (PRO) { form_own(xp2, q2); }
 		FI_STAMP(s, 0);
 		// stage plane z+1 into the LDS ring (needed by the cells of layer z) and refill its halo set HR planes ahead
 		write_plane((s + 1) % 3, xp1, h);
 		FI_STAMP(s, 1);
 		load_halo(z + 1 + HR, h);
 		if (!CELLS) { xload = load_own(z + 5); }
+		if (PRO) { qload = load_own_d(z + 5); }
 		__syncthreads();
 		FI_STAMP(s, 2);
 
@@ -876,11 +919,18 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 			const T* rv = reinterpret_cast<const T*>(&EP.rv);
 			T dv[VX];
 #pragma unroll
-			for (int j = 0; j < VX; ++j) { dv[j] = dinv_of(EP.dv, j); }
+			for (int j = 0; j < VX; ++j) { dv[j] = dinv_of(PRO ? qc : EP.dv, j); }
 			V zn;
 			T* pz = reinterpret_cast<T*>(&zn);
 			T  rz = T(0);
-			if (E.mode >= 2) {  // a workgroup without data cells: the model rows are the full operator here
+			if (PRO) {  // z_prev = 0 and Dinv r = z / pro_scale: z_new = a z + c2 (z / pro_scale - s); its r . z_new is not used
+				const T inv = T(1) / E.pro_scale;
+#pragma unroll
+				for (int j = 0; j < VX; ++j) {
+					const T sv = dv[j] * (po[j] - (mxy[j] + mz) * pc[j]) + pc[j];
+					pz[j] = E.a * pc[j] + E.c2 * (pc[j] * inv - sv);
+				}
+			} else if (E.mode >= 2) {  // a workgroup without data cells: the model rows are the full operator here
 				rz = epi_full(EP, pc, po, pz);
 			} else if (E.mode == 1) {
 #pragma unroll
@@ -901,9 +951,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 				*reinterpret_cast<V*>((E.znew + static_cast<int64_t>(z) * P.plane) + col) = zn;
 				dot_acc += static_cast<double>(rz);
 			} else if (tail) {
-				store_tail(E.znew + static_cast<int64_t>(z) * P.plane, E.mode == 1 ? pz : rv, pz);
+				store_tail(E.znew + static_cast<int64_t>(z) * P.plane, (PRO || E.mode == 1) ? pz : rv, pz);
 			}
-			load_epi(z + 1, EP);
+			if (!PRO) { load_epi(z + 1, EP); }
 		} else if (active) {
 #ifdef FI_TIMING_BUILD
 			if (!(P.dbg & 2))
@@ -916,17 +966,17 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	};
 
 	for (int s0 = 0; s0 < nsteps; s0 += 6) {
-		step(s0, X0, X1, X2, X5, Hr[1 % HR], PFr[1 % PR], U1, U2, U0, D1, D0);
+		step(s0, X0, X1, X2, X5, Hr[1 % HR], PFr[1 % PR], U1, U2, U0, D1, D0, Q0, Q2, Q5);
 		if (s0 + 1 >= nsteps) { break; }
-		step(s0 + 1, X1, X2, X3, X0, Hr[2 % HR], PFr[2 % PR], U2, U0, U1, D0, D1);
+		step(s0 + 1, X1, X2, X3, X0, Hr[2 % HR], PFr[2 % PR], U2, U0, U1, D0, D1, Q1, Q3, Q0);
 		if (s0 + 2 >= nsteps) { break; }
-		step(s0 + 2, X2, X3, X4, X1, Hr[3 % HR], PFr[3 % PR], U0, U1, U2, D1, D0);
+		step(s0 + 2, X2, X3, X4, X1, Hr[3 % HR], PFr[3 % PR], U0, U1, U2, D1, D0, Q2, Q4, Q1);
 		if (s0 + 3 >= nsteps) { break; }
-		step(s0 + 3, X3, X4, X5, X2, Hr[4 % HR], PFr[4 % PR], U1, U2, U0, D0, D1);
+		step(s0 + 3, X3, X4, X5, X2, Hr[4 % HR], PFr[4 % PR], U1, U2, U0, D0, D1, Q3, Q5, Q2);
 		if (s0 + 4 >= nsteps) { break; }
-		step(s0 + 4, X4, X5, X0, X3, Hr[5 % HR], PFr[5 % PR], U2, U0, U1, D1, D0);
+		step(s0 + 4, X4, X5, X0, X3, Hr[5 % HR], PFr[5 % PR], U2, U0, U1, D1, D0, Q4, Q0, Q3);
 		if (s0 + 5 >= nsteps) { break; }
-		step(s0 + 5, X5, X0, X1, X4, Hr[6 % HR], PFr[6 % PR], U0, U1, U2, D0, D1);
+		step(s0 + 5, X5, X0, X1, X4, Hr[6 % HR], PFr[6 % PR], U0, U1, U2, D0, D1, Q5, Q1, Q4);
 	}
 	if (CELLS) {  // the last plane of the chunk: x(z_end-1) sits in ring slot (nsteps-1) % 6
 		__syncthreads();
@@ -1296,7 +1346,7 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 // One Chebyshev step of the polynomial preconditioner: the plain variant with the epilogue, over the whole lattice
 // (its own chunking: MarchState::Pplain).  partial: r . z_new per workgroup.
 template <typename T>
-void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partial, int part = 0)
+void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partial, int part = 0, bool pro = false)
 {
 	const MarchParams& P = c->march.Pplain;
 	const MarchCoef<T> C = march_coef<T>(c->w);
@@ -1313,17 +1363,23 @@ void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partia
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, c->stream, P, C, L, z, static_cast<T*>(nullptr), partial, done,
 		                   list, nlist, static_cast<const uint32_t*>(nullptr), E);
 	};
-	auto pick = [&](auto txt) {
-		constexpr int TXT = decltype(txt)::value;
+	auto pick = [&](auto txt, auto pr) {
+		constexpr int  TXT = decltype(txt)::value;
+		constexpr bool PR  = decltype(pr)::value;
 		if (h1 && h2) {
-			launch(k_apply_march3d<T, true, true, false, TXT, false, true>);
+			launch(k_apply_march3d<T, true, true, false, TXT, false, true, PR>);
 		} else if (h2) {
-			launch(k_apply_march3d<T, false, true, false, TXT, false, true>);
+			launch(k_apply_march3d<T, false, true, false, TXT, false, true, PR>);
 		} else {
-			launch(k_apply_march3d<T, true, false, false, TXT, false, true>);
+			launch(k_apply_march3d<T, true, false, false, TXT, false, true, PR>);
 		}
 	};
-	if (P.txt == 32) { pick(std::integral_constant<int, 32>{}); } else { pick(std::integral_constant<int, 16>{}); }
+	using std::integral_constant;
+	if (pro) {
+		if (P.txt == 32) { pick(integral_constant<int, 32>{}, integral_constant<bool, true>{}); } else { pick(integral_constant<int, 16>{}, integral_constant<bool, true>{}); }
+	} else {
+		if (P.txt == 32) { pick(integral_constant<int, 32>{}, integral_constant<bool, false>{}); } else { pick(integral_constant<int, 16>{}, integral_constant<bool, false>{}); }
+	}
 	FI_HIP_TRY(hipGetLastError());
 }
 
@@ -1592,8 +1648,9 @@ namespace fi {
 bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid; }
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.Pplain.nwg; }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part, double zprev_scale)
+                       double* partial, int part, double zprev_scale, double pro_scale)
 {
+	// pro_scale != 0 (the first step, z_prev = 0): `z` is r and the kernel forms z_0 = pro_scale * Dinv * r on load
 	// zprev == nullptr: the step from z_prev = 0 (z itself stands in under a zero coefficient);
 	// zprev_scale != 0: z_prev = zprev_scale * Dinv r, read through r's own cache lines
 	const unsigned short* d16 = c->dinv16.as<unsigned short>();
@@ -1601,13 +1658,13 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	const bool  has_prev = zprev_scale != 0.0 || zprev;
 	if (c->dtype == FI_F64) {
 		ChebEpi<double> E{static_cast<const double*>(zp), static_cast<const double*>(r), d16, static_cast<double*>(znew), 1.0 + c1,
-		                  has_prev ? c1 : 0.0, c2, 0, zprev_scale};
-		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part);
+		                  has_prev ? c1 : 0.0, c2, 0, pro_scale, zprev_scale};
+		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part, pro_scale != 0.0);
 	} else {
 		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
 		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
-		                 static_cast<float>(zprev_scale)};
-		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part);
+		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale)};
+		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part, pro_scale != 0.0);
 	}
 }
 // v_new = (A_model v) / diag(A_model), partials of v_new . v_new (power method on the model operator)
@@ -1615,10 +1672,10 @@ void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 {
 	const unsigned short* d16 = c->dinv16.as<unsigned short>();  // loaded, not used
 	if (c->dtype == FI_F64) {
-		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), d16, static_cast<double*>(vnew), 0, 0, 0, 1, 0};
+		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), d16, static_cast<double*>(vnew), 0, 0, 0, 1, 0, 0};
 		march_launch_epi<double>(c, static_cast<const double*>(v), E, partial);
 	} else {
-		ChebEpi<float> E{static_cast<const float*>(v), static_cast<const float*>(v), d16, static_cast<float*>(vnew), 0, 0, 0, 1, 0};
+		ChebEpi<float> E{static_cast<const float*>(v), static_cast<const float*>(v), d16, static_cast<float*>(vnew), 0, 0, 0, 1, 0, 0};
 		march_launch_epi<float>(c, static_cast<const float*>(v), E, partial);
 	}
 }
@@ -1637,7 +1694,7 @@ void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	// a null z_prev is never used with its coefficient: z stands in
 	ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r), c->dinv16.as<unsigned short>(),
 	                 static_cast<float*>(znew), static_cast<float>(a), static_cast<float>(zprev ? c1 : 0.0),
-	                 static_cast<float>(c2), residual ? 3 : 2, 0.0f};
+	                 static_cast<float>(c2), residual ? 3 : 2, 0.0f, 0.0f};
 	march_launch<float>(c, zf, nullptr, nullptr, &E);
 }
 

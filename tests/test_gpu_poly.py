@@ -156,3 +156,35 @@ def test_timing_switches_do_nothing_in_the_shipped_library(fi, monkeypatch):
     monkeypatch.setenv("FI_DBG", "3")
     monkeypatch.setenv("FI_TXT", "16")
     np.testing.assert_array_equal(apply(), y0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-10)])
+@pytest.mark.parametrize("sizes,kw", [([40, 36, 44], dict(model_2=0.5)), ([33, 30, 21], dict(model_1=0.3, model_2=0.6)),
+                                      ([130, 9, 12], dict(model_2=0.0, model_1=0.8))])
+def test_first_step_forms_its_operand_on_load(fi, sizes, kw, dtype, tol, monkeypatch):
+    """Undivided lattices, 3 terms or more: the first step of the polynomial reads r and the bfloat16 scaling and forms
+    z_0 = Dinv r / theta while it loads them (template flag PRO of the marching kernel), k_pcg_resid stores no z_0 and
+    the second step recomputes it as its z_prev.  FI_NO_Z0_ON_LOAD keeps the stored z_0 (the form slabs use): the same
+    arithmetic, so the same iteration count and -- up to the order of two roundings -- the same iterates."""
+    rng = np.random.default_rng(sizes[0])
+    pos, nrm, pw, val = random_points(rng, sizes, 3000, margin=0.5)
+    w = fi.Weights(data_gradient=0.0, **kw)
+    out = []
+    for stored in (False, True):
+        if stored:
+            monkeypatch.setenv("FI_NO_Z0_ON_LOAD", "1")
+        else:
+            monkeypatch.delenv("FI_NO_Z0_ON_LOAD", raising=False)
+        for terms in (3, 4, 6):
+            f = fi.LatticeField(sizes, dtype=dtype)
+            f.add_field_constraints(w)
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, pw, values=val)
+            f.assemble()
+            f.set_polynomial(terms)
+            x, it, rel = f.solve_cg(None, 0, tol)
+            assert f.stats()["converged"] == 1 and f.true_residual() <= 1.5 * tol
+            out.append((it, f.solution_f64().copy()))
+    monkeypatch.delenv("FI_NO_Z0_ON_LOAD", raising=False)
+    for k in range(3):
+        assert abs(out[k][0] - out[3 + k][0]) <= 1, (out[k][0], out[3 + k][0])
+        assert rel_inf(out[k][1], out[3 + k][1]) <= (1e-3 if dtype == "f32" else 1e-8)

@@ -34,16 +34,17 @@ def test_marching_kernel_budget():
     rep = _variants(_report("fi_stencil.usage.txt"), "k_apply_march3d")
     # {fp32, fp64} x {model_1, model_2, both} x {plain, fused} x {128 x 8, 64 x 16 tiles}, the fused ones once more
     # for contexts that keep their multi-row cells as packed blocks, the plain ones once more with the Chebyshev
-    # epilogue of the polynomial preconditioner (template flag EPI, the last one of the mangled name), and the fp32
-    # fused ones once more with the epilogue of the V-cycle's smoother (register-allocated for 2 workgroups per CU)
-    assert len(rep) == 60
+    # epilogue of the polynomial preconditioner (template flag EPI, the last but one of the mangled name) and again with
+    # the operand formed on load (PRO, the last flag), and the fp32 fused ones once more with the epilogue of the
+    # V-cycle's smoother (register-allocated for 2 workgroups per CU)
+    assert len(rep) == 72
     for name, r in rep.items():
-        epi = "ELb1EEEv" in name
+        epi = "ELb1ELb0EEEv" in name or "ELb1ELb1EEEv" in name
         # (SGPR spills go to VGPR lanes, not to memory: the both-models variants keep 11-19 lane masks and bounds there,
         # the fused ones with the smoother's epilogue up to 40)
-        assert r["SGPRs Spill"] <= (40 if epi and r["LDS Size [bytes/block]"] > 30000 else 24) and r["AGPRs"] == 0, name
+        assert r["SGPRs Spill"] <= ((40 if r["LDS Size [bytes/block]"] > 30000 else 32) if epi else 24) and r["AGPRs"] == 0, name
         # the fp64 model_2 fused variant spills 4 VGPRs since the round-2 changes of the step's interface (round 1: none)
-        relaxed = "march3dIdLb0ELb1ELb1E" in name and "ELb0ELb0EEEv" in name
+        relaxed = "march3dIdLb0ELb1ELb1E" in name and "ELb0ELb0ELb0EEEv" in name
         assert r["VGPRs Spill"] <= (4 if relaxed else 0) and r["ScratchSize [bytes/lane]"] <= (20 if relaxed else 0), name
         if r["LDS Size [bytes/block]"] > 30000:           # fused variants: 3 workgroups per CU (2 with both models)
             assert r["LDS Size [bytes/block]"] * 3 <= 160 * 1024, name
@@ -53,11 +54,12 @@ def test_marching_kernel_budget():
             assert r["VGPRs"] <= (168 if both32 else 128) and r["Occupancy [waves/SIMD]"] >= (3 if both32 else 4), name
             assert r["LDS Size [bytes/block]"] * 4 <= 160 * 1024, name
     # the bench variant: fp32, model_2 only, fused -- three workgroups per CU
-    bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1ELi32ELb0ELb0E" in n]
+    bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1ELi32ELb0ELb0ELb0E" in n]
     assert len(bench) == 1 and bench[0]["VGPRs"] <= 168 and bench[0]["Occupancy [waves/SIMD]"] == 3
     # the Chebyshev step of the bench: fp32, model_2 only, plain + epilogue -- four workgroups per CU, no spills
-    cheb = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb0ELi32ELb0ELb1E" in n]
-    assert len(cheb) == 1 and cheb[0]["VGPRs"] <= 128 and cheb[0]["Occupancy [waves/SIMD]"] >= 4
+    for pro in "01":   # ... and its first step, which forms the operand while it loads r and the scaling
+        cheb = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb0ELi32ELb0ELb1ELb%sE" % pro in n]
+        assert len(cheb) == 1 and cheb[0]["VGPRs"] <= 128 and cheb[0]["Occupancy [waves/SIMD]"] >= 4
 
 
 def test_tile2d_kernel_budget():
