@@ -2216,28 +2216,44 @@ __global__ __launch_bounds__(kThreads) void k_pcg_resid(int64_t n, const CgScala
                                                          T inv_theta, double* __restrict__ prr, double* __restrict__ prz,
                                                          double* __restrict__ pbb)
 {
-	double alpha_d = 0.0;
-	if (phase == 1) {
-		if (in->done) { return; }
-		const double pq  = sum_partials(pq_partial, pq_count);
-		const bool   bad = !(pq > 0.0) || !isfinite(pq);
-		alpha_d = in->rz / pq;
-		if (blockIdx.x == 0 && threadIdx.x == 0) {
+	// one thread per workgroup reads the scalar record and the sum (see k_pcg_xp), the others take alpha from LDS
+	__shared__ double sh_alpha;
+	__shared__ int    sh_quit;
+	double pq_all = 0.0;
+	if (phase == 1 && pq_count > 1) { pq_all = sum_partials(pq_partial, pq_count); }  // folded form (undivided lattice)
+	if (threadIdx.x == 0) {
+		double a = 0.0;
+		int    quit = 0;
+		if (phase == 1) {
 			CgScalars s = *in;
-			s.pq    = pq;
-			s.alpha = alpha_d;
+			if (s.done) {
+				quit = 1;
+			} else {
+				const double pq  = pq_count > 1 ? pq_all : pq_partial[0];
+				const bool   bad = !(pq > 0.0) || !isfinite(pq);
+				a = s.rz / pq;
+				if (blockIdx.x == 0) {
+					s.pq    = pq;
+					s.alpha = a;
+					s.tag   = tag;
+					if (bad) { s.done = 2; }
+					*mid = s;
+				}
+				if (bad) { quit = 1; }
+			}
+		} else if (blockIdx.x == 0) {
+			CgScalars s = *in;
+			s.alpha = 0.0;
 			s.tag   = tag;
-			if (bad) { s.done = 2; }
+			s.done  = 0;
 			*mid = s;
 		}
-		if (bad) { return; }
-	} else if (blockIdx.x == 0 && threadIdx.x == 0) {
-		CgScalars s = *in;
-		s.alpha = 0.0;
-		s.tag   = tag;
-		s.done  = 0;
-		*mid = s;
+		sh_alpha = a;
+		sh_quit  = quit;
 	}
+	__syncthreads();
+	if (sh_quit) { return; }
+	const double alpha_d = sh_alpha;
 	using V = typename Vec16<T>::V;
 	constexpr int N = VEC ? Vec16<T>::N : 1;
 	const T alpha = static_cast<T>(alpha_d);
@@ -2296,41 +2312,62 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
                                                       const double* __restrict__ prz, int nrz, const double* __restrict__ pbb,
                                                       int nbb, const T* __restrict__ z, T* __restrict__ x, T* __restrict__ p)
 {
-	if (mid->tag != tag) { return; }  // the first half of this iteration did not run: the solve had finished
-	if (mid->done == 2) {
-		if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = *mid; }
-		return;
+	// The scalar record and the sums sit in two or three cache lines that EVERY wave of the launch would read: ~20 k
+	// requests to one or two L2 channels, which cost the launch 10-20 us (profiles/r2_ablation.md section 6).  One thread
+	// per workgroup reads them and forms the new record; the others take it from LDS.
+	__shared__ CgScalars sh;
+	__shared__ int       sh_quit;
+	double rr_all = 0.0, rz_all = 0.0, bb_all = 0.0;
+	const bool lists = nrr > 1 || nrz > 1 || nbb > 1;  // folded form (undivided lattice): fixed-order sums by the whole workgroup
+	if (lists) {
+		rr_all = sum_partials(prr, nrr);
+		rz_all = sum_partials(prz, nrz);
+		if (phase == 0) { bb_all = sum_partials(pbb, nbb); }
 	}
-	const double rr = sum_partials(prr, nrr);
-	const double rz = sum_partials(prz, nrz);
-	CgScalars s = *mid;
-	double beta_d = 0.0;
-	if (phase == 1) {
-		beta_d = rz / s.rz;
-		s.iter += 1;
-		s.done = !isfinite(rr) || !isfinite(rz) ? 2 : (!(rr > s.tol2) ? 1 : (s.iter >= s.max_iter ? 3 : 0));
-	} else {
-		if (phase == 0) {
-			s.bb   = sum_partials(pbb, nbb);
-			s.tol2 = s.tol2 * s.bb;
-			s.iter = 0;
-		} else if (phase == 2) {
-			s.restarts += 1;
-			s.true_rr = rr;
+	if (threadIdx.x == 0) {
+		CgScalars s = *mid;
+		int quit = 0;
+		if (s.tag != tag) {
+			quit = 1;  // the first half of this iteration did not run: the solve had finished
+		} else if (s.done == 2) {
+			if (blockIdx.x == 0) { *out_sc = s; }
+			quit = 1;
+		} else {
+			const double rr = lists ? rr_all : prr[0];
+			const double rz = lists ? rz_all : prz[0];
+			double beta_d = 0.0;
+			if (phase == 1) {
+				beta_d = rz / s.rz;
+				s.iter += 1;
+				s.done = !isfinite(rr) || !isfinite(rz) ? 2 : (!(rr > s.tol2) ? 1 : (s.iter >= s.max_iter ? 3 : 0));
+			} else {
+				if (phase == 0) {
+					s.bb   = lists ? bb_all : pbb[0];
+					s.tol2 = s.tol2 * s.bb;
+					s.iter = 0;
+				} else if (phase == 2) {
+					s.restarts += 1;
+					s.true_rr = rr;
+				}
+				s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase >= 2 ? 5 : 1) : (s.iter >= s.max_iter ? 3 : 0)));
+			}
+			s.rz_new = rz;
+			s.rr     = rr;
+			s.beta   = beta_d;
+			s.rz     = rz;
+			if (blockIdx.x == 0) { *out_sc = s; }
+			if (s.done == 2) { quit = 1; }
 		}
-		s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase >= 2 ? 5 : 1) : (s.iter >= s.max_iter ? 3 : 0)));
+		sh      = s;
+		sh_quit = quit;
 	}
-	s.rz_new = rz;
-	s.rr     = rr;
-	s.beta   = beta_d;
-	s.rz     = rz;
-	if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = s; }
-	if (s.done == 2) { return; }
+	__syncthreads();
+	if (sh_quit) { return; }
 	using V = typename Vec16<T>::V;
 	constexpr int N = VEC ? Vec16<T>::N : 1;
-	const T    alpha = static_cast<T>(s.alpha);
-	const T    beta  = static_cast<T>(beta_d);
-	const bool go_on = s.done == 0;
+	const T    alpha = static_cast<T>(sh.alpha);
+	const T    beta  = static_cast<T>(sh.beta);
+	const bool go_on = sh.done == 0;
 	const int64_t nv = n / N;
 	// all three streams are loaded before anything is stored (a load placed behind the store of x costs a second
 	// memory round trip per sweep: the kernel ran latency-bound, 69 instead of 53 us at 256^3)
@@ -2502,6 +2539,11 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	// loads them (fi_stencil.hip, PRO) -- k_pcg_resid then stores no z_0, and step 2 recomputes it as its z_prev.  (Slabs
 	// keep z_0: the scaling's ghost planes are not the neighbour's values.)
 	const bool z0_on_load = single && terms > 2 && !test_switch("FI_NO_Z0_ON_LOAD");
+	// Undivided lattice: the sums of the per-workgroup partials (p.q; r.r, r.z) are folded into their consumers (every
+	// workgroup sums the 1-4 k partials in the same fixed order); rank sets form them once, by a one-block kernel in
+	// front of the all-reduce.  Measured at 256^3 with both forms (profiles/r2_ablation.md section 6): folded 10.65 ms
+	// per bench step, one-block kernels 10.82 (two 4.6 us launches per outer iteration).
+	const bool folded = single && !tuning_switch("FI_POLY_UNFOLDED");
 	// partial regions of every member: [0] apply p.q, [1] r.r, [2] r.z, [3] b.b
 	auto region = [](fi_ctx* c, int k) { return c->partial.as<double>() + static_cast<size_t>(k) * c->max_blocks; };
 	auto slot2 = [](fi_ctx* c) { return (c->scal.as<CgScalars>() + 2)->sums; };
@@ -2527,7 +2569,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	// apply of x has been launched)
 	auto first_half = [&](int phase) {  // alpha, r, z1 (phase 0 / 2 / 3: r = b - A x)
 		++tag;
-		if (!single && phase == 1) {
+		if (!folded && phase == 1) {
 			for (fi_ctx* c : R) {
 				hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, region(c, 0),
 				                   apply_num_partials(c), static_cast<const double*>(nullptr), 0, static_cast<const double*>(nullptr), 0);
@@ -2538,8 +2580,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			const int64_t o = c->g.own_first;
 			const int     nbf = nbf_of(c);
 			CgScalars*    sc = c->scal.as<CgScalars>();
-			const double* pq = single ? region(c, 0) : slot2(c);
-			const int     npq = single ? apply_num_partials(c) : 1;
+			const double* pq = folded ? region(c, 0) : slot2(c);
+			const int     npq = folded ? apply_num_partials(c) : 1;
 			auto go = [&](auto kernel) {
 				hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc, sc + 1, tag, phase, pq, npq,
 				                   c->atb.as<T>() + o, c->q.as<T>() + o, c->dinv16.as<unsigned short>() + o, c->r.as<T>() + o,
@@ -2585,7 +2627,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			std::swap(zin, zout);
 		}
 		const Vec zfin = zin;
-		if (!single) {
+		if (!folded) {
 			for (fi_ctx* c : R) {
 				hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, region(c, 1), nbf_of(c),
 				                   region(c, 2), terms > 1 ? stencil_cheb_partials(c) : nbf_of(c),
@@ -2599,7 +2641,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			CgScalars*    sc = c->scal.as<CgScalars>();
 			const int     nrz = terms > 1 ? stencil_cheb_partials(c) : nbf;
 			auto go = [&](auto kernel) {
-				if (single) {
+				if (folded) {
 					hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc + 1, sc, tag, phase, region(c, 1), nbf,
 					                   region(c, 2), nrz, region(c, 3), nbf, vown<T>(c, zfin), c->x.as<T>() + o, c->p.as<T>() + o);
 				} else {
@@ -2646,7 +2688,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), 0); }
 			apply_exchanged(R, &fi_ctx::x, &fi_ctx::q, nullptr);
 			first_half(2);  // r = b - A x, z1, partials of r.r
-			if (!single) {
+			if (!folded) {
 				for (fi_ctx* c : R) {
 					hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, region(c, 1), nbf_of(c),
 					                   static_cast<const double*>(nullptr), 0, static_cast<const double*>(nullptr), 0);
@@ -2655,8 +2697,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			}
 			for (fi_ctx* c : R) {
 				CgScalars* sc = c->scal.as<CgScalars>();
-				hipLaunchKernelGGL(k_pcg_verify, dim3(1), dim3(kThreads), 0, c->stream, sc + 1, sc, single ? region(c, 1) : slot2(c),
-				                   single ? nbf_of(c) : 1);
+				hipLaunchKernelGGL(k_pcg_verify, dim3(1), dim3(kThreads), 0, c->stream, sc + 1, sc, folded ? region(c, 1) : slot2(c),
+				                   folded ? nbf_of(c) : 1);
 			}
 			FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
 			FI_HIP_TRY(hipStreamSynchronize(st));
