@@ -272,7 +272,7 @@ struct fi_ctx {
 	int        max_blocks = 0;
 
 	// assembly temporaries, kept between fi_assemble calls (hipMalloc/hipFree are slow and synchronising)
-	fi::DevBuf scratch[32];
+	fi::DevBuf scratch[36];
 
 	fi::Comm*  comm = nullptr;
 	hipStream_t comm_stream = nullptr;   // slabs over RCCL: the halo exchange runs here beside the interior launch

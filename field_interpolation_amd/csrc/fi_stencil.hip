@@ -1040,24 +1040,28 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 // A cell with global origin (cx, cy, cz) touches the tile columns {cx/TX, and (cx+1)/TX when cx+1 is a
 // tile start}, likewise rows, and along z the chunk holding plane cz plus the next chunk when plane cz+1
 // starts it (layer 0 of that chunk): up to 8 (workgroup, layer) lists.  Built without ordering hazards:
-//   k_cell_members  every cell writes its memberships into 8 fixed slots: key = kind*nbuckets + bucket
-//                   (kind 0: single-row cell, 1: block cell), the tile-relative origin, and bumps the
-//                   bucket's count;
+//   k_cell_members  pass 1: every cell counts its memberships (most have one; a two-row cell two per membership);
+//                   exclusive scan of the counts = the cell's first slot;  pass 2: it writes them there: key =
+//                   kind*nbuckets + bucket (kind 0: row records, 1: block record), the tile-relative origin, its
+//                   own index.  (Round 1 wrote 8 fixed slots per cell and sorted all of them, 7 of 8 empty: the sort
+//                   of 7.8 M pairs was the longest item of the assembly.)
 //   radix sort      slots by key (stable: the lists come out in cell order, run to run identical);
-//   exclusive scan  of the counts = list bounds;
+//   k_list_bounds   binary searches in the sorted keys = list bounds;
 //   k_cell_records  one thread per sorted slot copies the row / packed block into the self-contained record.
 
+template <bool WRITE>
 __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g, int64_t ncell, int64_t nbuckets,
                                                             const uint32_t* __restrict__ cell_id,
                                                             const uint32_t* __restrict__ nrow,
+                                                            uint32_t* __restrict__ nslot, const uint32_t* __restrict__ first,
                                                             uint32_t* __restrict__ key, uint32_t* __restrict__ pos,
-                                                            uint32_t* __restrict__ count)
+                                                            uint32_t* __restrict__ cell_of, uint32_t* __restrict__ count)
 {
 	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	const bool live = c < ncell;
 	const uint32_t rows_c = live ? nrow[c] : 0u;
 	const int  kind = (rows_c == 1u) ? 0 : 1;             // 0: single-row cell, 1: multi-row cell (statistics)
-	{
+	if (!WRITE) {
 		// distinct cells of each kind: one atomic per wave (a single hot address serialises in L2)
 		// distinct cells of each kind (statistics): one atomic per wave, spread over 64 counter pairs -- atomics on
 		// a single hot address serialise at ~10 ns each, 15 k waves would cost 0.15 ms
@@ -1099,6 +1103,10 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 	for (int m = 0; m < 8; ++m) { nmemb += (z_ok[m >> 2] && y_ok[(m >> 1) & 1] && x_ok[m & 1]) ? 1 : 0; }
 	const bool pair     = rows_c == 2u && nmemb <= 4;
 	const int  listkind = (rows_c == 1u || pair) ? 0 : 1;  // 0: row records, 1: block record
+	if (!WRITE) {
+		nslot[c] = static_cast<uint32_t>(pair ? 2 * nmemb : nmemb);
+		return;
+	}
 	uint32_t kk[8], pv[8];
 #pragma unroll
 	for (int m = 0; m < 8; ++m) { kk[m] = static_cast<uint32_t>(2 * nbuckets); pv[m] = 0; }  // unused slot: sorts last
@@ -1125,17 +1133,31 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 			}
 		}
 	}
+	// the used slots, in slot order (the order the fixed-slot form sorted them in)
+	uint32_t at = first[c];
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
-		key[c * 8 + m] = kk[m];
-		pos[c * 8 + m] = pv[m];
+		if (kk[m] != static_cast<uint32_t>(2 * nbuckets)) {
+			key[at]     = kk[m];
+			pos[at]     = pv[m];
+			cell_of[at] = static_cast<uint32_t>(c);
+			++at;
+		}
 	}
+}
+
+// total number of slots = first slot + count of the last cell
+__global__ void k_slot_total(int64_t ncell, const uint32_t* __restrict__ first, const uint32_t* __restrict__ nslot,
+                             uint32_t* __restrict__ total)
+{
+	*total = first[ncell - 1] + nslot[ncell - 1];
 }
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_t n_all,
                                                             const uint32_t* __restrict__ slot_sorted,
                                                             const uint32_t* __restrict__ pos,
+                                                            const uint32_t* __restrict__ cell_of,
                                                             const T* __restrict__ row1, const T* __restrict__ mrow,
                                                             const uint32_t* __restrict__ nfac,
                                                             uint32_t* __restrict__ pos_row, uint32_t* __restrict__ pos_blk,
@@ -1146,7 +1168,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_
 	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	if (i >= n_all) { return; }
 	const uint32_t slot = slot_sorted[i];
-	const int64_t  c    = slot >> 3;
+	const int64_t  c    = cell_of[slot];
 	if (i < n_row) {  // keys of kind 0 sort first
 		const uint32_t pp = pos[slot];
 		pos_row[i] = pp;
@@ -1422,38 +1444,56 @@ void build_cell_lists(fi_ctx* c)
 	const MarchParams& P = m.P;
 	const int64_t ncell = c->cells.ncell;
 	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1) * 4;  // (workgroup, layer, band of origin rows)
-	const int64_t nslots = ncell * 8;
-	FI_REQUIRE(nslots < (1LL << 31) && 2 * nbuckets < (1LL << 31), FI_ERR_UNSUPPORTED, "too many data cells for one context");
+	FI_REQUIRE(ncell * 8 < (1LL << 31) && 2 * nbuckets < (1LL << 31), FI_ERR_UNSUPPORTED, "too many data cells for one context");
 	hipStream_t st = c->stream;
 	DevBuf &count = c->scratch[14], &key = c->scratch[15], &pos = c->scratch[16], &slot_in = c->scratch[17],
-	       &key_sorted = c->scratch[18], &slot_sorted = c->scratch[19], &tmp = c->scratch[20];
+	       &key_sorted = c->scratch[18], &slot_sorted = c->scratch[19], &tmp = c->scratch[20], &nslot = c->scratch[31],
+	       &first = c->scratch[32], &cell_of = c->scratch[33];
 	count.alloc(sizeof(uint32_t) * (2 * nbuckets + 130));  // [0..127]: distinct cells per kind (64 pairs), [128..]: list bounds
-	key.alloc(sizeof(uint32_t) * nslots);
-	pos.alloc(sizeof(uint32_t) * nslots);
-	slot_in.alloc(sizeof(uint32_t) * nslots);
-	key_sorted.alloc(sizeof(uint32_t) * nslots);
-	slot_sorted.alloc(sizeof(uint32_t) * nslots);
+	nslot.alloc(sizeof(uint32_t) * (ncell + 1));
+	first.alloc(sizeof(uint32_t) * (ncell + 1));
 	m.lay_row.alloc(sizeof(uint32_t) * (nbuckets + 1));
 	m.lay_blk.alloc(sizeof(uint32_t) * (nbuckets + 1));
 	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * 128, st));
 	const int nb = static_cast<int>((ncell + kThreads - 1) / kThreads);
-	hipLaunchKernelGGL(k_cell_members, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
-	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), key.as<uint32_t>(),
-	                   pos.as<uint32_t>(), count.as<uint32_t>());
-	hipLaunchKernelGGL(k_iota32, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-	                   slot_in.as<uint32_t>(), nslots);
-	// unused slots carry key 2 * nbuckets and sort to the end; only the bits such keys have take part (256^3:
-	// 18 bits = 3 radix passes instead of 4)
-	int key_bits = 1;
-	while ((1LL << key_bits) <= 2 * nbuckets) { ++key_bits; }
-	size_t tb = 0;
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
-	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-	                                              static_cast<int>(nslots), 0, key_bits, st));
-	tmp.alloc(tb);
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
-	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-	                                              static_cast<int>(nslots), 0, key_bits, st));
+	hipLaunchKernelGGL(k_cell_members<false>, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
+	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), nslot.as<uint32_t>(),
+	                   static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+	                   static_cast<uint32_t*>(nullptr), count.as<uint32_t>());
+	size_t tb0 = 0;
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
+	tmp.alloc(tb0);
+	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
+	hipLaunchKernelGGL(k_slot_total, dim3(1), dim3(1), 0, st, ncell, first.as<uint32_t>(), nslot.as<uint32_t>(),
+	                   first.as<uint32_t>() + ncell);
+	uint32_t h_slots = 0;
+	FI_HIP_TRY(hipMemcpyAsync(&h_slots, first.as<uint32_t>() + ncell, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	FI_HIP_TRY(hipStreamSynchronize(st));  // the sort below is sized by it
+	const int64_t nslots = h_slots;
+	key.alloc(sizeof(uint32_t) * (nslots + 1));
+	pos.alloc(sizeof(uint32_t) * (nslots + 1));
+	cell_of.alloc(sizeof(uint32_t) * (nslots + 1));
+	slot_in.alloc(sizeof(uint32_t) * (nslots + 1));
+	key_sorted.alloc(sizeof(uint32_t) * (nslots + 1));
+	slot_sorted.alloc(sizeof(uint32_t) * (nslots + 1));
+	hipLaunchKernelGGL(k_cell_members<true>, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
+	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), static_cast<uint32_t*>(nullptr),
+	                   first.as<uint32_t>(), key.as<uint32_t>(), pos.as<uint32_t>(), cell_of.as<uint32_t>(), count.as<uint32_t>());
+	if (nslots > 0) {
+		hipLaunchKernelGGL(k_iota32, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+		                   slot_in.as<uint32_t>(), nslots);
+		// only the bits the keys have take part (256^3: 18 bits = 3 radix passes instead of 4)
+		int key_bits = 1;
+		while ((1LL << key_bits) < 2 * nbuckets) { ++key_bits; }
+		size_t tb = 0;
+		FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
+		                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
+		                                              static_cast<int>(nslots), 0, key_bits, st));
+		tmp.alloc(tb);
+		FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
+		                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
+		                                              static_cast<int>(nslots), 0, key_bits, st));
+	}
 	uint32_t* bound = count.as<uint32_t>() + 128;  // [2 * nbuckets + 1]
 	hipLaunchKernelGGL(k_list_bounds, dim3(static_cast<int>((2 * nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
 	                   st, nslots, 2 * nbuckets, key_sorted.as<uint32_t>(), bound);
@@ -1503,7 +1543,7 @@ void build_cell_lists(fi_ctx* c)
 	const int64_t n_all = m.n_row + m.n_blk;
 	if (n_all > 0) {
 		hipLaunchKernelGGL((k_cell_records<T>), dim3(static_cast<int>((n_all + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-		                   st, m.n_row, n_all, slot_sorted.as<uint32_t>(), pos.as<uint32_t>(), c->cells.row1.as<T>(),
+		                   st, m.n_row, n_all, slot_sorted.as<uint32_t>(), pos.as<uint32_t>(), cell_of.as<uint32_t>(), c->cells.row1.as<T>(),
 		                   c->cells.mrow.as<T>(), c->cells.nfac.as<uint32_t>(), m.pos_row.as<uint32_t>(),
 		                   m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(), m.coef_blk.as<T>());
 	}

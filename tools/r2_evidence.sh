@@ -24,8 +24,8 @@ if [ $part = c5 ]; then
   python3 tools/pmc_traffic.py $F $W "k_apply_march3d<double, false, true, true" $O/traffic_apply.json
   python3 tools/pmc_traffic.py $F $W "k_apply_march3d<float, false, true, true" $O/traffic_apply_f32.json
 else
-  python3 tools/pmc_traffic.py $F $W "k_apply_march3d<float, false, true, true, 32, false, false>" $O/traffic_apply.json
-  python3 tools/pmc_traffic.py $F $W "k_apply_march3d<float, false, true, false, 32, false, true>" $O/traffic_cheb.json 0.9
+  python3 tools/pmc_traffic.py $F $W "k_apply_march3d<float, false, true, true, 32, false, false, false>" $O/traffic_apply.json
+  python3 tools/pmc_traffic.py $F $W "k_apply_march3d<float, false, true, false, 32, false, true, false>" $O/traffic_cheb.json 0.9
   python3 tools/pmc_traffic.py $F $W "k_pcg_xp" $O/traffic_pcg_xp.json
   python3 tools/pmc_traffic.py $F $W "k_pcg_resid" $O/traffic_pcg_resid.json
 fi
