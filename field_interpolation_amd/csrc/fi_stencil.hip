@@ -55,6 +55,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstring>
 #include <cmath>
 #include <type_traits>
 #include <vector>
@@ -1146,6 +1147,29 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 	}
 }
 
+// the host's view of the lists in one buffer: [0..1] workgroups with / without cells, [2..3] row / block records,
+// [4..5] distinct cells per kind (sum of the 64 counter pairs), then one flag byte per workgroup
+__global__ __launch_bounds__(kThreads) void k_pack_readback(int nwg, const int* __restrict__ nsel, const uint32_t* __restrict__ n_row,
+                                                             const uint32_t* __restrict__ n_blk, const uint32_t* __restrict__ uniq64,
+                                                             const uint8_t* __restrict__ has, uint8_t* __restrict__ out)
+{
+	uint32_t* head = reinterpret_cast<uint32_t*>(out);
+	if (threadIdx.x == 0) {
+		uint32_t a = 0, b = 0;
+		for (int w = 0; w < 64; ++w) {
+			a += uniq64[2 * w];
+			b += uniq64[2 * w + 1];
+		}
+		head[0] = static_cast<uint32_t>(nsel[0]);
+		head[1] = static_cast<uint32_t>(nsel[1]);
+		head[2] = *n_row;
+		head[3] = *n_blk;
+		head[4] = a;
+		head[5] = b;
+	}
+	for (int i = threadIdx.x; i < nwg; i += kThreads) { out[24 + i] = has[i]; }
+}
+
 // total number of slots = first slot + count of the last cell
 __global__ void k_slot_total(int64_t ncell, const uint32_t* __restrict__ first, const uint32_t* __restrict__ nslot,
                              uint32_t* __restrict__ total)
@@ -1519,19 +1543,20 @@ void build_cell_lists(fi_ctx* c)
 	                                         nsel.as<int>(), nwg, st));
 	FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has_not.as<uint8_t>(),
 	                                         m.wg_plain.as<uint32_t>(), nsel.as<int>() + 1, nwg, st));
-	int counts[2] = {0, 0};
-	FI_HIP_TRY(hipMemcpyAsync(counts, nsel.p, sizeof(counts), hipMemcpyDeviceToHost, st));
-	std::vector<uint8_t> h_has(static_cast<size_t>(nwg));
-	FI_HIP_TRY(hipMemcpyAsync(h_has.data(), has.p, static_cast<size_t>(nwg), hipMemcpyDeviceToHost, st));
-	uint32_t totals[2] = {0, 0}, uniq[2] = {0, 0}, uniq64[128];
-	FI_HIP_TRY(hipMemcpyAsync(&totals[0], m.lay_row.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	FI_HIP_TRY(hipMemcpyAsync(&totals[1], m.lay_blk.as<uint32_t>() + nbuckets, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	FI_HIP_TRY(hipMemcpyAsync(uniq64, count.as<uint32_t>(), sizeof(uniq64), hipMemcpyDeviceToHost, st));
+	// everything the host needs in ONE copy (five separate ones cost ~15 us each): the two selection counts, the record
+	// totals, the distinct cells per kind, and the per-workgroup flags
+	DevBuf& pack = c->scratch[34];
+	pack.alloc(24 + static_cast<size_t>(nwg));
+	hipLaunchKernelGGL(k_pack_readback, dim3(1), dim3(kThreads), 0, st, nwg, nsel.as<int>(), m.lay_row.as<uint32_t>() + nbuckets,
+	                   m.lay_blk.as<uint32_t>() + nbuckets, count.as<uint32_t>(), has.as<uint8_t>(), pack.as<uint8_t>());
+	std::vector<uint8_t> h_pack(24 + static_cast<size_t>(nwg));
+	FI_HIP_TRY(hipMemcpyAsync(h_pack.data(), pack.p, h_pack.size(), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
-	for (int w = 0; w < 64; ++w) {
-		uniq[0] += uniq64[2 * w];
-		uniq[1] += uniq64[2 * w + 1];
-	}
+	uint32_t head[6];
+	memcpy(head, h_pack.data(), sizeof(head));
+	const int counts[2] = {static_cast<int>(head[0]), static_cast<int>(head[1])};
+	const uint32_t totals[2] = {head[2], head[3]}, uniq[2] = {head[4], head[5]};
+	const uint8_t* h_has = h_pack.data() + 24;
 	m.n_row = totals[0];
 	m.n_blk = totals[1];
 	m.cells_row = uniq[0];
