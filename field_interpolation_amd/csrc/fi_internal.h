@@ -276,6 +276,9 @@ struct fi_ctx {
 
 	fi::Comm*  comm = nullptr;
 	hipStream_t comm_stream = nullptr;   // slabs over RCCL: the halo exchange runs here beside the interior launch
+	hipStream_t level_stream = nullptr;  // fi_assemble: the coarser levels are assembled here, by a helper thread, beside
+	                                     // the finest level on `stream`
+	hipEvent_t  ev_level = nullptr;
 	hipEvent_t  ev_ready = nullptr, ev_halo = nullptr;
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
 	bool       owns_stream = true;

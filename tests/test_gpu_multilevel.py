@@ -203,3 +203,37 @@ def test_fused_smoother_equals_the_unfused_one(fi, sizes, kw, monkeypatch):
     monkeypatch.delenv("FI_NO_FUSED_SMOOTHER", raising=False)
     assert abs(out[0][1] - out[1][1]) <= 1
     assert rel_inf(out[0][0], out[1][0]) <= 2e-4      # two fp32 solves to a 1e-5 residual
+
+
+def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
+    """fi_assemble builds the coarser levels on a helper thread and a second stream while the calling thread assembles
+    the finest level; FI_SERIAL_LEVELS builds them afterwards on the solver stream.  Same kernels on the same data: the
+    solves are bitwise equal, assemble after assemble (the levels' buffers are reused)."""
+    sizes = [48, 44, 52]
+    rng = np.random.default_rng(21)
+    w = fi.Weights(model_2=0.5, data_gradient=0.0)
+    sols = {}
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("FI_SERIAL_LEVELS", "1")
+        else:
+            monkeypatch.delenv("FI_SERIAL_LEVELS", raising=False)
+        f = fi.LatticeField(sizes, dtype="f32")
+        f.add_field_constraints(w)
+        f.set_levels(2)
+        f.set_polynomial(4)
+        rng = np.random.default_rng(21)
+        out = []
+        for k in range(3):
+            pos = np.stack([rng.uniform(0, s - 1, 4000 + 500 * k) for s in sizes], axis=1).astype(np.float32)
+            val = rng.normal(size=len(pos)).astype(np.float32)
+            f.clear_points()
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+            f.assemble()
+            assert f.stats()["num_levels"] == 3
+            x, it, rel = f.solve_cg(None, 0, 1e-5)
+            out.append((x.copy(), it))
+        sols[serial] = out
+    monkeypatch.delenv("FI_SERIAL_LEVELS", raising=False)
+    for a, b in zip(sols[False], sols[True]):
+        assert a[1] == b[1] and np.array_equal(a[0], b[0])
