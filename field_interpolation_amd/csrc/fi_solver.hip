@@ -266,9 +266,18 @@ __global__ __launch_bounds__(kThreads) void k_cg_resid_f(int64_t n, const CgScal
                                                           const T* __restrict__ q, const T* __restrict__ dinv,
                                                           T* __restrict__ r, double* __restrict__ partial, int nblk)
 {
-	if (in->done) { return; }
+	// the scalar record is read by ONE thread per workgroup and handed on through LDS: thousands of waves reading the
+	// same cache lines queue on one L2 channel (profiles/r2_ablation.md section 6)
+	__shared__ double sh_rz;
+	__shared__ int    sh_done;
+	if (threadIdx.x == 0) {
+		sh_done = in->done;
+		sh_rz   = in->rz;
+	}
+	__syncthreads();
+	if (sh_done) { return; }
 	const double pq    = sum_partials(pq_partial, pq_count);
-	const double alpha_d = in->rz / pq;
+	const double alpha_d = sh_rz / pq;
 	const bool   bad   = !(pq > 0.0) || !isfinite(pq);
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		CgScalars s = *in;
@@ -322,18 +331,21 @@ __global__ __launch_bounds__(kThreads) void k_cg_xp_f(int64_t n, const CgScalars
                                                        const T* __restrict__ r, const T* __restrict__ dinv,
                                                        T* __restrict__ x, T* __restrict__ p)
 {
-	if (mid->tag != tag) { return; }  // the first half of this iteration did not run: the solve had finished
-	if (mid->done == 2) {
-		if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = *mid; }
+	__shared__ CgScalars sh;  // read once per workgroup (see k_cg_resid_f)
+	if (threadIdx.x == 0) { sh = *mid; }
+	__syncthreads();
+	if (sh.tag != tag) { return; }  // the first half of this iteration did not run: the solve had finished
+	if (sh.done == 2) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *out_sc = sh; }
 		return;
 	}
 	const double rz_new = sum_partials(partial, nblk);
 	const double rr     = sum_partials(partial + nblk, nblk);
-	const double beta_d = rz_new / mid->rz;
-	const int    iter   = mid->iter + 1;
-	const int    done   = !isfinite(rr) ? 2 : (!(rr > mid->tol2) ? 1 : (iter >= mid->max_iter ? 3 : 0));
+	const double beta_d = rz_new / sh.rz;
+	const int    iter   = sh.iter + 1;
+	const int    done   = !isfinite(rr) ? 2 : (!(rr > sh.tol2) ? 1 : (iter >= sh.max_iter ? 3 : 0));
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		CgScalars s = *mid;
+		CgScalars s = sh;
 		s.sums[0] = rz_new;
 		s.sums[1] = rr;
 		s.rz_new  = rz_new;
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void k_cg_xp_f(int64_t n, const CgScalars
 	if (done == 2) { return; }
 	using V = typename Vec16<T>::V;
 	constexpr int N = VEC ? Vec16<T>::N : 1;
-	const T    alpha = static_cast<T>(mid->alpha);
+	const T    alpha = static_cast<T>(sh.alpha);
 	const T    beta  = static_cast<T>(beta_d);
 	const bool go_on = done == 0;
 	const int64_t nv = n / N;
