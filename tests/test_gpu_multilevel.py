@@ -237,3 +237,28 @@ def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatc
     monkeypatch.delenv("FI_SERIAL_LEVELS", raising=False)
     for a, b in zip(sols[False], sols[True]):
         assert a[1] == b[1] and np.array_equal(a[0], b[0])
+
+
+def test_cubic_start_changes_the_path_not_the_solution(oracle, fi, monkeypatch):
+    """The coarse-to-fine start interpolates cubically on undivided 3-D lattices (FI_LINEAR_START: trilinear, the form
+    slabs and the V-cycle's P use).  A start is a start: both solves end at the oracle's solution."""
+    sizes = [24, 20, 28]          # the oracle's sparse Cholesky of a larger 3-D lattice takes minutes
+    (fo, _), (w, pos, nrm) = _problem(oracle, fi, sizes, "f64", n=600)
+    x_ref = fo.solve_exact_f64()
+    its = []
+    for linear in (False, True):
+        if linear:
+            monkeypatch.setenv("FI_LINEAR_START", "1")
+        else:
+            monkeypatch.delenv("FI_LINEAR_START", raising=False)
+        f = fi.LatticeField(sizes, dtype="f64")
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        f.set_levels(1)
+        f.assemble()
+        assert f.stats()["num_levels"] == 2
+        x, it, rel = f.solve_cg(None, 0, 1e-10)
+        assert rel <= 1e-10 and rel_inf(f.solution_f64(), x_ref) <= 1e-6
+        its.append(it)
+    monkeypatch.delenv("FI_LINEAR_START", raising=False)
+    assert its[0] <= its[1] + 2
