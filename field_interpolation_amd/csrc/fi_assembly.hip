@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, c
 		cidx[colour] = ok ? map[key] : 0xFFFFFFFFu;
 		cq[colour]   = q;
 	}
-	T a = atb[idx], dg = diag[idx];
+	T a = T(0), dg = T(0);  // both arrays are zero when this kernel runs (assemble): written, not accumulated
 #pragma unroll
 	for (int colour = 0; colour < NC; ++colour) {
 		const uint32_t c = cidx[colour];

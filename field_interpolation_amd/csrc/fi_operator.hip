@@ -217,7 +217,8 @@ __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell,
 
 // diag(A^T A) of the model rows, added onto `diag` (which already holds the data part).
 template <int D, typename T>
-__global__ __launch_bounds__(kThreads) void k_model_diag(Geom g, ModelCoef<T> mc, T* __restrict__ diag)
+__global__ __launch_bounds__(kThreads) void k_model_diag(Geom g, ModelCoef<T> mc, T* __restrict__ diag, T* __restrict__ dinv,
+                                                         unsigned short* __restrict__ d16)
 {
 	const int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	if (o >= g.nown) { return; }
@@ -250,7 +251,13 @@ __global__ __launch_bounds__(kThreads) void k_model_diag(Geom g, ModelCoef<T> mc
 			}
 		}
 	}
-	diag[idx] += acc;
+	const T d = diag[idx] + acc;
+	diag[idx] = d;
+	if (dinv) {  // undivided lattice: the Jacobi scaling in the same pass (k_invert_diag otherwise: ghost planes too)
+		const T v = (d != T(0)) ? T(1) / d : T(1);
+		dinv[idx] = v;
+		d16[idx]  = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
+	}
 }
 
 // Eigen::DiagonalPreconditioner semantics: 1/diag, or 1 where diag == 0.
@@ -311,12 +318,16 @@ void prepare_dim(fi_ctx* c)
 {
 	const Geom& g = c->g;
 	const ModelCoef<T> mc = make_coef<T>(c->w);
-	hipLaunchKernelGGL((k_model_diag<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g, mc,
-	                   c->diag.as<T>());
 	c->dinv.alloc(sizeof(T) * g.nloc);
 	c->dinv16.alloc(sizeof(unsigned short) * g.nloc);
-	hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc,
-	                   c->diag.as<T>(), c->dinv.as<T>(), c->dinv16.as<unsigned short>());
+	const bool whole = g.nown == g.nloc;  // no ghost planes: every local point is an owned one
+	hipLaunchKernelGGL((k_model_diag<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g, mc,
+	                   c->diag.as<T>(), whole ? c->dinv.as<T>() : static_cast<T*>(nullptr),
+	                   whole ? c->dinv16.as<unsigned short>() : static_cast<unsigned short*>(nullptr));
+	if (!whole) {
+		hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc,
+		                   c->diag.as<T>(), c->dinv.as<T>(), c->dinv16.as<unsigned short>());
+	}
 	FI_HIP_TRY(hipGetLastError());
 }
 
