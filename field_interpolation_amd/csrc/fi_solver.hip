@@ -3640,6 +3640,9 @@ int fi_assemble(fi_ctx* c)
 			fi::operator_prepare(c);
 		} catch (const fi::Fail& f) {
 			main_code = f.code;
+		} catch (...) {  // never leave the helper unjoined
+			main_code = FI_ERR_HIP;
+			fi::set_error("unexpected exception while assembling the finest level");
 		}
 		helper.join();
 		for (fi_ctx* l = c->coarse; l; l = l->coarse) { l->stream = c->stream; }
