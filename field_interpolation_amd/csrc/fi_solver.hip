@@ -54,6 +54,7 @@ namespace {
 constexpr int kThreads    = 256;
 constexpr int kCheckEvery = 16;
 constexpr int kMaxSamples = 128;
+constexpr int kPolySamples = 3;  // per solve and kind, in the polynomial PCG (see there)
 
 __device__ inline double wave_sum(double v)
 {
@@ -1147,7 +1148,7 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		for (int k = 0; k < kCheckEvery; ++k) {
 			++issued;
 			// every 4th apply is timed: an event record is a barrier packet of its own in the queue
-			const bool sample = samples < kMaxSamples && (issued & 3) == 1;
+			const bool sample = c0->level == 0 && samples < 8 && (issued & 3) == 1;  // event pairs cost the stream ~11 us each
 			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
 			apply_exchanged(R, &fi_ctx::p, &fi_ctx::q, +[](fi_ctx* c) -> double* { return c->partial.as<double>(); });
 			if (sample) {
@@ -1975,8 +1976,7 @@ void mg_prepare(RankSet& R, bool clear_finest)
 		for (fi_ctx* l : lev) {
 			mg_alloc<T>(l);
 			if (!finest || clear_finest) {  // the operator kernels of a level exit early while ITS stop flag is up
-				CgScalars clear{};
-				FI_HIP_TRY(hipMemcpyAsync(l->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, l->stream));
+				FI_HIP_TRY(hipMemsetAsync(l->scal.p, 0, sizeof(CgScalars), l->stream));  // (no host source that could go out of scope)
 			}
 		}
 		finest = false;
@@ -2527,8 +2527,7 @@ void estimate_poly_lambda(RankSet& R)
 	for (fi_ctx* c : R) { ensure_poly_vectors<T>(c); }
 	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
 	for (fi_ctx* c : R) {
-		CgScalars clear{};
-		FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &clear, sizeof(clear), hipMemcpyHostToDevice, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->scal.p, 0, sizeof(CgScalars), c->stream));  // (no host source that could go out of scope)
 		hipLaunchKernelGGL((k_seed<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, global_first(c),
 		                   c->mg_x.as<T>() + c->g.own_first);
 	}
@@ -2667,7 +2666,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		Vec zin = ZA, zout = ZB;
 		for (int k = 1; k < terms; ++k) {
 			// every 4th pass times its last step (5 lattice passes when the polynomial has 3 terms or more)
-			const bool sample = phase == 1 && k == terms - 1 && psamples < kMaxSamples && (tag & 3) == 1;
+			const bool sample = phase == 1 && k == terms - 1 && c0->level == 0 && psamples < kPolySamples && (tag & 3) == 3 &&
+			                    !tuning_switch("FI_NO_SAMPLES");
 			const bool overlap = R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
 			const bool pro = z0_on_load && k == 1;  // single rank: no ghost planes to exchange
 			if (overlap) { exchange_begin(c0, (c0->*zin).p); } else if (!pro) { halo_exchange(R, zin); }
@@ -2785,7 +2785,9 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		next_burst = burst > 2 ? 2 : burst;  // after the first look the solve is close to its end
 		for (int k = 0; k < nb; ++k) {
 			++issued;
-			const bool sample = samples < kMaxSamples && (issued & 1) == 1;
+			// timed launches: a pair of event records costs the stream ~11 us of idle time (two 5.6 us gaps around the
+			// launch), so only the finest level is sampled, three applies and three Chebyshev steps per solve
+			const bool sample = c0->level == 0 && samples < kPolySamples && (issued & 3) == 1 && !tuning_switch("FI_NO_SAMPLES");
 			if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
 			apply_exchanged(R, &fi_ctx::p, &fi_ctx::q, +[](fi_ctx* c) -> double* { return c->partial.as<double>(); });
 			if (sample) {
@@ -2805,7 +2807,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 
 	const CgScalars h = *c0->scal_host;
 	int used = samples;
-	if ((h.iter + 1) / 2 < used) { used = (h.iter + 1) / 2; }  // sample k belongs to outer iteration 2k + 1
+	if ((h.iter + 3) / 4 < used) { used = (h.iter + 3) / 4; }  // sample k belongs to outer iteration 4k + 1
 	double sum_ms = 0;
 	for (int k = 0; k < used; ++k) {
 		float t = 0;
