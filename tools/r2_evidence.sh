@@ -16,6 +16,7 @@ python bench.py --steps 3 --warmup 1 $ARGS > $O/bench.json 2> $O/bench.err; echo
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 1 $ARGS --no-accuracy > $O/trace.log 2>&1; echo "trace rc=$?"
 python3 $R/tools/trace_by_grid.py $O/trace > $O/by_grid.md
+python3 $R/tools/trace_poly_steps.py $O/trace > $O/poly_steps.md
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 $ARGS --no-accuracy > $O/pmc_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 $ARGS --no-accuracy > $O/pmc_write.log 2>&1; echo "write rc=$?"
 cd $R
