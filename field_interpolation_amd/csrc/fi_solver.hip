@@ -3857,9 +3857,27 @@ int fi_time_apply(fi_ctx* c, int reps, double* ms_per_launch)
 	hipEvent_t e0, e1;
 	FI_HIP_TRY(hipEventCreate(&e0));
 	FI_HIP_TRY(hipEventCreate(&e1));
-	fi::apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>());  // warm-up
+	// timing builds: FI_TIME_STEP = 1 / 2 / 3 times that step of the polynomial preconditioner instead (operands: the
+	// solver's vectors as they are -- isolated launches, the numbers of profiles/r2_ablation.md)
+	const char* which = fi::tuning_switch("FI_TIME_STEP");
+	const int   step = which ? atoi(which) : 0;
+	auto launch = [&]() {
+		if (step >= 1 && fi::stencil_cheb_available(c)) {
+			c->dtype == FI_F64 ? fi::ensure_poly_vectors<double>(c) : fi::ensure_poly_vectors<float>(c);
+			if (step == 1) {
+				fi::stencil_cheb_step(c, c->r.p, nullptr, c->r.p, c->mg_d.p, 0.3, 0.2, c->partial.as<double>(), 0, 0.0, 0.5);
+			} else if (step == 2) {
+				fi::stencil_cheb_step(c, c->mg_d.p, c->mg_x.p, c->r.p, c->mg_x.p, 0.3, 0.2, c->partial.as<double>(), 0, 0.5);
+			} else {
+				fi::stencil_cheb_step(c, c->mg_x.p, c->mg_d.p, c->r.p, c->mg_d.p, 0.3, 0.2, c->partial.as<double>());
+			}
+		} else {
+			fi::apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>());
+		}
+	};
+	launch();  // warm-up
 	FI_HIP_TRY(hipEventRecord(e0, c->stream));
-	for (int k = 0; k < reps; ++k) { fi::apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>()); }
+	for (int k = 0; k < reps; ++k) { launch(); }
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;

@@ -362,6 +362,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		h.vec = *reinterpret_cast<const NV*>(xp + hvg);
 		h.sc  = xp[hsg];
 		if (PRO) {
+#ifdef FI_TIMING_BUILD
+			if (P.dbg & 64) { return; }  // no halo loads of the scaling
+#endif
 			const unsigned short* dp = E.dinv + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
 			h.dvec = *reinterpret_cast<const DV16*>(dp + hvg);
 			h.dsc  = dp[hsg];
@@ -369,6 +372,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	};
 	// PRO: the scaling of the thread's own points of plane lz, and the operand formed from a loaded pair
 	auto load_own_d = [&](int lz) -> DV16 {
+#ifdef FI_TIMING_BUILD
+		if (P.dbg & 128) { return DV16{}; }  // no own loads of the scaling
+#endif
 		return *reinterpret_cast<const DV16*>(E.dinv + static_cast<int64_t>(clamp_plane(lz)) * P.plane + xoff);
 	};
 	auto form_own = [&](V& v, const DV16& d) {
