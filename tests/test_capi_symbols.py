@@ -79,7 +79,8 @@ def test_shipped_library_has_no_timing_hooks():
     from field_interpolation_amd import _capi
     blob = open(_capi.LIB_PATH, "rb").read()
     for name in (b"FI_DBG", b"FI_TXT", b"FI_RUN_CAP", b"FI_NO_SPLIT", b"FI_NO_FOLD", b"FI_MG_DEGREE", b"FI_MG_RATIO", b"FI_MG_POLY",
-                 b"FI_DUMMY"):
+                 b"FI_TIME_STEP", b"FI_NO_SAMPLES", b"FI_POLY_UNFOLDED", b"FI_DUMMY"):
         assert name not in blob, name
-    for name in (b"FI_NO_FUSE", b"FI_NO_MARCH", b"FI_ZC", b"FI_SOLVE_TIMEOUT_S"):      # the switches the tests use are there
+    for name in (b"FI_NO_FUSE", b"FI_NO_MARCH", b"FI_ZC", b"FI_SOLVE_TIMEOUT_S", b"FI_NO_FUSED_SMOOTHER", b"FI_NO_Z0_ON_LOAD",
+                 b"FI_SERIAL_LEVELS", b"FI_LINEAR_START"):                              # the switches the tests use are there
         assert name in blob, name
