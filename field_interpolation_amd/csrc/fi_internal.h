@@ -333,6 +333,9 @@ void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 void tile2d_prepare(fi_ctx* c);
 int  tile2d_partials(const fi_ctx* c);
 bool tile2d_apply(fi_ctx* c, const void* x, void* y, double* partial);
+bool tile2d_full_epi_available(const fi_ctx* c);  // the smoother's recurrence step / residual in the tile kernel's epilogue
+void tile2d_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a, double c1,
+                      double c2);
 
 // fi_generic.hip
 void generic_add_coo(fi_ctx* c, int64_t nrows, int64_t ntrip, const fi_triplet* trip, const float* rhs, int memory);

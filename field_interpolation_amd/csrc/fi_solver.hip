@@ -1506,13 +1506,13 @@ __global__ __launch_bounds__(kThreads) void k_cheb_first(int64_t n, const T* __r
 }
 
 // the same with the bfloat16 scaling of the fused smoother (one polynomial: every step scales by the same diagonal)
-__global__ __launch_bounds__(kThreads) void k_cheb_first16(int64_t n, const float* __restrict__ b,
-                                                            const unsigned short* __restrict__ dinv16, float* __restrict__ d,
-                                                            float alpha)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cheb_first16(int64_t n, const T* __restrict__ b,
+                                                            const unsigned short* __restrict__ dinv16, T* __restrict__ d, T alpha)
 {
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		d[i] = alpha * __uint_as_float(static_cast<unsigned int>(dinv16[i]) << 16) * b[i];
+		d[i] = alpha * static_cast<T>(__uint_as_float(static_cast<unsigned int>(dinv16[i]) << 16)) * b[i];
 	}
 }
 
@@ -1809,7 +1809,7 @@ void estimate_lambda(RankSet& R)
 // (d_k = x_{k+1} - x_k of the form below), so that a step is ONE launch that reads x_k, x_{k-1}, b, Dinv and the cell
 // records and writes x_{k+1}: 5 lattice passes instead of the 10 of apply + k_cheb_iter.  The iterates rotate through
 // x, mg_d and mg_r; the buffer that ends up holding the result is swapped into x.
-bool smooth_fused_ok(const RankSet& R)
+bool smooth_fused_ok(const RankSet& R)  // (stencil_full_epi_available knows which precisions a context's kernel covers)
 {
 	if (test_switch("FI_NO_FUSED_SMOOTHER")) { return false; }  // tests compare the two forms of the smoother
 	for (const fi_ctx* c : R) {
@@ -1825,6 +1825,7 @@ void swap_vectors(RankSet& R, Vec a, Vec b)
 		std::swap((c->*a).bytes, (c->*b).bytes);
 	}
 }
+template <typename T>
 void cheb_smooth_fused(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_zero)
 {
 	const double hi = 1.1 * R[0]->lambda_max, lo = hi / ratio;
@@ -1844,9 +1845,9 @@ void cheb_smooth_fused(RankSet& R, Vec b, Vec x, int degree, double ratio, bool 
 	bool have_prev = false;  // x_{k-1} is a vector (not the zero start)
 	if (from_zero) {
 		for (fi_ctx* c : R) {  // x_1 = Dinv b / theta
-			hipLaunchKernelGGL(k_cheb_first16, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
-			                   vown<float>(c, b), c->dinv16.as<unsigned short>() + c->g.own_first, vown<float>(c, x),
-			                   static_cast<float>(1.0 / theta));
+			hipLaunchKernelGGL((k_cheb_first16<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   vown<T>(c, b), c->dinv16.as<unsigned short>() + c->g.own_first, vown<T>(c, x),
+			                   static_cast<T>(1.0 / theta));
 		}
 	} else {
 		step(1.0, 0.0, 1.0 / theta);  // x_1 = x_0 + Dinv (b - A x_0) / theta
@@ -1868,8 +1869,8 @@ void cheb_smooth_fused(RankSet& R, Vec b, Vec x, int degree, double ratio, bool 
 template <typename T>
 void cheb_smooth(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_zero)
 {
-	if (std::is_same<T, float>::value && smooth_fused_ok(R)) {
-		cheb_smooth_fused(R, b, x, degree, ratio, from_zero);
+	if (smooth_fused_ok(R)) {
+		cheb_smooth_fused<T>(R, b, x, degree, ratio, from_zero);
 		return;
 	}
 	const double hi = 1.1 * R[0]->lambda_max, lo = hi / ratio;
@@ -1925,7 +1926,7 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	}
 	RankSet Rc = coarse_of(R);
 	cheb_smooth<T>(R, b, x, deg, ratio, true);
-	if (std::is_same<T, float>::value && smooth_fused_ok(R)) {  // mg_r = b - A x in one launch
+	if (smooth_fused_ok(R)) {  // mg_r = b - A x in one launch
 		halo_exchange(R, x);
 		for (fi_ctx* c : R) { stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, true, c->mg_r.p, 0.0, 0.0, 0.0); }
 	} else {

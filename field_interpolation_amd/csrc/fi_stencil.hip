@@ -1752,15 +1752,21 @@ void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 }
 
 // The recurrence step / residual on the FULL operator in one pass over the lattice (ChebEpi modes 2 and 3): the launches
-// of stencil_apply with the epilogue.  fp32 contexts whose data cells (if any) are fused into the marching kernel.
+// of stencil_apply with the epilogue.  3-D: fp32 contexts whose data cells (if any) are fused into the marching kernel;
+// 2-D: the tile kernel (fi_stencil2d.hip), both precisions.
 bool stencil_full_epi_available(const fi_ctx* c)
 {
-	return c->march.valid && !c->tile2.valid && c->dtype == FI_F32 && (c->cells.ncell == 0 || c->march.fused);
+	if (c->tile2.valid) { return tile2d_full_epi_available(c); }  // 2-D: the tile kernel, both precisions
+	return c->march.valid && c->dtype == FI_F32 && (c->cells.ncell == 0 || c->march.fused);
 }
 void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a,
                        double c1, double c2)
 {
 	FI_REQUIRE(stencil_full_epi_available(c), FI_ERR_UNSUPPORTED, "no fused recurrence step for this context");
+	if (c->tile2.valid) {
+		tile2d_full_step(c, z, zprev, r, residual, znew, a, c1, c2);
+		return;
+	}
 	const float* zf = static_cast<const float*>(z);
 	// a null z_prev is never used with its coefficient: z stands in
 	ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r), c->dinv16.as<unsigned short>(),

@@ -59,10 +59,24 @@ __device__ inline double wave_sum(double v)
 	return v;
 }
 
-template <typename T, bool HAS1, bool HAS2, bool CELLS>
+// Epilogue of the V-cycle's smoother (fi_solver.hip cheb_smooth_fused; the 3-D kernel's ChebEpi modes 2 and 3): instead of
+// storing q = A z the kernel stores  z_new = a z - c1 z_prev + c2 Dinv (r - q)  (residual: z_new = r - q), Dinv the
+// context's bfloat16 scaling.  z_prev may be z_new's own buffer (read and written by the point's owner only).
+template <typename T>
+struct Epi2 {
+	const T* zprev;
+	const T* r;
+	const unsigned short* dinv;
+	T*       znew;
+	T        a, c1, c2;
+	int      residual;
+};
+
+template <typename T, bool HAS1, bool HAS2, bool CELLS, bool EPI = false>
 __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<T> C, CellList2 L,
                                                             const T* __restrict__ x, T* __restrict__ y,
-                                                            double* __restrict__ partial, const int* __restrict__ done)
+                                                            double* __restrict__ partial, const int* __restrict__ done,
+                                                            Epi2<T> E = Epi2<T>{})
 {
 	using V = typename VecOf<T>::V;
 	constexpr int VX   = VecOf<T>::VX;
@@ -250,6 +264,24 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 			for (int j = 0; j < VX; ++j) { po[j] += pv[j]; }
 		}
 	}
+	if (EPI) {
+		T* const dst = E.znew + static_cast<int64_t>(lyr) * P.nx + gx;
+		for (int j = 0; j < VX; ++j) {  // (point by point: rows need not be 16-byte multiples)
+			if (j < nvalid) {
+				const int64_t i = static_cast<int64_t>(lyr) * P.nx + gx + j;
+				const T rv = E.r[i];
+				T zn;
+				if (E.residual) {
+					zn = rv - po[j];
+				} else {
+					const T dv = static_cast<T>(__uint_as_float(static_cast<unsigned int>(E.dinv[i]) << 16));
+					zn = E.a * pc[j] - E.c1 * E.zprev[i] + E.c2 * (dv * (rv - po[j]));
+				}
+				dst[j] = zn;
+			}
+		}
+		return;  // (no partials: the smoother takes no dot products)
+	}
 #pragma unroll
 	for (int j = 0; j < VX; ++j) { dsum += pc[j] * po[j]; }
 	double dot = 0.0;
@@ -408,7 +440,7 @@ void build_lists2(fi_ctx* c)
 }
 
 template <typename T, bool CELLS>
-void tile2_launch(fi_ctx* c, const T* x, T* y, double* partial)
+void tile2_launch(fi_ctx* c, const T* x, T* y, double* partial, const Epi2<T>* epi = nullptr)
 {
 	const Tile2State& m = c->tile2;
 	Coef2<T> C;
@@ -423,15 +455,26 @@ void tile2_launch(fi_ctx* c, const T* x, T* y, double* partial)
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
 	const int  grid = ((m.P.ntiles + 7) / 8) * 8;
 	const bool h1 = w.model_1 > 0, h2 = w.model_2 > 0;
-	if (h1 && h2) {
+	if (epi) {
+		if (h1 && h2) {
+			hipLaunchKernelGGL((k_apply_tile2d<T, true, true, CELLS, true>), dim3(grid), dim3(kThreads), 0, c->stream, m.P, C, L, x, y,
+			                   partial, done, *epi);
+		} else if (h2) {
+			hipLaunchKernelGGL((k_apply_tile2d<T, false, true, CELLS, true>), dim3(grid), dim3(kThreads), 0, c->stream, m.P, C, L, x, y,
+			                   partial, done, *epi);
+		} else {
+			hipLaunchKernelGGL((k_apply_tile2d<T, true, false, CELLS, true>), dim3(grid), dim3(kThreads), 0, c->stream, m.P, C, L, x, y,
+			                   partial, done, *epi);
+		}
+	} else if (h1 && h2) {
 		hipLaunchKernelGGL((k_apply_tile2d<T, true, true, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, m.P, C, L, x, y,
-		                   partial, done);
+		                   partial, done, Epi2<T>{});
 	} else if (h2) {
 		hipLaunchKernelGGL((k_apply_tile2d<T, false, true, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, m.P, C, L, x, y,
-		                   partial, done);
+		                   partial, done, Epi2<T>{});
 	} else {
 		hipLaunchKernelGGL((k_apply_tile2d<T, true, false, CELLS>), dim3(grid), dim3(kThreads), 0, c->stream, m.P, C, L, x, y,
-		                   partial, done);
+		                   partial, done, Epi2<T>{});
 	}
 	FI_HIP_TRY(hipGetLastError());
 }
@@ -452,6 +495,25 @@ void tile2d_prepare(fi_ctx* c)
 }
 
 int tile2d_partials(const fi_ctx* c) { return c->tile2.valid ? c->tile2.P.ntiles : 0; }
+
+// z_new = a z - c1 z_prev + c2 Dinv (r - A z)  (residual: z_new = r - A z) in one launch; z with valid ghost rows
+bool tile2d_full_epi_available(const fi_ctx* c) { return c->tile2.valid && (c->cells.ncell == 0 || c->tile2.fused); }
+template <typename T>
+static void tile2_full_step_t(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a,
+                              double c1, double c2)
+{
+	Epi2<T> E{static_cast<const T*>(zprev ? zprev : z), static_cast<const T*>(r), c->dinv16.as<unsigned short>(),
+	          static_cast<T*>(znew), static_cast<T>(a), static_cast<T>(zprev ? c1 : 0.0), static_cast<T>(c2), residual ? 1 : 0};
+	c->tile2.fused ? tile2_launch<T, true>(c, static_cast<const T*>(z), nullptr, nullptr, &E)
+	               : tile2_launch<T, false>(c, static_cast<const T*>(z), nullptr, nullptr, &E);
+}
+void tile2d_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a, double c1,
+                      double c2)
+{
+	FI_REQUIRE(tile2d_full_epi_available(c), FI_ERR_UNSUPPORTED, "no fused recurrence step for this context");
+	c->dtype == FI_F64 ? tile2_full_step_t<double>(c, z, zprev, r, residual, znew, a, c1, c2)
+	                   : tile2_full_step_t<float>(c, z, zprev, r, residual, znew, a, c1, c2);
+}
 
 bool tile2d_apply(fi_ctx* c, const void* x, void* y, double* partial)
 {

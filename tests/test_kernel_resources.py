@@ -64,7 +64,7 @@ def test_marching_kernel_budget():
 
 def test_tile2d_kernel_budget():
     rep = _variants(_report("fi_stencil2d.usage.txt"), "k_apply_tile2d")
-    assert len(rep) == 12
+    assert len(rep) == 24          # the 12 of round 1, and again with the smoother's epilogue
     for name, r in rep.items():
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, name
         assert r["VGPRs"] <= 128 and r["LDS Size [bytes/block]"] <= 40 * 1024, name
