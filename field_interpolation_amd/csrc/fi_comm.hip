@@ -223,6 +223,8 @@ void allreduce_sum(fi_ctx* c, double* dev, int count)
 	FI_NCCL_TRY(rccl().AllReduce(dev, dev, static_cast<size_t>(count), ncclFloat64, ncclSum, c->comm->comm, c->stream));
 }
 
+bool comm_ready(const fi_ctx* c) { return c->comm && (c->comm->comm || c->comm->host); }
+
 void exchange_halo(fi_ctx* c, void* v) { exchange_halo_on(c, v, c->stream); }
 
 void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream)

@@ -256,6 +256,8 @@ struct fi_ctx {
 	// operator pieces (T arrays over local storage)
 	fi::DevBuf atb, diag, dinv;
 	fi::DevBuf dinv16;  // dinv truncated to bfloat16 (k_invert_diag): the scaling of the epilogue recurrences
+	bool       scaling_ghosts = false;  // slabs: the ghost planes of diag / dinv / dinv16 hold the neighbours' values
+	                                    // (exchanged by operator_prepare when a transport exists)
 	// solver vectors
 	fi::DevBuf x, r, p, q;
 	// multigrid work vectors of this level: V-cycle rhs / result, smoother residual and direction
@@ -306,6 +308,7 @@ double apply_algorithmic_bytes(const fi_ctx* c);
 void error_map(fi_ctx* c, const void* x, void* out);                 // generate_error_map; x with valid ghost planes
 void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.hip
 void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream);       // the same on another stream
+bool comm_ready(const fi_ctx* c);                                   // a transport exists (fi_comm_init / fi_comm_init_host)
 
 // fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
 void stencil_prepare(fi_ctx* c);   // after assemble(): tiling + per-workgroup cell lists

@@ -324,7 +324,15 @@ void prepare_dim(fi_ctx* c)
 	hipLaunchKernelGGL((k_model_diag<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g, mc,
 	                   c->diag.as<T>(), whole ? c->dinv.as<T>() : static_cast<T*>(nullptr),
 	                   whole ? c->dinv16.as<unsigned short>() : static_cast<unsigned short*>(nullptr));
+	c->scaling_ghosts = false;
 	if (!whole) {
+		// one slab per process: the neighbours' diagonal on the ghost planes, so that the scaling there is theirs (the
+		// polynomial's first step forms its operand from r and the scaling, ghost planes included).  A collective: every
+		// rank assembles the same levels in the same order.
+		if (c->nranks > 1 && comm_ready(c)) {
+			exchange_halo(c, c->diag.p);
+			c->scaling_ghosts = true;
+		}
 		hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc,
 		                   c->diag.as<T>(), c->dinv.as<T>(), c->dinv16.as<unsigned short>());
 	}

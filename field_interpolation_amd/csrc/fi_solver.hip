@@ -2606,10 +2606,11 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		return (c->g.own_first % N == 0) && (c->g.nown % N == 0);
 	};
 	const bool single = R.size() == 1 && c0->nranks == 1;
-	// undivided lattice, 3 terms or more: the first step of the polynomial reads r and the scaling and forms z_0 as it
-	// loads them (fi_stencil.hip, PRO) -- k_pcg_resid then stores no z_0, and step 2 recomputes it as its z_prev.  (Slabs
-	// keep z_0: the scaling's ghost planes are not the neighbour's values.)
-	const bool z0_on_load = single && terms > 2 && !test_switch("FI_NO_Z0_ON_LOAD");
+	// 3 terms or more: the first step of the polynomial reads r and the scaling and forms z_0 as it loads them
+	// (fi_stencil.hip, PRO) -- k_pcg_resid then stores no z_0, and step 2 recomputes it as its z_prev.  One slab per
+	// process: the ghost planes of r are exchanged instead of z_0's, those of the scaling came with the assembly
+	// (operator_prepare); the loop-back group (no transport at assembly time) keeps the stored z_0.
+	const bool z0_on_load = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && !test_switch("FI_NO_Z0_ON_LOAD");
 	// Undivided lattice: the sums of the per-workgroup partials (p.q; r.r, r.z) are folded into their consumers (every
 	// workgroup sums the 1-4 k partials in the same fixed order); rank sets form them once, by a one-block kernel in
 	// front of the all-reduce.  Measured at 256^3 with both forms (profiles/r2_ablation.md section 6): folded 10.65 ms
@@ -2670,8 +2671,9 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			const bool sample = phase == 1 && k == terms - 1 && c0->level == 0 && psamples < kPolySamples && (tag & 3) == 3 &&
 			                    !tuning_switch("FI_NO_SAMPLES");
 			const bool overlap = R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
-			const bool pro = z0_on_load && k == 1;  // single rank: no ghost planes to exchange
-			if (overlap) { exchange_begin(c0, (c0->*zin).p); } else if (!pro) { halo_exchange(R, zin); }
+			const bool pro = z0_on_load && k == 1;
+			const Vec  zsrc = pro ? static_cast<Vec>(&fi_ctx::r) : zin;  // the vector whose ghost planes the step reads
+			if (overlap) { exchange_begin(c0, (c0->*zsrc).p); } else { halo_exchange(R, zsrc); }
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(pev[2 * psamples], st));
 				ptags.push_back(tag);
@@ -2681,7 +2683,13 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 				// the second step's z_prev is z_0 = Dinv r / theta: recomputed from r and Dinv, which the step reads anyway
 				const double zs = k == 2 ? 1.0 / theta : 0.0;
 				if (pro) {
-					stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 0, 0.0, 1.0 / theta);
+					if (overlap) {
+						stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 1, 0.0, 1.0 / theta);
+						exchange_wait(c);
+						stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 2, 0.0, 1.0 / theta);
+					} else {
+						stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 0, 0.0, 1.0 / theta);
+					}
 					continue;
 				}
 				if (overlap) {  // the workgroups that read no ghost plane, then the first and last z-chunk
