@@ -705,14 +705,14 @@ __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __r
 }
 // Cubic interpolation for the coarse-to-fine START (not the V-cycle: its P must stay the transpose of R): a fine point
 // between two coarse points takes (-1, 9, 9, -1) / 16 of the four nearest along that axis (indices clamped at the
-// lattice's ends), a coincident one the coarse value.  Undivided 3-D lattices.
+// lattice's ends), a coincident one the coarse value.  3-D lattices; slabs need two ghost planes of the coarse solution.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine)
 {
 	const int t  = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
 	const int fx = 2 * t;
 	if (fx >= L.nf[0]) { return; }
-	const int fy = static_cast<int>(blockIdx.y), fz = static_cast<int>(blockIdx.z);
+	const int fy = static_cast<int>(blockIdx.y), fz = static_cast<int>(blockIdx.z) + L.f_z0;  // global plane
 	auto clampi = [](int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); };
 	// taps of one axis: 4 coarse indices and weights (an even fine index puts all weight on the second)
 	auto taps = [&](int f, int nc, int* idx, T* w) {
@@ -739,13 +739,13 @@ __global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const 
 		for (int ky = 0; ky < 4; ++ky) {
 			const T wyz = wy[ky] * wz[kz];
 			if (wyz == T(0)) { continue; }
-			const T* row = coarse + csz * iz[kz] + csy * iy[ky];
+			const T* row = coarse + csz * (iz[kz] - L.c_base) + csy * iy[ky];  // slabs: two ghost planes hold the neighbours' values
 			const T c0 = row[ix[0]], c1 = row[ix[1]], c2 = row[ix[2]], c3 = row[ix[3]];
 			even += wyz * c1;
 			odd += wyz * (wx[0] * c0 + wx[1] * c1 + wx[2] * c2 + wx[3] * c3);
 		}
 	}
-	const int64_t i = (static_cast<int64_t>(fz) * L.nf[1] + fy) * L.nf[0] + fx;
+	const int64_t i = (static_cast<int64_t>(fz - L.f_base) * L.nf[1] + fy) * L.nf[0] + fx;
 	fine[i] = even;
 	if (fx + 1 < L.nf[0]) { fine[i + 1] = odd; }
 }
@@ -1330,11 +1330,11 @@ void cascade_guess(RankSet& R)
 			const LevelPair L = level_pair(lf[i], lc[i]);
 			// cubic where the coarse vector stays in cache (64 taps per pair of fine points): 256^3 from 128^3 20 -> 19
 			// outer iterations; at 512^3 the kernel would cost more than the start it improves
-			const bool cubic = L.ndim == 3 && lf.size() == 1 && lf[i]->nranks == 1 && !test_switch("FI_LINEAR_START") &&
+			const bool cubic = L.ndim == 3 && (lf[i]->nranks == 1 || lc[i]->halo >= 2) && !test_switch("FI_LINEAR_START") &&
 			                   sizeof(T) * static_cast<size_t>(lc[i]->g.nloc) <= (32u << 20);
 			if (cubic) {
 				const int pairs = (L.nf[0] + 1) / 2;
-				hipLaunchKernelGGL((k_prolong3_cubic<T>), dim3((pairs + kThreads - 1) / kThreads, L.nf[1], L.nf[2]), dim3(kThreads), 0,
+				hipLaunchKernelGGL((k_prolong3_cubic<T>), dim3((pairs + kThreads - 1) / kThreads, L.nf[1], L.f_planes), dim3(kThreads), 0,
 				                   lf[i]->stream, L, lc[i]->x.as<T>(), lf[i]->x.as<T>());
 			} else {
 				launch_prolong<T>(L, lc[i]->x.as<T>(), lf[i]->x.as<T>(), 0, lf[i]->stream);
