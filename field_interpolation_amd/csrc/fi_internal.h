@@ -258,6 +258,8 @@ struct fi_ctx {
 	fi::DevBuf dinv16;  // dinv truncated to bfloat16 (k_invert_diag): the scaling of the epilogue recurrences
 	bool       scaling_ghosts = false;  // slabs: the ghost planes of diag / dinv / dinv16 hold the neighbours' values
 	                                    // (exchanged by operator_prepare when a transport exists)
+	bool       defer_scaling_exchange = false;  // a level built by fi_assemble's helper thread: the exchange is the
+	                                            // calling thread's to do (operator_finish_ghosts), after the join
 	// solver vectors
 	fi::DevBuf x, r, p, q;
 	// multigrid work vectors of this level: V-cycle rhs / result, smoother residual and direction
@@ -309,6 +311,7 @@ void error_map(fi_ctx* c, const void* x, void* out);                 // generate
 void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.hip
 void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream);       // the same on another stream
 bool comm_ready(const fi_ctx* c);                                   // a transport exists (fi_comm_init / fi_comm_init_host)
+void operator_finish_ghosts(fi_ctx* c);  // the deferred exchange of the diagonal's ghost planes + the scaling over them
 
 // fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
 void stencil_prepare(fi_ctx* c);   // after assemble(): tiling + per-workgroup cell lists

@@ -329,7 +329,7 @@ void prepare_dim(fi_ctx* c)
 		// one slab per process: the neighbours' diagonal on the ghost planes, so that the scaling there is theirs (the
 		// polynomial's first step forms its operand from r and the scaling, ghost planes included).  A collective: every
 		// rank assembles the same levels in the same order.
-		if (c->nranks > 1 && comm_ready(c)) {
+		if (c->nranks > 1 && comm_ready(c) && !c->defer_scaling_exchange) {
 			exchange_halo(c, c->diag.p);
 			c->scaling_ghosts = true;
 		}
@@ -337,6 +337,17 @@ void prepare_dim(fi_ctx* c)
 		                   c->diag.as<T>(), c->dinv.as<T>(), c->dinv16.as<unsigned short>());
 	}
 	FI_HIP_TRY(hipGetLastError());
+}
+
+template <typename T>
+void finish_ghosts_t(fi_ctx* c)
+{
+	const Geom& g = c->g;
+	exchange_halo(c, c->diag.p);
+	hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc, c->diag.as<T>(),
+	                   c->dinv.as<T>(), c->dinv16.as<unsigned short>());
+	FI_HIP_TRY(hipGetLastError());
+	c->scaling_ghosts = true;
 }
 
 template <int D, typename T>
@@ -536,6 +547,13 @@ void error_map(fi_ctx* c, const void* x, void* out)
 		    : error_map_dim<3, float>(c, static_cast<const float*>(x), static_cast<float*>(out));
 		break;
 	}
+}
+
+void operator_finish_ghosts(fi_ctx* c)
+{
+	c->defer_scaling_exchange = false;
+	if (c->nranks <= 1 || !comm_ready(c) || c->g.nown == c->g.nloc) { return; }
+	c->dtype == FI_F64 ? finish_ghosts_t<double>(c) : finish_ghosts_t<float>(c);
 }
 
 void operator_prepare(fi_ctx* c)

@@ -3163,6 +3163,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		}
 		co->comm = c->comm;
 		co->stream = build_stream ? build_stream : c->stream;
+		co->defer_scaling_exchange = build_stream != nullptr;  // a helper thread never talks to the neighbours
 		const float vol = static_cast<float>(1 << D);
 		fi_weights w = fine->w;
 		w.model_0 = fine->w.model_0 * std::sqrt(vol);
@@ -3618,9 +3619,10 @@ int fi_assemble(fi_ctx* c)
 	}
 	// The coarser levels are problems of their own, assembled from the same point batches: a helper thread builds them on
 	// a second stream while this one assembles the finest level (both are chains of small launches with host round trips
-	// for list sizes; 256^3 with one coarser level: 2.05 -> 1.4 ms).  Undivided lattices without triplet rows; the
-	// helper's failure is re-raised here.
-	const bool beside = c->levels_wanted > 0 && c->nranks == 1 && c->generic.ntrip == 0 && !(c->mixed && c->dtype == FI_F64) &&
+	// for list sizes; 256^3 with one coarser level: 2.05 -> 1.6 ms).  Contexts without triplet rows; the
+	// helper's failure is re-raised here.  The helper does no communication: over slabs the levels' exchange of the
+	// diagonal's ghost planes is done below, by this thread.
+	const bool beside = c->levels_wanted > 0 && c->generic.ntrip == 0 && !(c->mixed && c->dtype == FI_F64) &&
 	                    !fi::test_switch("FI_SERIAL_LEVELS");
 	if (beside) {
 		if (!c->level_stream) {
@@ -3664,6 +3666,8 @@ int fi_assemble(fi_ctx* c)
 		}
 		FI_HIP_TRY(hipEventRecord(c->ev_level, c->level_stream));
 		FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_level, 0));
+		// slabs: the levels' share of the assembly's one exchange (the diagonal's ghost planes), in level order on every rank
+		for (fi_ctx* l = c->coarse; l; l = l->coarse) { fi::operator_finish_ghosts(l); }
 	} else {
 	fi::assemble(c);
 	fi::generic_assemble(c);
