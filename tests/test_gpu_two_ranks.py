@@ -26,9 +26,16 @@ def _free_port():
 
 def _torchrun(args, timeout=600, **extra_env):
     env = dict(os.environ, FI_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port())] + args
-    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    r = None
+    for _ in range(3):
+        # the port was free a moment ago; the rendezvous can still lose it to somebody else (EADDRINUSE comes before
+        # any rank has touched the GPU: the launcher is simply started again on another port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    return r
 
 
 def _worker_results(**extra_env):
