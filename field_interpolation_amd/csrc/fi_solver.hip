@@ -3633,7 +3633,7 @@ int fi_assemble(fi_ctx* c)
 		FI_HIP_TRY(hipStreamWaitEvent(c->level_stream, c->ev_level, 0));
 		int         helper_code = FI_OK;
 		std::string helper_msg;
-		std::thread helper([&]() {
+		auto build = [&]() {
 			try {
 				FI_HIP_TRY(hipSetDevice(c->device));
 				fi::build_levels(c, nullptr, c->level_stream);
@@ -3644,7 +3644,12 @@ int fi_assemble(fi_ctx* c)
 				helper_code = FI_ERR_HIP;
 				helper_msg  = "unexpected exception while building the coarser levels";
 			}
-		});
+		};
+		std::thread helper;
+		try {
+			helper = std::thread(build);
+		} catch (...) {  // no thread to be had: the levels are built below, after the finest level, on their stream
+		}
 		int main_code = FI_OK;
 		try {
 			fi::assemble(c);
@@ -3657,7 +3662,7 @@ int fi_assemble(fi_ctx* c)
 			main_code = FI_ERR_HIP;
 			fi::set_error("unexpected exception while assembling the finest level");
 		}
-		helper.join();
+		if (helper.joinable()) { helper.join(); } else if (main_code == FI_OK) { build(); }
 		for (fi_ctx* l = c->coarse; l; l = l->coarse) { l->stream = c->stream; }
 		if (main_code != FI_OK) { throw fi::Fail{main_code}; }
 		if (helper_code != FI_OK) {
