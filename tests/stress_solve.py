@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised solver sweep (run on the GPU box): small well-posed problems, every solver mode (plain Jacobi-PCG,
-coarse-to-fine cascade, V-cycle preconditioned CG, mixed precision, slabs through the loop-back group), the
+coarse-to-fine cascade, V-cycle preconditioned CG, mixed precision, polynomial preconditioner, slabs through the loop-back group), the
 solution against the oracle's float64 direct solve of the same rows.  usage: stress_solve.py [cases] [first seed]"""
 import os
 import sys
@@ -46,6 +46,10 @@ def one_case(seed):
     f.add_field_constraints(w)
     f.add_points(w.data_pos, w.value_kernel, w.data_gradient if sdf else 0.0, w.gradient_kernel, pos, nrm if sdf else None, None,
                  values=val)
+    poly = int(rng.choice([0, 0, 2, 3, 4, 6]))      # Chebyshev polynomial preconditioner (3-D lattices; ignored elsewhere)
+    if poly and mode in ("plain", "cascade"):
+        f.set_polynomial(poly)
+        desc += " poly %d" % poly
     if levels:
         f.set_levels(levels, 1e-4)
         f.set_multigrid(mode in ("mg", "mixed"))
