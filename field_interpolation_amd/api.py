@@ -295,6 +295,14 @@ class LatticeField:
         if ratio is not None:
             check(_capi.lib().fi_set_option(self._h, 7, float(ratio)))
 
+    def set_mg_smoother(self, polynomial=True, safe_factor=None):
+        """FI_OPT_MG_SMOOTHER / FI_OPT_MG_SAFE_FACTOR: the V-cycle's smoother on fp32 3-D levels -- the polynomial in
+        A_model + f diag(A_data) (default) or the Chebyshev polynomial in the full operator."""
+        check(_capi.lib().fi_set_option(self._h, 8, 1.0 if polynomial else 0.0))
+        if safe_factor is not None:
+            check(_capi.lib().fi_set_option(self._h, 9, float(safe_factor)))
+        self._dirty = True
+
     def jacobi(self, guess, num_iterations, weight):
         self._ready()
         g, kg, _kg = _buf(guess)
@@ -417,6 +425,10 @@ class LatticeGroup:
     def set_polynomial(self, terms, ratio=None):
         for m in self.members:
             m.set_polynomial(terms, ratio)
+
+    def set_mg_smoother(self, polynomial=True, safe_factor=None):
+        for m in self.members:
+            m.set_mg_smoother(polynomial, safe_factor)
 
     def assemble(self):
         check(_capi.lib().fi_group_assemble(self._g))

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 	bool  finite = true;
 	for (int d = 0; d < D; ++d) {
 		p[d]   = pos[i * D + d] * a.pos_scale;
+		if (g.pshift[d] != 0.0f) { p[d] += g.pshift[d]; }  // a level halved cell-centred along d
 		finite = finite && isfinite(p[d]);
 	}
 	const float w     = a.has_pw ? pw[i] : 1.0f;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_gradient_linear(Geom g, long 
 	float t[D];
 	bool  finite = true;
 	for (int d = 0; d < D; ++d) {
-		const float p  = pos[i * D + d] * pos_scale - 0.5f;
+		const float p  = (g.pshift[d] != 0.0f ? pos[i * D + d] * pos_scale + g.pshift[d] : pos[i * D + d] * pos_scale) - 0.5f;
 		finite = finite && isfinite(p);
 		const float fl = floorf(p);
 		const bool  in = fl >= -1.0f && fl <= static_cast<float>(g.gn[d]);

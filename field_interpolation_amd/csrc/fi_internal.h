@@ -97,6 +97,9 @@ struct Geom {
 	// extended cell grid (cell origins -1 .. size-1): local extents and the global origin of cell 0
 	int     cn[3];
 	int     coff[3];
+	// coarser levels: a data point at p on the caller's lattice sits at p / 2^level + pshift[d] on this one (non-zero along
+	// the axes that were halved cell-centred: fi_ctx::cc)
+	float   pshift[3];
 };
 
 // Coefficients of the model rows exactly as the reference stores them in A: fp32(stencil * weight)
@@ -248,6 +251,13 @@ struct fi_ctx {
 	fi_ctx*    coarse = nullptr;   // next coarser level
 	fi_ctx*    finer = nullptr;
 	int        level = 0;
+	// how this level was derived from the finer one, per axis.  1 (even fine extent n): cell-centred -- n / 2 coarse points,
+	// coarse point j halfway between fine 2j and 2j+1; every fine point interpolates (3/4, 1/4), the first and last
+	// extrapolate (5/4, -1/4).  0 (odd n): vertex-centred -- (n + 1) / 2 points, coarse j ON fine 2j.  An even extent halved
+	// vertex-centred leaves the last fine point beyond the last coarse one: its constant extrapolation costs the V-cycle
+	// a factor 3 in its condition number (tools/proto_multilevel.py: lattice-edge modes at 0.31 and 1.98 against 0.62 .. 1.18)
+	int        cc[3] = {0, 0, 0};
+	float      pos_shift[3] = {0, 0, 0};
 	fi::CellData              cells;
 	fi::MarchState            march;
 	fi::Tile2State            tile2;
@@ -256,6 +266,13 @@ struct fi_ctx {
 	// operator pieces (T arrays over local storage)
 	fi::DevBuf atb, diag, dinv;
 	fi::DevBuf dinv16;  // dinv truncated to bfloat16 (k_invert_diag): the scaling of the epilogue recurrences
+	// the V-cycle's polynomial smoother (fi_solver.hip, poly_smooth) scales by 1 / (m + f d), m = the model diagonal, d = the
+	// data diagonal: a cell block sum a a^T is bounded by 2^D diag(a_i^2), so A <= A_model + 2^D diag(A_data) and the
+	// polynomial in that operator is a convergent smoother of A whatever the data (f = mg_safe)
+	fi::DevBuf dinv16s;
+	bool       dinv16s_valid = false;
+	double     mg_safe = 4.0;
+	int        mg_smoother = 1;   // 1: the polynomial in A_model + f diag(A_data) where the marching kernel runs it; 0: Chebyshev in A
 	bool       scaling_ghosts = false;  // slabs: the ghost planes of diag / dinv / dinv16 hold the neighbours' values
 	                                    // (exchanged by operator_prepare when a transport exists)
 	bool       defer_scaling_exchange = false;  // a level built by fi_assemble's helper thread: the exchange is the
@@ -312,6 +329,7 @@ void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.
 void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream);       // the same on another stream
 bool comm_ready(const fi_ctx* c);                                   // a transport exists (fi_comm_init / fi_comm_init_host)
 void operator_finish_ghosts(fi_ctx* c);  // the deferred exchange of the diagonal's ghost planes + the scaling over them
+void prepare_safe_scaling(fi_ctx* c);    // dinv16s (see fi_ctx) from diag and the model diagonal, ghost planes included
 
 // fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
 void stencil_prepare(fi_ctx* c);   // after assemble(): tiling + per-workgroup cell lists
@@ -327,7 +345,8 @@ bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also a
 bool stencil_cheb_available(const fi_ctx* c);
 int  stencil_cheb_partials(const fi_ctx* c);
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part = 0, double zprev_scale = 0.0, double pro_scale = 0.0);
+                       double* partial, int part = 0, double zprev_scale = 0.0, double pro_scale = 0.0,
+                       const unsigned short* scaling = nullptr);  // scaling: bfloat16 array (default: the context's dinv16)
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 // z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the
 // marching kernel(s) over the lattice; z with valid ghost planes.  Dinv is the context's bfloat16 copy (dinv16).

@@ -279,6 +279,36 @@ __global__ __launch_bounds__(kThreads) void k_invert_diag(int64_t n, const T* __
 
 inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
 
+// The scaling of the V-cycle's polynomial smoother (fi_ctx::dinv16s): bfloat16 of 1 / (m + f (diag - m)), m = the model
+// diagonal from the global coordinates (as k_model_diag), over ALL local points: the ghost planes of `diag` hold the
+// neighbours' values where the scaling is read there (fi_ctx::scaling_ghosts).  Truncated like dinv16: never above.
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void k_safe_scaling(Geom g, ModelCoef<T> mc, const T* __restrict__ diag, T factor,
+                                                           unsigned short* __restrict__ d16)
+{
+	const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (idx >= g.nloc) { return; }
+	int64_t o = idx;
+	T m = 0;
+	for (int d = 0; d < D; ++d) {
+		const int c = static_cast<int>(o % g.n[d]) + g.off[d], n = g.gn[d];
+		o /= g.n[d];
+		if (mc.on[0]) { m += mc.w0sq; }
+		for (int k = 1; k <= 4; ++k) {
+			if (!mc.on[k]) { continue; }
+			for (int j = 0; j <= k; ++j) {
+				const int a = c - j;
+				if (a >= 0 && a + k < n) { m += mc.c[k][j] * mc.c[k][j]; }
+			}
+		}
+	}
+	const T dg = diag[idx];
+	const T dd = dg > m ? dg - m : T(0);
+	const T s  = m + factor * dd;
+	const T v  = (s > T(0)) ? T(1) / s : T(1);
+	d16[idx] = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
+}
+
 // grid-stride launch width: enough blocks to fill 256 CUs x 8, few enough that the fixed-order sum of
 // the per-block dot-product partials stays a ~microsecond single-block kernel
 inline int capped_blocks(int64_t n)
@@ -348,6 +378,18 @@ void finish_ghosts_t(fi_ctx* c)
 	                   c->dinv.as<T>(), c->dinv16.as<unsigned short>());
 	FI_HIP_TRY(hipGetLastError());
 	c->scaling_ghosts = true;
+}
+
+template <int D, typename T>
+void safe_scaling_dim(fi_ctx* c)
+{
+	const Geom& g = c->g;
+	const ModelCoef<T> mc = make_coef<T>(c->w);
+	c->dinv16s.alloc(sizeof(unsigned short) * g.nloc);
+	hipLaunchKernelGGL((k_safe_scaling<D, T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g, mc, c->diag.as<T>(),
+	                   static_cast<T>(c->mg_safe), c->dinv16s.as<unsigned short>());
+	FI_HIP_TRY(hipGetLastError());
+	c->dinv16s_valid = true;
 }
 
 template <int D, typename T>
@@ -554,11 +596,23 @@ void operator_finish_ghosts(fi_ctx* c)
 	c->defer_scaling_exchange = false;
 	if (c->nranks <= 1 || !comm_ready(c) || c->g.nown == c->g.nloc) { return; }
 	c->dtype == FI_F64 ? finish_ghosts_t<double>(c) : finish_ghosts_t<float>(c);
+	c->dinv16s_valid = false;
+}
+
+void prepare_safe_scaling(fi_ctx* c)
+{
+	const bool f64 = c->dtype == FI_F64;
+	switch (c->g.ndim) {
+	case 1: f64 ? safe_scaling_dim<1, double>(c) : safe_scaling_dim<1, float>(c); break;
+	case 2: f64 ? safe_scaling_dim<2, double>(c) : safe_scaling_dim<2, float>(c); break;
+	default: f64 ? safe_scaling_dim<3, double>(c) : safe_scaling_dim<3, float>(c); break;
+	}
 }
 
 void operator_prepare(fi_ctx* c)
 {
 	const bool f64 = c->dtype == FI_F64;
+	c->dinv16s_valid = false;
 	switch (c->g.ndim) {
 	case 1: f64 ? prepare_dim<1, double>(c) : prepare_dim<1, float>(c); break;
 	case 2: f64 ? prepare_dim<2, double>(c) : prepare_dim<2, float>(c); break;

@@ -594,12 +594,16 @@ __global__ __launch_bounds__(kThreads) void k_upscale(UpscaleArgs a, int64_t nla
 	out[li] = (wsum == 0.0f) ? 0.0f : fsum / wsum;
 }
 
-// Coarse -> fine interpolation between two levels of the multilevel hierarchy: fine point 2i coincides with
-// coarse point i, odd fine points take the mean of their two coarse neighbours (the last one copies when the
-// neighbour does not exist).  One thread per fine point; mode 0: fine = P coarse, mode 1: fine += P coarse.
+// Coarse -> fine interpolation between two levels of the multilevel hierarchy, per axis (fi_ctx::cc):
+//   vertex-centred (odd fine extent): fine point 2i coincides with coarse point i, odd fine points take the mean of their
+//     two coarse neighbours (an even extent halved this way: the last fine point copies its only neighbour);
+//   cell-centred (even fine extent): coarse point j sits between fine 2j and 2j+1; fine 2j takes 3/4 of coarse j and
+//     1/4 of j-1, fine 2j+1 takes 3/4 of j and 1/4 of j+1; the first and the last fine point extrapolate (5/4, -1/4).
+// One thread per fine point; mode 0: fine = P coarse, mode 1: fine += P coarse.
 struct LevelPair {
 	int ndim;
 	int nf[3], nc[3];  // GLOBAL extents of the fine and the coarse lattice
+	int cc[3];         // the axis was halved cell-centred
 	// slabs (slowest axis L = ndim-1): the kernels walk `f_planes` owned fine planes starting at global plane
 	// f_z0 / `c_planes` owned coarse planes from c_z0; local storage of either level starts at global plane *_base
 	int f_z0, f_planes, f_base;
@@ -613,6 +617,7 @@ LevelPair level_pair(const fi_ctx* fine, const fi_ctx* coarse)
 	for (int d = 0; d < 3; ++d) {
 		L.nf[d] = fine->g.gn[d];
 		L.nc[d] = coarse->g.gn[d];
+		L.cc[d] = coarse->cc[d];
 	}
 	const int a = L.ndim - 1;
 	L.f_z0     = fine->g.off[a] + fine->g.own_lo[a];
@@ -623,6 +628,28 @@ LevelPair level_pair(const fi_ctx* fine, const fi_ctx* coarse)
 	L.c_base   = coarse->g.off[a];
 	return L;
 }
+
+// the two coarse points fine index f interpolates from along one axis, and their weights
+template <typename T>
+__device__ inline void prolong_taps(int f, int nc, int cc, int* i0, int* i1, T* w0, T* w1)
+{
+	const int j = f >> 1;
+	if (cc) {
+		const int nb = (f & 1) ? j + 1 : j - 1;
+		const bool in = nb >= 0 && nb < nc;
+		*i0 = j;
+		*i1 = in ? nb : ((f & 1) ? j - 1 : j + 1);
+		*w0 = in ? T(0.75) : T(1.25);
+		*w1 = in ? T(0.25) : T(-0.25);
+	} else {
+		const int c0 = j > nc - 1 ? nc - 1 : j;
+		*i0 = c0;
+		*i1 = c0 + 1 < nc ? c0 + 1 : c0;
+		*w1 = (f & 1) ? T(0.5) : T(0);
+		*w0 = T(1) - *w1;
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine,
                                                        int mode)
@@ -634,13 +661,8 @@ __global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, const T* __re
 	if (f[0] >= (a == 0 ? L.f_planes : L.nf[0])) { return; }
 	f[a] += L.f_z0;  // global coordinate along the decomposed axis
 	int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
-	T   w1[3] = {T(0), T(0), T(0)};
-	for (int d = 0; d < L.ndim; ++d) {
-		c0[d] = f[d] >> 1;
-		if (c0[d] > L.nc[d] - 1) { c0[d] = L.nc[d] - 1; }
-		c1[d] = (c0[d] + 1 < L.nc[d]) ? c0[d] + 1 : c0[d];
-		w1[d] = (f[d] & 1) ? T(0.5) : T(0);
-	}
+	T   w0[3] = {T(1), T(1), T(1)}, w1[3] = {T(0), T(0), T(0)};
+	for (int d = 0; d < L.ndim; ++d) { prolong_taps<T>(f[d], L.nc[d], L.cc[d], &c0[d], &c1[d], &w0[d], &w1[d]); }
 	c0[a] -= L.c_base;  // local plane indices of the coarse slab (ghost planes hold the neighbours' values)
 	c1[a] -= L.c_base;
 	f[a] -= L.f_base;
@@ -648,10 +670,10 @@ __global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, const T* __re
 	T acc = T(0);
 	for (int q = 0; q < (1 << L.ndim); ++q) {
 		const int ux = q & 1, uy = (q >> 1) & 1, uz = (q >> 2) & 1;
-		T w = ux ? w1[0] : T(1) - w1[0];
+		T w = ux ? w1[0] : w0[0];
 		int64_t idx = ux ? c1[0] : c0[0];
-		if (L.ndim > 1) { w *= uy ? w1[1] : T(1) - w1[1]; idx += csy * (uy ? c1[1] : c0[1]); }
-		if (L.ndim > 2) { w *= uz ? w1[2] : T(1) - w1[2]; idx += csz * (uz ? c1[2] : c0[2]); }
+		if (L.ndim > 1) { w *= uy ? w1[1] : w0[1]; idx += csy * (uy ? c1[1] : c0[1]); }
+		if (L.ndim > 2) { w *= uz ? w1[2] : w0[2]; idx += csz * (uz ? c1[2] : c0[2]); }
 		if (w != T(0)) { acc += w * coarse[idx]; }
 	}
 	const int64_t i = (L.ndim > 2 ? static_cast<int64_t>(f[2]) * L.nf[1] * L.nf[0] : 0) +
@@ -661,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, const T* __re
 
 // The same for 3-D lattices with everything resolved at compile time (the generic kernel indexes its coordinate
 // arrays by the runtime axis: they live in scratch memory -- 1.15 ms per call at 512^3 against 0.3 ms here).  A thread
-// owns the fine points 2t and 2t+1 of a row: both read coarse t, the odd one also t+1.
+// owns the fine points 2t and 2t+1 of a row.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine,
                                                         int mode)
@@ -671,41 +693,66 @@ __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __r
 	if (fx >= L.nf[0]) { return; }
 	const int fy = static_cast<int>(blockIdx.y);
 	const int fz = static_cast<int>(blockIdx.z) + L.f_z0;  // global plane
-	const int cx0 = t > L.nc[0] - 1 ? L.nc[0] - 1 : t;
-	const int cx1 = cx0 + 1 < L.nc[0] ? cx0 + 1 : cx0;
-	int cy0 = fy >> 1;
-	if (cy0 > L.nc[1] - 1) { cy0 = L.nc[1] - 1; }
-	const int cy1 = cy0 + 1 < L.nc[1] ? cy0 + 1 : cy0;
-	int cz0 = fz >> 1;
-	if (cz0 > L.nc[2] - 1) { cz0 = L.nc[2] - 1; }
-	const int cz1 = cz0 + 1 < L.nc[2] ? cz0 + 1 : cz0;
-	const T wy = (fy & 1) ? T(0.5) : T(0), wz = (fz & 1) ? T(0.5) : T(0);
+	int xe0, xe1, xo0, xo1, cy[2], cz[2];
+	T   we0, we1, wo0, wo1, wy[2], wz[2];
+	prolong_taps<T>(fx, L.nc[0], L.cc[0], &xe0, &xe1, &we0, &we1);
+	prolong_taps<T>(fx + 1 < L.nf[0] ? fx + 1 : fx, L.nc[0], L.cc[0], &xo0, &xo1, &wo0, &wo1);
+	prolong_taps<T>(fy, L.nc[1], L.cc[1], &cy[0], &cy[1], &wy[0], &wy[1]);
+	prolong_taps<T>(fz, L.nc[2], L.cc[2], &cz[0], &cz[1], &wz[0], &wz[1]);
 	const int64_t csy = L.nc[0], csz = static_cast<int64_t>(L.nc[0]) * L.nc[1];
-	// the generic kernel's order of summation: x fastest, then y, then z; zero weights skipped
 	T even = T(0), odd = T(0);
 #pragma unroll
 	for (int uz = 0; uz < 2; ++uz) {
-		const T     wz_ = uz ? wz : T(1) - wz;
-		const int64_t oz = csz * ((uz ? cz1 : cz0) - L.c_base);
+		const int64_t oz = csz * (cz[uz] - L.c_base);
 #pragma unroll
 		for (int uy = 0; uy < 2; ++uy) {
-			const T wyz = (uy ? wy : T(1) - wy) * wz_;
+			const T wyz = wy[uy] * wz[uz];
 			if (wyz == T(0)) { continue; }
-			const int64_t o = oz + csy * (uy ? cy1 : cy0);
-			const T a = coarse[o + cx0], b = coarse[o + cx1];
-			// weights as the generic kernel forms them: ((wx * wy) * wz), wx in {1, 0.5}
-			even += (T(1) * (uy ? wy : T(1) - wy)) * wz_ * a;
-			odd += (T(0.5) * (uy ? wy : T(1) - wy)) * wz_ * a;
-			odd += (T(0.5) * (uy ? wy : T(1) - wy)) * wz_ * b;
+			const T* row = coarse + oz + csy * cy[uy];
+			even += wyz * (we0 * row[xe0] + we1 * row[xe1]);
+			odd += wyz * (wo0 * row[xo0] + wo1 * row[xo1]);
 		}
 	}
 	const int64_t i = (static_cast<int64_t>(fz - L.f_base) * L.nf[1] + fy) * L.nf[0] + fx;
 	fine[i] = mode ? fine[i] + even : even;
 	if (fx + 1 < L.nf[0]) { fine[i + 1] = mode ? fine[i + 1] + odd : odd; }
 }
-// Cubic interpolation for the coarse-to-fine START (not the V-cycle: its P must stay the transpose of R): a fine point
-// between two coarse points takes (-1, 9, 9, -1) / 16 of the four nearest along that axis (indices clamped at the
-// lattice's ends), a coincident one the coarse value.  3-D lattices; slabs need two ghost planes of the coarse solution.
+// Cubic interpolation for the coarse-to-fine START (not the V-cycle: its P must stay the transpose of R).  Vertex-centred
+// axis: a fine point between two coarse points takes (-1, 9, 9, -1) / 16 of the four nearest (indices clamped at the
+// lattice's ends), a coincident one the coarse value.  Cell-centred axis: a fine point sits a quarter of a coarse cell
+// from its coarse point j -- the cubic through j-1 .. j+2 at +1/4 (mirrored at -1/4); where the four taps do not fit
+// (first and last two fine points) the linear taps of k_prolong.  3-D lattices; slabs need two ghost planes of the
+// coarse solution.
+template <typename T>
+__device__ inline void cubic_taps(int f, int nc, int cc, int* idx, T* w)
+{
+	const int j = f >> 1;
+	if (!cc) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int v = j - 1 + k;
+			idx[k] = v < 0 ? 0 : (v > nc - 1 ? nc - 1 : v);
+		}
+		if (f & 1) {
+			w[0] = T(-1.0 / 16.0); w[1] = T(9.0 / 16.0); w[2] = T(9.0 / 16.0); w[3] = T(-1.0 / 16.0);
+		} else {
+			w[0] = T(0); w[1] = T(1); w[2] = T(0); w[3] = T(0);
+		}
+		return;
+	}
+	const int base = (f & 1) ? j - 1 : j - 2;
+	if (base >= 0 && base + 3 < nc) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { idx[k] = base + k; }
+		// Lagrange weights of the nodes -1, 0, 1, 2 at t = 1/4
+		const T a = T(-0.0546875), b = T(0.8203125), c = T(0.2734375), d = T(-0.0390625);
+		if (f & 1) { w[0] = a; w[1] = b; w[2] = c; w[3] = d; } else { w[0] = d; w[1] = c; w[2] = b; w[3] = a; }
+	} else {
+		prolong_taps<T>(f, nc, 1, &idx[0], &idx[1], &w[0], &w[1]);
+		idx[2] = idx[3] = idx[0];
+		w[2] = w[3] = T(0);
+	}
+}
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine)
 {
@@ -713,23 +760,12 @@ __global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const 
 	const int fx = 2 * t;
 	if (fx >= L.nf[0]) { return; }
 	const int fy = static_cast<int>(blockIdx.y), fz = static_cast<int>(blockIdx.z) + L.f_z0;  // global plane
-	auto clampi = [](int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); };
-	// taps of one axis: 4 coarse indices and weights (an even fine index puts all weight on the second)
-	auto taps = [&](int f, int nc, int* idx, T* w) {
-		const int c = f >> 1;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { idx[k] = clampi(c - 1 + k, nc); }
-		if (f & 1) {
-			w[0] = T(-1.0 / 16.0); w[1] = T(9.0 / 16.0); w[2] = T(9.0 / 16.0); w[3] = T(-1.0 / 16.0);
-		} else {
-			w[0] = T(0); w[1] = T(1); w[2] = T(0); w[3] = T(0);
-		}
-	};
-	int ix[4], iy[4], iz[4];
-	T   wx[4], wy[4], wz[4];
-	taps(fx + 1, L.nc[0], ix, wx);  // the odd point of the pair; the even one is coarse ix[1]
-	taps(fy, L.nc[1], iy, wy);
-	taps(fz, L.nc[2], iz, wz);
+	int ie[4], io[4], iy[4], iz[4];
+	T   we[4], wo[4], wy[4], wz[4];
+	cubic_taps<T>(fx, L.nc[0], L.cc[0], ie, we);
+	cubic_taps<T>(fx + 1 < L.nf[0] ? fx + 1 : fx, L.nc[0], L.cc[0], io, wo);
+	cubic_taps<T>(fy, L.nc[1], L.cc[1], iy, wy);
+	cubic_taps<T>(fz, L.nc[2], L.cc[2], iz, wz);
 	const int64_t csy = L.nc[0], csz = static_cast<int64_t>(L.nc[0]) * L.nc[1];
 	T even = T(0), odd = T(0);
 #pragma unroll
@@ -740,9 +776,8 @@ __global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const 
 			const T wyz = wy[ky] * wz[kz];
 			if (wyz == T(0)) { continue; }
 			const T* row = coarse + csz * (iz[kz] - L.c_base) + csy * iy[ky];  // slabs: two ghost planes hold the neighbours' values
-			const T c0 = row[ix[0]], c1 = row[ix[1]], c2 = row[ix[2]], c3 = row[ix[3]];
-			even += wyz * c1;
-			odd += wyz * (wx[0] * c0 + wx[1] * c1 + wx[2] * c2 + wx[3] * c3);
+			even += wyz * (we[0] * row[ie[0]] + we[1] * row[ie[1]] + we[2] * row[ie[2]] + we[3] * row[ie[3]]);
+			odd += wyz * (wo[0] * row[io[0]] + wo[1] * row[io[1]] + wo[2] * row[io[2]] + wo[3] * row[io[3]]);
 		}
 	}
 	const int64_t i = (static_cast<int64_t>(fz - L.f_base) * L.nf[1] + fy) * L.nf[0] + fx;
@@ -789,6 +824,7 @@ void compute_geom(fi_ctx* c, int ndim, const int* sizes)
 		g.own_hi[d] = g.gn[d];
 		g.cn[d]     = d < ndim ? g.gn[d] + 1 : 1;
 		g.coff[d]   = d < ndim ? -1 : 0;
+		g.pshift[d] = c->pos_shift[d];
 	}
 	const int G = g.gn[L];
 	if (!c->slab_fixed) {
@@ -1281,6 +1317,8 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 bool poly_ok(const fi_ctx* c);
 template <typename T>
 void cg_run_poly(RankSet& R, int max_iterations, float tol);
+template <typename T>
+void estimate_poly_lambda(RankSet& R);
 
 // Coarse-to-fine start (the reference's own remedy for large lattices: solve a coarser lattice, upscale, use
 // as the guess -- src/sdf_field.cpp:272-288, README.md "My resolution is huge"): every coarser level is
@@ -1352,8 +1390,42 @@ void cascade_guess(RankSet& R)
 // coarse correction makes V symmetric positive definite, as CG needs.  lambda_max comes from 10 steps of the
 // power method per level at assemble time (one host read per level).
 
-// restriction = transpose of k_prolong: coarse point c gathers fine 2c (weight 1) and 2c-1, 2c+1 (weight 1/2;
-// the last coarse point also takes the full weight of a fine point beyond it)
+// restriction = transpose of k_prolong.  Vertex-centred axis: coarse point c gathers fine 2c (weight 1) and 2c-1, 2c+1
+// (weight 1/2; the last coarse point also takes the full weight of a fine point beyond it).  Cell-centred axis: fine
+// 2c-1 .. 2c+2 with (1/4, 3/4, 3/4, 1/4); the end points' extrapolation puts 5/4 of fine 0 on coarse 0 and -1/4 of it on
+// coarse 1 (mirrored at the other end): five taps.  Indices are relative to `base` and clamped where the weight is 0.
+constexpr int kRTaps = 5;
+template <typename T>
+__device__ inline void restrict_taps(int c, int nf, int nc, int cc, int base, int* f, T* w)
+{
+	if (cc) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int ff = 2 * c - 1 + k;
+			const bool in = ff >= 0 && ff < nf;
+			T ww = (k == 1 || k == 2) ? T(0.75) : T(0.25);
+			if (in && (ff == 0 || ff == nf - 1)) { ww = T(1.25); }  // c == 0 / c == nc - 1: the extrapolated end point
+			f[k] = (in ? ff : 2 * c) - base;
+			w[k] = in ? ww : T(0);
+		}
+		const bool lo = c == 1, hi = c == nc - 2;  // (extents >= 8: never both)
+		f[4] = (lo ? 0 : (hi ? nf - 1 : 2 * c)) - base;
+		w[4] = (lo || hi) ? T(-0.25) : T(0);
+	} else {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			const int ff = 2 * c + k - 1;
+			const bool in = ff >= 0 && ff < nf;
+			T ww = (k == 1) ? T(1) : T(0.5);
+			if (k == 2 && c + 1 >= nc && in) { ww = T(1); }  // fine point 2c+1 when coarse c+1 does not exist
+			f[k] = (in ? ff : 2 * c) - base;
+			w[k] = in ? ww : T(0);
+		}
+		f[3] = f[4] = 2 * c - base;
+		w[3] = w[4] = T(0);
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, const T* __restrict__ fine, T* __restrict__ coarse)
 {
@@ -1363,36 +1435,23 @@ __global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, const T* __r
 	            static_cast<int>(blockIdx.z)};
 	if (c[0] >= (a == 0 ? L.c_planes : L.nc[0])) { return; }
 	c[a] += L.c_z0;
-	int f[3][3];
-	T   w[3][3];
+	int f[3][kRTaps];
+	T   w[3][kRTaps];
 	for (int d = 0; d < 3; ++d) {
-		for (int k = 0; k < 3; ++k) { f[d][k] = 0; w[d][k] = (k == 1) ? T(1) : T(0); }
+		for (int k = 0; k < kRTaps; ++k) { f[d][k] = 0; w[d][k] = (k == 0) ? T(1) : T(0); }
 	}
-	for (int d = 0; d < L.ndim; ++d) {
-		for (int k = 0; k < 3; ++k) {
-			const int ff = 2 * c[d] + k - 1;
-			T ww = (k == 1) ? T(1) : T(0.5);
-			f[d][k] = ff;
-			if (ff < 0 || ff >= L.nf[d]) { ww = T(0); f[d][k] = (d == a) ? L.f_base : 0; }
-			// fine point 2c+1 when coarse c+1 does not exist: P put all of it on c
-			if (k == 2 && c[d] + 1 >= L.nc[d] && ff < L.nf[d]) { ww = T(1); }
-			w[d][k] = ww;
-			if (d == a) { f[d][k] -= L.f_base; }
-		}
-	}
+	for (int d = 0; d < L.ndim; ++d) { restrict_taps<T>(c[d], L.nf[d], L.nc[d], L.cc[d], d == a ? L.f_base : 0, f[d], w[d]); }
 	c[a] -= L.c_base;
 	const int64_t sy = L.nf[0];
 	const int64_t sz = static_cast<int64_t>(L.nf[0]) * L.nf[1];
 	T acc = T(0);
-	const int n1 = L.ndim > 1 ? 3 : 1, n2 = L.ndim > 2 ? 3 : 1;
+	const int n1 = L.ndim > 1 ? kRTaps : 1, n2 = L.ndim > 2 ? kRTaps : 1;
 	for (int k2 = 0; k2 < n2; ++k2) {
 		for (int k1 = 0; k1 < n1; ++k1) {
-			const int i1 = k1 + (n1 == 1), i2 = k2 + (n2 == 1);
-			const T w12 = (L.ndim > 1 ? w[1][i1] : T(1)) * (L.ndim > 2 ? w[2][i2] : T(1));
+			const T w12 = w[1][k1] * w[2][k2];
 			if (w12 == T(0)) { continue; }
-			const int64_t base = (L.ndim > 1 ? sy * f[1][i1] : 0) + (L.ndim > 2 ? sz * f[2][i2] : 0);
-#pragma unroll
-			for (int k0 = 0; k0 < 3; ++k0) {
+			const int64_t base = (L.ndim > 1 ? sy * f[1][k1] : 0) + (L.ndim > 2 ? sz * f[2][k2] : 0);
+			for (int k0 = 0; k0 < kRTaps; ++k0) {
 				if (w[0][k0] != T(0)) { acc += w[0][k0] * w12 * fine[base + f[0][k0]]; }
 			}
 		}
@@ -1410,36 +1469,24 @@ __global__ __launch_bounds__(kThreads) void k_restrict3(LevelPair L, const T* __
 	if (cx >= L.nc[0]) { return; }
 	const int cy = static_cast<int>(blockIdx.y);
 	const int cz = static_cast<int>(blockIdx.z) + L.c_z0;  // global plane
-	// per axis: fine index (clamped when its weight is zero) and weight of the three taps 2c-1, 2c, 2c+1
-	auto taps = [](int c, int nf, int nc, int base, int* f, T* w) {
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			const int ff = 2 * c + k - 1;
-			T ww = (k == 1) ? T(1) : T(0.5);
-			int fi_ = ff;
-			if (ff < 0 || ff >= nf) { ww = T(0); fi_ = base; }
-			if (k == 2 && c + 1 >= nc && ff < nf) { ww = T(1); }  // fine point 2c+1 when coarse c+1 does not exist
-			f[k] = fi_ - base;
-			w[k] = ww;
-		}
-	};
-	int fx[3], fy[3], fz[3];
-	T   wx[3], wy[3], wz[3];
-	taps(cx, L.nf[0], L.nc[0], 0, fx, wx);
-	taps(cy, L.nf[1], L.nc[1], 0, fy, wy);
-	taps(cz, L.nf[2], L.nc[2], L.f_base, fz, wz);
+	int fx[kRTaps], fy[kRTaps], fz[kRTaps];
+	T   wx[kRTaps], wy[kRTaps], wz[kRTaps];
+	restrict_taps<T>(cx, L.nf[0], L.nc[0], L.cc[0], 0, fx, wx);
+	restrict_taps<T>(cy, L.nf[1], L.nc[1], L.cc[1], 0, fy, wy);
+	restrict_taps<T>(cz, L.nf[2], L.nc[2], L.cc[2], L.f_base, fz, wz);
 	const int64_t sy = L.nf[0], sz = static_cast<int64_t>(L.nf[0]) * L.nf[1];
 	T acc = T(0);
 #pragma unroll
-	for (int k2 = 0; k2 < 3; ++k2) {
+	for (int k2 = 0; k2 < kRTaps; ++k2) {
+		if (wz[k2] == T(0)) { continue; }
 #pragma unroll
-		for (int k1 = 0; k1 < 3; ++k1) {
+		for (int k1 = 0; k1 < kRTaps; ++k1) {
 			const T w12 = wy[k1] * wz[k2];
 			if (w12 == T(0)) { continue; }
-			const int64_t base = sy * fy[k1] + sz * fz[k2];
+			const T* row = fine + sy * fy[k1] + sz * fz[k2];
 #pragma unroll
-			for (int k0 = 0; k0 < 3; ++k0) {
-				if (wx[k0] != T(0)) { acc += wx[k0] * w12 * fine[base + fx[k0]]; }
+			for (int k0 = 0; k0 < kRTaps; ++k0) {
+				if (wx[k0] != T(0)) { acc += wx[k0] * w12 * row[fx[k0]]; }
 			}
 		}
 	}
@@ -1908,6 +1955,80 @@ void cheb_smooth(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_z
 	}
 }
 
+// ---- the V-cycle's polynomial smoother ----------------------------------------------------------------------------
+// M = p_d(D^-1 A^) D^-1 with A^ = A_model + f diag(A_data), D = diag(A^): the polynomial of cg_run_poly's preconditioner
+// (same kernel, same recurrence: fi_stencil.hip ChebEpi mode 0) over an operator that BOUNDS the full one -- a cell's
+// block is sum a a^T <= 2^D diag(a_i^2), so with f = 2^D, A <= A^ and the spectrum of M A stays below 1 + eps < 2: a
+// convergent smoother whatever the data; f = mg_safe = 4 is the measured optimum (tools/proto_cc.py: 11 / 11 / 13
+// iterations for f = 2 / 4 / 8 on config 4, f = 1 diverges on dense data).  A smoothing pass is
+//     pre  (from zero):  x = M b                                   d - 1 plain launches of (2.5 .. 4.5) lattice passes
+//     post:              x += M (b - A x)                          one full apply with the residual epilogue + the same
+// against 2 d launches of the fused (data-cell) kernel with the epilogue for the Chebyshev smoother in A itself.
+int    mg_poly_terms() { const char* e = tuning_switch("FI_MG_TERMS"); return e && atoi(e) > 0 ? atoi(e) : 4; }
+template <typename T>
+bool poly_smoother_ok(const RankSet& R)
+{
+	if (sizeof(T) != 4 || test_switch("FI_MG_FULL_SMOOTHER")) { return false; }  // tests compare the two smoothers
+	for (const fi_ctx* c : R) {
+		if (c->mg_smoother != 1 || !c->march.valid || !stencil_cheb_available(c) || !stencil_full_epi_available(c) ||
+		    c->generic.ntrip != 0) {
+			return false;
+		}
+	}
+	return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_add_vec(int64_t n, const T* __restrict__ d, T* __restrict__ x)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += d[i];
+	}
+}
+
+// z = M r through the work vectors za / zb; returns the one that holds the result (ghost planes not exchanged)
+template <typename T>
+Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb)
+{
+	fi_ctx* c0 = R[0];
+	const int    terms = mg_poly_terms();
+	const double lam = c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0;
+	const double hi = 1.1 * lam, lo = hi / mg_ratio();
+	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	const bool single = R.size() == 1 && c0->nranks == 1;
+	const bool pro = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && !test_switch("FI_NO_Z0_ON_LOAD");
+	auto region2 = [](fi_ctx* c) { return c->partial.as<double>() + 2 * static_cast<size_t>(c->max_blocks); };
+	if (!pro) {
+		for (fi_ctx* c : R) {  // z_0 = Dinv r / theta
+			hipLaunchKernelGGL((k_cheb_first16<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   vown<T>(c, r), c->dinv16s.as<unsigned short>() + c->g.own_first, vown<T>(c, za),
+			                   static_cast<T>(1.0 / theta));
+		}
+	}
+	Vec zin = za, zout = zb;
+	double rho = 1.0 / sigma;
+	for (int k = 1; k < terms; ++k) {
+		const double rho_new = 1.0 / (2.0 * sigma - rho);
+		const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+		const bool   first_on_load = pro && k == 1;
+		halo_exchange(R, first_on_load ? r : zin);
+		for (fi_ctx* c : R) {
+			const unsigned short* sc = c->dinv16s.as<unsigned short>();
+			if (first_on_load) {
+				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc);
+			} else {
+				// the second step's z_prev is z_0 = Dinv r / theta, recomputed from r and the scaling
+				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0,
+				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc);
+			}
+		}
+		std::swap(zin, zout);
+		rho = rho_new;
+	}
+	return zin;
+}
+
 // x = V(b) on the level of R.  Over slabs every level is a slab decomposition of its own (coarse plane k lives
 // with fine plane 2k): restriction reads one ghost plane of the fine residual, interpolation one of the coarse
 // correction.
@@ -1920,11 +2041,49 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		cheb_smooth<T>(R, b, x, deg, ratio, true);
 		return;
 	}
-	if (!R[0]->coarse) {  // coarsest level: a longer polynomial over a wider band
+	const bool poly = poly_smoother_ok<T>(R);
+	auto residual = [&]() {  // mg_r = b - A x
+		halo_exchange(R, x);
+		for (fi_ctx* c : R) { stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, true, c->mg_r.p, 0.0, 0.0, 0.0); }
+	};
+	auto post_smooth = [&]() {  // x += M (b - A x)
+		residual();
+		const Vec d = poly_chain<T>(R, &fi_ctx::mg_r, &fi_ctx::mg_d, &fi_ctx::q);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_add_vec<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, d),
+			                   vown<T>(c, x));
+		}
+	};
+	if (!R[0]->coarse) {
+		// coarsest level: a longer polynomial over a wider band, in the full operator.  (Two sweeps of the polynomial
+		// smoother do as well where data pins every smooth mode -- config 4: tools/proto_cc.py -- but an SDF's coarsest
+		// level still has weakly held global modes: 97 instead of 37 iterations on the 40 x 32 x 48 test problem.)
+		if (poly && tuning_switch("FI_MG_COARSEST_POLY")) {
+			swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d));
+			post_smooth();
+			return;
+		}
 		cheb_smooth<T>(R, b, x, 4 * deg + 4, 10.0 * ratio, true);
 		return;
 	}
 	RankSet Rc = coarse_of(R);
+	if (poly) {
+		swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d));  // x = M b
+		residual();
+		halo_exchange(R, &fi_ctx::mg_r);
+		for (size_t i = 0; i < R.size(); ++i) {
+			const LevelPair L = level_pair(R[i], Rc[i]);
+			launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream);
+		}
+		vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
+		halo_exchange(Rc, &fi_ctx::mg_x);
+		for (size_t i = 0; i < R.size(); ++i) {
+			const LevelPair L = level_pair(R[i], Rc[i]);
+			launch_prolong<T>(L, vbase<T>(Rc[i], &fi_ctx::mg_x), vbase<T>(R[i], x), 1, R[i]->stream);
+		}
+		post_smooth();
+		return;
+	}
 	cheb_smooth<T>(R, b, x, deg, ratio, true);
 	if (smooth_fused_ok(R)) {  // mg_r = b - A x in one launch
 		halo_exchange(R, x);
@@ -1984,17 +2143,33 @@ void mg_prepare(RankSet& R, bool clear_finest)
 		if (!lev[0]->coarse) { break; }
 		lev = coarse_of(lev);
 	}
-	// smoother bounds: power method on every coarser level (once per assemble); the finest level (8x the work)
-	// takes the estimate of the level below it -- same operator family, and the interval has 10 % headroom
-	if (!(R[0]->lambda_max > 0) && R[0]->coarse) {
-		RankSet l = coarse_of(R);
-		while (!l.empty() && l[0]) {
-			estimate_lambda<T>(l);
-			if (!l[0]->coarse) { break; }
-			l = coarse_of(l);
+	// smoother bounds.  Levels that smooth with the polynomial in A_model + f diag(A_data) (poly_smoother_ok): the bound of
+	// the model operator (a number of the lattice and the weights: kept across assembles) and the scaling array.  The
+	// others (Chebyshev in the full operator; the coarsest level always): power method on Dinv A, once per assemble; a
+	// finest level of that kind (8x the work) takes the estimate of the level below it -- same operator family, and the
+	// interval has 10 % headroom.
+	if (!R[0]->coarse) { return; }
+	std::vector<RankSet> chain;
+	for (RankSet l = R;; l = coarse_of(l)) {
+		chain.push_back(l);
+		if (!l[0]->coarse) { break; }
+	}
+	for (size_t k = chain.size(); k-- > 0;) {
+		RankSet& l = chain[k];
+		const bool coarsest = k + 1 == chain.size();
+		if (poly_smoother_ok<T>(l) && (!coarsest || tuning_switch("FI_MG_COARSEST_POLY"))) {
+			if (!(l[0]->poly_lambda > 0)) { estimate_poly_lambda<T>(l); }
+			for (fi_ctx* c : l) {
+				if (!c->dinv16s_valid) { prepare_safe_scaling(c); }
+			}
+		} else if (!(l[0]->lambda_max > 0)) {
+			const bool borrow = k == 0 && chain.size() > 1 && chain[1][0]->lambda_max > 0 && !tuning_switch("FI_MG_FINE_POWER");
+			if (borrow) {
+				for (fi_ctx* c : l) { c->lambda_max = c->coarse->lambda_max; }
+			} else {
+				estimate_lambda<T>(l);
+			}
 		}
-		for (fi_ctx* c : R) { c->lambda_max = c->coarse->lambda_max; }
-		if (tuning_switch("FI_MG_FINE_POWER")) { estimate_lambda<T>(R); }
 	}
 }
 
@@ -3121,11 +3296,16 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		hi[r] = static_cast<int>(static_cast<int64_t>(r + 1) * c->g.gn[D - 1] / c->nranks);
 	}
 	for (int l = 1; l <= c->levels_wanted; ++l) {
-		int sizes[3] = {1, 1, 1};
+		int sizes[3] = {1, 1, 1}, cc[3] = {0, 0, 0};
+		float shift[3] = {0, 0, 0};
 		bool ok = true;
 		for (int d = 0; d < D; ++d) {
 			sizes[d] = (fine->g.gn[d] + 1) / 2;
 			ok = ok && sizes[d] >= 8;
+			// even extents are halved cell-centred (fi_ctx::cc); along the decomposed axis the transfers then reach two
+			// planes beyond the slab, which the ghost planes of model_2 and wider stencils cover
+			cc[d] = fine->g.gn[d] % 2 == 0 && (d != D - 1 || c->nranks == 1 || c->halo >= 2) && !test_switch("FI_VERTEX_LEVELS");
+			shift[d] = 0.5f * (fine->pos_shift[d] - (cc[d] ? 0.5f : 0.0f));
 		}
 		// coarse plane k sits on fine plane 2k: a rank keeps the coarse planes whose fine plane it owns
 		for (int r = 0; r < c->nranks; ++r) {
@@ -3136,7 +3316,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		if (!ok) { break; }
 		fi_ctx* co = fine->coarse;
 		if (co && (co->g.gn[0] != sizes[0] || co->g.gn[1] != sizes[1] || co->g.gn[2] != sizes[2] || co->dtype != c->dtype ||
-		           co->halo != c->halo)) {
+		           co->halo != c->halo || co->cc[0] != cc[0] || co->cc[1] != cc[1] || co->cc[2] != cc[2])) {
 			fi_ctx_destroy(co);
 			co = nullptr;
 		}
@@ -3158,10 +3338,16 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 			co->slab_lo     = lo[c->rank];
 			co->slab_hi     = hi[c->rank];
 			co->halo        = c->halo;
+			for (int d = 0; d < 3; ++d) {
+				co->cc[d]        = cc[d];
+				co->pos_shift[d] = shift[d];
+			}
 			compute_geom(co, D, sizes);
 			fine->coarse    = co;
 		}
 		co->comm = c->comm;
+		co->mg_smoother = c->mg_smoother;
+		co->mg_safe     = c->mg_safe;
 		co->stream = build_stream ? build_stream : c->stream;
 		co->defer_scaling_exchange = build_stream != nullptr;  // a helper thread never talks to the neighbours
 		const float vol = static_cast<float>(1 << D);
@@ -3254,6 +3440,8 @@ void build_twin(fi_ctx* c)
 	t->levels_wanted   = c->levels_wanted;
 	t->coarse_tol      = c->coarse_tol;
 	t->mg_mode         = c->mg_mode;
+	t->mg_smoother     = c->mg_smoother;
+	t->mg_safe         = c->mg_safe;
 	for (auto* b : c->batches) {
 		const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
 		const float* pw  = b->has_pw ? b->pw.as<float>() : nullptr;
@@ -3438,11 +3626,13 @@ int fi_slab_point_range(const fi_ctx* c, float* lo, float* hi)
 	fi::check_ctx(c);
 	// Level l halves the lattice l times (coarse plane k sits on fine plane k * 2^l; this rank keeps coarse planes
 	// ceil(slab_lo / 2^l) .. ceil(slab_hi / 2^l) - 1), and a rank needs every cell that touches an owned plane of
-	// that level plus one cell of margin for the nearest-neighbour kernels: 2 cells of 2^l fine planes below, 1 above.
+	// that level plus one cell of margin for the nearest-neighbour kernels: 2 cells of 2^l fine planes below, 1 above --
+	// 2 above as well, because a level halved cell-centred (fi_ctx::cc) sees a point up to half a coarse cell further down
+	// (position / 2^l - (1 - 2^-l) / 2).
 	const int L = c->levels_wanted > 0 ? c->levels_wanted : 0;
 	const float cell = static_cast<float>(1 << (L < 20 ? L : 20));
 	if (lo) { *lo = static_cast<float>(c->slab_lo) - 2.0f * cell; }
-	if (hi) { *hi = static_cast<float>(c->slab_hi) + cell; }
+	if (hi) { *hi = static_cast<float>(c->slab_hi) + (L > 0 ? 2.0f : 1.0f) * cell; }
 	FI_API_END
 }
 
@@ -3746,6 +3936,15 @@ int fi_set_option(fi_ctx* c, int option, double value)
 	case FI_OPT_POLY_RATIO:
 		FI_REQUIRE(value > 1.0, FI_ERR_INVALID, "FI_OPT_POLY_RATIO must be above 1");
 		c->poly_ratio = value;
+		break;
+	case FI_OPT_MG_SMOOTHER:
+		c->mg_smoother = value != 0.0 ? 1 : 0;
+		c->assembled = false;  // the levels take the setting when they are built
+		break;
+	case FI_OPT_MG_SAFE_FACTOR:
+		FI_REQUIRE(value >= 1.0 && value <= 64.0, FI_ERR_INVALID, "FI_OPT_MG_SAFE_FACTOR must be 1..64");
+		c->mg_safe = value;
+		c->assembled = false;
 		break;
 	default: FI_REQUIRE(false, FI_ERR_INVALID, "unknown option %d", option);
 	}

@@ -1719,12 +1719,12 @@ namespace fi {
 bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid; }
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.Pplain.nwg; }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part, double zprev_scale, double pro_scale)
+                       double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling)
 {
 	// pro_scale != 0 (the first step, z_prev = 0): `z` is r and the kernel forms z_0 = pro_scale * Dinv * r on load
 	// zprev == nullptr: the step from z_prev = 0 (z itself stands in under a zero coefficient);
 	// zprev_scale != 0: z_prev = zprev_scale * Dinv r, read through r's own cache lines
-	const unsigned short* d16 = c->dinv16.as<unsigned short>();
+	const unsigned short* d16 = scaling ? scaling : c->dinv16.as<unsigned short>();
 	const void* zp = zprev_scale != 0.0 ? r : (zprev ? zprev : z);
 	const bool  has_prev = zprev_scale != 0.0 || zprev;
 	if (c->dtype == FI_F64) {

@@ -34,7 +34,9 @@ def point_range(lo, hi, levels=0):
     its own points, so the margin grows with the level count -- two cells of the coarsest level below (cell origin
     floor(pos) one plane under the slab, plus one cell for the nearest-neighbour kernels), one above."""
     cell = float(1 << max(int(levels), 0))
-    return lo - 2.0 * cell, hi + cell
+    # (two cells above as well once there are levels: a level halved cell-centred sees a point at
+    # position / 2^l - (1 - 2^-l) / 2, up to half a coarse cell further down)
+    return lo - 2.0 * cell, hi + (2.0 if levels > 0 else 1.0) * cell
 
 
 def points_of_slab(positions, ndim, lo, hi, levels=0):

@@ -225,6 +225,13 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * are reduced twice per d applications.  3-D lattices with model_0 / model_1 / model_2; other contexts ignore it. */
 #define FI_OPT_POLY_TERMS 6
 #define FI_OPT_POLY_RATIO 7
+/* FI_OPT_MG_SMOOTHER (default 1): the V-cycle's smoother on fp32 3-D levels with model_0 / model_1 / model_2.
+ * 1: the polynomial of FI_OPT_POLY_TERMS' kind in A_model + f diag(A_data) -- plain-stencil launches without cell
+ * records, two full applies per level and cycle; f = FI_OPT_MG_SAFE_FACTOR (default 4; 2^D makes that operator a bound of
+ * the full one, so the smoother converges for any data).  0: the Chebyshev polynomial in the full operator on every
+ * level (the only smoother of 2-D / fp64 levels).  Both give symmetric positive definite preconditioners. */
+#define FI_OPT_MG_SMOOTHER 8
+#define FI_OPT_MG_SAFE_FACTOR 9
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */

@@ -185,11 +185,14 @@ def test_points_of_slab_covers_the_cells_of_every_coarse_level():
                 for lev in range(levels + 1):
                     if lev > 0:
                         clo, chi = (clo + 1) // 2, (chi + 1) // 2
-                    cz = np.floor(z / 2.0 ** lev)                 # cell origin on level lev
-                    rz = np.round(z / 2.0 ** lev)                 # nearest-neighbour row on level lev
-                    must = ((cz >= clo - 1) & (cz <= chi - 1)) | ((rz >= clo) & (rz <= chi - 1))
-                    assert not (must & ~keep).any(), (nranks, levels, rank, lev)
+                    # an even extent is halved cell-centred (coarse point j between fine 2j and 2j+1): level lev sees the
+                    # point at z / 2^lev - (1 - 2^-lev) / 2; odd extents (vertex-centred) see it at z / 2^lev
+                    for zl in (z / 2.0 ** lev, z / 2.0 ** lev - 0.5 * (1.0 - 2.0 ** -lev)):
+                        cz = np.floor(zl)                         # cell origin on level lev
+                        rz = np.round(zl)                         # nearest-neighbour row on level lev
+                        must = ((cz >= clo - 1) & (cz <= chi - 1)) | ((rz >= clo) & (rz <= chi - 1))
+                        assert not (must & ~keep).any(), (nranks, levels, rank, lev)
             # and the margins stay small: the ranks together upload each point a bounded number of times
             total = sum(int(fdist.points_of_slab(pos, 3, *fdist.slab_range(planes, r, nranks), levels).sum())
                         for r in range(nranks))
-            assert total <= len(pos) * (1.0 + 3.0 * nranks * 2.0 ** levels / planes) + 1
+            assert total <= len(pos) * (1.0 + 4.0 * nranks * 2.0 ** levels / planes) + 1

@@ -20,7 +20,7 @@ def main(path, title):
     print("# %s\n" % title)
     print("| kernel | calls | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|")
-    for r in rows[:16]:
+    for r in rows[:28]:
         print("| `%s` | %s | %.1f | %.1f | %.1f | %.2f |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                      float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
                                                      float(r["Percentage"])))
