@@ -2806,6 +2806,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	int tag = 0;
 	int psamples = 0;  // timed Chebyshev steps
 	std::vector<int> ptags;
+	std::vector<double> pbytes;  // algorithmic bytes of the sampled steps
 	std::vector<hipEvent_t>& pev = c0->ev_prec;
 	while (static_cast<int>(pev.size()) < 2 * kMaxSamples) {
 		hipEvent_t e;
@@ -2842,9 +2843,10 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		// the polynomial: z_{k+1} from z_k (ZA / ZB alternate; the result ends in `zfin`)
 		Vec zin = ZA, zout = ZB;
 		for (int k = 1; k < terms; ++k) {
-			// every 4th pass times its last step (5 lattice passes when the polynomial has 3 terms or more)
-			const bool sample = phase == 1 && k == terms - 1 && c0->level == 0 && psamples < kPolySamples && (tag & 3) == 3 &&
-			                    !tuning_switch("FI_NO_SAMPLES");
+			// every 4th pass times one step, the steps in turn (first: 2.5 lattice passes, second: 3.5, the others 4.5): the
+			// roofline figure is bytes over time of ALL sampled steps
+			const bool sample = phase == 1 && k == 1 + psamples % (terms - 1) && c0->level == 0 && psamples < kPolySamples &&
+			                    (tag & 3) == 3 && !tuning_switch("FI_NO_SAMPLES");
 			const bool overlap = R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
 			const bool pro = z0_on_load && k == 1;
 			const Vec  zsrc = pro ? static_cast<Vec>(&fi_ctx::r) : zin;  // the vector whose ghost planes the step reads
@@ -2852,6 +2854,10 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(pev[2 * psamples], st));
 				ptags.push_back(tag);
+				// z, z_prev, r in, z_new out + the bfloat16 scaling; the first step has no z_prev and (formed on load) reads r as
+				// its z; the second step's z_prev is recomputed from r
+				const double vecs = k == 1 ? (pro ? 2.0 : 3.0) : (k == 2 ? 3.0 : 4.0);
+				pbytes.push_back((static_cast<double>(sizeof(T)) * vecs + 2.0) * static_cast<double>(c0->g.nown));
 			}
 			for (fi_ctx* c : R) {
 				const void* zp = k == 1 ? nullptr : (c->*zout).p;
@@ -3000,12 +3006,13 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	}
 	// the timed steps of passes that ran (pass t is outer iteration t - 1; passes past the stop exited at once)
 	int pused = 0;
-	double psum = 0;
+	double psum = 0, pbsum = 0;
 	for (int k = 0; k < psamples; ++k) {
 		if (ptags[k] - 1 > h.iter) { break; }  // pass `tag` is CG step tag - 1 (or earlier, after restarts): it ran
 		float t = 0;
 		FI_HIP_TRY(hipEventElapsedTime(&t, pev[2 * k], pev[2 * k + 1]));
 		psum += t;
+		pbsum += pbytes[k];
 		++pused;
 	}
 	for (fi_ctx* c : R) {
@@ -3014,8 +3021,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
 		c->stats.prec_samples = pused;
 		c->stats.prec_ms_avg  = pused ? psum / pused : 0.0;
-		// a sampled step reads z, z_prev (none on the first step), r and the bfloat16 scaling, and writes z_new
-		c->stats.prec_bytes   = (static_cast<double>(sizeof(T)) * (terms > 2 ? 4.0 : 3.0) + 2.0) * static_cast<double>(c->g.nown);
+		c->stats.prec_bytes   = pused ? pbsum / pused : 0.0;  // mean over the sampled steps: bytes / time is their byte-weighted rate
 		c->stats.operator_applies = (h.iter + 1) * terms + h.restarts;
 		c->last_outer_iterations = h.iter;
 		c->stats.solve_ms     = ms;
