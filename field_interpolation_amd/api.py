@@ -406,10 +406,6 @@ class LatticeGroup:
         for m in self.members:          # every rank sees every point and keeps the cells touching its slab
             m.add_points(*a, **kw)
 
-    def add_border_prior(self, weight):
-        for m in self.members:
-            m.add_border_prior(weight)
-
     def set_levels(self, levels, coarse_tolerance=None):
         for m in self.members:
             m.set_levels(levels, coarse_tolerance)

@@ -854,7 +854,7 @@ int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val)
 	const int D = g.ndim;
 	int64_t total = 1;
 	for (int d = 0; d < D; ++d) { total *= g.gn[d]; }
-	FI_REQUIRE(total < (1LL << 32), FI_ERR_UNSUPPORTED, "border prior: lattice too large for 32-bit point indices");
+	FI_REQUIRE(total <= 0x7fffffffLL, FI_ERR_UNSUPPORTED, "border prior: lattice too large for the 32-bit item count of the selection");
 	BorderPred pred{{g.gn[0], D > 1 ? g.gn[1] : 1, D > 2 ? g.gn[2] : 1}, D};
 	int64_t inner = 1;
 	for (int d = 0; d < D; ++d) { inner *= g.gn[d] > 2 ? g.gn[d] - 2 : 0; }
@@ -879,7 +879,7 @@ int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val)
 	const int blocks = static_cast<int>((nb + 255) / 256);
 	hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), INFINITY, d2.as<float>());
 	for (const PointBatch* b : c->batches) {
-		if (b->n <= 0) { continue; }
+		if (b->n <= 0 || b->prior) { continue; }
 		switch (D) {
 		case 1: hipLaunchKernelGGL(k_border_min_dist<1>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, b->n, b->pos.as<float>(), d2.as<float>()); break;
 		case 2: hipLaunchKernelGGL(k_border_min_dist<2>, dim3(blocks), dim3(256), 0, st, static_cast<int64_t>(nb), idx.as<uint32_t>(), pred, b->n, b->pos.as<float>(), d2.as<float>()); break;

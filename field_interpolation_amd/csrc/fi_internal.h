@@ -213,6 +213,7 @@ struct PointBatch {
 	bool   has_nrm = false, has_pw = false, has_val = false;
 	float  vw = 0, gw = 0;
 	int    vk = 0, gk = 0;
+	bool   prior = false;  // the rows of fi_add_border_prior: lattice points, not data -- no distance source of a later call
 };
 
 struct Comm;  // RCCL state (fi_comm.cpp)

@@ -2586,7 +2586,9 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
 			if (phase == 1) {
 				beta_d = rz / s.rz;
 				s.iter += 1;
-				s.done = !isfinite(rr) || !isfinite(rz) ? 2 : (!(rr > s.tol2) ? 1 : (s.iter >= s.max_iter ? 3 : 0));
+				// r.z <= 0 with a residual above the tolerance: the preconditioner is not positive definite (cg_run_poly widens
+				// the polynomial's interval and goes on)
+				s.done = !isfinite(rr) || !isfinite(rz) ? 2 : (!(rr > s.tol2) ? 1 : (!(rz > 0.0) ? 2 : (s.iter >= s.max_iter ? 3 : 0)));
 			} else {
 				if (phase == 0) {
 					s.bb   = lists ? bb_all : pbb[0];
@@ -2596,7 +2598,7 @@ __global__ __launch_bounds__(kThreads) void k_pcg_xp(int64_t n, const CgScalars*
 					s.restarts += 1;
 					s.true_rr = rr;
 				}
-				s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase >= 2 ? 5 : 1) : (s.iter >= s.max_iter ? 3 : 0)));
+				s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase >= 2 ? 5 : 1) : (!(rz > 0.0) ? 2 : (s.iter >= s.max_iter ? 3 : 0))));
 			}
 			s.rz_new = rz;
 			s.rr     = rr;
@@ -2754,12 +2756,24 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	FI_HIP_TRY(hipEventCreate(&e1));
 	FI_HIP_TRY(hipEventRecord(e0, st));
 
-	// Chebyshev interval and recurrence constants (the same polynomial as cheb_smooth)
-	const double lam = c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0;
-	const double hi = 1.1 * lam, lo = hi / (c0->poly_ratio > 1.0 ? c0->poly_ratio : 10.0);
-	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	// Chebyshev interval and recurrence constants (the same polynomial as cheb_smooth).  The preconditioner is positive
+	// definite while the spectrum of Dinv A~ stays below hi + lo; poly_lambda is a power-method estimate -- a LOWER bound of
+	// the largest eigenvalue -- with 10 % headroom, so a lattice it underestimates by more shows up as non-positive
+	// curvature (done == 2).  The solve then widens the interval (x 1.25, twice) and goes on from its last iterate, and
+	// after that falls back to the Jacobi diagonal (cg_run): see the end of the loop.  FI_POLY_LAMBDA_SCALE (tests):
+	// scales the estimate, to drive that path.
+	double lam_scale = 1.0;
+	if (const char* env = test_switch("FI_POLY_LAMBDA_SCALE")) { lam_scale = atof(env) > 0 ? atof(env) : 1.0; }
+	double theta = 1.0, delta = 1.0;
 	std::vector<double> c1s, c2s;
-	{
+	auto set_interval = [&]() {
+		const double lam = (c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0) * lam_scale;
+		const double hi = 1.1 * lam, lo = hi / (c0->poly_ratio > 1.0 ? c0->poly_ratio : 10.0);
+		theta = 0.5 * (hi + lo);
+		delta = 0.5 * (hi - lo);
+		const double sigma = theta / delta;
+		c1s.clear();
+		c2s.clear();
 		double rho = 1.0 / sigma;
 		for (int k = 1; k < terms; ++k) {
 			const double rho_new = 1.0 / (2.0 * sigma - rho);
@@ -2767,7 +2781,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			c2s.push_back(2.0 * rho_new / delta);
 			rho = rho_new;
 		}
-	}
+	};
+	set_interval();
 
 	CgScalars init{};
 	init.tol2     = tolerance * tolerance;
@@ -2935,6 +2950,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	bool timed_out = false;
 	CgScalars* sc0 = c0->scal.as<CgScalars>();
 	int restarts_left = c0->verify_residual ? 3 : 0;
+	int widenings_left = 2, iter_base = 0;
 	const int burst = terms >= 4 ? 4 : 8;  // outer iterations between two looks at the stop flag
 	// the first look comes when the context's previous solve had finished (the per-frame / re-assembled problem of a
 	// caller changes little): every look is a host round trip of ~35 us
@@ -2943,6 +2959,21 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	for (;;) {
 		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
+		if (c0->scal_host->done == 2 && widenings_left > 0 && std::isfinite(c0->scal_host->pq) && std::isfinite(c0->scal_host->rr) &&
+		    std::isfinite(c0->scal_host->rz)) {
+			// non-positive curvature with finite numbers: the polynomial's interval is too narrow for this lattice (see
+			// set_interval).  Widen it -- for the context's later solves too -- and go on from the last iterate: x has
+			// not been touched by the step that broke down.
+			--widenings_left;
+			iter_base += c0->scal_host->iter;
+			for (fi_ctx* c : R) { c->poly_lambda = (c->poly_lambda > 1.0 ? c->poly_lambda : 1.0) * 1.25; }
+			set_interval();
+			init.max_iter = max_iterations > iter_base ? max_iterations - iter_base : 1;
+			reset_scalars(R, init);
+			FI_HIP_TRY(hipStreamSynchronize(st));  // (reset_scalars copies from `init`)
+			start(0);
+			continue;
+		}
 		if (c0->scal_host->done) {
 			if (c0->scal_host->done != 1 || restarts_left <= 0) { break; }
 			--restarts_left;  // the recurrence met the tolerance: check b - A x, go on from it if it misses
@@ -3022,10 +3053,10 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		c->stats.prec_samples = pused;
 		c->stats.prec_ms_avg  = pused ? psum / pused : 0.0;
 		c->stats.prec_bytes   = pused ? pbsum / pused : 0.0;  // mean over the sampled steps: bytes / time is their byte-weighted rate
-		c->stats.operator_applies = (h.iter + 1) * terms + h.restarts;
+		c->stats.operator_applies = (iter_base + h.iter + 1) * terms + h.restarts;
 		c->last_outer_iterations = h.iter;
 		c->stats.solve_ms     = ms;
-		c->stats.iterations   = h.iter;
+		c->stats.iterations   = iter_base + h.iter;
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
 		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
 		c->stats.restarts     = h.restarts;
@@ -3035,6 +3066,19 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
 	FI_REQUIRE(!timed_out, FI_ERR_TIMEOUT, "solve stopped by the wall-clock guard (FI_SOLVE_TIMEOUT_S = %g s) after %d iterations, "
 	           "relative residual %g", limit_s, h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0);
+}
+
+// polynomial PCG; if its preconditioner stays indefinite after two widenings of the interval: the Jacobi diagonal, from
+// the last iterate (x is finite: the step that breaks down does not touch it)
+template <typename T>
+void cg_run_poly_or_jacobi(RankSet& R, int max_iterations, float tol)
+{
+	try {
+		cg_run_poly<T>(R, max_iterations, tol);
+	} catch (const Fail& f) {
+		if (f.code != FI_ERR_BREAKDOWN) { throw; }
+		cg_run<T>(R, max_iterations, tol);
+	}
 }
 
 template <typename T>
@@ -3058,7 +3102,7 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	if (c->mg_mode == 1 && (c->coarse || (c->twin && c->twin->coarse))) {
 		cg_run_mg<T>(R, max_iterations, tol);
 	} else if (poly_ok(c)) {
-		cg_run_poly<T>(R, max_iterations, tol);
+		cg_run_poly_or_jacobi<T>(R, max_iterations, tol);
 	} else {
 		cg_run<T>(R, max_iterations, tol);
 	}
@@ -3722,6 +3766,7 @@ void add_points_device(fi_ctx* c, long n, const float* p, const float* g, const 
 			return true;
 		};
 		b->n = n;
+		b->prior = false;
 		keep(b->pos, p, static_cast<size_t>(n) * D);
 		b->has_nrm = keep(b->nrm, g, static_cast<size_t>(n) * D);
 		b->has_pw  = keep(b->pw, w, static_cast<size_t>(n));
@@ -3749,7 +3794,13 @@ int fi_add_border_prior(fi_ctx* c, float weight)
 	fi::check_ctx(c);
 	fi::bind_device(c);
 	if (weight == 0.0f) { return FI_OK; }  // add_equation skips zero weights (sparse_linear.cpp:36)
-	FI_REQUIRE(!c->batches.empty(), FI_ERR_STATE, "fi_add_border_prior needs the data points: call it after fi_add_points");
+	// The distance is to the nearest point of the WHOLE cloud (sdf_field.cpp:218-246); a slab context holds only the points
+	// of fi_slab_point_range, so the prior of a decomposed lattice would be silently wrong (or infinite on a rank without
+	// points): not supported -- add the prior's rows with fi_add_points(FI_VALUE_NEAREST_NEIGHBOR) from the caller's side.
+	FI_REQUIRE(c->nranks == 1, FI_ERR_UNSUPPORTED, "fi_add_border_prior on a slab context: a rank sees only its own points");
+	bool any = false;
+	for (const fi::PointBatch* b : c->batches) { any = any || (b->n > 0 && !b->prior); }
+	FI_REQUIRE(any, FI_ERR_STATE, "fi_add_border_prior needs the data points: call it after fi_add_points");
 	fi::DevBuf pos, val, zero;
 	const int64_t nb = fi::border_prior_points(c, pos, val);
 	if (nb > 0) {
@@ -3758,6 +3809,7 @@ int fi_add_border_prior(fi_ctx* c, float weight)
 		// the row [1] * w, rhs d * w at the lattice point itself: a nearest-neighbour value constraint with a zero gradient
 		fi::add_points_device(c, static_cast<long>(nb), pos.as<float>(), zero.as<float>(), nullptr, val.as<float>(), weight,
 		                      FI_VALUE_NEAREST_NEIGHBOR, 0.0f, FI_GRADIENT_NEAREST_NEIGHBOR);
+		c->batches.back()->prior = true;
 	}
 	c->assembled = false;
 	FI_API_END
@@ -3940,7 +3992,7 @@ int fi_set_option(fi_ctx* c, int option, double value)
 		c->poly_terms = static_cast<int>(value);
 		break;
 	case FI_OPT_POLY_RATIO:
-		FI_REQUIRE(value > 1.0, FI_ERR_INVALID, "FI_OPT_POLY_RATIO must be above 1");
+		FI_REQUIRE(value > 1.0 && value <= 1000.0, FI_ERR_INVALID, "FI_OPT_POLY_RATIO must be in (1, 1000]");
 		c->poly_ratio = value;
 		break;
 	case FI_OPT_MG_SMOOTHER:
@@ -4270,8 +4322,8 @@ int fi_group_solve_cg(fi_group* g, const float* guess, int max_iterations, float
 		g->dtype == FI_F64 ? fi::cg_run_mg<double>(g->members, max_iterations, tol)
 		                   : fi::cg_run_mg<float>(g->members, max_iterations, tol);
 	} else if (fi::poly_ok(c0)) {
-		g->dtype == FI_F64 ? fi::cg_run_poly<double>(g->members, max_iterations, tol)
-		                   : fi::cg_run_poly<float>(g->members, max_iterations, tol);
+		g->dtype == FI_F64 ? fi::cg_run_poly_or_jacobi<double>(g->members, max_iterations, tol)
+		                   : fi::cg_run_poly_or_jacobi<float>(g->members, max_iterations, tol);
 	} else {
 		g->dtype == FI_F64 ? fi::cg_run<double>(g->members, max_iterations, tol) : fi::cg_run<float>(g->members, max_iterations, tol);
 	}

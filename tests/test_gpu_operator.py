@@ -363,3 +363,27 @@ def test_border_prior_equals_the_reference_rows(oracle, fi, sizes, dtype):
     x = rng.normal(size=int(np.prod(sizes)))
     assert rel_inf(fg.apply_AtA(x), AtA @ x) <= tol
     assert fg.stats()["num_data_rows"] == fo.num_rows - _model_rows(oracle, sizes, w)
+    # a second call measures to the DATA points again (the first call's border rows are no distance source): the same
+    # rows once more
+    for c, index in zip(bc, bl):
+        dd = pos.astype(np.float32) - c.astype(np.float32)
+        s = np.zeros(len(pos), np.float32)
+        for d in range(D):
+            s = (s + dd[:, d] * dd[:, d]).astype(np.float32)
+        fo.add_equation(bw, float(np.sqrt(np.float32(s.min()))), [(int(index), 1.0)])
+    fg.add_border_prior(bw)
+    fg.assemble()
+    AtA, atb, diag = fo.normal_equations()
+    assert rel_inf(fg.Atb(), atb) <= tol and rel_inf(fg.diag(), diag) <= tol
+
+
+def test_border_prior_is_refused_on_a_slab(fi):
+    """A slab context holds only the points near its slab: the nearest point of the whole cloud is not its to know."""
+    from field_interpolation_amd._capi import FiError
+    f = fi.LatticeField([12, 10, 16], dtype="f32", rank=1, nranks=2)
+    f.add_field_constraints(fi.Weights())
+    f.add_points(1.0, fi.ValueKernel.kLinearInterpolation, 0.0, fi.GradientKernel.kCellEdges,
+                 np.array([[3.0, 4.0, 9.0]], np.float32), None, None)
+    with pytest.raises(FiError) as e:
+        f.add_border_prior(0.5)
+    assert e.value.code == 5      # FI_ERR_UNSUPPORTED

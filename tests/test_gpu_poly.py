@@ -188,3 +188,39 @@ def test_first_step_forms_its_operand_on_load(fi, sizes, kw, dtype, tol, monkeyp
     for k in range(3):
         assert abs(out[k][0] - out[3 + k][0]) <= 1, (out[k][0], out[3 + k][0])
         assert rel_inf(out[k][1], out[3 + k][1]) <= (1e-3 if dtype == "f32" else 1e-8)
+
+
+@pytest.mark.parametrize("scale,expect_jacobi", [(0.55, False), (0.2, True)])
+def test_too_narrow_an_interval_is_widened_or_given_up(oracle, fi, monkeypatch, scale, expect_jacobi):
+    """The polynomial is positive definite only while the spectrum of Dinv A~ stays below the interval's end; the bound is a
+    power-method estimate (a lower bound + 10 %).  FI_POLY_LAMBDA_SCALE narrows the interval on purpose: CG then meets
+    non-positive curvature, the solve widens the interval (x 1.25, twice, kept for the context's later solves) and goes
+    on from its last iterate -- or, when that is not enough, finishes with the Jacobi diagonal.  Same answer either way."""
+    sizes = [40, 36, 33]
+    rng = np.random.default_rng(11)
+    pos, nrm, pw, val = random_points(rng, sizes, 3000, margin=0.5, with_edge_cases=False)
+    w = fi.Weights(model_2=0.5, data_gradient=0.0)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, None, None, val, dtype="f64")
+    fg.set_polynomial(4, 30.0)
+    fg.assemble()
+    x0, it0, rel0 = fg.solve_cg(None, 0, 1e-10)
+    ref = fg.solution_f64().copy()
+    monkeypatch.setenv("FI_POLY_LAMBDA_SCALE", str(scale))
+    x1, it1, rel1 = fg.solve_cg(None, 0, 1e-10)
+    st = fg.stats()
+    assert x1 is not None and st["converged"] == 1 and fg.true_residual() <= 1.01e-10
+    assert rel_inf(fg.solution_f64(), ref) <= 1e-7
+    if expect_jacobi:
+        assert it1 > 3 * it0          # Jacobi-PCG steps, one operator application each
+    monkeypatch.delenv("FI_POLY_LAMBDA_SCALE")
+    # ... and a wide ratio (a long interval has the least headroom) on a larger lattice
+    sizes = [96, 96, 96]
+    from field_interpolation_amd import synth
+    sz, w4, p4, v4 = synth.config4(side=96, num_points=52734, seed=3)
+    f = fi.LatticeField(sz, dtype="f32")
+    f.add_field_constraints(w4)
+    f.set_polynomial(6, 300.0)
+    f.add_points(w4.data_pos, w4.value_kernel, 0.0, w4.gradient_kernel, p4, None, None, values=v4)
+    f.assemble()
+    res = f.solve_cg(None, 0, 1e-5)
+    assert res is not None and f.stats()["converged"] == 1 and f.true_residual() <= 1.5e-5
