@@ -120,6 +120,7 @@ namespace {
 
 namespace {
 
+#ifdef FI_TEST_TRANSPORT  // libfi_hip_test.so only: the release library carries RCCL alone
 constexpr uint32_t kHostMagic = 0x46494853u;  // "FIHS"
 
 void host_close(HostComm* h)
@@ -203,6 +204,10 @@ void host_exchange(fi_ctx* c, void* v, hipStream_t stream)
 	host_barrier(h);
 }
 
+#else
+void host_close(HostComm*) {}
+#endif
+
 }  // namespace
 
 void comm_destroy(Comm* cm)
@@ -216,10 +221,12 @@ void comm_destroy(Comm* cm)
 void allreduce_sum(fi_ctx* c, double* dev, int count)
 {
 	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+#ifdef FI_TEST_TRANSPORT
 	if (c->comm->host) {
 		host_allreduce(c, dev, count);
 		return;
 	}
+#endif
 	FI_NCCL_TRY(rccl().AllReduce(dev, dev, static_cast<size_t>(count), ncclFloat64, ncclSum, c->comm->comm, c->stream));
 }
 
@@ -231,10 +238,12 @@ void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream)
 {
 	if (c->nranks <= 1) { return; }
 	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+#ifdef FI_TEST_TRANSPORT
 	if (c->comm->host) {
 		host_exchange(c, v, stream);
 		return;
 	}
+#endif
 	const Geom&  g     = c->g;
 	const int    L     = g.ndim - 1;
 	const int    H     = c->halo;
@@ -353,6 +362,11 @@ int fi_comm_init(fi_ctx* c, const void* unique_id128)
 
 int fi_comm_init_host(fi_ctx* c, const char* name, int create)
 {
+#ifndef FI_TEST_TRANSPORT
+	(void)c; (void)name; (void)create;
+	fi::set_error("fi_comm_init_host: the host-staged TEST transport is built into libfi_hip_test.so only (-DFI_TEST_TRANSPORT)");
+	return FI_ERR_UNSUPPORTED;
+#else
 	fi::HostComm* h = nullptr;
 	try {
 		FI_REQUIRE(c != nullptr && name != nullptr && name[0] == '/', FI_ERR_INVALID, "bad argument (the name starts with '/')");
@@ -394,6 +408,7 @@ int fi_comm_init_host(fi_ctx* c, const char* name, int create)
 		return f.code;
 	}
 	return FI_OK;
+#endif
 }
 
 }  // extern "C"

@@ -301,6 +301,8 @@ struct fi_ctx {
 	hipStream_t level_stream = nullptr;  // fi_assemble: the coarser levels are assembled here, by a helper thread, beside
 	                                     // the finest level on `stream`
 	hipEvent_t  ev_level = nullptr;
+	hipStream_t level_stream2 = nullptr;  // mixed precision: the replica's coarser levels (a second helper thread)
+	hipEvent_t  ev_level2 = nullptr;
 	hipEvent_t  ev_ready = nullptr, ev_halo = nullptr;
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)
 	bool       owns_stream = true;

@@ -1492,9 +1492,67 @@ __global__ __launch_bounds__(kThreads) void k_restrict3(LevelPair L, const T* __
 	}
 	coarse[(static_cast<int64_t>(cz - L.c_base) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
 }
+// The same restriction in two passes (P is a tensor product): first along x and y inside every LOCAL fine plane (ghost
+// planes included) into tmp[fine plane][cy][cx], then along z.  Cell-centred axes have 4 - 5 taps: the one-pass kernel
+// gathers up to 125 fine values per coarse point (171 us from 256^3 to 128^3), the two passes 16 + 4 (about 45 us).
 template <typename T>
-void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t st)
+__global__ __launch_bounds__(kThreads) void k_restrict3_xy(LevelPair L, int planes, const T* __restrict__ fine, T* __restrict__ tmp)
 {
+	const int cx = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
+	if (cx >= L.nc[0]) { return; }
+	const int cy = static_cast<int>(blockIdx.y);
+	const int fz = static_cast<int>(blockIdx.z);  // local plane
+	if (fz >= planes) { return; }
+	int fx[kRTaps], fy[kRTaps];
+	T   wx[kRTaps], wy[kRTaps];
+	restrict_taps<T>(cx, L.nf[0], L.nc[0], L.cc[0], 0, fx, wx);
+	restrict_taps<T>(cy, L.nf[1], L.nc[1], L.cc[1], 0, fy, wy);
+	const T* plane = fine + static_cast<int64_t>(fz) * L.nf[0] * L.nf[1];
+	T acc = T(0);
+#pragma unroll
+	for (int k1 = 0; k1 < kRTaps; ++k1) {
+		if (wy[k1] == T(0)) { continue; }
+		const T* row = plane + static_cast<int64_t>(fy[k1]) * L.nf[0];
+		T r = T(0);
+#pragma unroll
+		for (int k0 = 0; k0 < kRTaps; ++k0) {
+			if (wx[k0] != T(0)) { r += wx[k0] * row[fx[k0]]; }
+		}
+		acc += wy[k1] * r;
+	}
+	tmp[(static_cast<int64_t>(fz) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_restrict3_z(LevelPair L, const T* __restrict__ tmp, T* __restrict__ coarse)
+{
+	const int cx = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
+	if (cx >= L.nc[0]) { return; }
+	const int cy = static_cast<int>(blockIdx.y);
+	const int cz = static_cast<int>(blockIdx.z) + L.c_z0;  // global plane
+	int fz[kRTaps];
+	T   wz[kRTaps];
+	restrict_taps<T>(cz, L.nf[2], L.nc[2], L.cc[2], L.f_base, fz, wz);
+	const int64_t cplane = static_cast<int64_t>(L.nc[0]) * L.nc[1];
+	const int64_t o = static_cast<int64_t>(cy) * L.nc[0] + cx;
+	T acc = T(0);
+#pragma unroll
+	for (int k = 0; k < kRTaps; ++k) {
+		if (wz[k] != T(0)) { acc += wz[k] * tmp[fz[k] * cplane + o]; }
+	}
+	coarse[(static_cast<int64_t>(cz - L.c_base)) * cplane + o] = acc;
+}
+
+// tmp (3-D, optional): a work array of the fine level with room for (local fine planes) x nc[1] x nc[0] values -- any of
+// the fine level's lattice vectors will do -- selects the two-pass form; f_local_planes = the fine level's local planes
+template <typename T>
+void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t st, T* tmp = nullptr, int f_local_planes = 0)
+{
+	if (L.ndim == 3 && tmp && f_local_planes > 0 && !test_switch("FI_ONE_PASS_RESTRICT")) {
+		hipLaunchKernelGGL((k_restrict3_xy<T>), dim3((L.nc[0] + kThreads - 1) / kThreads, L.nc[1], f_local_planes), dim3(kThreads), 0, st,
+		                   L, f_local_planes, fine, tmp);
+		hipLaunchKernelGGL((k_restrict3_z<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, st, L, tmp, coarse);
+		return;
+	}
 	if (L.ndim == 3) {
 		hipLaunchKernelGGL((k_restrict3<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, st, L, fine, coarse);
 	} else {
@@ -2073,7 +2131,8 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		halo_exchange(R, &fi_ctx::mg_r);
 		for (size_t i = 0; i < R.size(); ++i) {
 			const LevelPair L = level_pair(R[i], Rc[i]);
-			launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream);
+			launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream, vbase<T>(R[i], &fi_ctx::q),
+			                   R[i]->g.n[2]);
 		}
 		vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
 		halo_exchange(Rc, &fi_ctx::mg_x);
@@ -2098,7 +2157,8 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	halo_exchange(R, &fi_ctx::mg_r);
 	for (size_t i = 0; i < R.size(); ++i) {
 		const LevelPair L = level_pair(R[i], Rc[i]);
-		launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream);
+		launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream, vbase<T>(R[i], &fi_ctx::q),
+		                   R[i]->g.n[2]);
 	}
 	vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
 	halo_exchange(Rc, &fi_ctx::mg_x);
@@ -2310,7 +2370,15 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		}
 	};
 
-	auto restart = [&]() {  // r = b - A x, z = V(r), p = z, rz, rr (b.b on the first call)
+	auto read_flag = [&]() {
+		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		return c0->scal_host->done;
+	};
+	// r = b - A x, rr (b.b on the first call) and the stop test on it; unless that ends the solve: z = V(r), p = z, rz.
+	// Returns the stop flag.  (The flag is read BEFORE the V-cycle is spent: a verification that confirms the recurrence's
+	// residual -- the usual outcome -- costs one operator application, not a cycle.)
+	auto restart = [&]() -> int {
 		apply_all(R, X, Q, false);
 		for (fi_ctx* c : R) {
 			hipLaunchKernelGGL((k_sub<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, B), vown<T>(c, Q),
@@ -2321,27 +2389,29 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
 		dot(Rv, Rv);
 		mg_reduce(R, nbv, kMgInitRr);
+		const int flag = read_flag();
+		if (flag) { return flag; }
 		precondition<T>(R, Tw, Rv, Z, false);
 		dot_rz();
 		mg_reduce(R, nbv, kMgInitRz);
 		direction(1);
+		return 0;
 	};
-	restart();
+	int done = restart();
 
 	double limit_s = 600.0;
 	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
 	const auto wall0 = std::chrono::steady_clock::now();
 	bool timed_out = false;
 	int restarts_left = c0->verify_residual ? 3 : 0;
+	// One look at the stop flag per iteration, right behind the residual update: the V-cycle of an iteration that has just
+	// converged is not launched.
 	for (;;) {
-		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
-		FI_HIP_TRY(hipStreamSynchronize(st));
-		const int done = c0->scal_host->done;
 		if (done) {
 			if (done != 1 || restarts_left <= 0) { break; }
 			--restarts_left;  // recurrence converged: check b - A x, continue from it if it misses the tolerance
 			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_bump_restarts, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
-			restart();
+			done = restart();
 			continue;
 		}
 		if (timed_out_anywhere(R, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s)) {
@@ -2376,7 +2446,9 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			}
 		}
 		mg_reduce(R, nbv, kMgResid);
-		precondition<T>(R, Tw, Rv, Z, stepped);  // wasted when this step just converged; one V-cycle at most
+		done = read_flag();
+		if (done) { continue; }
+		precondition<T>(R, Tw, Rv, Z, stepped);
 		dot_rz();
 		mg_reduce(R, nbv, kMgBeta);
 		direction(0);
@@ -3441,15 +3513,18 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 
 // fp32 replica of an FI_F64 context for the mixed-precision solve: same lattice, same slab, same weights, the
 // same data points (re-emitted from the batches kept in HBM), with the levels and solver options of `c`.
-void build_twin(fi_ctx* c)
+// In three parts, so that fi_assemble can run the replica's finest level and the replica's coarser levels on two helper
+// threads beside the fp64 finest level: twin_prepare (the context; cheap, on the caller's thread), twin_assemble (rows +
+// finest level on `stream`), build_levels(c->twin, c, stream) and twin_finish.
+fi_ctx* twin_prepare(fi_ctx* c)
 {
-	if (c->level != 0) { return; }
+	if (c->level != 0) { return nullptr; }
 	if (!(c->mixed && c->dtype == FI_F64)) {
 		if (c->twin) {
 			fi_ctx_destroy(c->twin);
 			c->twin = nullptr;
 		}
-		return;
+		return nullptr;
 	}
 	const int D = c->g.ndim;
 	{
@@ -3484,6 +3559,8 @@ void build_twin(fi_ctx* c)
 		c->twin = t;
 	}
 	t->comm            = c->comm;
+	t->stream          = c->stream;
+	t->defer_scaling_exchange = false;
 	t->w               = c->w;
 	t->model_set       = true;
 	t->verify_residual = 0;
@@ -3492,6 +3569,16 @@ void build_twin(fi_ctx* c)
 	t->mg_mode         = c->mg_mode;
 	t->mg_smoother     = c->mg_smoother;
 	t->mg_safe         = c->mg_safe;
+	return t;
+}
+
+void twin_assemble(fi_ctx* c, hipStream_t build_stream)
+{
+	fi_ctx* t = c->twin;
+	if (build_stream) {
+		t->stream = build_stream;
+		t->defer_scaling_exchange = true;  // a helper thread never talks to the neighbours
+	}
 	for (auto* b : c->batches) {
 		const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
 		const float* pw  = b->has_pw ? b->pw.as<float>() : nullptr;
@@ -3505,12 +3592,24 @@ void build_twin(fi_ctx* c)
 	generic_assemble(t);
 	stencil_prepare(t);
 	operator_prepare(t);
-	build_levels(t, c);
+}
+
+void twin_finish(fi_ctx* c)
+{
+	fi_ctx* t = c->twin;
 	t->assembled = true;
 	t->vectors_ready = t->vectors_ready && t->max_blocks >= apply_num_partials(t);
 	t->stats.num_unknowns = t->g.nown;
 	t->stats.num_levels = 1;
 	for (fi_ctx* l = t->coarse; l; l = l->coarse) { t->stats.num_levels += 1; }
+}
+
+void build_twin(fi_ctx* c)  // the three parts one after the other, on the context's stream
+{
+	if (!twin_prepare(c)) { return; }
+	twin_assemble(c, nullptr);
+	build_levels(c->twin, c);
+	twin_finish(c);
 }
 
 void check_ctx(const fi_ctx* c) { FI_REQUIRE(c != nullptr, FI_ERR_INVALID, "null context"); }
@@ -3631,6 +3730,8 @@ int fi_ctx_destroy(fi_ctx* c)
 	for (auto e : c->ev_prec) { (void)hipEventDestroy(e); }
 	if (c->level_stream) { (void)hipStreamDestroy(c->level_stream); }
 	if (c->ev_level) { (void)hipEventDestroy(c->ev_level); }
+	if (c->level_stream2) { (void)hipStreamDestroy(c->level_stream2); }
+	if (c->ev_level2) { (void)hipEventDestroy(c->ev_level2); }
 	if (c->comm_stream) {
 		(void)hipStreamDestroy(c->comm_stream);
 		(void)hipEventDestroy(c->ev_ready);
@@ -3870,8 +3971,15 @@ int fi_assemble(fi_ctx* c)
 	// for list sizes; 256^3 with one coarser level: 2.05 -> 1.6 ms).  Contexts without triplet rows; the
 	// helper's failure is re-raised here.  The helper does no communication: over slabs the levels' exchange of the
 	// diagonal's ghost planes is done below, by this thread.
-	const bool beside = c->levels_wanted > 0 && c->generic.ntrip == 0 && !(c->mixed && c->dtype == FI_F64) &&
-	                    !fi::test_switch("FI_SERIAL_LEVELS");
+	// Mixed precision: the fp32 replica and ITS levels are the helper's work (the fp64 context keeps no levels of its own).
+	const bool mixed64 = c->mixed && c->dtype == FI_F64;
+	const bool beside = (c->levels_wanted > 0 || mixed64) && c->generic.ntrip == 0 && !fi::test_switch("FI_SERIAL_LEVELS");
+	if (beside && mixed64) {  // (levels an earlier, unmixed assemble may have left on this context)
+		const int keep = c->levels_wanted;
+		c->levels_wanted = 0;
+		fi::build_levels(c);
+		c->levels_wanted = keep;
+	}
 	if (beside) {
 		if (!c->level_stream) {
 			FI_HIP_TRY(hipStreamCreateWithFlags(&c->level_stream, hipStreamNonBlocking));
@@ -3881,21 +3989,47 @@ int fi_assemble(fi_ctx* c)
 		FI_HIP_TRY(hipStreamWaitEvent(c->level_stream, c->ev_level, 0));
 		int         helper_code = FI_OK;
 		std::string helper_msg;
-		auto build = [&]() {
+		// mixed precision: the replica's finest level on `level_stream`, its coarser levels on `level_stream2` -- two more
+		// chains of small launches beside this thread's (256^3, 3 coarser levels: 4.9 ms one after the other, 4.3 with one
+		// helper, 3 with two)
+		if (mixed64) {
+			fi::twin_prepare(c);
+			if (!c->level_stream2) {
+				FI_HIP_TRY(hipStreamCreateWithFlags(&c->level_stream2, hipStreamNonBlocking));
+				FI_HIP_TRY(hipEventCreateWithFlags(&c->ev_level2, hipEventDisableTiming));
+			}
+			FI_HIP_TRY(hipStreamWaitEvent(c->level_stream2, c->ev_level, 0));
+		}
+		auto guarded = [&](auto&& work, int* code, std::string* msg) {
 			try {
 				FI_HIP_TRY(hipSetDevice(c->device));
-				fi::build_levels(c, nullptr, c->level_stream);
+				work();
 			} catch (const fi::Fail& f) {
-				helper_code = f.code;
-				helper_msg  = fi_last_error();  // thread-local: carried over to the caller's thread below
+				*code = f.code;
+				*msg  = fi_last_error();  // thread-local: carried over to the caller's thread below
 			} catch (...) {
-				helper_code = FI_ERR_HIP;
-				helper_msg  = "unexpected exception while building the coarser levels";
+				*code = FI_ERR_HIP;
+				*msg  = "unexpected exception while building the coarser levels";
 			}
 		};
-		std::thread helper;
+		auto build = [&]() {
+			guarded([&]() {
+				if (mixed64) {
+					fi::twin_assemble(c, c->level_stream);
+				} else {
+					fi::build_levels(c, nullptr, c->level_stream);
+				}
+			}, &helper_code, &helper_msg);
+		};
+		int         helper2_code = FI_OK;
+		std::string helper2_msg;
+		auto build2 = [&]() {
+			guarded([&]() { fi::build_levels(c->twin, c, c->level_stream2); }, &helper2_code, &helper2_msg);
+		};
+		std::thread helper, helper2;
 		try {
 			helper = std::thread(build);
+			if (mixed64) { helper2 = std::thread(build2); }
 		} catch (...) {  // no thread to be had: the levels are built below, after the finest level, on their stream
 		}
 		int main_code = FI_OK;
@@ -3911,16 +4045,31 @@ int fi_assemble(fi_ctx* c)
 			fi::set_error("unexpected exception while assembling the finest level");
 		}
 		if (helper.joinable()) { helper.join(); } else if (main_code == FI_OK) { build(); }
-		for (fi_ctx* l = c->coarse; l; l = l->coarse) { l->stream = c->stream; }
-		if (main_code != FI_OK) { throw fi::Fail{main_code}; }
-		if (helper_code != FI_OK) {
+		if (mixed64) {
+			if (helper2.joinable()) { helper2.join(); } else if (main_code == FI_OK) { build2(); }
+			if (helper_code == FI_OK && helper2_code != FI_OK) {
+				helper_code = helper2_code;
+				helper_msg  = helper2_msg;
+			}
+		}
+		fi_ctx* const first_built = mixed64 ? c->twin : c->coarse;  // the replica, then its levels / the levels
+		for (fi_ctx* l = first_built; l; l = l->coarse) { l->stream = c->stream; }
+		if (main_code != FI_OK || helper_code != FI_OK) {
+			(void)hipStreamSynchronize(c->level_stream);  // nothing of the helpers' work stays in flight behind the error
+			if (c->level_stream2) { (void)hipStreamSynchronize(c->level_stream2); }
+			if (main_code != FI_OK) { throw fi::Fail{main_code}; }
 			fi::set_error("%s", helper_msg.c_str());
 			throw fi::Fail{helper_code};
 		}
 		FI_HIP_TRY(hipEventRecord(c->ev_level, c->level_stream));
 		FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_level, 0));
+		if (mixed64) {
+			FI_HIP_TRY(hipEventRecord(c->ev_level2, c->level_stream2));
+			FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_level2, 0));
+			fi::twin_finish(c);
+		}
 		// slabs: the levels' share of the assembly's one exchange (the diagonal's ghost planes), in level order on every rank
-		for (fi_ctx* l = c->coarse; l; l = l->coarse) { fi::operator_finish_ghosts(l); }
+		for (fi_ctx* l = first_built; l; l = l->coarse) { fi::operator_finish_ghosts(l); }
 	} else {
 	fi::assemble(c);
 	fi::generic_assemble(c);
@@ -3928,16 +4077,17 @@ int fi_assemble(fi_ctx* c)
 	fi::operator_prepare(c);
 	}
 	if (beside) {
-		// done above
-	} else if (c->mixed && c->dtype == FI_F64) {  // the fp32 replica carries the levels
+		if (!mixed64) { fi::build_twin(c); }  // (drops a replica left by an earlier, mixed assemble)
+	} else if (mixed64) {  // the fp32 replica carries the levels
 		const int keep = c->levels_wanted;
 		c->levels_wanted = 0;
 		fi::build_levels(c);
 		c->levels_wanted = keep;
+		fi::build_twin(c);
 	} else {
 		fi::build_levels(c);
+		fi::build_twin(c);
 	}
-	fi::build_twin(c);
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;

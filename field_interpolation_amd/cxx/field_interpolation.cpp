@@ -226,23 +226,21 @@ LatticeField sdf_from_points(const std::vector<int>& sizes, const Weights& weigh
 	return field;
 }
 
-// Post-processing helper (field_interpolation.cpp:402-429), host side: it consumes host vectors the caller
-// already holds and is not on the solve path.
+// generate_error_map (field_interpolation.cpp:402-429): the caller's rows are uploaded (fi_add_rows_coo) and the blame of
+// the squared row residuals is computed on the device (fi_error_map), like every other consumer of the rows.
+namespace detail {
+std::vector<float> error_map_on_gpu(const std::vector<Triplet>& triplets, const std::vector<float>& solution,
+                                    const std::vector<float>& rhs);  // sparse_linear.cpp
+}
 std::vector<float> generate_error_map(const std::vector<Triplet>& triplets, const std::vector<float>& solution,
                                       const std::vector<float>& rhs)
 {
-	std::vector<float> residual = rhs;
-	std::vector<float> norm2(rhs.size(), 0.0f);
-	for (const Triplet& t : triplets) {
-		residual[t.row] -= solution[t.col] * t.value;
-		norm2[t.row] += t.value * t.value;
+	for (const Triplet& t : triplets) {  // the reference indexes without checks; a bad index must not reach the device
+		if (t.row < 0 || static_cast<size_t>(t.row) >= rhs.size() || t.col < 0 || static_cast<size_t>(t.col) >= solution.size()) {
+			fatal("generate_error_map: triplet index out of range");
+		}
 	}
-	for (float& r : residual) { r *= r; }
-	std::vector<float> blame(solution.size(), 0.0f);
-	for (const Triplet& t : triplets) {
-		if (norm2[t.row] != 0) { blame[t.col] += (t.value * t.value) / norm2[t.row] * residual[t.row]; }
-	}
-	return blame;
+	return detail::error_map_on_gpu(triplets, solution, rhs);
 }
 
 std::vector<float> upscale_field(const float* field, const std::vector<int>& small_sizes,

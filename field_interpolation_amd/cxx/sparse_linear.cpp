@@ -114,7 +114,13 @@ CtxCache& cache()
 struct RowsOnGpu {
 	fi_ctx* ctx = nullptr;
 	RowsOnGpu(const LinearEquation& eq, int num_columns, int dtype, const std::vector<int>* lattice = nullptr)
+	    : RowsOnGpu(eq.triplets, eq.rhs, num_columns, dtype, lattice)
 	{
+	}
+	RowsOnGpu(const std::vector<Triplet>& triplets, const std::vector<float>& rhs, int num_columns, int dtype,
+	          const std::vector<int>* lattice = nullptr)
+	{
+		struct { const std::vector<Triplet>& triplets; const std::vector<float>& rhs; } eq{triplets, rhs};
 		if (num_columns < 1) { return; }
 		const bool nd = lattice && !lattice->empty() && lattice->size() <= 3;
 		const std::vector<int> shape = nd ? *lattice : std::vector<int>{num_columns};
@@ -271,5 +277,25 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 	}
 	return out;
 }
+
+namespace detail {
+
+// generate_error_map (field_interpolation.cpp:402-429) through the device: the caller's rows go up like for a solve
+// (fi_add_rows_coo), fi_error_map distributes the squared row residuals.  {} when the GPU path fails.
+std::vector<float> error_map_on_gpu(const std::vector<Triplet>& triplets, const std::vector<float>& solution,
+                                    const std::vector<float>& rhs)
+{
+	if (solution.empty()) { return {}; }
+	RowsOnGpu rows(triplets, rhs, static_cast<int>(solution.size()), FI_F32);
+	if (!rows.ctx) { return {}; }
+	std::vector<float> blame(solution.size(), 0.0f);
+	if (fi_error_map(rows.ctx, solution.data(), blame.data(), FI_HOST) != FI_OK) {
+		warn("fi_error_map");
+		return {};
+	}
+	return blame;
+}
+
+}  // namespace detail
 
 }  // namespace field_interpolation

@@ -10,6 +10,7 @@
 //      steps per requested BiCGSTAB step), the singular-system {} convention, and the latency of warm calls (the
 //      device context is cached per lattice shape).
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -163,6 +164,22 @@ int main()
 		float total = 0;
 		for (float h : heat) { total += h; }
 		require(heat.size() == n && total > 0, "generate_error_map");
+		{   // the definition itself (blame_j = sum over rows of (a_ij^2 / |a_i|^2) (b_i - a_i x)^2), in double on the host
+			std::vector<double> res(field.eq.rhs.begin(), field.eq.rhs.end()), n2(field.eq.rhs.size(), 0.0), want(n, 0.0);
+			for (const auto& t : field.eq.triplets) {
+				res[t.row] -= static_cast<double>(exact[t.col]) * t.value;
+				n2[t.row] += static_cast<double>(t.value) * t.value;
+			}
+			for (const auto& t : field.eq.triplets) {
+				if (n2[t.row] != 0) { want[t.col] += static_cast<double>(t.value) * t.value / n2[t.row] * res[t.row] * res[t.row]; }
+			}
+			double worst = 0, scale = 0;
+			for (size_t i = 0; i < n; ++i) {
+				worst = std::max(worst, std::fabs(heat[i] - want[i]));
+				scale = std::max(scale, std::fabs(want[i]));
+			}
+			require(worst <= 1e-4 * scale, "generate_error_map: the device's blame == the definition");
+		}
 		auto heat_gpu = gpu.generate_error_map(exact);
 		require(heat_gpu.size() == n && max_rel(heat_gpu, heat) <= 1e-4f, "generate_error_map: device rows == host triplets");
 		fi::SolveOptions tiled;

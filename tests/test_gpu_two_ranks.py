@@ -25,7 +25,9 @@ def _free_port():
 
 
 def _torchrun(args, timeout=600, **extra_env):
-    env = dict(os.environ, FI_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
+    # the host-staged transport exists only in the test build of the library (csrc/Makefile: -DFI_TEST_TRANSPORT)
+    env = dict(os.environ, FI_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               FI_HIP_LIB=os.path.join(ROOT, "field_interpolation_amd", "libfi_hip_test.so"), **extra_env)
     r = None
     for _ in range(3):
         # the port was free a moment ago; the rendezvous can still lose it to somebody else (EADDRINUSE comes before
@@ -80,3 +82,15 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     assert line["config"]["true_rel_residual"] <= 1.5e-5
     assert ("64x64x128" if scaling == "weak" else "64x64x64") in line["config"]["workload"]
     assert line["value"] > 0
+
+
+def test_release_library_has_no_host_transport():
+    """libfi_hip.so carries RCCL only: fi_comm_init_host answers FI_ERR_UNSUPPORTED and no shared-memory call is linked."""
+    import ctypes as C
+    import field_interpolation_amd as fi
+    from field_interpolation_amd import _capi
+    f = fi.LatticeField([16, 16, 32], dtype="f32", rank=0, nranks=2)
+    assert _capi.lib().fi_comm_init_host(f._h, b"/fi_test_none", 1) == 5
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(ROOT, "field_interpolation_amd", "libfi_hip.so")],
+                                   text=True)
+    assert "shm_open" not in syms and "shm_unlink" not in syms
