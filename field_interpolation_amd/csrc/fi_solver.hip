@@ -1319,6 +1319,8 @@ template <typename T>
 void cg_run_poly(RankSet& R, int max_iterations, float tol);
 template <typename T>
 void estimate_poly_lambda(RankSet& R);
+template <typename T>
+void cg_run_mg(RankSet& R, int max_iterations, float tol);
 
 // Coarse-to-fine start (the reference's own remedy for large lattices: solve a coarser lattice, upscale, use
 // as the guess -- src/sdf_field.cpp:272-288, README.md "My resolution is huge"): every coarser level is
@@ -1354,8 +1356,26 @@ void cascade_guess(RankSet& R)
 				l->poly_terms = root->poly_terms;
 				l->poly_ratio = root->poly_ratio;
 			}
+			// with the V-cycle preconditioner on, a level that has coarser levels below it is solved with it too (a full
+			// multigrid start): Jacobi-PCG needs thousands of iterations on the coarse levels of an SDF (config 3: 4 338,
+			// most of the solve's wall time)
+			const bool mg = root->mg_mode == 1 && lc[0]->coarse && !test_switch("FI_CASCADE_NO_MG");
+			for (fi_ctx* l : lc) { l->mg_mode = root->mg_mode; }
 			if (poly_ok(lc[0])) {
 				cg_run_poly<T>(lc, 0, static_cast<float>(root->coarse_tol));
+			} else if (mg) {
+				// Data-rich levels (config 4) are done after a few dozen cheap Jacobi-PCG steps; where that is not enough the
+				// V-cycle takes over from the iterate.  A start guess is worth a bounded effort, and fp32 levels cannot go
+				// below ~1e-5 anyway (the recurrence stalls there: 29 000 iterations without reaching 1e-6 at 48^3).
+				const double floor_tol = sizeof(T) == 4 ? 1e-5 : 0.0;
+				const float  ltol = static_cast<float>(root->coarse_tol > floor_tol ? root->coarse_tol : floor_tol);
+				cg_run<T>(lc, 48, ltol);
+				int coarse_it = lc[0]->stats.iterations;
+				if (!lc[0]->stats.converged) {
+					cg_run_mg<T>(lc, 40, ltol);
+					coarse_it += lc[0]->stats.iterations;
+				}
+				for (fi_ctx* l : lc) { l->stats.iterations = coarse_it; }
 			} else {
 				cg_run<T>(lc, 0, static_cast<float>(root->coarse_tol));
 			}
@@ -2223,7 +2243,10 @@ void mg_prepare(RankSet& R, bool clear_finest)
 				if (!c->dinv16s_valid) { prepare_safe_scaling(c); }
 			}
 		} else if (!(l[0]->lambda_max > 0)) {
-			const bool borrow = k == 0 && chain.size() > 1 && chain[1][0]->lambda_max > 0 && !tuning_switch("FI_MG_FINE_POWER");
+			// (only the finest level of the whole hierarchy borrows: a coarser level that heads the chain of a cascade solve
+			// keeps the estimate for the V-cycles of the finer solves that follow)
+			const bool borrow = k == 0 && l[0]->level == 0 && chain.size() > 1 && chain[1][0]->lambda_max > 0 &&
+			                    !tuning_switch("FI_MG_FINE_POWER");
 			if (borrow) {
 				for (fi_ctx* c : l) { c->lambda_max = c->coarse->lambda_max; }
 			} else {

@@ -120,6 +120,7 @@ def test_mixed_precision_vcycle(oracle, fi, sizes, levels, gk):
         f.set_levels(levels)
         f.set_multigrid(True)
     mixed.set_mixed_precision(True)
+    mixed.set_mg_smoother(False)      # like for like: the pure-fp64 V-cycle smooths with the Chebyshev polynomial in A
     for f in (pure, mixed):
         f.assemble()
     assert mixed.stats()["num_levels"] == pure.stats()["num_levels"] == levels + 1
@@ -134,6 +135,20 @@ def test_mixed_precision_vcycle(oracle, fi, sizes, levels, gk):
     if len(sizes) == 2:   # sparse Cholesky of a 3-D lattice this size takes minutes on the CPU
         x64 = fo.solve_exact_f64()
         assert rel_inf(mixed.solution_f64(), x64) <= 1e-6
+    # the default smoother of fp32 3-D levels (the polynomial in A_model + f diag(A_data)): another preconditioner, the same
+    # answer, about as many iterations
+    if len(sizes) == 3:
+        mp = fi.LatticeField(sizes, dtype="f64")
+        mp.add_field_constraints(w)
+        mp.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        mp.set_levels(levels)
+        mp.set_multigrid(True)
+        mp.set_mixed_precision(True)
+        mp.assemble()
+        xq, itq, rq = mp.solve_cg(None, 0, tol)
+        assert mp.stats()["converged"] == 1 and mp.true_residual() <= tol * 1.01
+        assert itq <= itp + max(3, itp // 3), (itq, itp)
+        assert rel_inf(mp.solution_f64(), pure.solution_f64()) <= 1e-7
     # a caller's guess is honoured (warm start from the fp32-rounded answer: a handful of iterations)
     xw, itw, rw = mixed.solve_cg(xm, 0, 1e-6)
     assert rw <= 1e-6 and itw <= itm // 2
