@@ -67,6 +67,20 @@ struct CtxCache {
 	{
 		for (CachedCtx& s : slots) { fi_ctx_destroy(s.ctx); }
 	}
+	// Only small systems are kept: the cache exists for the per-frame caller's latency (a 128^2 system), and a context
+	// holds every vector and sort buffer of its system -- a few cached 256^3 contexts would pin gigabytes of HBM until the
+	// thread ends.  Larger systems get a context of their own, destroyed with the call (RowsOnGpu::owned).
+	static bool cacheable(const std::vector<int>& shape)
+	{
+		long long n = 1;
+		for (int s : shape) { n *= s; }
+		return n <= (1LL << 20);
+	}
+	void clear()
+	{
+		for (CachedCtx& s : slots) { fi_ctx_destroy(s.ctx); }
+		slots.clear();
+	}
 	fi_ctx* get(const std::vector<int>& shape, int dtype)
 	{
 		++clock;
@@ -113,6 +127,11 @@ CtxCache& cache()
 // caller's lattice, which only the tile pre-solver looks at), no model rows.
 struct RowsOnGpu {
 	fi_ctx* ctx = nullptr;
+	bool    owned = false;  // not from the cache: destroyed with this object
+	~RowsOnGpu()
+	{
+		if (owned && ctx) { fi_ctx_destroy(ctx); }
+	}
 	RowsOnGpu(const LinearEquation& eq, int num_columns, int dtype, const std::vector<int>* lattice = nullptr)
 	    : RowsOnGpu(eq.triplets, eq.rhs, num_columns, dtype, lattice)
 	{
@@ -124,7 +143,14 @@ struct RowsOnGpu {
 		if (num_columns < 1) { return; }
 		const bool nd = lattice && !lattice->empty() && lattice->size() <= 3;
 		const std::vector<int> shape = nd ? *lattice : std::vector<int>{num_columns};
-		ctx = cache().get(shape, dtype);
+		if (CtxCache::cacheable(shape)) {
+			ctx = cache().get(shape, dtype);
+		} else if (fi_ctx_create(&ctx, static_cast<int>(shape.size()), shape.data(), dtype) == FI_OK) {
+			owned = true;
+		} else {
+			warn("fi_ctx_create");
+			ctx = nullptr;
+		}
 		if (!ctx) { return; }
 		const fi_weights none = {1, 1, 0, 0, 0, 0, 0, 0, FI_VALUE_LINEAR_INTERPOLATION, FI_GRADIENT_CELL_EDGES};
 		const bool ok = fi_clear_points(ctx) == FI_OK && fi_set_model(ctx, &none) == FI_OK &&
@@ -133,7 +159,8 @@ struct RowsOnGpu {
 		                fi_assemble(ctx) == FI_OK;
 		if (!ok) {
 			warn("assembling the linear equation");
-			cache().drop(ctx);
+			if (owned) { fi_ctx_destroy(ctx); } else { cache().drop(ctx); }
+			owned = false;
 			ctx = nullptr;
 		}
 	}
@@ -277,6 +304,9 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 	}
 	return out;
 }
+
+// Frees the device contexts this thread's stateless calls have cached (gpu_field.hpp).
+void clear_context_cache() { cache().clear(); }
 
 namespace detail {
 

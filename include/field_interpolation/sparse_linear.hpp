@@ -65,6 +65,11 @@ std::ostream& operator<<(std::ostream& os, const LinearEquation& eq);
 
 // ---- solving (least squares over eq.rhs.size() rows) -------------------------------------------------------
 
+// "Exact" / "fast": the normal equations iterated on the GPU to a relative residual of 1e-12 in double / 1e-7 in float.
+// An empty vector where a factorisation would fail -- an unknown without any equation (zero pivot) -- or on a solver
+// breakdown.  A well-posed but badly conditioned system whose attainable residual stays above the target returns its best
+// iterate (one line on stderr); an iteration budget given to the *_with_guess calls buys that many operator applications
+// (two CG steps per BiCGSTAB step of the original).
 std::vector<float> solve_sparse_linear_exact(const LinearEquation& eq, int num_columns);
 std::vector<float> solve_sparse_linear_fast(const LinearEquation& eq, int num_columns);
 

@@ -268,6 +268,14 @@ int main()
 			require(last.size() == n128 && ms_cg < 200.0 && ms_jac < 200.0, "per-frame calls stay interactive");
 		}
 	}
+	fi::clear_context_cache();   // (and a call after it still works: the cache refills)
+	{
+		fi::LinearEquation eq;
+		fi::add_equation(&eq, fi::Weight{1.0f}, fi::Rhs{2.0f}, {{0, 1.0f}});
+		fi::add_equation(&eq, fi::Weight{1.0f}, fi::Rhs{4.0f}, {{1, 2.0f}});
+		auto x = fi::solve_sparse_linear_exact(eq, 2);
+		require(x.size() == 2 && std::fabs(x[0] - 2.0f) < 1e-5f && std::fabs(x[1] - 2.0f) < 1e-5f, "solve after clear_context_cache");
+	}
 	std::printf("all drop-in checks passed\n");
 	return 0;
 }

@@ -16,8 +16,9 @@ SHARE = 0.5
 
 
 def avg(path, counter, needle):
+    needles = needle.split("|")           # several kernel names: the mean over the launches of all of them
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if any(n in r["Kernel_Name"] for n in needles) and r["Counter_Name"] == counter]
     big = [v for v in vals if v > SHARE * max(vals)]        # drop the launches that exited on the done flag
     return sum(big) / len(big), len(big)
 
