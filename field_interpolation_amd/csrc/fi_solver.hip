@@ -1094,6 +1094,20 @@ bool timed_out_anywhere(RankSet& R, bool mine)
 	return v > 0.0;
 }
 
+// One slab per process: do all ranks report success?  (An all-reduce of a flag, like timed_out_anywhere.)  A rank that
+// failed before a collective would leave its peers waiting in it forever -- RCCL has no timeout.
+bool all_ranks_ok(fi_ctx* c, bool mine)
+{
+	if (!(c->nranks > 1 && comm_ready(c))) { return mine; }
+	double* flag = (c->scal.as<CgScalars>() + 2)->sums + 3;
+	double  v = mine ? 0.0 : 1.0;
+	FI_HIP_TRY(hipMemcpyAsync(flag, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+	allreduce_sum(c, flag, 1);
+	FI_HIP_TRY(hipMemcpyAsync(&v, flag, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	FI_HIP_TRY(hipStreamSynchronize(c->stream));
+	return v == 0.0;
+}
+
 // Jacobi-PCG over a rank set; x of every member holds the guess on entry and the solution on return.
 template <typename T>
 void cg_run(RankSet& R, int max_iterations, float tol)
@@ -4056,6 +4070,7 @@ int fi_assemble(fi_ctx* c)
 		} catch (...) {  // no thread to be had: the levels are built below, after the finest level, on their stream
 		}
 		int main_code = FI_OK;
+		c->defer_scaling_exchange = true;  // slabs: the one exchange of the assembly comes after the ranks have agreed (below)
 		try {
 			fi::assemble(c);
 			fi::generic_assemble(c);
@@ -4077,12 +4092,24 @@ int fi_assemble(fi_ctx* c)
 		}
 		fi_ctx* const first_built = mixed64 ? c->twin : c->coarse;  // the replica, then its levels / the levels
 		for (fi_ctx* l = first_built; l; l = l->coarse) { l->stream = c->stream; }
-		if (main_code != FI_OK || helper_code != FI_OK) {
+		const bool mine_ok = main_code == FI_OK && helper_code == FI_OK;
+		bool peers_ok = true;
+		try {
+			peers_ok = fi::all_ranks_ok(c, mine_ok);  // (every rank gets here: nothing above is collective)
+		} catch (const fi::Fail&) {
+			peers_ok = false;
+		}
+		if (!mine_ok || !peers_ok) {
 			(void)hipStreamSynchronize(c->level_stream);  // nothing of the helpers' work stays in flight behind the error
 			if (c->level_stream2) { (void)hipStreamSynchronize(c->level_stream2); }
+			c->defer_scaling_exchange = false;
 			if (main_code != FI_OK) { throw fi::Fail{main_code}; }
-			fi::set_error("%s", helper_msg.c_str());
-			throw fi::Fail{helper_code};
+			if (helper_code != FI_OK) {
+				fi::set_error("%s", helper_msg.c_str());
+				throw fi::Fail{helper_code};
+			}
+			fi::set_error("fi_assemble: another rank failed while assembling its slab");
+			throw fi::Fail{FI_ERR_COMM};
 		}
 		FI_HIP_TRY(hipEventRecord(c->ev_level, c->level_stream));
 		FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_level, 0));
@@ -4092,6 +4119,7 @@ int fi_assemble(fi_ctx* c)
 			fi::twin_finish(c);
 		}
 		// slabs: the levels' share of the assembly's one exchange (the diagonal's ghost planes), in level order on every rank
+		fi::operator_finish_ghosts(c);
 		for (fi_ctx* l = first_built; l; l = l->coarse) { fi::operator_finish_ghosts(l); }
 	} else {
 	fi::assemble(c);
