@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""Experiment: which solver mode reaches a 1e-5 FIELD error on config 4 fastest (run on the GPU box).
-MODES="name:dtype:levels:mg:mixed:poly:ratio:tol,..."  e.g. "p64:f64:1:0:0:4:30:3e-9"."""
+"""The one experiment driver of the repository (run on the GPU box): solver modes on a BASELINE configuration -- time per
+step (clear + add + assemble + solve, inputs in HBM), iterations, verified residual and, for config 4, the FIELD error
+against an fp64 solve to 1e-11.
+  MODES="name:dtype:levels:mg:mixed:poly:ratio:tol,..."   e.g. "p64:f64:1:0:0:4:30:3e-9,mgmix:f64:3:1:1:0:0:1e-7"
+  CFG=4|5 (default 4)  SIDE=<lattice side>  CTOL=<coarse tolerance>  NOREF=1 (skip the reference solve)
+Library switches pass through the environment (FI_MG_FULL_SMOOTHER, FI_VERTEX_LEVELS, FI_SERIAL_LEVELS, ...).
+(The one-off scripts of rounds 1 and 2 -- tools/exp_*.py, tools/r2_*.sh, cited in profiles/r1_ablation.md and
+r2_ablation.md -- are in the history up to commit d1c1349.)"""
 import os
 import sys
 import time
@@ -10,12 +16,19 @@ import torch
 import field_interpolation_amd as fi
 from field_interpolation_amd import synth
 
-side = int(os.environ.get("SIDE", "256"))
-npts = int(1e6 * (side / 256) ** 3)
-sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3)
+cfg = os.environ.get("CFG", "4")
+if cfg == "5":
+    side = int(os.environ.get("SIDE", "512"))
+    sizes, w, pos, nrm = synth.config5(side=side, num_points=int(5e6 * (side / 512) ** 2), seed=4)
+    val = None
+else:
+    side = int(os.environ.get("SIDE", "256"))
+    sizes, w, pos, val = synth.config4(side=side, num_points=int(1e6 * (side / 256) ** 3), seed=3)
+    nrm = None
 dev = torch.device("cuda", 0)
 d_pos = torch.from_numpy(pos).to(dev)
-d_val = torch.from_numpy(val).to(dev)
+d_val = torch.from_numpy(val).to(dev) if val is not None else None
+d_nrm = torch.from_numpy(nrm).to(dev) if nrm is not None else None
 d_out = torch.empty(int(np.prod(sizes)), dtype=torch.float32, device=dev)
 
 
@@ -35,12 +48,13 @@ def make(dtype, levels, mg, mixed, poly, ratio, ctol):
 
 def step(f, tol):
     f.clear_points()
-    f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, d_pos, None, None, values=d_val)
+    f.add_points(w.data_pos, w.value_kernel, w.data_gradient if d_nrm is not None else 0.0, w.gradient_kernel, d_pos, d_nrm, None,
+                 values=d_val)
     f.assemble()
     return f.solve_cg(None, 0, tol, out=d_out)
 
 
-if os.environ.get("NOREF"):
+if os.environ.get("NOREF") or cfg != "4":
     x64, xmax = np.zeros(int(np.prod(sizes))), 1.0
 else:
     ref = make("f64", 1, False, False, 4, 30.0, 1e-6)
