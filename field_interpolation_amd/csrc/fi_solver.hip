@@ -1383,10 +1383,16 @@ void cascade_guess(RankSet& R)
 				// below ~1e-5 anyway (the recurrence stalls there: 29 000 iterations without reaching 1e-6 at 48^3).
 				const double floor_tol = sizeof(T) == 4 ? 1e-5 : 0.0;
 				const float  ltol = static_cast<float>(root->coarse_tol > floor_tol ? root->coarse_tol : floor_tol);
+				// (measured, tools/r3_sweep_cascade.sh: config 3 wants its levels converged -- 13 fine iterations at 4096^2
+				// instead of 19 / 26 with 8 / 4 cycles per level --, config 5's 256^3 level is not worth more than 8 cycles:
+				// 439 -> 396 ms per step)
+				int64_t n_level = 1;
+				for (int d = 0; d < 3; ++d) { n_level *= lc[0]->g.gn[d]; }
+				const int cap_mg = n_level <= (1LL << 22) ? 40 : 8;
 				cg_run<T>(lc, 48, ltol);
 				int coarse_it = lc[0]->stats.iterations;
 				if (!lc[0]->stats.converged) {
-					cg_run_mg<T>(lc, 40, ltol);
+					cg_run_mg<T>(lc, cap_mg, ltol);
 					coarse_it += lc[0]->stats.iterations;
 				}
 				for (fi_ctx* l : lc) { l->stats.iterations = coarse_it; }
