@@ -2068,8 +2068,9 @@ bool poly_smoother_ok(const RankSet& R)
 {
 	if (sizeof(T) != 4 || test_switch("FI_MG_FULL_SMOOTHER")) { return false; }  // tests compare the two smoothers
 	for (const fi_ctx* c : R) {
-		if (c->mg_smoother != 1 || !c->march.valid || !stencil_cheb_available(c) || !stencil_full_epi_available(c) ||
-		    c->generic.ntrip != 0) {
+		// 3-D levels only: the 2-D tile kernel applies its cells in the same single launch, so the Chebyshev smoother in
+		// the full operator costs no more per step there and is the better smoother (config 3: 13 iterations against 38)
+		if (c->mg_smoother != 1 || !c->value_rows_only || !c->march.valid || !stencil_full_epi_available(c) || c->generic.ntrip != 0) {
 			return false;
 		}
 	}
@@ -2095,7 +2096,8 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb)
 	const double hi = 1.1 * lam, lo = hi / mg_ratio();
 	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
 	const bool single = R.size() == 1 && c0->nranks == 1;
-	const bool pro = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && !test_switch("FI_NO_Z0_ON_LOAD");
+	const bool pro = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && c0->march.valid &&
+	                 !test_switch("FI_NO_Z0_ON_LOAD");
 	auto region2 = [](fi_ctx* c) { return c->partial.as<double>() + 2 * static_cast<size_t>(c->max_blocks); };
 	if (!pro) {
 		for (fi_ctx* c : R) {  // z_0 = Dinv r / theta
@@ -2915,7 +2917,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	// (fi_stencil.hip, PRO) -- k_pcg_resid then stores no z_0, and step 2 recomputes it as its z_prev.  One slab per
 	// process: the ghost planes of r are exchanged instead of z_0's, those of the scaling came with the assembly
 	// (operator_prepare); the loop-back group (no transport at assembly time) keeps the stored z_0.
-	const bool z0_on_load = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && !test_switch("FI_NO_Z0_ON_LOAD");
+	const bool z0_on_load = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && c0->march.valid &&
+	                        !test_switch("FI_NO_Z0_ON_LOAD");  // (3-D: the marching kernel; 2-D lattices store z_0)
 	// Undivided lattice: the sums of the per-workgroup partials (p.q; r.r, r.z) are folded into their consumers (every
 	// workgroup sums the 1-4 k partials in the same fixed order); rank sets form them once, by a one-block kernel in
 	// front of the all-reduce.  Measured at 256^3 with both forms (profiles/r2_ablation.md section 6): folded 10.65 ms
@@ -3432,6 +3435,14 @@ fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks);
 // coarsen: contexts holding them stay single-level.
 // build_stream: the stream the levels are ASSEMBLED on (fi_assemble runs this function on a helper thread beside the
 // assembly of the finest level); the levels then go back to the solver stream of `c`.
+bool holds_value_rows_only(const fi_ctx* src)
+{
+	for (const PointBatch* b : src->batches) {
+		if (b->n > 0 && b->has_nrm && b->gw != 0.0f) { return false; }
+	}
+	return src->generic.ntrip == 0;
+}
+
 void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = nullptr)  // src: the context holding the point batches (default: c)
 {
 	if (c->level != 0) { return; }
@@ -3513,6 +3524,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		co->comm = c->comm;
 		co->mg_smoother = c->mg_smoother;
 		co->mg_safe     = c->mg_safe;
+		co->value_rows_only = holds_value_rows_only(src);
 		co->stream = build_stream ? build_stream : c->stream;
 		co->defer_scaling_exchange = build_stream != nullptr;  // a helper thread never talks to the neighbours
 		const float vol = static_cast<float>(1 << D);
@@ -3612,6 +3624,7 @@ fi_ctx* twin_prepare(fi_ctx* c)
 	t->mg_mode         = c->mg_mode;
 	t->mg_smoother     = c->mg_smoother;
 	t->mg_safe         = c->mg_safe;
+	t->value_rows_only = holds_value_rows_only(c);
 	return t;
 }
 
@@ -4014,6 +4027,7 @@ int fi_assemble(fi_ctx* c)
 	// for list sizes; 256^3 with one coarser level: 2.05 -> 1.6 ms).  Contexts without triplet rows; the
 	// helper's failure is re-raised here.  The helper does no communication: over slabs the levels' exchange of the
 	// diagonal's ghost planes is done below, by this thread.
+	c->value_rows_only = fi::holds_value_rows_only(c);
 	// Mixed precision: the fp32 replica and ITS levels are the helper's work (the fp64 context keeps no levels of its own).
 	const bool mixed64 = c->mixed && c->dtype == FI_F64;
 	const bool beside = (c->levels_wanted > 0 || mixed64) && c->generic.ntrip == 0 && !fi::test_switch("FI_SERIAL_LEVELS");

@@ -1716,14 +1716,19 @@ namespace fi {
 #endif
 
 // Chebyshev step through the marching kernel (see ChebEpi); false when the kernel does not apply to this context.
-bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid; }
-int  stencil_cheb_partials(const fi_ctx* c) { return c->march.Pplain.nwg; }
+bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid || c->tile2.valid; }  // (2-D: the tile kernel)
+int  stencil_cheb_partials(const fi_ctx* c) { return c->march.valid ? c->march.Pplain.nwg : tile2d_partials(c); }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
                        double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling)
 {
 	// pro_scale != 0 (the first step, z_prev = 0): `z` is r and the kernel forms z_0 = pro_scale * Dinv * r on load
 	// zprev == nullptr: the step from z_prev = 0 (z itself stands in under a zero coefficient);
 	// zprev_scale != 0: z_prev = zprev_scale * Dinv r, read through r's own cache lines
+	if (c->tile2.valid) {  // 2-D lattices: no operand formed on load, no partial launches
+		FI_REQUIRE(pro_scale == 0.0 && part == 0, FI_ERR_UNSUPPORTED, "2-D polynomial step: stored z_0, whole lattice");
+		tile2d_cheb_step(c, z, zprev, r, znew, c1, c2, partial, zprev_scale, scaling);
+		return;
+	}
 	const unsigned short* d16 = scaling ? scaling : c->dinv16.as<unsigned short>();
 	const void* zp = zprev_scale != 0.0 ? r : (zprev ? zprev : z);
 	const bool  has_prev = zprev_scale != 0.0 || zprev;
@@ -1741,6 +1746,10 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 // v_new = (A_model v) / diag(A_model), partials of v_new . v_new (power method on the model operator)
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 {
+	if (c->tile2.valid) {
+		tile2d_power_step(c, v, vnew, partial);
+		return;
+	}
 	const unsigned short* d16 = c->dinv16.as<unsigned short>();  // loaded, not used
 	if (c->dtype == FI_F64) {
 		ChebEpi<double> E{static_cast<const double*>(v), static_cast<const double*>(v), d16, static_cast<double*>(vnew), 0, 0, 0, 1, 0, 0};

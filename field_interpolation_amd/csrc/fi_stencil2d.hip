@@ -62,6 +62,10 @@ __device__ inline double wave_sum(double v)
 // Epilogue of the V-cycle's smoother (fi_solver.hip cheb_smooth_fused; the 3-D kernel's ChebEpi modes 2 and 3): instead of
 // storing q = A z the kernel stores  z_new = a z - c1 z_prev + c2 Dinv (r - q)  (residual: z_new = r - q), Dinv the
 // context's bfloat16 scaling.  z_prev may be z_new's own buffer (read and written by the point's owner only).
+// residual = 2 (plain launches; the polynomial preconditioner / smoother of fi_solver.hip, the 3-D kernel's ChebEpi mode 0):
+//     s = Dinv (q - m z) + z = Dinv (A_model + diag(A_data)) z,  m = the model diagonal from the boundary masks,
+//     z_new = a z - c1 z_prev + c2 (Dinv r - s),  partials r . z_new;   zp_scale != 0: z_prev = zp_scale Dinv (vector zprev)
+// residual = 3: a power-method step on the model operator, z_new = q / m, partials z_new . z_new.
 template <typename T>
 struct Epi2 {
 	const T* zprev;
@@ -70,6 +74,7 @@ struct Epi2 {
 	T*       znew;
 	T        a, c1, c2;
 	int      residual;
+	T        zp_scale;
 };
 
 template <typename T, bool HAS1, bool HAS2, bool CELLS, bool EPI = false>
@@ -266,21 +271,56 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 	}
 	if (EPI) {
 		T* const dst = E.znew + static_cast<int64_t>(lyr) * P.nx + gx;
+		// the model diagonal along y (the same for the thread's VX points), for the polynomial's modes
+		T my = T(0);
+		if (E.residual >= 2) {
+			if (HAS2) {
+				my += C.w2sq * (((gy - 2 >= 0 && gy < P.gy) ? T(1) : T(0)) + ((gy - 1 >= 0 && gy + 1 < P.gy) ? T(4) : T(0)) +
+				                ((gy >= 0 && gy + 2 < P.gy) ? T(1) : T(0)));
+			}
+			if (HAS1) { my += C.w1sq * (((gy - 1 >= 0 && gy < P.gy) ? T(1) : T(0)) + ((gy >= 0 && gy + 1 < P.gy) ? T(1) : T(0))); }
+			my += C.w0x2;
+		}
+		T part = T(0);
 		for (int j = 0; j < VX; ++j) {  // (point by point: rows need not be 16-byte multiples)
 			if (j < nvalid) {
 				const int64_t i = static_cast<int64_t>(lyr) * P.nx + gx + j;
-				const T rv = E.r[i];
 				T zn;
-				if (E.residual) {
-					zn = rv - po[j];
-				} else {
+				if (E.residual == 1) {
+					zn = E.r[i] - po[j];
+				} else if (E.residual == 0) {
 					const T dv = static_cast<T>(__uint_as_float(static_cast<unsigned int>(E.dinv[i]) << 16));
-					zn = E.a * pc[j] - E.c1 * E.zprev[i] + E.c2 * (dv * (rv - po[j]));
+					zn = E.a * pc[j] - E.c1 * E.zprev[i] + E.c2 * (dv * (E.r[i] - po[j]));
+				} else {
+					const int g = gx + j;
+					T m = my;
+					if (HAS2) {
+						m += C.w2sq * (((g - 2 >= 0 && g < P.nx) ? T(1) : T(0)) + ((g - 1 >= 0 && g + 1 < P.nx) ? T(4) : T(0)) +
+						               ((g + 2 < P.nx) ? T(1) : T(0)));
+					}
+					if (HAS1) { m += C.w1sq * (((g - 1 >= 0) ? T(1) : T(0)) + ((g + 1 < P.nx) ? T(1) : T(0))); }
+					if (E.residual == 3) {
+						zn = po[j] / m;
+						part += zn * zn;
+					} else {
+						const T dv = static_cast<T>(__uint_as_float(static_cast<unsigned int>(E.dinv[i]) << 16));
+						const T rv = E.r[i];
+						const T sv = dv * (po[j] - m * pc[j]) + pc[j];
+						const T zq = E.zp_scale != T(0) ? E.zp_scale * dv * E.zprev[i] : E.zprev[i];
+						zn = E.a * pc[j] - E.c1 * zq + E.c2 * (dv * rv - sv);
+						part += rv * zn;
+					}
 				}
 				dst[j] = zn;
 			}
 		}
-		return;  // (no partials: the smoother takes no dot products)
+		if (E.residual >= 2 && partial) {
+			const double wsum = wave_sum(static_cast<double>(part));
+			if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wsum; }
+			__syncthreads();
+			if (threadIdx.x == 0) { partial[tile] = red[0] + red[1] + red[2] + red[3]; }
+		}
+		return;  // (modes 0 and 1 write no partials: the smoother takes no dot products)
 	}
 #pragma unroll
 	for (int j = 0; j < VX; ++j) { dsum += pc[j] * po[j]; }
@@ -503,7 +543,7 @@ static void tile2_full_step_t(fi_ctx* c, const void* z, const void* zprev, const
                               double c1, double c2)
 {
 	Epi2<T> E{static_cast<const T*>(zprev ? zprev : z), static_cast<const T*>(r), c->dinv16.as<unsigned short>(),
-	          static_cast<T*>(znew), static_cast<T>(a), static_cast<T>(zprev ? c1 : 0.0), static_cast<T>(c2), residual ? 1 : 0};
+	          static_cast<T*>(znew), static_cast<T>(a), static_cast<T>(zprev ? c1 : 0.0), static_cast<T>(c2), residual ? 1 : 0, T(0)};
 	c->tile2.fused ? tile2_launch<T, true>(c, static_cast<const T*>(z), nullptr, nullptr, &E)
 	               : tile2_launch<T, false>(c, static_cast<const T*>(z), nullptr, nullptr, &E);
 }
@@ -513,6 +553,31 @@ void tile2d_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r
 	FI_REQUIRE(tile2d_full_epi_available(c), FI_ERR_UNSUPPORTED, "no fused recurrence step for this context");
 	c->dtype == FI_F64 ? tile2_full_step_t<double>(c, z, zprev, r, residual, znew, a, c1, c2)
 	                   : tile2_full_step_t<float>(c, z, zprev, r, residual, znew, a, c1, c2);
+}
+
+// One step of the Chebyshev polynomial in Dinv (A_model + diag(A_data)) / of the power method on the model operator:
+// plain launches of the tile kernel (no cell records), one partial per tile.  The 2-D form of stencil_cheb_step.
+template <typename T>
+static void tile2_cheb_step_t(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
+                              double* partial, double zprev_scale, const unsigned short* scaling, int mode)
+{
+	const void* zp = zprev_scale != 0.0 ? r : (zprev ? zprev : z);
+	const bool  has_prev = zprev_scale != 0.0 || zprev;
+	Epi2<T> E{static_cast<const T*>(zp), static_cast<const T*>(r), scaling ? scaling : c->dinv16.as<unsigned short>(),
+	          static_cast<T*>(znew), static_cast<T>(1.0 + c1), static_cast<T>(has_prev ? c1 : 0.0), static_cast<T>(c2), mode,
+	          static_cast<T>(zprev_scale)};
+	tile2_launch<T, false>(c, static_cast<const T*>(z), nullptr, partial, &E);
+}
+void tile2d_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2, double* partial,
+                      double zprev_scale, const unsigned short* scaling)
+{
+	c->dtype == FI_F64 ? tile2_cheb_step_t<double>(c, z, zprev, r, znew, c1, c2, partial, zprev_scale, scaling, 2)
+	                   : tile2_cheb_step_t<float>(c, z, zprev, r, znew, c1, c2, partial, zprev_scale, scaling, 2);
+}
+void tile2d_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
+{
+	c->dtype == FI_F64 ? tile2_cheb_step_t<double>(c, v, nullptr, v, vnew, 0, 0, partial, 0.0, nullptr, 3)
+	                   : tile2_cheb_step_t<float>(c, v, nullptr, v, vnew, 0, 0, partial, 0.0, nullptr, 3);
 }
 
 bool tile2d_apply(fi_ctx* c, const void* x, void* y, double* partial)

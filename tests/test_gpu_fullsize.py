@@ -151,7 +151,7 @@ def test_config5_512cubed_sdf_tol_1e6(fi):
     x, it, rel = f.solve_cg(None, 1000, 1e-6)
     st = f.stats()
     assert st["converged"] == 1 and st["verified_residual"] <= 1e-6
-    assert abs(it - 35) <= 3, it                     # bench.py --config 5: 35 iterations
+    assert abs(it - 25) <= 3, it                     # bench.py --config 5: 25 iterations
     field = x.reshape(512, 512, 512)
     c, R = 255.5, 0.3 * 511
     # "only accurate near field = 0" (field_interpolation.hpp:165): a signed distance close to the surface,

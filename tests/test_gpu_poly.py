@@ -10,7 +10,8 @@ stop rule (sparse_linear.cpp:199-206 semantics, ||r|| <= tol ||Atb||), the same 
   * operator applications: about as many as Jacobi-PCG takes iterations (the point of the method is cheaper ones);
   * slabs (loop-back group): the decomposed solve takes the same outer iterations and gives the same solution;
   * cascade start with the polynomial on every level;
-  * contexts the marching kernel does not cover ignore the option.
+  * 2-D lattices run it through the tile kernel; contexts neither tiled kernel covers (1-D, model_3 / model_4,
+    gradient_smoothness, triplet rows) ignore the option.
 """
 import numpy as np
 import pytest
@@ -125,9 +126,41 @@ def test_cascade_start_with_polynomial_levels(fi):
     assert np.abs(x1 - x0).max() <= 2e-3 * np.abs(x0).max()      # two fp32 solves to a 1e-5 residual
 
 
-def test_contexts_without_the_marching_kernel_ignore_the_option(oracle, fi):
-    """2-D lattices and model_3 rows run the Jacobi-preconditioned recurrence whatever the option says."""
-    for sizes, kw in (([30, 28], dict()), ([10, 9, 8], dict(model_3=0.3))):
+@pytest.mark.parametrize("sizes,kw,n", [([30, 28], dict(), 120), ([70, 41], dict(model_1=0.3, model_2=0.8), 400),
+                                        ([131, 33], dict(model_0=0.1, model_2=0.5), 500), ([64, 64], dict(model_2=0.0, model_1=1.0), 300)])
+@pytest.mark.parametrize("terms", [2, 3, 4, 6])
+def test_two_dimensional_lattices(oracle, fi, sizes, kw, n, terms):
+    """2-D lattices run the polynomial through the tile kernel's epilogue (fi_stencil2d.hip, Epi2 mode 2): the same answers
+    as the oracle's float64 direct solve, fewer outer iterations than Jacobi-PCG takes steps."""
+    rng = np.random.default_rng(terms + sizes[0])
+    pos, nrm = sphere_points(rng, sizes, n)
+    fo, fg = build_pair(oracle, fi, sizes, fi.Weights(**kw), pos, nrm, None, None, dtype="f64")
+    x_ref = fo.solve_exact_f64()
+    fg.assemble()
+    x0, it0, _ = fg.solve_cg(None, 0, 1e-12)
+    fg.set_polynomial(terms)
+    x, it, rel = fg.solve_cg(None, 0, 1e-12)
+    assert x is not None and rel <= 1e-12 and fg.true_residual() <= 1.01e-12
+    assert rel_inf(fg.solution_f64(), x_ref) <= 1e-7
+    assert it < it0 and it * terms <= (2.0 if terms <= 4 else 3.0) * it0 + 2 * terms, (it, it0)
+    # fp32, and over slabs (loop-back group): the same outer iterations, the same solution
+    one = fi.LatticeField(sizes, dtype="f32")
+    grp = fi.LatticeGroup(sizes, 3, dtype="f32")
+    w = fi.Weights(**kw)
+    for f in (one, grp):
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        f.set_polynomial(terms)
+        f.assemble()
+    x1, it1, r1 = one.solve_cg(None, 0, 1e-5)
+    xg, itg, rg = grp.solve_cg(None, 0, 1e-5)
+    assert r1 <= 1e-5 and rg <= 1e-5 and abs(it1 - itg) <= max(2, it1 // 10)
+    assert np.abs(xg - x1).max() <= 5e-3 * np.abs(x1).max()
+
+
+def test_contexts_without_the_tiled_kernels_ignore_the_option(oracle, fi):
+    """model_3 rows and 1-D lattices run the Jacobi-preconditioned recurrence whatever the option says."""
+    for sizes, kw in (([40], dict()), ([10, 9, 8], dict(model_3=0.3))):
         rng = np.random.default_rng(1)
         pos, nrm = sphere_points(rng, sizes, 120)
         fo, fg = build_pair(oracle, fi, sizes, fi.Weights(**kw), pos, nrm, None, None, dtype="f64")
