@@ -175,6 +175,36 @@ void host_allreduce(fi_ctx* c, double* dev, int count)
 	FI_HIP_TRY(hipStreamSynchronize(c->stream));
 }
 
+// a whole (small) vector: the right-hand side of a replicated coarse level (build_levels), in chunks of the slot size
+void host_allreduce_vec(fi_ctx* c, void* dev, int64_t count, bool f64)
+{
+	HostComm* h = c->comm->host;
+	const size_t es = f64 ? sizeof(double) : sizeof(float);
+	const int64_t chunk = static_cast<int64_t>((h->hdr()->slot_bytes - 64) / es);
+	std::vector<double> sum;
+	for (int64_t o = 0; o < count; o += chunk) {
+		const int64_t n = count - o < chunk ? count - o : chunk;
+		char* mine = h->slot(c->rank) + 64;
+		FI_HIP_TRY(hipMemcpyAsync(mine, static_cast<char*>(dev) + o * es, es * n, hipMemcpyDeviceToHost, c->stream));
+		FI_HIP_TRY(hipStreamSynchronize(c->stream));
+		host_barrier(h);
+		sum.assign(static_cast<size_t>(n), 0.0);
+		for (int r = 0; r < c->nranks; ++r) {  // rank order: every rank forms the same bits
+			const char* v = h->slot(r) + 64;
+			for (int64_t k = 0; k < n; ++k) {
+				sum[k] += f64 ? reinterpret_cast<const double*>(v)[k] : static_cast<double>(reinterpret_cast<const float*>(v)[k]);
+			}
+		}
+		host_barrier(h);  // everybody has read: the slots may be rewritten
+		for (int64_t k = 0; k < n; ++k) {
+			if (f64) { reinterpret_cast<double*>(mine)[k] = sum[k]; } else { reinterpret_cast<float*>(mine)[k] = static_cast<float>(sum[k]); }
+		}
+		FI_HIP_TRY(hipMemcpyAsync(static_cast<char*>(dev) + o * es, mine, es * n, hipMemcpyHostToDevice, c->stream));
+		FI_HIP_TRY(hipStreamSynchronize(c->stream));
+		host_barrier(h);  // (my slot is rewritten by the next chunk only after everybody is done with this one)
+	}
+}
+
 void host_exchange(fi_ctx* c, void* v, hipStream_t stream)
 {
 	HostComm* h = c->comm->host;
@@ -228,6 +258,19 @@ void allreduce_sum(fi_ctx* c, double* dev, int count)
 	}
 #endif
 	FI_NCCL_TRY(rccl().AllReduce(dev, dev, static_cast<size_t>(count), ncclFloat64, ncclSum, c->comm->comm, c->stream));
+}
+
+// sum of a device vector over the ranks, in place (fp32 or fp64): the right-hand side of a replicated coarse level
+void allreduce_sum_vec(fi_ctx* c, void* dev, int64_t count, bool f64)
+{
+	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+#ifdef FI_TEST_TRANSPORT
+	if (c->comm->host) {
+		host_allreduce_vec(c, dev, count, f64);
+		return;
+	}
+#endif
+	FI_NCCL_TRY(rccl().AllReduce(dev, dev, static_cast<size_t>(count), f64 ? ncclFloat64 : ncclFloat32, ncclSum, c->comm->comm, c->stream));
 }
 
 bool comm_ready(const fi_ctx* c) { return c->comm && (c->comm->comm || c->comm->host); }

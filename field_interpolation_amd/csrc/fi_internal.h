@@ -252,6 +252,10 @@ struct fi_ctx {
 	fi_ctx*    coarse = nullptr;   // next coarser level
 	fi_ctx*    finer = nullptr;
 	int        level = 0;
+	// A level of the REPLICATED TAIL of a slab hierarchy: once a level's slabs would be thinner than 4 planes, the levels
+	// below are undivided lattices that every rank holds and solves in full (a 16^3 lattice over 8 GPUs is not worth one
+	// message); the right-hand side reaches them through one all-reduce per V-cycle (build_levels, vcycle)
+	bool       replicated = false;
 	// how this level was derived from the finer one, per axis.  1 (even fine extent n): cell-centred -- n / 2 coarse points,
 	// coarse point j halfway between fine 2j and 2j+1; every fine point interpolates (3/4, 1/4), the first and last
 	// extrapolate (5/4, -1/4).  0 (odd n): vertex-centred -- (n + 1) / 2 points, coarse j ON fine 2j.  An even extent halved
@@ -399,5 +403,6 @@ void add_points_device(fi_ctx* c, long n, const float* p, const float* g, const 
 // fi_comm.cpp
 void comm_destroy(Comm* cm);
 void allreduce_sum(fi_ctx* c, double* dev, int count);
+void allreduce_sum_vec(fi_ctx* c, void* dev, int64_t count, bool f64);  // a whole vector, in place
 
 }  // namespace fi

@@ -626,6 +626,16 @@ LevelPair level_pair(const fi_ctx* fine, const fi_ctx* coarse)
 	L.c_z0     = coarse->g.off[a] + coarse->g.own_lo[a];
 	L.c_planes = coarse->g.own_hi[a] - coarse->g.own_lo[a];
 	L.c_base   = coarse->g.off[a];
+	if (coarse->replicated && !fine->replicated && fine->nranks > 1) {
+		// a slab level above the replicated tail: the coarse lattice is whole on every rank; a rank RESTRICTS into the
+		// coarse planes whose fine plane 2k it owns (the slab rule of build_levels; the parts are summed over the ranks) and
+		// INTERPOLATES from any plane it needs
+		const int lo = L.f_z0, hi = L.f_z0 + L.f_planes;
+		L.c_z0     = (lo + 1) / 2;
+		L.c_planes = (hi + 1) / 2 - L.c_z0;
+		if (L.c_z0 + L.c_planes > L.nc[a]) { L.c_planes = L.nc[a] - L.c_z0; }
+		if (L.c_planes < 0) { L.c_planes = 0; }
+	}
 	return L;
 }
 
@@ -951,6 +961,7 @@ __global__ void k_group_sum(CgScalars* const* sc, int nranks, int nvec, int slot
 
 void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec)
 {
+	if (R[0]->nranks == 1) { return; }  // whole lattices (a loop-back group's copies of the replicated tail included)
 	if (R.size() == 1) {
 		exchange_halo(R[0], (R[0]->*vec).p);
 		return;
@@ -1375,6 +1386,7 @@ void cascade_guess(RankSet& R)
 			// most of the solve's wall time)
 			const bool mg = root->mg_mode == 1 && lc[0]->coarse && !test_switch("FI_CASCADE_NO_MG");
 			for (fi_ctx* l : lc) { l->mg_mode = root->mg_mode; }
+			for_each_copy(lc, [&](RankSet& lc) {  // (the copies of a replicated level: each on its own)
 			if (poly_ok(lc[0])) {
 				cg_run_poly<T>(lc, 0, static_cast<float>(root->coarse_tol));
 			} else if (mg) {
@@ -1399,6 +1411,7 @@ void cascade_guess(RankSet& R)
 			} else {
 				cg_run<T>(lc, 0, static_cast<float>(root->coarse_tol));
 			}
+			});
 		} catch (const Fail& f) {
 			if (f.code != FI_ERR_BREAKDOWN) { throw; }  // a coarse level without data: keep what it has
 		}
@@ -1893,6 +1906,50 @@ T* vbase(fi_ctx* c, Vec v) { return (c->*v).template as<T>(); }
 template <typename T>
 T* vown(fi_ctx* c, Vec v) { return (c->*v).template as<T>() + c->g.own_first; }
 
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_add_vec(int64_t n, const T* __restrict__ d, T* __restrict__ x)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += d[i];
+	}
+}
+
+// A loop-back group's copies of a replicated level: every member holds the WHOLE lattice and does everything on its own,
+// like the ranks of a real decomposition do (R.size() == 1 there, and nranks == 1 switches every collective off).
+bool replicated_copies(const RankSet& R) { return R.size() > 1 && R[0]->nranks == 1; }
+template <typename Fn>
+void for_each_copy(RankSet& R, Fn fn)
+{
+	if (replicated_copies(R)) {
+		for (fi_ctx* c : R) {
+			RankSet one{c};
+			fn(one);
+		}
+	} else {
+		fn(R);
+	}
+}
+
+// Sum of vector `v` (whole lattices: the replicated level below a slab level) over the ranks, in place: every rank has
+// restricted its slab's residual into its own coarse planes, the others are zero.
+template <typename T>
+void sum_over_ranks(RankSet& Rfine, RankSet& Rc, DevBuf fi_ctx::*v)
+{
+	const int64_t n = Rc[0]->g.nloc;
+	if (Rc.size() > 1) {  // loop-back group: add up into member 0 in member order, copy back
+		fi_ctx* c0 = Rc[0];
+		for (size_t m = 1; m < Rc.size(); ++m) {
+			hipLaunchKernelGGL((k_add_vec<T>), dim3(stream_blocks(n)), dim3(kThreads), 0, c0->stream, n, (Rc[m]->*v).as<T>(), (c0->*v).as<T>());
+		}
+		for (size_t m = 1; m < Rc.size(); ++m) {
+			FI_HIP_TRY(hipMemcpyAsync((Rc[m]->*v).p, (c0->*v).p, sizeof(T) * n, hipMemcpyDeviceToDevice, c0->stream));
+		}
+	} else if (Rfine[0]->nranks > 1) {
+		allreduce_sum_vec(Rfine[0], (Rc[0]->*v).p, n, sizeof(T) == 8);
+	}
+}
+
 RankSet coarse_of(const RankSet& R)
 {
 	RankSet r;
@@ -2077,15 +2134,6 @@ bool poly_smoother_ok(const RankSet& R)
 	return true;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_add_vec(int64_t n, const T* __restrict__ d, T* __restrict__ x)
-{
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
-	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		x[i] += d[i];
-	}
-}
-
 // z = M r through the work vectors za / zb; returns the one that holds the result (ghost planes not exchanged)
 template <typename T>
 Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb)
@@ -2135,6 +2183,10 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb)
 template <typename T>
 void vcycle(RankSet& R, Vec b, Vec x)
 {
+	if (replicated_copies(R)) {  // the replicated tail in a loop-back group: every member's copy on its own
+		for_each_copy(R, [&](RankSet& one) { vcycle<T>(one, b, x); });
+		return;
+	}
 	const int deg = mg_degree();
 	const double ratio = mg_ratio();
 	if (tuning_switch("FI_MG_POLY")) {  // experiment: the polynomial alone as the preconditioner, no coarse correction
@@ -2167,15 +2219,20 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		return;
 	}
 	RankSet Rc = coarse_of(R);
+	// a slab level above the replicated tail: every rank restricts into its own coarse planes of the WHOLE coarse lattice,
+	// the parts are summed over the ranks (the one collective of the tail), the interpolation needs no exchange
+	const bool junction = Rc[0]->replicated && !R[0]->replicated && R[0]->nranks > 1;
 	if (poly) {
 		swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d));  // x = M b
 		residual();
 		halo_exchange(R, &fi_ctx::mg_r);
 		for (size_t i = 0; i < R.size(); ++i) {
 			const LevelPair L = level_pair(R[i], Rc[i]);
+			if (junction) { FI_HIP_TRY(hipMemsetAsync(Rc[i]->mg_b.p, 0, sizeof(T) * Rc[i]->g.nloc, R[i]->stream)); }
 			launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream, vbase<T>(R[i], &fi_ctx::q),
 			                   R[i]->g.n[2]);
 		}
+		if (junction) { sum_over_ranks<T>(R, Rc, &fi_ctx::mg_b); }
 		vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
 		halo_exchange(Rc, &fi_ctx::mg_x);
 		for (size_t i = 0; i < R.size(); ++i) {
@@ -2199,9 +2256,11 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	halo_exchange(R, &fi_ctx::mg_r);
 	for (size_t i = 0; i < R.size(); ++i) {
 		const LevelPair L = level_pair(R[i], Rc[i]);
+		if (junction) { FI_HIP_TRY(hipMemsetAsync(Rc[i]->mg_b.p, 0, sizeof(T) * Rc[i]->g.nloc, R[i]->stream)); }
 		launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream, vbase<T>(R[i], &fi_ctx::q),
 		                   R[i]->g.n[2]);
 	}
+	if (junction) { sum_over_ranks<T>(R, Rc, &fi_ctx::mg_b); }
 	vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
 	halo_exchange(Rc, &fi_ctx::mg_x);
 	for (size_t i = 0; i < R.size(); ++i) {
@@ -2260,7 +2319,7 @@ void mg_prepare(RankSet& R, bool clear_finest)
 		RankSet& l = chain[k];
 		const bool coarsest = k + 1 == chain.size();
 		if (poly_smoother_ok<T>(l) && (!coarsest || tuning_switch("FI_MG_COARSEST_POLY"))) {
-			if (!(l[0]->poly_lambda > 0)) { estimate_poly_lambda<T>(l); }
+			if (!(l[0]->poly_lambda > 0)) { for_each_copy(l, [&](RankSet& s) { estimate_poly_lambda<T>(s); }); }
 			for (fi_ctx* c : l) {
 				if (!c->dinv16s_valid) { prepare_safe_scaling(c); }
 			}
@@ -2272,7 +2331,7 @@ void mg_prepare(RankSet& R, bool clear_finest)
 			if (borrow) {
 				for (fi_ctx* c : l) { c->lambda_max = c->coarse->lambda_max; }
 			} else {
-				estimate_lambda<T>(l);
+				for_each_copy(l, [&](RankSet& s) { estimate_lambda<T>(s); });
 			}
 		}
 	}
@@ -3435,6 +3494,45 @@ fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks);
 // coarsen: contexts holding them stay single-level.
 // build_stream: the stream the levels are ASSEMBLED on (fi_assemble runs this function on a helper thread beside the
 // assembly of the finest level); the levels then go back to the solver stream of `c`.
+// Pure arithmetic every rank agrees on: how many of the wanted levels exist (extents >= 8) and from which level on the
+// slabs would be thinner than max(halo, 4) planes -- the REPLICATED TAIL: those levels are whole lattices on every rank.
+// first_tail = levels + 1 when there is none.
+int plan_levels(const fi_ctx* c, int* first_tail)
+{
+	const int D = c->g.ndim;
+	int n[3] = {c->g.gn[0], c->g.gn[1], c->g.gn[2]};
+	std::vector<int> lo(c->nranks), hi(c->nranks);
+	for (int r = 0; r < c->nranks; ++r) {
+		lo[r] = static_cast<int>(static_cast<int64_t>(r) * n[D - 1] / c->nranks);
+		hi[r] = static_cast<int>(static_cast<int64_t>(r + 1) * n[D - 1] / c->nranks);
+	}
+	int levels = 0, tail = 0;
+	const bool allow_tail = c->nranks > 1 && !test_switch("FI_NO_REPLICATED_TAIL");
+	for (int l = 1; l <= c->levels_wanted; ++l) {
+		bool ok = true;
+		for (int d = 0; d < D; ++d) {
+			n[d] = (n[d] + 1) / 2;
+			ok = ok && n[d] >= 8;
+		}
+		if (!ok) { break; }
+		if (c->nranks > 1 && !tail) {
+			bool thick = true;
+			for (int r = 0; r < c->nranks; ++r) {
+				lo[r] = (lo[r] + 1) / 2;
+				hi[r] = (hi[r] + 1) / 2;
+				thick = thick && (hi[r] - lo[r]) >= (c->halo > 4 ? c->halo : 4);
+			}
+			if (!thick) {
+				if (!allow_tail) { break; }
+				tail = l;
+			}
+		}
+		levels = l;
+	}
+	if (first_tail) { *first_tail = tail ? tail : levels + 1; }
+	return levels;
+}
+
 bool holds_value_rows_only(const fi_ctx* src)
 {
 	for (const PointBatch* b : src->batches) {
@@ -3471,28 +3569,31 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		lo[r] = static_cast<int>(static_cast<int64_t>(r) * c->g.gn[D - 1] / c->nranks);
 		hi[r] = static_cast<int>(static_cast<int64_t>(r + 1) * c->g.gn[D - 1] / c->nranks);
 	}
-	for (int l = 1; l <= c->levels_wanted; ++l) {
+	int first_tail = 0;
+	const int nlevels = plan_levels(c, &first_tail);
+	for (int l = 1; l <= nlevels; ++l) {
+		// from first_tail on the levels are whole lattices that every rank assembles -- from ALL the data points, which
+		// fi_slab_point_range asks the caller for in that case -- and solves in full (fi_ctx::replicated)
+		const bool tail = l >= first_tail;
 		int sizes[3] = {1, 1, 1}, cc[3] = {0, 0, 0};
 		float shift[3] = {0, 0, 0};
-		bool ok = true;
 		for (int d = 0; d < D; ++d) {
 			sizes[d] = (fine->g.gn[d] + 1) / 2;
-			ok = ok && sizes[d] >= 8;
 			// even extents are halved cell-centred (fi_ctx::cc); along the decomposed axis the transfers then reach two
 			// planes beyond the slab, which the ghost planes of model_2 and wider stencils cover
-			cc[d] = fine->g.gn[d] % 2 == 0 && (d != D - 1 || c->nranks == 1 || c->halo >= 2) && !test_switch("FI_VERTEX_LEVELS");
+			cc[d] = fine->g.gn[d] % 2 == 0 && (d != D - 1 || c->nranks == 1 || c->halo >= 2 || (tail && fine->replicated)) &&
+			        !test_switch("FI_VERTEX_LEVELS");
 			shift[d] = 0.5f * (fine->pos_shift[d] - (cc[d] ? 0.5f : 0.0f));
 		}
 		// coarse plane k sits on fine plane 2k: a rank keeps the coarse planes whose fine plane it owns
 		for (int r = 0; r < c->nranks; ++r) {
 			lo[r] = (lo[r] + 1) / 2;
 			hi[r] = (hi[r] + 1) / 2;
-			if (c->nranks > 1) { ok = ok && (hi[r] - lo[r]) >= (c->halo > 4 ? c->halo : 4); }
 		}
-		if (!ok) { break; }
+		const int co_nranks = tail ? 1 : c->nranks;
 		fi_ctx* co = fine->coarse;
 		if (co && (co->g.gn[0] != sizes[0] || co->g.gn[1] != sizes[1] || co->g.gn[2] != sizes[2] || co->dtype != c->dtype ||
-		           co->halo != c->halo || co->cc[0] != cc[0] || co->cc[1] != cc[1] || co->cc[2] != cc[2])) {
+		           co->halo != c->halo || co->cc[0] != cc[0] || co->cc[1] != cc[1] || co->cc[2] != cc[2] || co->nranks != co_nranks)) {
 			fi_ctx_destroy(co);
 			co = nullptr;
 		}
@@ -3501,18 +3602,20 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 			co->pending.clear();
 			generic_clear(co);
 		} else {
-			co = create_ctx(D, sizes, c->dtype, c->rank, c->nranks);
+			co = create_ctx(D, sizes, c->dtype, tail ? 0 : c->rank, co_nranks);
 			(void)hipStreamDestroy(co->stream);
 			co->stream      = c->stream;
 			co->owns_stream = false;
-			co->comm        = c->comm;
 			co->owns_comm   = false;
 			co->level       = l;
 			co->finer       = fine;
 			co->verify_residual = 0;
-			co->slab_fixed  = true;
-			co->slab_lo     = lo[c->rank];
-			co->slab_hi     = hi[c->rank];
+			co->replicated  = tail;
+			if (!tail) {
+				co->slab_fixed  = true;
+				co->slab_lo     = lo[c->rank];
+				co->slab_hi     = hi[c->rank];
+			}
 			co->halo        = c->halo;
 			for (int d = 0; d < 3; ++d) {
 				co->cc[d]        = cc[d];
@@ -3521,7 +3624,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 			compute_geom(co, D, sizes);
 			fine->coarse    = co;
 		}
-		co->comm = c->comm;
+		co->comm = tail ? nullptr : c->comm;
 		co->mg_smoother = c->mg_smoother;
 		co->mg_safe     = c->mg_safe;
 		co->value_rows_only = holds_value_rows_only(src);
@@ -3836,7 +3939,16 @@ int fi_slab_point_range(const fi_ctx* c, float* lo, float* hi)
 	// that level plus one cell of margin for the nearest-neighbour kernels: 2 cells of 2^l fine planes below, 1 above --
 	// 2 above as well, because a level halved cell-centred (fi_ctx::cc) sees a point up to half a coarse cell further down
 	// (position / 2^l - (1 - 2^-l) / 2).
+	// A hierarchy whose deeper levels are replicated (whole lattices on every rank once the slabs would be thinner than 4
+	// planes: build_levels) is assembled from ALL the points: the range is then everything.
 	const int L = c->levels_wanted > 0 ? c->levels_wanted : 0;
+	int first_tail = 0;
+	const int nlevels = fi::plan_levels(c, &first_tail);
+	if (c->nranks > 1 && first_tail <= nlevels) {
+		if (lo) { *lo = -std::numeric_limits<float>::max(); }
+		if (hi) { *hi = std::numeric_limits<float>::max(); }
+		return FI_OK;
+	}
 	const float cell = static_cast<float>(1 << (L < 20 ? L : 20));
 	if (lo) { *lo = static_cast<float>(c->slab_lo) - 2.0f * cell; }
 	if (hi) { *hi = static_cast<float>(c->slab_hi) + (L > 0 ? 2.0f : 1.0f) * cell; }

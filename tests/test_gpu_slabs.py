@@ -187,3 +187,47 @@ def test_tile_pass_and_error_map_over_slabs(fi, sizes, nranks, ts):
     assert rel_inf(grp.error_map(g), one.error_map(g)) <= 1e-6
     t1, tg = one.tile_pass(g, ts), grp.tile_pass(g, ts)
     assert np.abs(tg - t1).max() <= 1e-5 * np.abs(t1).max()
+
+
+@pytest.mark.parametrize("dtype,mixed", [("f32", False), ("f64", True)])
+def test_replicated_tail_of_a_slab_hierarchy(fi, monkeypatch, dtype, mixed):
+    """Eight slabs of a 64^3 lattice are 8 planes thick: level 1 (32^3, 4 planes per slab) is the last one a slab
+    decomposition can carry.  The levels below it (16^3, 8^3) are whole lattices that every rank assembles from all the
+    points and solves in full; a V-cycle reaches them through one sum of the restricted residual over the ranks.  Same
+    levels, same iteration counts and the same solution as the undivided solve -- and without the tail the hierarchy stops
+    at 32^3 and the SDF problem takes far more iterations."""
+    sizes = [64, 64, 64]
+    rng = np.random.default_rng(12)
+    pos, nrm = sphere_points(rng, sizes, 4000)
+    w = fi.Weights()
+    tol = 1e-5 if dtype == "f32" else 1e-9
+
+    def build(f):
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        f.set_levels(3, 1e-4)
+        f.set_multigrid(True)
+        if mixed:
+            f.set_mixed_precision(True)
+        f.assemble()
+        return f
+
+    one = build(fi.LatticeField(sizes, dtype=dtype))
+    grp = build(fi.LatticeGroup(sizes, 8, dtype=dtype))
+    assert one.stats()["num_levels"] == grp.stats()["num_levels"] == 4
+    # a rank of such a hierarchy has to be given every point
+    lo, hi = grp.members[3].point_range()
+    assert lo < -1e30 and hi > 1e30
+    x1, it1, r1 = one.solve_cg(None, 0, tol)
+    xg, itg, rg = grp.solve_cg(None, 0, tol)
+    assert r1 <= tol and rg <= tol and grp.true_residual() <= 1.5 * tol
+    assert abs(itg - it1) <= max(2, it1 // 10), (itg, it1)
+    assert rel_inf(grp.solution_f64(), one.solution_f64()) <= (2e-2 if dtype == "f32" else 1e-6)
+    # the same decomposition without the tail: two levels, a much weaker preconditioner
+    monkeypatch.setenv("FI_NO_REPLICATED_TAIL", "1")
+    cut = build(fi.LatticeGroup(sizes, 8, dtype=dtype))
+    assert cut.stats()["num_levels"] == 2
+    xc, itc, rc = cut.solve_cg(None, 0, tol)
+    assert rc <= tol and itc > itg + itg // 2, (itc, itg)
+    lo, hi = cut.members[3].point_range()
+    assert -100 < lo < hi < 200

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(args, timeout=600, **extra_env):
+def _torchrun(args, timeout=600, nproc=2, **extra_env):
     # the host-staged transport exists only in the test build of the library (csrc/Makefile: -DFI_TEST_TRANSPORT)
     env = dict(os.environ, FI_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
                FI_HIP_LIB=os.path.join(ROOT, "field_interpolation_amd", "libfi_hip_test.so"), **extra_env)
@@ -32,7 +32,7 @@ def _torchrun(args, timeout=600, **extra_env):
     for _ in range(3):
         # the port was free a moment ago; the rendezvous can still lose it to somebody else (EADDRINUSE comes before
         # any rank has touched the GPU: the launcher is simply started again on another port)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + args
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
         if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
@@ -40,8 +40,8 @@ def _torchrun(args, timeout=600, **extra_env):
     return r
 
 
-def _worker_results(**extra_env):
-    r = _torchrun([os.path.join(ROOT, "tests", "two_rank_worker.py")], **extra_env)
+def _worker_results(nproc=2, **extra_env):
+    r = _torchrun([os.path.join(ROOT, "tests", "two_rank_worker.py")], nproc=nproc, **extra_env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULTS ")]
     assert line, r.stdout[-3000:] + r.stderr[-3000:]
@@ -69,6 +69,21 @@ def test_two_processes_equal_the_undivided_solve():
         if res["coarse_iterations_one"]:
             # the slabs' coarse operators are the undivided ones (fi_slab_point_range covers the coarse cells)
             assert abs(res["coarse_iterations"][0] - res["coarse_iterations_one"]) <= max(3, res["coarse_iterations_one"] // 10), res
+
+
+def test_four_processes_with_a_replicated_tail():
+    """Four ranks on one GPU, a hierarchy whose deepest level is replicated (whole on every rank): every rank is given all
+    the points (fi_slab_point_range says so), the restricted residual crosses the ranks through the transport's vector
+    all-reduce, and the solve takes the undivided solve's iterations."""
+    results = _worker_results(nproc=4, FI_WORKER_CASES="tail")
+    assert len(results) == 2
+    for res in results:
+        it = res["iterations"]
+        assert len(set(it)) == 1, res
+        assert abs(it[0] - res["iterations_one"]) <= max(2, res["iterations_one"] // 10), res
+        assert max(res["rel"]) <= res["tol"] and max(res["true_rel"]) <= 1.5 * res["tol"], res
+        assert min(res["points_kept"]) == res["points"], res        # the replicated levels are assembled from every point
+        assert res["max_diff"] <= (5e-2 if res["tol"] >= 1e-6 else 1e-4), res
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

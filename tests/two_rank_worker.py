@@ -76,6 +76,20 @@ def run(name, sizes, w, pos, nrm, val, dtype, tol, levels=0, poly=0, multigrid=F
 
 
 results = []
+if os.environ.get("FI_WORKER_CASES") == "tail":
+    # four slabs of 16 planes: levels 32^3 (8 planes per slab) and 16^3 (4) are slab decompositions, 8^3 is the replicated
+    # tail -- whole on every rank, reached through the vector all-reduce of the transport
+    rng = np.random.default_rng(9)
+    sizes = [64, 64, 64]
+    spos, snrm = sphere_points(rng, sizes, 4000)
+    results.append(run("SDF 64^3, 4 slabs, V-cycle PCG f64 mixed, 3 levels (8^3 replicated)", sizes, fi.Weights(), spos, snrm, None,
+                       "f64", 1e-8, levels=3, multigrid=True, mixed=True))
+    results.append(run("SDF 64^3, 4 slabs, V-cycle PCG f32, 3 levels (8^3 replicated)", sizes, fi.Weights(), spos, snrm, None,
+                       "f32", 1e-5, levels=3, multigrid=True))
+    if rank == 0:
+        print("RESULTS " + json.dumps(results), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0)
 sizes, w, pos, val = synth.config4(side=48, num_points=6591, seed=3)
 results.append(run("config4 48^3 cascade(2 levels) + polynomial PCG f32", sizes, w, pos, None, val, "f32", 1e-5, levels=2, poly=4))
 results.append(run("config4 48^3 Jacobi-PCG f64", sizes, w, pos, None, val, "f64", 1e-9))
