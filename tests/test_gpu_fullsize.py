@@ -187,3 +187,23 @@ def test_config3_mixed_precision_equals_fp64(fi):
     (x0, it0), (x1, it1) = out
     assert abs(it1 - it0) <= it0 // 4      # measured: 198 / 199 (fp64, fused / unfused smoother) against 239 / 236 (mixed)
     assert np.abs(x1 - x0).max() <= 0.05 * np.abs(x0).max()
+
+
+def test_config5_over_eight_slabs_keeps_all_levels(fi):
+    """Config 5 over 8 slabs of 64 planes (the loop-back group: the RCCL path's kernels, geometry and ownership rules): the
+    slab decomposition carries the levels down to 32^3 (4 planes per slab); 16^3 and 8^3 are the replicated tail.  All 6
+    coarser levels exist and the solve takes the undivided solve's iterations -- cut at 32^3 it would take twice as many
+    (bench.py --config 5 --levels 4: 51 against 25)."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, nrm = synth.config5()
+    grp = fi.LatticeGroup(sizes, 8, dtype="f64")
+    grp.add_field_constraints(w)
+    grp.set_levels(6, 1e-4)
+    grp.set_multigrid(True)
+    grp.set_mixed_precision(True)
+    grp.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    grp.assemble()
+    assert grp.stats()["num_levels"] == 7
+    x, it, rel = grp.solve_cg(None, 1000, 1e-6)
+    assert rel <= 1e-6 and grp.true_residual() <= 1.5e-6
+    assert abs(it - 25) <= 3, it
