@@ -1850,7 +1850,10 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 			sc->done = 3;
 		}
 		break;
-	case kMgInitRz: sc->rz = s; break;
+	case kMgInitRz:
+		sc->rz = s;
+		if (!(s > 0.0) && sc->rr > sc->tol2) { sc->done = 2; }  // r.V(r) <= 0: the preconditioner is not positive definite
+		break;
 	case kMgAlpha:
 		sc->pq    = s;
 		sc->alpha = sc->rz / s;
@@ -1871,6 +1874,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 	case kMgBeta:
 		sc->beta = s / sc->rz;
 		sc->rz   = s;
+		if (!(s > 0.0) || !isfinite(s)) { sc->done = 2; }  // (an indefinite or diverging V-cycle: see cg_run_mg)
 		break;
 	}
 }
@@ -2306,9 +2310,7 @@ void mg_prepare(RankSet& R, bool clear_finest)
 	}
 	// smoother bounds.  Levels that smooth with the polynomial in A_model + f diag(A_data) (poly_smoother_ok): the bound of
 	// the model operator (a number of the lattice and the weights: kept across assembles) and the scaling array.  The
-	// others (Chebyshev in the full operator; the coarsest level always): power method on Dinv A, once per assemble; a
-	// finest level of that kind (8x the work) takes the estimate of the level below it -- same operator family, and the
-	// interval has 10 % headroom.
+	// others (Chebyshev in the full operator; the coarsest level always): power method on Dinv A, once per assemble.
 	if (!R[0]->coarse) { return; }
 	std::vector<RankSet> chain;
 	for (RankSet l = R;; l = coarse_of(l)) {
@@ -2324,15 +2326,11 @@ void mg_prepare(RankSet& R, bool clear_finest)
 				if (!c->dinv16s_valid) { prepare_safe_scaling(c); }
 			}
 		} else if (!(l[0]->lambda_max > 0)) {
-			// (only the finest level of the whole hierarchy borrows: a coarser level that heads the chain of a cascade solve
-			// keeps the estimate for the V-cycles of the finer solves that follow)
-			const bool borrow = k == 0 && l[0]->level == 0 && chain.size() > 1 && chain[1][0]->lambda_max > 0 &&
-			                    !tuning_switch("FI_MG_FINE_POWER");
-			if (borrow) {
-				for (fi_ctx* c : l) { c->lambda_max = c->coarse->lambda_max; }
-			} else {
-				for_each_copy(l, [&](RankSet& s) { estimate_lambda<T>(s); });
-			}
+			// Every level estimates its own bound.  (Rounds 1-2 let the finest level -- 8x the work -- take the estimate of
+			// the level below it: the coarse replicas weigh data against model differently, and a stress case with
+			// nearest-neighbour gradient rows, tests/stress_solve.py seed 5039, stagnated at 2e-3 for 60 000 iterations under
+			// a smoother whose interval was too short.  Levels that smooth with the polynomial need no estimate at all.)
+			for_each_copy(l, [&](RankSet& s) { estimate_lambda<T>(s); });
 		}
 	}
 }
@@ -2508,9 +2506,26 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	const auto wall0 = std::chrono::steady_clock::now();
 	bool timed_out = false;
 	int restarts_left = c0->verify_residual ? 3 : 0;
+	int widenings_left = 2;
 	// One look at the stop flag per iteration, right behind the residual update: the V-cycle of an iteration that has just
 	// converged is not launched.
 	for (;;) {
+		if (done == 2 && widenings_left > 0 && std::isfinite(c0->scal_host->rr) && std::isfinite(c0->scal_host->pq)) {
+			// r.V(r) <= 0 with finite numbers: a smoother's interval is too short for its level (the bounds are power-method
+			// estimates: lower bounds with 10 % headroom) and the V-cycle is not positive definite.  Widen every level's
+			// interval and go on from the last iterate.
+			--widenings_left;
+			RankSet top = mixed ? Tw : R;
+			for (fi_ctx* c : top) {
+				for (fi_ctx* l = c; l; l = l->coarse) {
+					if (l->lambda_max > 0) { l->lambda_max *= 1.5; }
+					if (l->poly_lambda > 0) { l->poly_lambda = (l->poly_lambda > 1.0 ? l->poly_lambda : 1.0) * 1.25; }
+				}
+			}
+			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), 0); }
+			done = restart();
+			continue;
+		}
 		if (done) {
 			if (done != 1 || restarts_left <= 0) { break; }
 			--restarts_left;  // recurrence converged: check b - A x, continue from it if it misses the tolerance

@@ -29,3 +29,26 @@ def test_random_cases(sweep, first):
         if errs:
             failures.append((desc, errs))
     assert not failures, failures[:3]
+
+
+@pytest.fixture(scope="module")
+def solve_sweep():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_solve.py")
+    spec = importlib.util.spec_from_file_location("stress_solve", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_random_solver_cases(solve_sweep, monkeypatch):
+    """A fixed-seed slice of tests/stress_solve.py (every solver mode, 1-4 slabs, against the oracle's float64 direct solve).
+    Seed 5039 -- nearest-neighbour gradient rows, mixed precision, one coarser level -- stagnated at 2e-3 for 60 000
+    iterations while the finest level's smoother took its bound from the level below it (rounds 1-2); 700 seeds of round 3
+    without a failure."""
+    monkeypatch.setenv("FI_SOLVE_TIMEOUT_S", "30")
+    failures = []
+    for seed in [5039] + list(range(5000, 5012)):
+        desc, errs = solve_sweep.one_case(seed)
+        if errs:
+            failures.append((desc, errs))
+    assert not failures, failures[:3]
