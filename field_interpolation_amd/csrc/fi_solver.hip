@@ -3742,6 +3742,8 @@ fi_ctx* twin_prepare(fi_ctx* c)
 	t->mg_mode         = c->mg_mode;
 	t->mg_smoother     = c->mg_smoother;
 	t->mg_safe         = c->mg_safe;
+	t->poly_terms      = c->poly_terms;   // (the coarse-to-fine start on the replica solves its levels with them)
+	t->poly_ratio      = c->poly_ratio;
 	t->value_rows_only = holds_value_rows_only(c);
 	return t;
 }

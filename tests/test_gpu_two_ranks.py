@@ -99,6 +99,18 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     assert line["value"] > 0
 
 
+def test_bench_four_ranks_strong_scaling_on_one_gpu():
+    """bench.py --gpus 4 in its default form (strong: the configuration's own lattice split 4 ways, 16 planes of a 64^3
+    lattice per rank, one coarser level of 8 planes per rank) through the real orchestration."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--side", "64", "--cpu-side", "0"],
+                  nproc=4)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["config"]["parallelism"] == "slab4"
+    assert "64x64x64" in line["config"]["workload"] and line["config"]["levels"] == 2
+    assert line["config"]["true_rel_residual"] <= 1.5e-5 and line["value"] > 0
+
+
 def test_release_library_has_no_host_transport():
     """libfi_hip.so carries RCCL only: fi_comm_init_host answers FI_ERR_UNSUPPORTED and no shared-memory call is linked."""
     import ctypes as C
