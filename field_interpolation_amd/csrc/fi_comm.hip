@@ -205,12 +205,12 @@ void host_allreduce_vec(fi_ctx* c, void* dev, int64_t count, bool f64)
 	}
 }
 
-void host_exchange(fi_ctx* c, void* v, hipStream_t stream)
+void host_exchange(fi_ctx* c, void* v, hipStream_t stream, int width)
 {
 	HostComm* h = c->comm->host;
 	const Geom&  g     = c->g;
 	const int    L     = g.ndim - 1;
-	const int    H     = c->halo;
+	const int    H     = width;   // planes exchanged: they land in the ghost planes next to the slab
 	const size_t es    = elem_size(c);
 	const size_t plane = static_cast<size_t>(g.stride[L]);
 	const size_t bytes = es * plane * H;
@@ -225,7 +225,7 @@ void host_exchange(fi_ctx* c, void* v, hipStream_t stream)
 	FI_HIP_TRY(hipStreamSynchronize(stream));
 	host_barrier(h);
 	if (c->rank > 0) {  // the lower neighbour's planes for its upper neighbour -> my lower ghost planes
-		FI_HIP_TRY(hipMemcpyAsync(base, h->slot(c->rank - 1) + 64 + bytes, bytes, hipMemcpyHostToDevice, stream));
+		FI_HIP_TRY(hipMemcpyAsync(base + es * plane * (g.own_lo[L] - H), h->slot(c->rank - 1) + 64 + bytes, bytes, hipMemcpyHostToDevice, stream));
 	}
 	if (c->rank + 1 < c->nranks) {
 		FI_HIP_TRY(hipMemcpyAsync(base + es * plane * g.own_hi[L], h->slot(c->rank + 1) + 64, bytes, hipMemcpyHostToDevice, stream));
@@ -275,27 +275,29 @@ void allreduce_sum_vec(fi_ctx* c, void* dev, int64_t count, bool f64)
 
 bool comm_ready(const fi_ctx* c) { return c->comm && (c->comm->comm || c->comm->host); }
 
-void exchange_halo(fi_ctx* c, void* v) { exchange_halo_on(c, v, c->stream); }
+void exchange_halo(fi_ctx* c, void* v, int width) { exchange_halo_on(c, v, c->stream, width); }
 
-void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream)
+void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream, int width)
 {
 	if (c->nranks <= 1) { return; }
 	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+	if (width <= 0) { width = c->reach; }
+	FI_REQUIRE(width <= c->halo, FI_ERR_INVALID, "exchange of %d planes into %d ghost planes", width, c->halo);
 #ifdef FI_TEST_TRANSPORT
 	if (c->comm->host) {
-		host_exchange(c, v, stream);
+		host_exchange(c, v, stream, width);
 		return;
 	}
 #endif
 	const Geom&  g     = c->g;
 	const int    L     = g.ndim - 1;
-	const int    H     = c->halo;
+	const int    H     = width;  // planes exchanged: they land in the ghost planes next to the slab
 	const size_t es    = elem_size(c);
 	const size_t plane = static_cast<size_t>(g.stride[L]);
 	const size_t count = plane * H;
 	const ncclDataType_t dt = c->dtype == FI_F64 ? ncclFloat64 : ncclFloat32;
 	char* base = static_cast<char*>(v);
-	char* lower_ghost = base;
+	char* lower_ghost = base + es * plane * (g.own_lo[L] - H);
 	char* first_owned = base + es * plane * g.own_lo[L];
 	char* last_owned  = base + es * plane * (g.own_hi[L] - H);
 	char* upper_ghost = base + es * plane * g.own_hi[L];
@@ -414,12 +416,12 @@ int fi_comm_init_host(fi_ctx* c, const char* name, int create)
 	try {
 		FI_REQUIRE(c != nullptr && name != nullptr && name[0] == '/', FI_ERR_INVALID, "bad argument (the name starts with '/')");
 		FI_REQUIRE(c->nranks > 1, FI_ERR_STATE, "fi_comm_init_host on a single-rank context");
-		// slot: 64 bytes of sums + the ghost planes for both neighbours at the finest level in fp64 with the widest halo
-		// any model needs (model_4: 4 planes; the model may be set after the communicator) -- coarser levels and fp32
-		// replicas are smaller
+		// slot: 64 bytes of sums + the ghost planes for both neighbours at the finest level in fp64 with the widest exchange
+		// (8 planes: model_4 needs 4, the polynomial's deep exchange 2 (d - 1); the model may be set after the
+		// communicator) -- coarser levels and fp32 replicas are smaller
 		const fi::Geom& g = c->g;
 		const size_t plane = static_cast<size_t>(g.stride[g.ndim - 1]);
-		const size_t slot = ((64 + 2 * plane * 4 * sizeof(double)) + 4095) / 4096 * 4096;
+		const size_t slot = ((64 + 2 * plane * 8 * sizeof(double)) + 4095) / 4096 * 4096;
 		h = new fi::HostComm();
 		h->name  = name;
 		h->bytes = 4096 + slot * static_cast<size_t>(c->nranks);

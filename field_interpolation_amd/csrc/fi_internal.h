@@ -232,7 +232,11 @@ struct fi_ctx {
 	int        dtype = FI_F32;
 	int        device = 0;
 	int        rank = 0, nranks = 1;
-	int        halo = 0;
+	int        halo = 0;    // ghost planes STORED on each side of the slab along the slowest axis (>= reach)
+	int        min_slab = 0;  // the thinnest slab of this level over all ranks (a deep exchange needs that many planes to send)
+	int        reach = 1;   // planes a stencil / transfer reads beyond the slab = the default width of an exchange.  halo > reach:
+	                        // the polynomial preconditioner exchanges 2 (d - 1) planes of r ONCE and runs its steps redundantly on
+	                        // the shrinking ghost zone (cg_run_poly, "deep halo")
 	int        slab_lo = 0, slab_hi = 0;
 	bool       slab_fixed = false;   // coarser levels: the slab range follows the finest level's, not the equal split
 	fi::Geom   g{};
@@ -336,10 +340,11 @@ void apply_AtA(fi_ctx* c, const void* x, void* y, double* pq_partial);  // y = A
 int  apply_num_partials(const fi_ctx* c);
 double apply_algorithmic_bytes(const fi_ctx* c);
 void error_map(fi_ctx* c, const void* x, void* out);                 // generate_error_map; x with valid ghost planes
-void exchange_halo(fi_ctx* c, void* v);                              // fi_comm.hip
-void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream);       // the same on another stream
+void exchange_halo(fi_ctx* c, void* v, int width = 0);               // fi_comm.hip; width planes next to the slab (0: reach)
+void exchange_halo_on(fi_ctx* c, void* v, hipStream_t stream, int width = 0);  // the same on another stream
 bool comm_ready(const fi_ctx* c);                                   // a transport exists (fi_comm_init / fi_comm_init_host)
 void operator_finish_ghosts(fi_ctx* c);  // the deferred exchange of the diagonal's ghost planes + the scaling over them
+void operator_rescale_with_ghosts(fi_ctx* c);  // dinv / dinv16 over all local planes from diag as it stands (loop-back group)
 void prepare_safe_scaling(fi_ctx* c);    // dinv16s (see fi_ctx) from diag and the model diagonal, ghost planes included
 
 // fi_stencil.hip: LDS-tiled z-marching kernel for 3-D lattices (model_0/1/2); false => use the generic kernel
@@ -357,7 +362,9 @@ bool stencil_cheb_available(const fi_ctx* c);
 int  stencil_cheb_partials(const fi_ctx* c);
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
                        double* partial, int part = 0, double zprev_scale = 0.0, double pro_scale = 0.0,
-                       const unsigned short* scaling = nullptr);  // scaling: bfloat16 array (default: the context's dinv16)
+                       const unsigned short* scaling = nullptr,   // scaling: bfloat16 array (default: the context's dinv16)
+                       int extend = 0);  // slabs, deep exchange: the step also covers `extend` ghost planes on either side
+int  stencil_cheb_partials_max(const fi_ctx* c);  // room for the partials of a step extended over the whole ghost zone
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 // z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the
 // marching kernel(s) over the lattice; z with valid ghost planes.  Dinv is the context's bfloat16 copy (dinv16).

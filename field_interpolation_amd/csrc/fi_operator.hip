@@ -360,7 +360,7 @@ void prepare_dim(fi_ctx* c)
 		// polynomial's first step forms its operand from r and the scaling, ghost planes included).  A collective: every
 		// rank assembles the same levels in the same order.
 		if (c->nranks > 1 && comm_ready(c) && !c->defer_scaling_exchange) {
-			exchange_halo(c, c->diag.p);
+			exchange_halo(c, c->diag.p, c->min_slab >= c->halo ? c->halo : c->reach);  // (deep: the scaling of the whole ghost zone)
 			c->scaling_ghosts = true;
 		}
 		hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc,
@@ -373,7 +373,7 @@ template <typename T>
 void finish_ghosts_t(fi_ctx* c)
 {
 	const Geom& g = c->g;
-	exchange_halo(c, c->diag.p);
+	exchange_halo(c, c->diag.p, c->min_slab >= c->halo ? c->halo : c->reach);
 	hipLaunchKernelGGL((k_invert_diag<T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc, c->diag.as<T>(),
 	                   c->dinv.as<T>(), c->dinv16.as<unsigned short>());
 	FI_HIP_TRY(hipGetLastError());
@@ -597,6 +597,23 @@ void operator_finish_ghosts(fi_ctx* c)
 	if (c->nranks <= 1 || !comm_ready(c) || c->g.nown == c->g.nloc) { return; }
 	c->dtype == FI_F64 ? finish_ghosts_t<double>(c) : finish_ghosts_t<float>(c);
 	c->dinv16s_valid = false;
+}
+
+// The scaling over ALL local planes from `diag` as it stands (the loop-back group has filled the ghost planes by device
+// copies: fi_group_assemble)
+void operator_rescale_with_ghosts(fi_ctx* c)
+{
+	const Geom& g = c->g;
+	if (c->dtype == FI_F64) {
+		hipLaunchKernelGGL((k_invert_diag<double>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc, c->diag.as<double>(),
+		                   c->dinv.as<double>(), c->dinv16.as<unsigned short>());
+	} else {
+		hipLaunchKernelGGL((k_invert_diag<float>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc, c->diag.as<float>(),
+		                   c->dinv.as<float>(), c->dinv16.as<unsigned short>());
+	}
+	FI_HIP_TRY(hipGetLastError());
+	c->scaling_ghosts = true;
+	c->dinv16s_valid  = false;
 }
 
 void prepare_safe_scaling(fi_ctx* c)

@@ -892,7 +892,7 @@ void ensure_vectors(fi_ctx* c)
 	FI_HIP_TRY(hipMemsetAsync(c->q.p, 0, es * g.nloc, c->stream));
 	int nb = apply_num_partials(c);
 	if (nb < 4096) { nb = 4096; }  // also covers the plain kernels of the tile operator (fi_tile_pass)
-	if (stencil_cheb_available(c) && nb < stencil_cheb_partials(c)) { nb = stencil_cheb_partials(c); }
+	if (stencil_cheb_available(c) && nb < stencil_cheb_partials_max(c)) { nb = stencil_cheb_partials_max(c); }
 	c->max_blocks = nb;
 	c->partial.alloc(sizeof(double) * 4 * nb);
 	c->vectors_ready = true;
@@ -959,11 +959,11 @@ __global__ void k_group_sum(CgScalars* const* sc, int nranks, int nvec, int slot
 	}
 }
 
-void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec)
+void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec, int width = 0)  // width planes next to the slabs (0: the stencil's reach)
 {
 	if (R[0]->nranks == 1) { return; }  // whole lattices (a loop-back group's copies of the replicated tail included)
 	if (R.size() == 1) {
-		exchange_halo(R[0], (R[0]->*vec).p);
+		exchange_halo(R[0], (R[0]->*vec).p, width);
 		return;
 	}
 	for (size_t i = 0; i + 1 < R.size(); ++i) {
@@ -972,15 +972,15 @@ void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec)
 		const Geom& gl = lo->g;
 		const Geom& gh = hi->g;
 		const int    L     = gl.ndim - 1;
-		const int    H     = lo->halo;
+		const int    H     = width > 0 ? width : lo->reach;
 		const size_t es    = elem_size(lo);
 		const size_t plane = static_cast<size_t>(gl.stride[L]);
 		const size_t bytes = es * plane * H;
 		char* lo_base = static_cast<char*>((lo->*vec).p);
 		char* hi_base = static_cast<char*>((hi->*vec).p);
-		// lo's last H owned planes -> hi's lower ghost planes
-		FI_HIP_TRY(hipMemcpyAsync(hi_base, lo_base + es * plane * (gl.own_hi[L] - H), bytes, hipMemcpyDeviceToDevice,
-		                          lo->stream));
+		// lo's last H owned planes -> hi's lower ghost planes (the ones next to its slab)
+		FI_HIP_TRY(hipMemcpyAsync(hi_base + es * plane * (gh.own_lo[L] - H), lo_base + es * plane * (gl.own_hi[L] - H), bytes,
+		                          hipMemcpyDeviceToDevice, lo->stream));
 		// hi's first H owned planes -> lo's upper ghost planes
 		FI_HIP_TRY(hipMemcpyAsync(lo_base + es * plane * gl.own_hi[L], hi_base + es * plane * gh.own_lo[L], bytes,
 		                          hipMemcpyDeviceToDevice, lo->stream));
@@ -1421,7 +1421,7 @@ void cascade_guess(RankSet& R)
 			const LevelPair L = level_pair(lf[i], lc[i]);
 			// cubic where the coarse vector stays in cache (64 taps per pair of fine points): 256^3 from 128^3 20 -> 19
 			// outer iterations; at 512^3 the kernel would cost more than the start it improves
-			const bool cubic = L.ndim == 3 && (lf[i]->nranks == 1 || lc[i]->halo >= 2) && !test_switch("FI_LINEAR_START") &&
+			const bool cubic = L.ndim == 3 && (lf[i]->nranks == 1 || lc[i]->reach >= 2) && !test_switch("FI_LINEAR_START") &&
 			                   sizeof(T) * static_cast<size_t>(lc[i]->g.nloc) <= (32u << 20);
 			if (cubic) {
 				const int pairs = (L.nf[0] + 1) / 2;
@@ -2148,8 +2148,9 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb)
 	const double hi = 1.1 * lam, lo = hi / mg_ratio();
 	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
 	const bool single = R.size() == 1 && c0->nranks == 1;
-	const bool pro = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && c0->march.valid &&
-	                 !test_switch("FI_NO_Z0_ON_LOAD");
+	bool ghosts_scaled = true;
+	for (const fi_ctx* c : R) { ghosts_scaled = ghosts_scaled && c->scaling_ghosts; }
+	const bool pro = (single || ghosts_scaled) && terms > 2 && c0->march.valid && !test_switch("FI_NO_Z0_ON_LOAD");
 	auto region2 = [](fi_ctx* c) { return c->partial.as<double>() + 2 * static_cast<size_t>(c->max_blocks); };
 	if (!pro) {
 		for (fi_ctx* c : R) {  // z_0 = Dinv r / theta
@@ -2991,8 +2992,17 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	// (fi_stencil.hip, PRO) -- k_pcg_resid then stores no z_0, and step 2 recomputes it as its z_prev.  One slab per
 	// process: the ghost planes of r are exchanged instead of z_0's, those of the scaling came with the assembly
 	// (operator_prepare); the loop-back group (no transport at assembly time) keeps the stored z_0.
-	const bool z0_on_load = (single || (R.size() == 1 && c0->scaling_ghosts)) && terms > 2 && c0->march.valid &&
+	bool ghosts_scaled = true;  // slabs: the scaling on the ghost planes is the neighbour's (exchanged with the assembly)
+	for (const fi_ctx* c : R) { ghosts_scaled = ghosts_scaled && c->scaling_ghosts; }
+	const bool z0_on_load = (single || ghosts_scaled) && terms > 2 && c0->march.valid &&
 	                        !test_switch("FI_NO_Z0_ON_LOAD");  // (3-D: the marching kernel; 2-D lattices store z_0)
+	// Deep exchange (slabs; fi_assemble has given the vectors 2 (d - 1) ghost planes): the ghost planes of r travel ONCE per
+	// polynomial; step k then also computes its 2 (d - 1 - k) nearest ghost planes -- the values the neighbour computes
+	// for its own planes, bit for bit -- so that no step waits for an exchange: 2 exchanges per outer iteration (p for the
+	// apply, r for the polynomial) instead of d.  FI_NO_DEEP_HALO: one exchange per step (tests: identical results).
+	const int  deep_width = 2 * (terms - 1);
+	const bool deep = z0_on_load && c0->nranks > 1 && c0->halo >= deep_width && c0->min_slab >= deep_width &&
+	                  !test_switch("FI_NO_DEEP_HALO");
 	// Undivided lattice: the sums of the per-workgroup partials (p.q; r.r, r.z) are folded into their consumers (every
 	// workgroup sums the 1-4 k partials in the same fixed order); rank sets form them once, by a one-block kernel in
 	// front of the all-reduce.  Measured at 256^3 with both forms (profiles/r2_ablation.md section 6): folded 10.65 ms
@@ -3001,7 +3011,9 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	// partial regions of every member: [0] apply p.q, [1] r.r, [2] r.z, [3] b.b
 	auto region = [](fi_ctx* c, int k) { return c->partial.as<double>() + static_cast<size_t>(k) * c->max_blocks; };
 	auto slot2 = [](fi_ctx* c) { return (c->scal.as<CgScalars>() + 2)->sums; };
+	int n_exchanges = 0, n_reductions = 0;  // (statistics: what an outer iteration costs over slabs)
 	auto cross = [&](int nvec) {  // sums[0..nvec) of slot 2 over the slabs
+		if (R.size() > 1 || c0->nranks > 1) { ++n_reductions; }
 		if (R.size() > 1) {
 			hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, st, c0->group_scal.as<CgScalars*>(), static_cast<int>(R.size()), nvec, 2);
 		} else if (c0->nranks > 1) {
@@ -3054,10 +3066,19 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			// roofline figure is bytes over time of ALL sampled steps
 			const bool sample = phase == 1 && k == 1 + psamples % (terms - 1) && c0->level == 0 && psamples < kPolySamples &&
 			                    (tag & 3) == 3 && !tuning_switch("FI_NO_SAMPLES");
-			const bool overlap = R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
+			const bool overlap = !deep && R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
 			const bool pro = z0_on_load && k == 1;
 			const Vec  zsrc = pro ? static_cast<Vec>(&fi_ctx::r) : zin;  // the vector whose ghost planes the step reads
-			if (overlap) { exchange_begin(c0, (c0->*zsrc).p); } else { halo_exchange(R, zsrc); }
+			const int  ext = deep ? 2 * (terms - 1 - k) : 0;            // ghost planes this step computes for the next one
+			if (deep) {
+				if (k == 1) {
+					halo_exchange(R, &fi_ctx::r, deep_width);
+					++n_exchanges;
+				}
+			} else {
+				if (overlap) { exchange_begin(c0, (c0->*zsrc).p); } else { halo_exchange(R, zsrc); }
+				if (c0->nranks > 1) { ++n_exchanges; }
+			}
 			if (sample) {
 				FI_HIP_TRY(hipEventRecord(pev[2 * psamples], st));
 				ptags.push_back(tag);
@@ -3076,7 +3097,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 						exchange_wait(c);
 						stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 2, 0.0, 1.0 / theta);
 					} else {
-						stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 0, 0.0, 1.0 / theta);
+						stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 0, 0.0, 1.0 / theta, nullptr, ext);
 					}
 					continue;
 				}
@@ -3085,7 +3106,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 					exchange_wait(c);
 					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 2, zs);
 				} else {
-					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 0, zs);
+					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 0, zs, 0.0, nullptr, ext);
 				}
 			}
 			if (sample) {
@@ -3246,6 +3267,9 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		c->stats.prec_ms_avg  = pused ? psum / pused : 0.0;
 		c->stats.prec_bytes   = pused ? pbsum / pused : 0.0;  // mean over the sampled steps: bytes / time is their byte-weighted rate
 		c->stats.operator_applies = (iter_base + h.iter + 1) * terms + h.restarts;
+		// (+ one exchange of p per full apply: every outer iteration, the start and each verification)
+		c->stats.halo_exchanges = c0->nranks > 1 ? n_exchanges + issued + 1 + h.restarts : 0;
+		c->stats.reductions     = n_reductions;
 		c->last_outer_iterations = h.iter;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = iter_base + h.iter;
@@ -3535,7 +3559,7 @@ int plan_levels(const fi_ctx* c, int* first_tail)
 			for (int r = 0; r < c->nranks; ++r) {
 				lo[r] = (lo[r] + 1) / 2;
 				hi[r] = (hi[r] + 1) / 2;
-				thick = thick && (hi[r] - lo[r]) >= (c->halo > 4 ? c->halo : 4);
+				thick = thick && (hi[r] - lo[r]) >= (c->reach > 4 ? c->reach : 4);
 			}
 			if (!thick) {
 				if (!allow_tail) { break; }
@@ -3596,7 +3620,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 			sizes[d] = (fine->g.gn[d] + 1) / 2;
 			// even extents are halved cell-centred (fi_ctx::cc); along the decomposed axis the transfers then reach two
 			// planes beyond the slab, which the ghost planes of model_2 and wider stencils cover
-			cc[d] = fine->g.gn[d] % 2 == 0 && (d != D - 1 || c->nranks == 1 || c->halo >= 2 || (tail && fine->replicated)) &&
+			cc[d] = fine->g.gn[d] % 2 == 0 && (d != D - 1 || c->nranks == 1 || c->reach >= 2 || (tail && fine->replicated)) &&
 			        !test_switch("FI_VERTEX_LEVELS");
 			shift[d] = 0.5f * (fine->pos_shift[d] - (cc[d] ? 0.5f : 0.0f));
 		}
@@ -3604,6 +3628,10 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		for (int r = 0; r < c->nranks; ++r) {
 			lo[r] = (lo[r] + 1) / 2;
 			hi[r] = (hi[r] + 1) / 2;
+		}
+		int min_slab = sizes[D - 1];
+		if (!tail) {
+			for (int r = 0; r < c->nranks; ++r) { min_slab = hi[r] - lo[r] < min_slab ? hi[r] - lo[r] : min_slab; }
 		}
 		const int co_nranks = tail ? 1 : c->nranks;
 		fi_ctx* co = fine->coarse;
@@ -3632,6 +3660,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 				co->slab_hi     = hi[c->rank];
 			}
 			co->halo        = c->halo;
+			co->reach       = c->reach;
 			for (int d = 0; d < 3; ++d) {
 				co->cc[d]        = cc[d];
 				co->pos_shift[d] = shift[d];
@@ -3639,6 +3668,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 			compute_geom(co, D, sizes);
 			fine->coarse    = co;
 		}
+		co->min_slab = min_slab;
 		co->comm = tail ? nullptr : c->comm;
 		co->mg_smoother = c->mg_smoother;
 		co->mg_safe     = c->mg_safe;
@@ -3728,6 +3758,7 @@ fi_ctx* twin_prepare(fi_ctx* c)
 		t->slab_lo     = c->slab_lo;
 		t->slab_hi     = c->slab_hi;
 		t->halo        = c->halo;
+		t->reach       = c->reach;
 		compute_geom(t, D, sizes);
 		c->twin = t;
 	}
@@ -3742,6 +3773,7 @@ fi_ctx* twin_prepare(fi_ctx* c)
 	t->mg_mode         = c->mg_mode;
 	t->mg_smoother     = c->mg_smoother;
 	t->mg_safe         = c->mg_safe;
+	t->min_slab        = c->min_slab;
 	t->poly_terms      = c->poly_terms;   // (the coarse-to-fine start on the replica solves its levels with them)
 	t->poly_ratio      = c->poly_ratio;
 	t->value_rows_only = holds_value_rows_only(c);
@@ -4137,19 +4169,30 @@ int fi_assemble(fi_ctx* c)
 	FI_HIP_TRY(hipEventCreate(&e0));
 	FI_HIP_TRY(hipEventCreate(&e1));
 	FI_HIP_TRY(hipEventRecord(e0, c->stream));
-	// halo width along the decomposed axis: reach of the widest model stencil, at least the cell reach (1)
+	// Ghost planes along the decomposed axis.  reach: the widest model stencil, at least the cell reach (1) -- the width of
+	// an exchange.  halo (planes stored): the reach, or the polynomial preconditioner's DEEP exchange: 2 (d - 1) planes of
+	// r travel once per polynomial and the steps run redundantly on the shrinking ghost zone (cg_run_poly) instead of one
+	// exchange per step -- 3-D lattices, 3 to 5 terms set before the assemble, slabs at least that thick on every rank.
 	const int reach = fi::model_reach(c->w);
-	const int want  = reach > 1 ? reach : 1;
-	if (c->nranks > 1 && want != c->halo) {
-		FI_REQUIRE(c->pending.empty() || true, FI_ERR_STATE, "unreachable");
-		c->halo = want;
+	const int want_reach = reach > 1 ? reach : 1;
+	int want_halo = want_reach;
+	if (c->nranks > 1 && c->g.ndim == 3 && c->poly_terms >= 3 && c->poly_terms <= 5 && c->generic.ntrip == 0 &&
+	    !fi::test_switch("FI_NO_DEEP_HALO")) {
+		const int deep = 2 * (c->poly_terms - 1);
+		const int thinnest = c->g.gn[2] / c->nranks;  // (the equal split: floor(G / n) is the thinnest slab)
+		if (deep > want_halo && thinnest >= deep) { want_halo = deep; }
+	}
+	c->min_slab = c->nranks > 1 ? c->g.gn[c->g.ndim - 1] / c->nranks : c->g.gn[c->g.ndim - 1];
+	if (c->nranks > 1 && (want_halo != c->halo || want_reach != c->reach)) {
+		c->halo  = want_halo;
+		c->reach = want_reach;
 		int sizes[3] = {c->g.gn[0], c->g.gn[1], c->g.gn[2]};
 		fi::compute_geom(c, c->g.ndim, sizes);
 		c->vectors_ready = false;
 	}
 	if (c->nranks > 1) {
-		FI_REQUIRE(c->slab_hi - c->slab_lo >= c->halo, FI_ERR_UNSUPPORTED,
-		           "slab of %d planes is thinner than the stencil reach %d", c->slab_hi - c->slab_lo, c->halo);
+		FI_REQUIRE(c->slab_hi - c->slab_lo >= c->reach, FI_ERR_UNSUPPORTED,
+		           "slab of %d planes is thinner than the stencil reach %d", c->slab_hi - c->slab_lo, c->reach);
 	}
 	// The coarser levels are problems of their own, assembled from the same point batches: a helper thread builds them on
 	// a second stream while this one assembles the finest level (both are chains of small launches with host round trips
@@ -4610,6 +4653,16 @@ int fi_group_assemble(fi_group* g)
 	}
 	// coarser levels (and the fp32 replicas of mixed precision with theirs): the loop-back dot-product sum needs
 	// the scalar blocks of every member of a level
+	// The diagonal's ghost planes, like a process per slab gets them through its transport at assembly time: the scaling
+	// on the ghost planes is then the neighbour's, the polynomial's first step forms its operand on load and the deep
+	// exchange has the scaling of the whole ghost zone.
+	auto ghosts = [&](std::vector<fi_ctx*>& lev) {
+		if (lev[0]->nranks <= 1 || lev[0]->g.nown == lev[0]->g.nloc) { return; }
+		fi::RankSet R(lev.begin(), lev.end());
+		fi::halo_exchange(R, &fi_ctx::diag, lev[0]->min_slab >= lev[0]->halo ? lev[0]->halo : lev[0]->reach);
+		for (fi_ctx* c : lev) { fi::operator_rescale_with_ghosts(c); }
+	};
+	ghosts(g->members);
 	auto link_chain = [&](std::vector<fi_ctx*> lev) {
 		while (lev[0]) {
 			std::vector<fi::CgScalars*> ptrs;
@@ -4617,6 +4670,7 @@ int fi_group_assemble(fi_group* g)
 				FI_REQUIRE(c != nullptr, FI_ERR_STATE, "members disagree on the number of levels");
 				ptrs.push_back(c->scal.as<fi::CgScalars>());
 			}
+			ghosts(lev);
 			lev[0]->group_scal.alloc(sizeof(fi::CgScalars*) * ptrs.size());
 			FI_HIP_TRY(hipMemcpy(lev[0]->group_scal.p, ptrs.data(), sizeof(fi::CgScalars*) * ptrs.size(), hipMemcpyHostToDevice));
 			for (fi_ctx*& c : lev) { c = c->coarse; }

@@ -1400,10 +1400,27 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 
 // One Chebyshev step of the polynomial preconditioner: the plain variant with the epilogue, over the whole lattice
 // (its own chunking: MarchState::Pplain).  partial: r . z_new per workgroup.
-template <typename T>
-void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partial, int part = 0, bool pro = false)
+// extend > 0 (slabs, the polynomial's deep exchange): the launch also covers `extend` ghost planes below and above the
+// slab -- as far as the lattice goes -- so that the next step finds its operand there without an exchange; the values are
+// the neighbour's own, bit for bit (a point's result does not depend on the workgroup that computes it).
+MarchParams extended_params(const MarchParams& P0, int extend)
 {
-	const MarchParams& P = c->march.Pplain;
+	MarchParams P = P0;
+	if (extend <= 0) { return P; }
+	const int lo_room = P.own_z0 + P.zoff;                 // lattice planes below the slab
+	const int hi_room = P.gz - (P.own_z1 + P.zoff);        // ... above it
+	const int e_lo = extend < lo_room ? extend : lo_room, e_hi = extend < hi_room ? extend : hi_room;
+	P.own_z0 -= e_lo < P.own_z0 ? e_lo : P.own_z0;
+	P.own_z1 += e_hi < P.nzl - P.own_z1 ? e_hi : P.nzl - P.own_z1;
+	P.chunks = (P.own_z1 - P.own_z0 + P.zc - 1) / P.zc;
+	P.nwg    = P.tiles_x * P.tiles_y * P.chunks;
+	return P;
+}
+
+template <typename T>
+void march_launch_epi(fi_ctx* c, const T* z, const ChebEpi<T>& E, double* partial, int part = 0, bool pro = false, int extend = 0)
+{
+	const MarchParams P = extended_params(c->march.Pplain, extend);
 	const MarchCoef<T> C = march_coef<T>(c->w);
 	CellLists L{};
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
@@ -1679,7 +1696,7 @@ void build_edge_lists(fi_ctx* c, const MarchParams& P, DevBuf& edge, DevBuf& inn
 {
 	const int tiles_xy = P.tiles_x * P.tiles_y;
 	const int nz_own = P.own_z1 - P.own_z0;
-	const int reach = c->halo > 1 ? c->halo : 1;  // planes a chunk reads beyond its own (short chunks: several chunks deep)
+	const int reach = c->reach > 1 ? c->reach : 1;  // planes a chunk reads beyond its own (short chunks: several chunks deep)
 	std::vector<uint32_t> e, in;
 	for (int ch = 0; ch < P.chunks; ++ch) {
 		const int z0 = ch * P.zc, z1 = (ch + 1) * P.zc < nz_own ? (ch + 1) * P.zc : nz_own;
@@ -1721,14 +1738,19 @@ namespace fi {
 // Chebyshev step through the marching kernel (see ChebEpi); false when the kernel does not apply to this context.
 bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid || c->tile2.valid; }  // (2-D: the tile kernel)
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.valid ? c->march.Pplain.nwg : tile2d_partials(c); }
+int  stencil_cheb_partials_max(const fi_ctx* c)
+{
+	if (!c->march.valid) { return tile2d_partials(c); }
+	return extended_params(c->march.Pplain, c->nranks > 1 ? c->halo : 0).nwg;
+}
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling)
+                       double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling, int extend)
 {
 	// pro_scale != 0 (the first step, z_prev = 0): `z` is r and the kernel forms z_0 = pro_scale * Dinv * r on load
 	// zprev == nullptr: the step from z_prev = 0 (z itself stands in under a zero coefficient);
 	// zprev_scale != 0: z_prev = zprev_scale * Dinv r, read through r's own cache lines
 	if (c->tile2.valid) {  // 2-D lattices: no operand formed on load, no partial launches
-		FI_REQUIRE(pro_scale == 0.0 && part == 0, FI_ERR_UNSUPPORTED, "2-D polynomial step: stored z_0, whole lattice");
+		FI_REQUIRE(pro_scale == 0.0 && part == 0 && extend == 0, FI_ERR_UNSUPPORTED, "2-D polynomial step: stored z_0, whole lattice");
 		tile2d_cheb_step(c, z, zprev, r, znew, c1, c2, partial, zprev_scale, scaling);
 		return;
 	}
@@ -1738,12 +1760,12 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	if (c->dtype == FI_F64) {
 		ChebEpi<double> E{static_cast<const double*>(zp), static_cast<const double*>(r), d16, static_cast<double*>(znew), 1.0 + c1,
 		                  has_prev ? c1 : 0.0, c2, 0, pro_scale, zprev_scale};
-		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part, pro_scale != 0.0);
+		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part, pro_scale != 0.0, extend);
 	} else {
 		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
 		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
 		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale)};
-		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part, pro_scale != 0.0);
+		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part, pro_scale != 0.0, extend);
 	}
 }
 // v_new = (A_model v) / diag(A_model), partials of v_new . v_new (power method on the model operator)

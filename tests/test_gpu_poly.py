@@ -257,3 +257,51 @@ def test_too_narrow_an_interval_is_widened_or_given_up(oracle, fi, monkeypatch, 
     f.assemble()
     res = f.solve_cg(None, 0, 1e-5)
     assert res is not None and f.stats()["converged"] == 1 and f.true_residual() <= 1.5e-5
+
+
+@pytest.mark.parametrize("dtype,terms,nranks,sizes", [("f32", 4, 4, [40, 36, 64]), ("f64", 4, 3, [24, 20, 40]), ("f32", 3, 2, [33, 30, 26]),
+                                                      ("f32", 5, 2, [48, 16, 40])])
+def test_deep_exchange_equals_one_exchange_per_step(fi, monkeypatch, dtype, terms, nranks, sizes):
+    """Slabs: with the polynomial set before the assemble the vectors carry 2 (d - 1) ghost planes; r's travel once per
+    polynomial and every step also computes the ghost planes the next one reads (what the neighbour computes for its own
+    planes, bit for bit).  The same iterates as with one exchange per step (FI_NO_DEEP_HALO): equal iteration counts, equal
+    bits -- with a cascade level below, whose slabs are too thin for the deep exchange and fall back by themselves."""
+    from field_interpolation_amd import synth
+    rng = np.random.default_rng(terms)
+    pos, nrm, pw, val = random_points(rng, sizes, 3000, margin=0.5, with_edge_cases=False)
+    w = fi.Weights(model_2=0.5, data_gradient=0.0)
+    out = []
+    for deep in (True, False):
+        if deep:
+            monkeypatch.delenv("FI_NO_DEEP_HALO", raising=False)
+        else:
+            monkeypatch.setenv("FI_NO_DEEP_HALO", "1")
+        g = fi.LatticeGroup(sizes, nranks, dtype=dtype)
+        g.add_field_constraints(w)
+        g.set_polynomial(terms, 30.0)
+        g.set_levels(1, 1e-5)
+        g.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        g.assemble()
+        x, it, rel = g.solve_cg(None, 0, 1e-5 if dtype == "f32" else 1e-9)
+        st = g.stats()
+        out.append((x.copy(), it, rel, st["coarse_iterations"], g.true_residual(), st["halo_exchanges"], st["reductions"]))
+        del g
+    (xd, itd, reld, cd, td, exd, red), (xs, its, rels, cs, ts, exs, res) = out
+    assert itd == its and cd == cs, (itd, its, cd, cs)
+    # per pass of the recurrence (start, each outer iteration, each restart): 1 exchange for the apply + 1 for the polynomial
+    # instead of 1 + (d - 1); two reductions either way
+    passes = (exs - exd) // (terms - 2)
+    assert exs - exd == passes * (terms - 2) and passes >= itd + 1, (exd, exs, itd)
+    assert exd <= 2 * passes + 2 and red == res
+    np.testing.assert_array_equal(xd, xs)
+    assert td <= 1.5 * (1e-5 if dtype == "f32" else 1e-9)
+    # and the undivided solve agrees
+    one = fi.LatticeField(sizes, dtype=dtype)
+    one.add_field_constraints(w)
+    one.set_polynomial(terms, 30.0)
+    one.set_levels(1, 1e-5)
+    one.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    one.assemble()
+    x1, it1, _ = one.solve_cg(None, 0, 1e-5 if dtype == "f32" else 1e-9)
+    assert abs(it1 - itd) <= max(2, it1 // 10)
+    assert np.abs(x1 - xd).max() <= (2e-2 if dtype == "f32" else 1e-6) * np.abs(x1).max()

@@ -56,6 +56,11 @@ def test_two_processes_equal_the_undivided_solve():
     plain = _worker_results(FI_NO_OVERLAP="1")
     for a, b in zip(results, plain):
         assert a["iterations"] == b["iterations"] and a["checksum"] == b["checksum"], (a, b)
+    # likewise the polynomial's deep exchange (r's ghost planes once per polynomial, the steps redundant on the ghost zone)
+    # against one exchange per step
+    shallow = _worker_results(FI_NO_DEEP_HALO="1")
+    for a, b in zip(results, shallow):
+        assert a["iterations"] == b["iterations"] and a["checksum"] == b["checksum"], (a, b)
     for res in results:
         it = res["iterations"]
         assert it[0] == it[1], res                                  # both ranks stop in the same iteration
