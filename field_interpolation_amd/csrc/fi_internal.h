@@ -280,6 +280,9 @@ struct fi_ctx {
 	// polynomial in that operator is a convergent smoother of A whatever the data (f = mg_safe)
 	fi::DevBuf dinv16s;
 	bool       dinv16s_valid = false;
+	bool       data_pinned = false;  // (levels of <= 2^16 points, set with dinv16s) every point's data diagonal reaches its model
+	                                 // diagonal: value rows that dense hold every smooth mode, and two sweeps of the polynomial
+	                                 // smoother solve such a coarsest level as well as an exact solve (tools/proto_cc.py)
 	double     mg_safe = 4.0;
 	int        mg_smoother = 1;   // 1: the polynomial in A_model + f diag(A_data) where the marching kernel runs it; 0: Chebyshev in A
 	bool       value_rows_only = false;  // set by fi_assemble (levels and replicas: from the context that holds the points): no

@@ -284,7 +284,7 @@ inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / 
 // neighbours' values where the scaling is read there (fi_ctx::scaling_ghosts).  Truncated like dinv16: never above.
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_safe_scaling(Geom g, ModelCoef<T> mc, const T* __restrict__ diag, T factor,
-                                                           unsigned short* __restrict__ d16)
+                                                           unsigned short* __restrict__ d16, unsigned int* __restrict__ weak)
 {
 	const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	if (idx >= g.nloc) { return; }
@@ -304,6 +304,8 @@ __global__ __launch_bounds__(kThreads) void k_safe_scaling(Geom g, ModelCoef<T> 
 	}
 	const T dg = diag[idx];
 	const T dd = dg > m ? dg - m : T(0);
+	// (small levels only: how many points the data hold less firmly than the model couples them -- fi_ctx::data_pinned)
+	if (weak && dd < m) { atomicAdd(weak, 1u); }
 	const T s  = m + factor * dd;
 	const T v  = (s > T(0)) ? T(1) / s : T(1);
 	d16[idx] = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
@@ -386,9 +388,24 @@ void safe_scaling_dim(fi_ctx* c)
 	const Geom& g = c->g;
 	const ModelCoef<T> mc = make_coef<T>(c->w);
 	c->dinv16s.alloc(sizeof(unsigned short) * g.nloc);
+	// levels of up to 2^16 points (a coarsest level): count the points whose data diagonal is below their model diagonal
+	unsigned int* weak = nullptr;
+	DevBuf cnt;
+	if (g.nloc <= (1 << 16) && c->nranks == 1) {
+		cnt.alloc(sizeof(unsigned int));
+		FI_HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), c->stream));
+		weak = cnt.as<unsigned int>();
+	}
 	hipLaunchKernelGGL((k_safe_scaling<D, T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g, mc, c->diag.as<T>(),
-	                   static_cast<T>(c->mg_safe), c->dinv16s.as<unsigned short>());
+	                   static_cast<T>(c->mg_safe), c->dinv16s.as<unsigned short>(), weak);
 	FI_HIP_TRY(hipGetLastError());
+	c->data_pinned = false;
+	if (weak) {
+		unsigned int h = 1;
+		FI_HIP_TRY(hipMemcpyAsync(&h, weak, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+		FI_HIP_TRY(hipStreamSynchronize(c->stream));
+		c->data_pinned = h == 0;
+	}
 	c->dinv16s_valid = true;
 }
 

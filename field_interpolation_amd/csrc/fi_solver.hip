@@ -2212,10 +2212,11 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		}
 	};
 	if (!R[0]->coarse) {
-		// coarsest level: a longer polynomial over a wider band, in the full operator.  (Two sweeps of the polynomial
-		// smoother do as well where data pins every smooth mode -- config 4: tools/proto_cc.py -- but an SDF's coarsest
-		// level still has weakly held global modes: 97 instead of 37 iterations on the 40 x 32 x 48 test problem.)
-		if (poly && tuning_switch("FI_MG_COARSEST_POLY")) {
+		// coarsest level: two sweeps of the polynomial smoother where the data pin every point (fi_ctx::data_pinned: config
+		// 4 -- as good as an exact solve there, tools/proto_cc.py, and 7 launches instead of 20); else a longer polynomial
+		// over a wider band, in the full operator: an SDF's coarsest level still has weakly held global modes (97 instead of
+		// 37 iterations on the 40 x 32 x 48 test problem with the sweeps).
+		if (poly && R[0]->dinv16s_valid && R[0]->data_pinned && !test_switch("FI_MG_COARSEST_CHEB")) {
 			swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d));
 			post_smooth();
 			return;
@@ -2321,11 +2322,22 @@ void mg_prepare(RankSet& R, bool clear_finest)
 	for (size_t k = chain.size(); k-- > 0;) {
 		RankSet& l = chain[k];
 		const bool coarsest = k + 1 == chain.size();
-		if (poly_smoother_ok<T>(l) && (!coarsest || tuning_switch("FI_MG_COARSEST_POLY"))) {
-			if (!(l[0]->poly_lambda > 0)) { for_each_copy(l, [&](RankSet& s) { estimate_poly_lambda<T>(s); }); }
+		bool poly_level = poly_smoother_ok<T>(l);
+		if (poly_level) {
 			for (fi_ctx* c : l) {
-				if (!c->dinv16s_valid) { prepare_safe_scaling(c); }
+				if (!c->dinv16s_valid) { prepare_safe_scaling(c); }  // (also says whether the data pin a small level)
 			}
+			// the coarsest level: the polynomial only where the data hold every point at least as firmly as the model
+			// couples it -- an SDF's coarsest level keeps weakly held global modes and needs the long Chebyshev polynomial in A
+			if (coarsest) {
+				for (const fi_ctx* c : l) { poly_level = poly_level && c->data_pinned && !test_switch("FI_MG_COARSEST_CHEB"); }
+				if (!poly_level) {
+					for (fi_ctx* c : l) { c->data_pinned = false; }
+				}
+			}
+		}
+		if (poly_level) {
+			if (!(l[0]->poly_lambda > 0)) { for_each_copy(l, [&](RankSet& s) { estimate_poly_lambda<T>(s); }); }
 		} else if (!(l[0]->lambda_max > 0)) {
 			// Every level estimates its own bound.  (Rounds 1-2 let the finest level -- 8x the work -- take the estimate of
 			// the level below it: the coarse replicas weigh data against model differently, and a stress case with
