@@ -3296,11 +3296,351 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	           "relative residual %g", limit_s, h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0);
 }
 
+// ---- the same solve over slabs with ONE reduction per outer iteration ---------------------------------------------------
+// Chronopoulos-Gear form of preconditioned CG: with z = M r and w = A z
+//     gamma = r.z, delta = z.w (and r.r for the stop test) -- ONE all-reduce of three numbers --
+//     beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old),
+//     p = z + beta p,  s = w + beta s  (s = A p by recurrence),  x += alpha p,  r -= alpha s.
+// Against cg_run_poly an outer iteration trades its second all-reduce for a fourth vector recurrence (22.5 instead of 20.5
+// lattice passes): over slabs of a strong split, where an iteration is a few dozen microseconds of kernels between
+// latency-bound collectives, that is the better trade -- 2 exchanges (p's role is taken by z; r's deep exchange) + 1
+// all-reduce per outer iteration.  r.z comes out of the polynomial's last step, z.w out of the apply, r.r out of the
+// previous update: no extra pass for the dot products.  Same stop rule (on the residual the iteration STARTS from: x and r
+// are left consistent), same verified stop; a breakdown hands over to cg_run_poly (which widens the polynomial's
+// interval) from the current iterate.  Undivided lattices keep the two-reduction form (folded sums, fewer passes).
+
+// r = b - q, partials r.r and b.b (start / verification)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_sr_residual(int64_t n, const T* __restrict__ b, const T* __restrict__ q, T* __restrict__ r,
+                                                           double* __restrict__ prr, double* __restrict__ pbb)
+{
+	double acc[2] = {0, 0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T bv = b[i], rv = bv - q[i];
+		r[i] = rv;
+		acc[0] += static_cast<double>(rv) * static_cast<double>(rv);
+		acc[1] += static_cast<double>(bv) * static_cast<double>(bv);
+	}
+	double out[2];
+	block_sum<2>(acc, out);
+	if (threadIdx.x == 0) {
+		prr[blockIdx.x] = out[0];
+		pbb[blockIdx.x] = out[1];
+	}
+}
+
+// the scalar record after the start (phase 0: b.b, the tolerance) or a verification (phase 2): sums = {r.r, b.b}
+__global__ void k_sr_setup(CgScalars* state, const CgScalars* sums_slot, int phase)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
+	CgScalars s = *state;
+	const double rr = sums_slot->sums[0];
+	if (phase == 0) {
+		s.bb   = sums_slot->sums[1];
+		s.tol2 = s.tol2 * s.bb;
+		s.iter = 0;
+	} else {
+		s.restarts += 1;
+		s.true_rr = rr;
+	}
+	s.rr   = rr;
+	s.done = !isfinite(rr) ? 2 : (s.bb == 0.0 ? 4 : (!(rr > s.tol2) ? (phase == 2 ? 5 : 1) : (s.iter >= s.max_iter ? 3 : 0)));
+	*state = s;
+}
+
+// scalars of one step from the all-reduced sums {r.z, z.w, r.r}, then the four recurrences; partials of the new r.r
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_sr_update(int64_t n, const CgScalars* __restrict__ in, CgScalars* __restrict__ out,
+                                                         const CgScalars* __restrict__ sums_slot, int first,
+                                                         const T* __restrict__ z, const T* __restrict__ w, T* __restrict__ p,
+                                                         T* __restrict__ s, T* __restrict__ x, T* __restrict__ r,
+                                                         double* __restrict__ prr)
+{
+	__shared__ double sh_alpha, sh_beta;
+	__shared__ int    sh_quit;
+	if (threadIdx.x == 0) {
+		CgScalars st = *in;
+		int quit = 0;
+		double alpha = 0.0, beta = 0.0;
+		if (st.done) {
+			quit = 1;
+		} else {
+			const double gamma = sums_slot->sums[0], delta = sums_slot->sums[1], rr = sums_slot->sums[2];
+			st.rr = rr;
+			if (!isfinite(rr) || !isfinite(gamma) || !isfinite(delta)) {
+				st.done = 2;
+			} else if (!(rr > st.tol2)) {
+				st.done = 1;
+			} else if (st.iter >= st.max_iter) {
+				st.done = 3;
+			} else {
+				beta = first ? 0.0 : gamma / st.rz;
+				const double denom = first ? delta : delta - beta * gamma / st.alpha;
+				alpha = gamma / denom;
+				if (!(gamma > 0.0) || !(denom > 0.0) || !isfinite(alpha)) { st.done = 2; }
+				st.pq = denom;
+			}
+			if (st.done) {
+				quit = 1;
+			} else {
+				st.rz    = gamma;
+				st.alpha = alpha;
+				st.beta  = beta;
+				st.iter += 1;
+			}
+		}
+		if (blockIdx.x == 0) { *out = st; }
+		sh_alpha = alpha;
+		sh_beta  = beta;
+		sh_quit  = quit;
+	}
+	__syncthreads();
+	if (sh_quit) { return; }
+	const T alpha = static_cast<T>(sh_alpha), beta = static_cast<T>(sh_beta);
+	double acc = 0.0;
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T pv = first ? z[i] : z[i] + beta * p[i];
+		const T sv = first ? w[i] : w[i] + beta * s[i];
+		p[i] = pv;
+		s[i] = sv;
+		x[i] += alpha * pv;
+		const T rv = r[i] - alpha * sv;
+		r[i] = rv;
+		acc += static_cast<double>(rv) * static_cast<double>(rv);
+	}
+	double accv[1] = {acc}, sum[1];
+	block_sum<1>(accv, sum);
+	if (threadIdx.x == 0) { prr[blockIdx.x] = sum[0]; }
+}
+
+template <typename T>
+void cg_run_poly_sr(RankSet& R, int max_iterations, float tol)
+{
+	fi_ctx* c0 = R[0];
+	hipStream_t st = c0->stream;
+	const int terms = c0->poly_terms;
+	if (max_iterations <= 0) {
+		const int64_t dflt = 2 * static_cast<int64_t>(c0->g.gn[0]) * c0->g.gn[1] * c0->g.gn[2];
+		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
+	}
+	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
+	for (fi_ctx* c : R) {
+		ensure_poly_vectors<T>(c);
+		const size_t bytes = sizeof(T) * c->g.nloc;
+		if (c->mg_r.bytes < bytes) {
+			c->mg_r.alloc(bytes);
+			FI_HIP_TRY(hipMemsetAsync(c->mg_r.p, 0, bytes, c->stream));
+		}
+	}
+	if (!(c0->poly_lambda > 0)) { estimate_poly_lambda<T>(R); }
+	hipEvent_t e0, e1;
+	FI_HIP_TRY(hipEventCreate(&e0));
+	FI_HIP_TRY(hipEventCreate(&e1));
+	FI_HIP_TRY(hipEventRecord(e0, st));
+
+	double lam_scale = 1.0;
+	if (const char* env = test_switch("FI_POLY_LAMBDA_SCALE")) { lam_scale = atof(env) > 0 ? atof(env) : 1.0; }
+	const double lam = (c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0) * lam_scale;
+	const double hi = 1.1 * lam, lo = hi / (c0->poly_ratio > 1.0 ? c0->poly_ratio : 10.0);
+	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	std::vector<double> c1s, c2s;
+	{
+		double rho = 1.0 / sigma;
+		for (int k = 1; k < terms; ++k) {
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			c1s.push_back(rho_new * rho);
+			c2s.push_back(2.0 * rho_new / delta);
+			rho = rho_new;
+		}
+	}
+	CgScalars init{};
+	init.tol2     = tolerance * tolerance;
+	init.max_iter = max_iterations;
+	init.rz       = 1.0;
+	init.alpha    = 1.0;
+	reset_scalars(R, init);
+
+	auto nbf_of = [](fi_ctx* c) { const int b = stream_blocks(c->g.nown); return b > 1024 ? 1024 : b; };
+	auto region = [](fi_ctx* c, int k) { return c->partial.as<double>() + static_cast<size_t>(k) * c->max_blocks; };
+	auto slot   = [](fi_ctx* c, int k) { return c->scal.as<CgScalars>() + k; };
+	int n_exchanges = 0, n_reductions = 0;
+	auto cross = [&](int nvec) {
+		++n_reductions;
+		if (R.size() > 1) {
+			hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, st, c0->group_scal.as<CgScalars*>(), static_cast<int>(R.size()), nvec, 2);
+		} else if (c0->nranks > 1) {
+			allreduce_sum(c0, slot(c0, 2)->sums, nvec);
+		}
+	};
+	bool ghosts_scaled = true;
+	for (const fi_ctx* c : R) { ghosts_scaled = ghosts_scaled && c->scaling_ghosts; }
+	const bool z0_on_load = ghosts_scaled && terms > 2 && c0->march.valid && !test_switch("FI_NO_Z0_ON_LOAD");
+	const int  deep_width = 2 * (terms - 1);
+	const bool deep = z0_on_load && c0->halo >= deep_width && c0->min_slab >= deep_width && !test_switch("FI_NO_DEEP_HALO");
+	const Vec ZA = &fi_ctx::mg_x, ZB = &fi_ctx::mg_d, W = &fi_ctx::mg_r, S = &fi_ctx::q;
+
+	// z = M r (the polynomial of cg_run_poly, without its sampling and overlap); returns the buffer holding z; the partials
+	// of r . z are in region 2
+	auto polynomial = [&]() -> Vec {
+		if (!z0_on_load) {
+			for (fi_ctx* c : R) {
+				hipLaunchKernelGGL((k_cheb_first16<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+				                   vown<T>(c, &fi_ctx::r), c->dinv16.as<unsigned short>() + c->g.own_first, vown<T>(c, ZA),
+				                   static_cast<T>(1.0 / theta));
+			}
+		}
+		Vec zin = ZA, zout = ZB;
+		for (int k = 1; k < terms; ++k) {
+			const bool pro = z0_on_load && k == 1;
+			const int  ext = deep ? 2 * (terms - 1 - k) : 0;
+			if (deep) {
+				if (k == 1) {
+					halo_exchange(R, &fi_ctx::r, deep_width);
+					++n_exchanges;
+				}
+			} else {
+				halo_exchange(R, pro ? static_cast<Vec>(&fi_ctx::r) : zin);
+				++n_exchanges;
+			}
+			for (fi_ctx* c : R) {
+				if (pro) {
+					stencil_cheb_step(c, c->r.p, nullptr, c->r.p, (c->*zout).p, c1s[0], c2s[0], region(c, 2), 0, 0.0, 1.0 / theta, nullptr, ext);
+				} else {
+					stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1],
+					                  region(c, 2), 0, k == 2 ? 1.0 / theta : 0.0, 0.0, nullptr, ext);
+				}
+			}
+			std::swap(zin, zout);
+		}
+		return zin;
+	};
+	// r = b - A x with its norm (and b's): start (phase 0) and verification (phase 2)
+	auto true_residual = [&](int phase) {
+		apply_exchanged(R, &fi_ctx::x, S, nullptr);
+		++n_exchanges;
+		for (fi_ctx* c : R) {
+			const int64_t o = c->g.own_first;
+			hipLaunchKernelGGL((k_sr_residual<T>), dim3(nbf_of(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->atb.as<T>() + o,
+			                   c->q.as<T>() + o, c->r.as<T>() + o, region(c, 1), region(c, 3));
+			hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, slot(c, 2), region(c, 1), nbf_of(c), region(c, 3), nbf_of(c),
+			                   static_cast<const double*>(nullptr), 0);
+		}
+		cross(2);
+		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_sr_setup, dim3(1), dim3(1), 0, c->stream, slot(c, 0), slot(c, 2), phase); }
+	};
+	int  replace_every = 16, since_replace = 0;
+	if (const char* env = test_switch("FI_SR_REPLACE")) { replace_every = atoi(env); }
+	int  state = 0;      // the slot holding the current scalar record (0 / 1 alternate: no block reads the slot its kernel writes)
+	bool first = true;   // the next update starts the recurrences (p = z, s = w)
+	auto iterate = [&]() {
+		const Vec zfin = polynomial();
+		apply_exchanged(R, zfin, W, +[](fi_ctx* c) -> double* { return c->partial.as<double>(); });
+		++n_exchanges;
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, slot(c, 2), region(c, 2), stencil_cheb_partials(c),
+			                   region(c, 0), apply_num_partials(c), region(c, 1), nbf_of(c));
+		}
+		cross(3);
+		for (fi_ctx* c : R) {
+			const int64_t o = c->g.own_first;
+			hipLaunchKernelGGL((k_sr_update<T>), dim3(nbf_of(c)), dim3(kThreads), 0, c->stream, c->g.nown, slot(c, state), slot(c, state ^ 1),
+			                   slot(c, 2), first ? 1 : 0, vown<T>(c, zfin), vown<T>(c, W), c->p.as<T>() + o, c->q.as<T>() + o,
+			                   c->x.as<T>() + o, c->r.as<T>() + o, region(c, 1));
+		}
+		state ^= 1;
+		first = false;
+		// The recurrence s = w + beta s drifts from A p in fp32 (a 2-D system of 150 outer iterations took 168 over three
+		// slabs): every 16th step s is recomputed as A p -- one more apply and exchange per 16 outer iterations.  In fp64 the
+		// recurrence tracks the two-reduction form to rounding for hundreds of steps (563 = 563).  FI_SR_REPLACE: tests.
+		if (replace_every > 0 && ++since_replace >= replace_every) {
+			since_replace = 0;
+			apply_exchanged(R, &fi_ctx::p, S, nullptr);
+			++n_exchanges;
+		}
+	};
+	auto read_state = [&]() -> const CgScalars& {
+		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, slot(c0, state), sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		return *c0->scal_host;
+	};
+
+	true_residual(0);
+	double limit_s = 600.0;
+	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
+	const auto wall0 = std::chrono::steady_clock::now();
+	bool timed_out = false;
+	int  restarts_left = c0->verify_residual ? 3 : 0;
+	int  next_burst = c0->last_outer_iterations > 0 ? (c0->last_outer_iterations < 64 ? c0->last_outer_iterations + 1 : 64) : 4;
+	for (;;) {
+		const CgScalars& h = read_state();
+		if (h.done) {
+			if (h.done != 1 || restarts_left <= 0) { break; }
+			--restarts_left;  // the recurrence's residual met the tolerance: check b - A x, go on from it if it misses
+			if (state != 0) {  // (k_sr_setup works on slot 0)
+				for (fi_ctx* c : R) { FI_HIP_TRY(hipMemcpyAsync(slot(c, 0), slot(c, 1), sizeof(CgScalars), hipMemcpyDeviceToDevice, c->stream)); }
+				state = 0;
+			}
+			// (the operator kernels exit at once while the stop flag of slot 0 is up)
+			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, slot(c, 0), 0); }
+			true_residual(2);
+			first = true;
+			continue;
+		}
+		if (timed_out_anywhere(R, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s)) {
+			timed_out = true;
+			break;
+		}
+		for (int k = 0; k < next_burst; ++k) { iterate(); }
+		next_burst = 2;
+		FI_HIP_TRY(hipGetLastError());
+	}
+	FI_HIP_TRY(hipEventRecord(e1, st));
+	FI_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	const CgScalars h = *c0->scal_host;
+	for (fi_ctx* c : R) {
+		c->stats.spmv_samples = 0;
+		c->stats.spmv_ms_avg  = 0.0;
+		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		c->stats.prec_samples = 0;
+		c->stats.prec_ms_avg  = 0.0;
+		c->stats.prec_bytes   = 0.0;
+		c->stats.operator_applies = h.iter * terms + 1 + h.restarts;
+		c->stats.halo_exchanges = n_exchanges;
+		c->stats.reductions     = n_reductions;
+		c->last_outer_iterations = h.iter;
+		c->stats.solve_ms     = ms;
+		c->stats.iterations   = h.iter;
+		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
+		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+		c->stats.restarts     = h.restarts;
+		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
+		if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
+	}
+	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown in the single-reduction recurrence (r.M r or p.A p not positive)");
+	FI_REQUIRE(!timed_out, FI_ERR_TIMEOUT, "solve stopped by the wall-clock guard (FI_SOLVE_TIMEOUT_S = %g s) after %d iterations, "
+	           "relative residual %g", limit_s, h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0);
+}
+
 // polynomial PCG; if its preconditioner stays indefinite after two widenings of the interval: the Jacobi diagonal, from
-// the last iterate (x is finite: the step that breaks down does not touch it)
+// the last iterate (x is finite: the step that breaks down does not touch it).  Over slabs the single-reduction form
+// runs first (cg_run_poly_sr); a breakdown there hands over to the two-reduction form, which knows how to widen.
 template <typename T>
 void cg_run_poly_or_jacobi(RankSet& R, int max_iterations, float tol)
 {
+	if ((R.size() > 1 || R[0]->nranks > 1 || test_switch("FI_FORCE_SINGLE_REDUCTION")) && !test_switch("FI_NO_SINGLE_REDUCTION")) {
+		try {
+			cg_run_poly_sr<T>(R, max_iterations, tol);
+			return;
+		} catch (const Fail& f) {
+			if (f.code != FI_ERR_BREAKDOWN) { throw; }
+		}
+	}
 	try {
 		cg_run_poly<T>(R, max_iterations, tol);
 	} catch (const Fail& f) {
