@@ -183,7 +183,10 @@ __host__ __device__ constexpr int fused_waves(bool has1, bool has2, bool pack)
 {
 	// fp64: the bound of 2 leaves the allocator room; it still lands at 166-168 VGPRs = 3 workgroups per CU, without the
 	// 4 spilled registers (20 bytes of scratch per lane) the bound of 3 cost the model_2 variant
-	if (sizeof(T) == 8) { return FI_CELL_WAVES - 1; }
+#ifndef FI_F64_FUSED_WAVES
+#define FI_F64_FUSED_WAVES (FI_CELL_WAVES - 1)
+#endif
+	if (sizeof(T) == 8) { return FI_F64_FUSED_WAVES; }
 	return (has1 && (has2 || (pack && sizeof(T) == 4))) ? FI_CELL_WAVES - 1 : FI_CELL_WAVES;
 }
 
