@@ -388,6 +388,11 @@ def main():
         "roofline": roof_main,
         "roofline_apply": roof_apply,
     }
+    if world > 1 and st["iterations"] > 0:
+        # what an outer iteration of the finest level costs in collectives (fi_stats counts them; the start and the
+        # verification are in the totals)
+        line["config"]["halo_exchanges_per_iteration"] = st["halo_exchanges"] / float(st["iterations"])
+        line["config"]["allreduces_per_iteration"] = st["reductions"] / float(st["iterations"])
     if world == 1 and not args.no_cold:
         # Cold step: a FRESH context -- hipMalloc of every vector and list, the power method of the polynomial's bound
         # (fi_set_model: 16 marching launches + 2 host reads per level), the first assemble and a solve whose first look at
