@@ -1793,6 +1793,9 @@ void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial)
 // 2-D: the tile kernel (fi_stencil2d.hip), both precisions.
 bool stencil_full_epi_available(const fi_ctx* c)
 {
+	// rows kept as triplets (GradientKernel::kLinearInterpolation, fi_add_rows_coo) are applied by fi_generic.hip, not by
+	// the tiled kernels: a recurrence step in THEIR epilogue would smooth with an operator that lacks those rows
+	if (c->generic.ntrip != 0) { return false; }
 	if (c->tile2.valid) { return tile2d_full_epi_available(c); }  // 2-D: the tile kernel, both precisions
 	return c->march.valid && c->dtype == FI_F32 && (c->cells.ncell == 0 || c->march.fused);
 }
