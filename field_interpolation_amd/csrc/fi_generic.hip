@@ -101,10 +101,22 @@ __global__ __launch_bounds__(kThreads) void k_emit_gradient_linear(Geom g, long 
 	int     idx[NC];
 	float   lw[NC];
 	int     kept = 0;
+	// Slabs: a point's rows reach the planes base .. base + 2 of the
+	// slowest axis.  The rank keeps them whole if one of those planes is its own -- the others are then ghost planes (the
+	// stencil's reach is at least 2) -- and not at all otherwise: every rank applies a row to its own columns only, like a
+	// data cell.  Which samples exist is decided on GLOBAL coordinates, the same on every rank.
+	// (The columns stay GLOBAL here -- the ghost planes, and with them the local numbering, are fixed by fi_assemble, which
+	// shifts the sorted copy: generic_assemble_t.)
+	constexpr int L = D - 1;
+	bool mine = true;
+	if (g.nown != g.nloc) {
+		const int lo = g.off[L] + g.own_lo[L], hi = g.off[L] + g.own_hi[L];
+		mine = base[L] + 2 >= lo && base[L] < hi;
+	}
 	for (int q = 0; q < NC; ++q) {
 		int64_t ix = 0;
 		float   ww = 1.0f;
-		bool    in = finite && cw != 0.0f;
+		bool    in = finite && cw != 0.0f && mine;
 		for (int d = 0; d < D; ++d) {
 			const int up = (q >> d) & 1;
 			const int cc = base[d] + up;
@@ -147,6 +159,15 @@ __global__ __launch_bounds__(kThreads) void k_widen(int64_t n, const float* __re
 	if (i < n) { out[i] = static_cast<T>(in[i]); }
 }
 
+__global__ __launch_bounds__(kThreads) void k_shift_cols(int64_t n, uint64_t* __restrict__ key, int64_t shift)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= n) { return; }
+	const uint64_t k = key[i];
+	const int64_t  col = static_cast<int64_t>(k & 0xFFFFFFFFull) - shift;   // (empty rows carry column 0 with value 0: clamp)
+	key[i] = (k & 0xFFFFFFFF00000000ull) | static_cast<uint64_t>(col < 0 ? 0 : col);
+}
+
 __global__ __launch_bounds__(kThreads) void k_unpack_csr(int64_t nnz, const uint64_t* __restrict__ key,
                                                           uint32_t* __restrict__ col, uint32_t* __restrict__ row_count)
 {
@@ -180,10 +201,11 @@ __global__ __launch_bounds__(kThreads) void k_generic_rhs_diag(int64_t ncols, co
                                                                 const uint32_t* __restrict__ row,
                                                                 const T* __restrict__ val,
                                                                 const float* __restrict__ rhs, T* __restrict__ atb,
-                                                                T* __restrict__ diag)
+                                                                T* __restrict__ diag, int64_t own_first, int64_t nown)
 {
 	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
 	if (c >= ncols) { return; }
+	if (static_cast<uint64_t>(static_cast<int64_t>(cols[c]) - own_first) >= static_cast<uint64_t>(nown)) { return; }  // a ghost column: the neighbour's
 	double b = 0, d = 0;
 	for (uint32_t k = ptr[c]; k < ptr[c + 1]; ++k) {
 		const double a = static_cast<double>(val[k]);
@@ -215,12 +237,14 @@ __global__ __launch_bounds__(kThreads) void k_generic_Aty(int64_t ncols, const u
                                                            const uint32_t* __restrict__ row,
                                                            const T* __restrict__ val, const T* __restrict__ t,
                                                            const T* __restrict__ x, T* __restrict__ y,
-                                                           double* __restrict__ partial, const int* __restrict__ done)
+                                                           double* __restrict__ partial, const int* __restrict__ done,
+                                                           int64_t own_first, int64_t nown)
 {
 	if (done && *done) { return; }
 	double contrib = 0;
 	for (int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; c < ncols;
 	     c += static_cast<int64_t>(gridDim.x) * kThreads) {
+		if (static_cast<uint64_t>(static_cast<int64_t>(cols[c]) - own_first) >= static_cast<uint64_t>(nown)) { continue; }  // ghost column
 		T s = 0;
 		for (uint32_t k = ptr[c]; k < ptr[c + 1]; ++k) { s += val[k] * t[row[k]]; }
 		const uint32_t j = cols[c];
@@ -348,6 +372,13 @@ static void generic_assemble_t(fi_ctx* c)
 	tmp.alloc(tb);
 	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, G.key.as<uint64_t>(), ksort.as<uint64_t>(), G.val.as<float>(),
 	                                              vsort.as<float>(), n, 0, 64, st));
+	// slabs: global -> local column numbers (the local array starts at global plane g.off[L]: a uniform shift, the order
+	// stays).  Every kept row lies within the ghost planes: it touches an owned plane and reaches 2 planes (reach >= 2).
+	const int64_t col_shift = static_cast<int64_t>(c->g.off[c->g.ndim - 1]) * c->g.stride[c->g.ndim - 1];
+	if (col_shift != 0) {
+		hipLaunchKernelGGL(k_shift_cols, dim3(blocks_for(n)), dim3(kThreads), 0, st, static_cast<int64_t>(n), ksort.as<uint64_t>(),
+		                   col_shift);
+	}
 	// duplicates: summed in input order (stable sort) -- sparse_linear.hpp:43, Eigen setFromTriplets -- in the
 	// context's precision: fp32 like as_sparse_matrix_float (:59-70), fp64 like as_sparse_matrix_double (:72-93)
 	DevBuf vT;
@@ -420,15 +451,17 @@ static void generic_assemble_t(fi_ctx* c)
 	G.t.alloc(elem_size(c) * (G.nrows + 1));
 	hipLaunchKernelGGL((k_generic_rhs_diag<T>), dim3(blocks_for(ncols)), dim3(kThreads), 0, st, ncols,
 	                   G.csc_cols.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), G.csc_row.as<uint32_t>(), G.csc_val.as<T>(),
-	                   G.rhs.as<float>(), c->atb.as<T>(), c->diag.as<T>());
+	                   G.rhs.as<float>(), c->atb.as<T>(), c->diag.as<T>(), c->g.own_first, c->g.nown);
 	FI_HIP_TRY(hipGetLastError());
 	FI_HIP_TRY(hipStreamSynchronize(st));
 }
 
 void generic_assemble(fi_ctx* c)
 {
-	FI_REQUIRE(c->nranks == 1 || c->generic.ntrip == 0, FI_ERR_UNSUPPORTED,
-	           "generic rows (fi_add_rows_coo, GradientKernel::kLinearInterpolation) need an undivided lattice");
+	// (slabs: only rows emitted from points -- GradientKernel::kLinearInterpolation, local columns -- get here:
+	// fi_add_rows_coo refuses slab contexts)
+	FI_REQUIRE(c->nranks == 1 || c->generic.ntrip == 0 || c->reach >= 2, FI_ERR_UNSUPPORTED,
+	           "GradientKernel::kLinearInterpolation over slabs needs two ghost planes (model_2 or wider)");
 	c->dtype == FI_F64 ? generic_assemble_t<double>(c) : generic_assemble_t<float>(c);
 }
 
@@ -507,7 +540,7 @@ static void generic_apply_t(fi_ctx* c, const T* x, T* y, double* partial)
 	                   G.csr_ptr.as<uint32_t>(), G.csr_col.as<uint32_t>(), G.csr_val.as<T>(), x, G.t.as<T>(), done);
 	hipLaunchKernelGGL((k_generic_Aty<T>), dim3(capped_blocks(G.ncols)), dim3(kThreads), 0, c->stream, G.ncols,
 	                   G.csc_cols.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), G.csc_row.as<uint32_t>(), G.csc_val.as<T>(),
-	                   G.t.as<T>(), x, y, partial, done);
+	                   G.t.as<T>(), x, y, partial, done, c->g.own_first, c->g.nown);
 	FI_HIP_TRY(hipGetLastError());
 }
 
@@ -516,11 +549,12 @@ static void generic_apply_t(fi_ctx* c, const T* x, T* y, double* partial)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_errmap_rows(int64_t ntrip, const uint64_t* __restrict__ key,
                                                            const float* __restrict__ val, const T* __restrict__ x,
-                                                           double* __restrict__ res, double* __restrict__ sq)
+                                                           double* __restrict__ res, double* __restrict__ sq, int64_t shift)
 {
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < ntrip;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		const uint32_t row = static_cast<uint32_t>(key[i] >> 32), col = static_cast<uint32_t>(key[i] & 0xFFFFFFFFull);
+		const uint32_t row = static_cast<uint32_t>(key[i] >> 32);
+		const int64_t  col = static_cast<int64_t>(key[i] & 0xFFFFFFFFull) - shift;  // (slabs: the raw keys are global)
 		const double a = static_cast<double>(val[i]);
 		if (a == 0.0) { continue; }
 		unsafeAtomicAdd(&res[row], -a * static_cast<double>(x[col]));
@@ -531,11 +565,12 @@ __global__ __launch_bounds__(kThreads) void k_errmap_rows(int64_t ntrip, const u
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_errmap_blame(int64_t ntrip, const uint64_t* __restrict__ key,
                                                             const float* __restrict__ val, const double* __restrict__ res,
-                                                            const double* __restrict__ sq, T* __restrict__ out)
+                                                            const double* __restrict__ sq, T* __restrict__ out, int64_t shift)
 {
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < ntrip;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		const uint32_t row = static_cast<uint32_t>(key[i] >> 32), col = static_cast<uint32_t>(key[i] & 0xFFFFFFFFull);
+		const uint32_t row = static_cast<uint32_t>(key[i] >> 32);
+		const int64_t  col = static_cast<int64_t>(key[i] & 0xFFFFFFFFull) - shift;
 		const double a = static_cast<double>(val[i]);
 		if (a == 0.0 || !(sq[row] > 0.0)) { continue; }
 		unsafeAtomicAdd(&out[col], static_cast<T>(a * a / sq[row] * res[row] * res[row]));
@@ -557,14 +592,15 @@ static void generic_error_map_t(fi_ctx* c, const T* x, T* out)
 {
 	GenericRows& G = c->generic;
 	DevBuf &res = c->scratch[22], &sq = c->scratch[23];
+	const int64_t shift = static_cast<int64_t>(c->g.off[c->g.ndim - 1]) * c->g.stride[c->g.ndim - 1];
 	res.alloc(sizeof(double) * G.nrows);
 	sq.alloc(sizeof(double) * G.nrows);
 	hipLaunchKernelGGL(k_errmap_init, dim3(blocks_for(G.nrows)), dim3(kThreads), 0, c->stream, G.nrows, G.rhs.as<float>(),
 	                   res.as<double>(), sq.as<double>());
 	hipLaunchKernelGGL((k_errmap_rows<T>), dim3(capped_blocks(G.ntrip)), dim3(kThreads), 0, c->stream, G.ntrip,
-	                   G.key.as<uint64_t>(), G.val.as<float>(), x, res.as<double>(), sq.as<double>());
+	                   G.key.as<uint64_t>(), G.val.as<float>(), x, res.as<double>(), sq.as<double>(), shift);
 	hipLaunchKernelGGL((k_errmap_blame<T>), dim3(capped_blocks(G.ntrip)), dim3(kThreads), 0, c->stream, G.ntrip,
-	                   G.key.as<uint64_t>(), G.val.as<float>(), res.as<double>(), sq.as<double>(), out);
+	                   G.key.as<uint64_t>(), G.val.as<float>(), res.as<double>(), sq.as<double>(), out, shift);
 	FI_HIP_TRY(hipGetLastError());
 }
 

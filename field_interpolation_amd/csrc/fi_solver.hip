@@ -4388,8 +4388,7 @@ int fi_add_points(fi_ctx* c, long n, const float* positions, const float* normal
 	if (normals) {
 		FI_REQUIRE(gradient_kernel >= 0 && gradient_kernel <= 2, FI_ERR_INVALID, "Unknown gradient kernel: %d",
 		           gradient_kernel);  // ABORT_F, cpp:238
-		FI_REQUIRE(gradient_kernel != FI_GRADIENT_LINEAR_INTERPOLATION || gradient_weight == 0.0f || c->nranks == 1,
-		           FI_ERR_UNSUPPORTED, "GradientKernel::kLinearInterpolation needs an undivided lattice");
+// (GradientKernel::kLinearInterpolation over slabs: its rows are kept as triplets with local columns, fi_generic.hip)
 	}
 	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
 	const int D = c->g.ndim;
@@ -4800,6 +4799,7 @@ int fi_tile_pass(fi_ctx* c, const float* guess, int tile_size, float* out, int m
 	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
 	FI_REQUIRE(tile_size >= 2, FI_ERR_INVALID, "tile_size %d < 2 (sparse_linear.cpp:254)", tile_size);
 	FI_REQUIRE(guess && out, FI_ERR_INVALID, "fi_tile_pass needs a guess and an output buffer");
+	FI_REQUIRE(c->nranks == 1 || c->generic.ntrip == 0, FI_ERR_UNSUPPORTED, "the tile pre-solver over triplet rows needs an undivided lattice");
 	if (c->dtype == FI_F64) {
 		fi::tile_pass_t<double>(c, guess, tile_size, out, memory);
 	} else {
@@ -5118,6 +5118,7 @@ int fi_group_tile_pass(fi_group* g, const float* guess, int tile_size, float* ou
 	FI_API_BEGIN
 	group_ready(g);
 	FI_REQUIRE(tile_size >= 2 && guess && out, FI_ERR_INVALID, "fi_group_tile_pass: tile_size >= 2, guess and out required");
+	FI_REQUIRE(g->members[0]->generic.ntrip == 0, FI_ERR_UNSUPPORTED, "the tile pre-solver over triplet rows needs an undivided lattice");
 	int64_t at = 0;
 	for (fi_ctx* c : g->members) {
 		g->dtype == FI_F64 ? fi::load_owned<double>(c, c->x, guess + at, FI_HOST) : fi::load_owned<float>(c, c->x, guess + at, FI_HOST);

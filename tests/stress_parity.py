@@ -72,7 +72,7 @@ def one_case(seed):
     if sizes[-1] >= 4 and D >= 1:
         reach = max([k for k, v in ((1, w.model_1), (2, w.model_2), (3, w.model_3), (4, w.model_4)) if v > 0] + [1])
         maxr = sizes[-1] // max(reach, 1)
-        if maxr >= 2 and gk != 2:                       # generic rows need an undivided lattice
+        if maxr >= 2 and (gk != 2 or (reach >= 2 and use_nrm)):   # kLinearInterpolation rows over slabs need two ghost planes
             nr = int(rng.integers(2, min(maxr, 6) + 1))
             grp = fi.LatticeGroup(sizes, nr, dtype=dtype)
             grp.add_field_constraints(w)

@@ -38,7 +38,7 @@ def one_case(seed):
     fo, _ = build_pair(oracle, fi, sizes, w, pos, nrm if sdf else None, None, val, dtype="f64")
     x64 = fo.solve_exact_f64()
     mode = ["plain", "cascade", "mg", "mixed"][int(rng.integers(0, 4))]
-    nranks = int(rng.integers(1, 5)) if gk != 2 else 1
+    nranks = int(rng.integers(1, 5))
     levels = 0 if mode == "plain" else int(rng.integers(1, 3))
     desc = "seed %d: sizes %s pts %d sdf %d gk %d %s levels %d ranks %d %s" % (
         seed, sizes, npts, sdf, gk, mode, levels, nranks, {k: round(v, 2) for k, v in kw.items()})

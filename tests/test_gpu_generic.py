@@ -48,6 +48,39 @@ def test_gradient_linear_interpolation_kernel(oracle, fi, dtype, sizes):
         assert g1.add_gradient_constraint(p, nrm[0], 1.0, 2) in (True, f1.add_gradient_constraint(p, nrm[0], 1.0, 2))
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("sizes,nranks", [([13, 22], 3), ([16, 7, 24], 4), ([9, 8, 17], 2)])
+def test_gradient_linear_interpolation_kernel_over_slabs(oracle, fi, dtype, sizes, nranks):
+    """GradientKernel::kLinearInterpolation rows (three planes wide, kept as triplets) over slabs: a rank keeps the rows
+    that touch one of its planes, whole, with local column numbers, and applies them to its own columns -- like a data cell.
+    The decomposed operator, right-hand side and diagonal equal the oracle's explicit normal equations; the error map and
+    the solve equal the undivided ones.  (Hand-built rows, fi_add_rows_coo, stay with undivided lattices.)"""
+    rng = np.random.default_rng(len(sizes) + nranks)
+    pos, nrm, pw, val = random_points(rng, sizes, 200, margin=1.2)
+    w = fi.Weights(data_gradient=0.9, gradient_kernel=fi.GradientKernel.kLinearInterpolation)
+    fo, one = build_pair(oracle, fi, sizes, w, pos, nrm, pw, val, dtype=dtype)
+    grp = fi.LatticeGroup(sizes, nranks, dtype=dtype)
+    grp.add_field_constraints(w)
+    grp.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, pw, values=val)
+    grp.assemble()
+    AtA, atb, diag = fo.normal_equations()
+    tol = TOL[dtype]
+    assert np.abs(grp.Atb() - atb).max() <= tol * np.abs(atb).max()
+    assert np.abs(grp.diag() - diag).max() <= tol * np.abs(diag).max()
+    x = rng.normal(size=fo.num_unknowns)
+    y = grp.apply_AtA(x)
+    assert np.abs(y - AtA @ x).max() <= tol * (abs(AtA) @ np.abs(x)).max()
+    np.testing.assert_array_equal(y, grp.apply_AtA(x))
+    sol = rng.normal(size=fo.num_unknowns).astype(np.float32)
+    e1, eg = one.error_map(sol), grp.error_map(sol)
+    assert np.abs(eg - e1).max() <= 1e-4 * np.abs(e1).max()
+    t = 1e-9 if dtype == "f64" else 1e-5
+    x1, it1, r1 = one.solve_cg(None, 0, t)
+    xg, itg, rg = grp.solve_cg(None, 0, t)
+    assert r1 <= t and rg <= t and abs(itg - it1) <= max(3, it1 // 10)
+    assert rel_inf(grp.solution_f64(), one.solution_f64()) <= (1e-6 if dtype == "f64" else 2e-2)
+
+
 def _line_2d_like(oracle, n=60, seed=0):
     """Rows in the spirit of src/line_2d.cpp:49-104: unknowns 2i+d (interleaved xy of a polyline), data rows
     pinning noisy points, second-difference smoothness rows; duplicates on purpose."""
