@@ -727,6 +727,34 @@ __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __r
 	fine[i] = mode ? fine[i] + even : even;
 	if (fx + 1 < L.nf[0]) { fine[i + 1] = mode ? fine[i + 1] + odd : odd; }
 }
+// 2-D form (the generic kernel indexes its coordinate arrays by the runtime axis -- scratch memory: 127 us per call at
+// 4096^2 against the 25 us two lattice passes take).  A thread owns the fine points 2t and 2t+1 of a row; y is the
+// decomposed axis.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_prolong2(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine, int mode)
+{
+	const int t  = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
+	const int fx = 2 * t;
+	if (fx >= L.nf[0]) { return; }
+	const int fy = static_cast<int>(blockIdx.y) + L.f_z0;  // global row
+	int xe0, xe1, xo0, xo1, cy[2];
+	T   we0, we1, wo0, wo1, wy[2];
+	prolong_taps<T>(fx, L.nc[0], L.cc[0], &xe0, &xe1, &we0, &we1);
+	prolong_taps<T>(fx + 1 < L.nf[0] ? fx + 1 : fx, L.nc[0], L.cc[0], &xo0, &xo1, &wo0, &wo1);
+	prolong_taps<T>(fy, L.nc[1], L.cc[1], &cy[0], &cy[1], &wy[0], &wy[1]);
+	T even = T(0), odd = T(0);
+#pragma unroll
+	for (int uy = 0; uy < 2; ++uy) {
+		if (wy[uy] == T(0)) { continue; }
+		const T* row = coarse + static_cast<int64_t>(cy[uy] - L.c_base) * L.nc[0];
+		even += wy[uy] * (we0 * row[xe0] + we1 * row[xe1]);
+		odd += wy[uy] * (wo0 * row[xo0] + wo1 * row[xo1]);
+	}
+	const int64_t i = static_cast<int64_t>(fy - L.f_base) * L.nf[0] + fx;
+	fine[i] = mode ? fine[i] + even : even;
+	if (fx + 1 < L.nf[0]) { fine[i + 1] = mode ? fine[i + 1] + odd : odd; }
+}
+
 // Cubic interpolation for the coarse-to-fine START (not the V-cycle: its P must stay the transpose of R).  Vertex-centred
 // axis: a fine point between two coarse points takes (-1, 9, 9, -1) / 16 of the four nearest (indices clamped at the
 // lattice's ends), a coincident one the coarse value.  Cell-centred axis: a fine point sits a quarter of a coarse cell
@@ -813,6 +841,10 @@ void launch_prolong(const LevelPair& L, const T* coarse, T* fine, int mode, hipS
 		const int pairs = (L.nf[0] + 1) / 2;
 		hipLaunchKernelGGL((k_prolong3<T>), dim3((pairs + kThreads - 1) / kThreads, L.nf[1], L.f_planes), dim3(kThreads), 0, st, L,
 		                   coarse, fine, mode);
+	} else if (L.ndim == 2) {
+		const int pairs = (L.nf[0] + 1) / 2;
+		hipLaunchKernelGGL((k_prolong2<T>), dim3((pairs + kThreads - 1) / kThreads, L.f_planes), dim3(kThreads), 0, st, L, coarse, fine,
+		                   mode);
 	} else {
 		hipLaunchKernelGGL((k_prolong<T>), owned_grid(L.nf, L.ndim, L.f_planes), dim3(kThreads), 0, st, L, coarse, fine, mode);
 	}
@@ -1545,6 +1577,32 @@ __global__ __launch_bounds__(kThreads) void k_restrict3(LevelPair L, const T* __
 	}
 	coarse[(static_cast<int64_t>(cz - L.c_base) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
 }
+// 2-D form of k_restrict with compile-time loops
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_restrict2(LevelPair L, const T* __restrict__ fine, T* __restrict__ coarse)
+{
+	const int cx = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
+	if (cx >= L.nc[0]) { return; }
+	const int cy = static_cast<int>(blockIdx.y) + L.c_z0;  // global row
+	int fx[kRTaps], fy[kRTaps];
+	T   wx[kRTaps], wy[kRTaps];
+	restrict_taps<T>(cx, L.nf[0], L.nc[0], L.cc[0], 0, fx, wx);
+	restrict_taps<T>(cy, L.nf[1], L.nc[1], L.cc[1], L.f_base, fy, wy);
+	T acc = T(0);
+#pragma unroll
+	for (int k1 = 0; k1 < kRTaps; ++k1) {
+		if (wy[k1] == T(0)) { continue; }
+		const T* row = fine + static_cast<int64_t>(fy[k1]) * L.nf[0];
+		T r = T(0);
+#pragma unroll
+		for (int k0 = 0; k0 < kRTaps; ++k0) {
+			if (wx[k0] != T(0)) { r += wx[k0] * row[fx[k0]]; }
+		}
+		acc += wy[k1] * r;
+	}
+	coarse[static_cast<int64_t>(cy - L.c_base) * L.nc[0] + cx] = acc;
+}
+
 // The same restriction in two passes (P is a tensor product): first along x and y inside every LOCAL fine plane (ghost
 // planes included) into tmp[fine plane][cy][cx], then along z.  Cell-centred axes have 4 - 5 taps: the one-pass kernel
 // gathers up to 125 fine values per coarse point (171 us from 256^3 to 128^3), the two passes 16 + 4 (about 45 us).
@@ -1608,6 +1666,8 @@ void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t s
 	}
 	if (L.ndim == 3) {
 		hipLaunchKernelGGL((k_restrict3<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, st, L, fine, coarse);
+	} else if (L.ndim == 2) {
+		hipLaunchKernelGGL((k_restrict2<T>), dim3((L.nc[0] + kThreads - 1) / kThreads, L.c_planes), dim3(kThreads), 0, st, L, fine, coarse);
 	} else {
 		hipLaunchKernelGGL((k_restrict<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, st, L, fine, coarse);
 	}
