@@ -213,22 +213,32 @@ __global__ void k_iota(uint32_t* v, long n)
 constexpr uint32_t kHeavyRows = 192;  // cells with more rows are summed by a whole workgroup (k_build_heavy)
 
 // everything after the sums of a cell: block, first row, rhs, factor rows
-template <int D, typename T>
+// DIRECT: block, first row and the (rhs, diagonal) record go straight to memory (k_build_heavy: one thread per
+// workgroup); k_build_blocks sends them through LDS instead and calls this for the factor rows only.
+template <int D, typename T, bool DIRECT = true>
 __device__ inline void finish_cell(long c, long ncell, uint32_t s, uint32_t m, double* B, const double* gvec,
                                    const uint32_t* __restrict__ sorted_row, const float* __restrict__ coef,
-                                   T* __restrict__ blk, double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
+                                   T* __restrict__ blk, T* __restrict__ cell_dr, uint32_t* __restrict__ nrow,
                                    T* __restrict__ row1, T* __restrict__ mrow, uint32_t* __restrict__ nfac,
                                    uint32_t pack_min)
 {
 	constexpr int NC = 1 << D;
 	constexpr int NB = NC * (NC + 1) / 2;
-	for (int e = 0; e < NB; ++e) { blk[c * NB + e] = static_cast<T>(B[e]); }
 	nrow[c] = m;
-	{
+	if (DIRECT) {
+		for (int e = 0; e < NB; ++e) { blk[c * NB + e] = static_cast<T>(B[e]); }
 		const long row = sorted_row[s];  // first row of the cell (the only one when m == 1)
 		for (int q = 0; q < NC; ++q) { row1[c * NC + q] = static_cast<T>(coef[row * NC + q]); }
 	}
-	for (int q = 0; q < NC; ++q) { cell_rhs[static_cast<long>(c) * NC + q] = gvec[q]; }
+	// what the sums over the lattice points read (k_gather_cells*, k_scatter_cells): the cell's share of A^T b and of the
+	// diagonal, rounded to T here, side by side -- one 64-byte line per 3-D cell in fp32 instead of an fp64 vector and
+	// eight entries strewn over the 144-byte block (256^3, 1 M cells: the gather 372 -> ... us)
+	if (DIRECT) {
+		for (int q = 0; q < NC; ++q) {
+			cell_dr[static_cast<long>(c) * 2 * NC + q]      = static_cast<T>(gvec[q]);
+			cell_dr[static_cast<long>(c) * 2 * NC + NC + q] = static_cast<T>(B[packed_index(q, q, NC)]);
+		}
+	}
 
 	// Factor rows for the fused 3-D kernel: the cell's block as a sum of <= 2^D outer products a a^T.
 	//   m <= 2^D rows : the data rows themselves (nothing to compute);
@@ -242,7 +252,8 @@ __device__ inline void finish_cell(long c, long ncell, uint32_t s, uint32_t m, d
 	if (mrow) {
 		uint32_t k = 0;
 		if (m <= static_cast<uint32_t>(NC) && m < pack_min) {
-			for (uint32_t r = 0; r < m; ++r) {
+			// (a single-row cell's factor row is row1: k_cell_records takes row 0 from there, nothing to write)
+			for (uint32_t r = 0; r < m && m > 1; ++r) {
 				const long row = sorted_row[s + r];
 				for (int q = 0; q < NC; ++q) { mrow[(c * NC + r) * NC + q] = static_cast<T>(coef[row * NC + q]); }
 			}
@@ -287,42 +298,95 @@ __device__ inline void finish_cell(long c, long ncell, uint32_t s, uint32_t m, d
 	}
 }
 
+// One thread per cell.  What every cell gets -- block, first row, (rhs, diagonal) record: 60 values -- leaves through LDS
+// so that a store instruction covers consecutive addresses (a thread storing its own cell's 144-byte block puts 64
+// lanes on 64 different lines: 256^3 with 1 M cells 143 -> ... us); the factor rows of the multi-row cells are stored
+// directly (finish_cell).
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uint32_t* __restrict__ start,
                                                             const uint32_t* __restrict__ count,
                                                             const uint32_t* __restrict__ sorted_row,
                                                             const float* __restrict__ coef,
                                                             const float* __restrict__ rhs, T* __restrict__ blk,
-                                                            double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
+                                                            T* __restrict__ cell_dr, uint32_t* __restrict__ nrow,
                                                             T* __restrict__ row1, T* __restrict__ mrow,
                                                             uint32_t* __restrict__ nfac, uint32_t* __restrict__ heavy,
                                                             uint32_t pack_min)
 {
 	constexpr int NC = 1 << D;
 	constexpr int NB = NC * (NC + 1) / 2;
-	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
-	if (c >= ncell) { return; }
-	const uint32_t s = start[c], m = count[c];
-	if (m > kHeavyRows) {  // coarse levels put 10^4..10^6 rows into one cell: not a job for one thread
-		heavy[1 + atomicAdd(&heavy[0], 1u)] = static_cast<uint32_t>(c);
-		return;
+	// the block in ROUNDS parts (fp64 3-D: two halves of 18, 64 KB of static LDS is the limit), then record + first row
+	constexpr int ROUNDS = (D == 3 && sizeof(T) == 8) ? 2 : 1;
+	constexpr int EPR    = NB / ROUNDS;
+	constexpr int ST1 = EPR | 1, ST2 = 3 * NC + 1;  // odd strides: a column of the tile spreads over the banks
+	__shared__ T tile[kThreads * (ST1 > ST2 ? ST1 : ST2)];
+	const long c0 = static_cast<long>(blockIdx.x) * kThreads;
+	const long c  = c0 + threadIdx.x;
+	const int  nb = static_cast<int>(ncell - c0 < kThreads ? ncell - c0 : kThreads);
+	uint32_t s = 0, m = 0;
+	bool     mine = false;
+	if (c < ncell) {
+		s = start[c];
+		m = count[c];
+		if (m > kHeavyRows) {  // coarse levels put 10^4..10^6 rows into one cell: not a job for one thread
+			heavy[1 + atomicAdd(&heavy[0], 1u)] = static_cast<uint32_t>(c);
+		} else {
+			mine = true;
+		}
 	}
 	double B[NB];
 	double gvec[NC];
 	for (int e = 0; e < NB; ++e) { B[e] = 0.0; }
 	for (int q = 0; q < NC; ++q) { gvec[q] = 0.0; }
-	for (uint32_t r = 0; r < m; ++r) {
-		const long row = sorted_row[s + r];
-		double     a[NC];
-		for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(coef[row * NC + q]); }
-		const double b = static_cast<double>(rhs[row]);
-		int e = 0;
-		for (int i = 0; i < NC; ++i) {
-			for (int j = i; j < NC; ++j) { B[e++] += a[i] * a[j]; }
-			gvec[i] += a[i] * b;
+	T first[NC];
+	for (int q = 0; q < NC; ++q) { first[q] = T(0); }
+	if (mine) {
+		for (uint32_t r = 0; r < m; ++r) {
+			const long row = sorted_row[s + r];
+			double     a[NC];
+			for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(coef[row * NC + q]); }
+			if (r == 0) {
+				for (int q = 0; q < NC; ++q) { first[q] = static_cast<T>(coef[row * NC + q]); }
+			}
+			const double b = static_cast<double>(rhs[row]);
+			int e = 0;
+			for (int i = 0; i < NC; ++i) {
+				for (int j = i; j < NC; ++j) { B[e++] += a[i] * a[j]; }
+				gvec[i] += a[i] * b;
+			}
 		}
 	}
-	finish_cell<D, T>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_rhs, nrow, row1, mrow, nfac, pack_min);
+	// (the heavy cells' slots receive zeros here and their values from k_build_heavy, the next launch on the stream)
+#pragma unroll
+	for (int round = 0; round < ROUNDS; ++round) {
+		if (round) { __syncthreads(); }
+#pragma unroll
+		for (int e = 0; e < EPR; ++e) { tile[threadIdx.x * ST1 + e] = static_cast<T>(B[round * EPR + e]); }
+		__syncthreads();
+		for (int i = threadIdx.x; i < nb * EPR; i += kThreads) {
+			const int cell = i / EPR, e = i - cell * EPR;
+			blk[(c0 + cell) * NB + round * EPR + e] = tile[cell * ST1 + e];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < NC; ++q) {
+		tile[threadIdx.x * ST2 + q]          = static_cast<T>(gvec[q]);
+		tile[threadIdx.x * ST2 + NC + q]     = static_cast<T>(B[packed_index(q, q, NC)]);
+		tile[threadIdx.x * ST2 + 2 * NC + q] = first[q];
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < nb * 2 * NC; i += kThreads) {
+		const int cell = i / (2 * NC), e = i - cell * 2 * NC;
+		cell_dr[c0 * 2 * NC + i] = tile[cell * ST2 + e];
+	}
+	for (int i = threadIdx.x; i < nb * NC; i += kThreads) {
+		const int cell = i / NC, e = i - cell * NC;
+		row1[c0 * NC + i] = tile[cell * ST2 + 2 * NC + e];
+	}
+	if (mine) {
+		finish_cell<D, T, false>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_dr, nrow, row1, mrow, nfac, pack_min);
+	}
 }
 
 // One workgroup per heavy cell: threads stride over the cell's rows, then a fixed-shape tree (wave shuffles,
@@ -333,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void k_build_heavy(long ncell, const uint
                                                            const uint32_t* __restrict__ sorted_row,
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ rhs, T* __restrict__ blk,
-                                                           double* __restrict__ cell_rhs, uint32_t* __restrict__ nrow,
+                                                           T* __restrict__ cell_dr, uint32_t* __restrict__ nrow,
                                                            T* __restrict__ row1, T* __restrict__ mrow,
                                                            uint32_t* __restrict__ nfac, const uint32_t* __restrict__ heavy,
                                                            uint32_t pack_min)
@@ -373,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void k_build_heavy(long ncell, const uint
 				for (int w = 0; w < kThreads / 64; ++w) { v += part[w][e]; }
 				if (e < NB) { B[e] = v; } else { gvec[e - NB] = v; }
 			}
-			finish_cell<D, T>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_rhs, nrow, row1, mrow, nfac, pack_min);
+			finish_cell<D, T>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_dr, nrow, row1, mrow, nfac, pack_min);
 		}
 		__syncthreads();
 	}
@@ -381,8 +445,7 @@ __global__ __launch_bounds__(kThreads) void k_build_heavy(long ncell, const uint
 
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, const uint32_t* __restrict__ cell_id,
-                                                             const T* __restrict__ blk,
-                                                             const double* __restrict__ cell_rhs,
+                                                             const T* __restrict__ cell_dr,
                                                              T* __restrict__ atb, T* __restrict__ diag, int colour)
 {
 	constexpr int NC = 1 << D;
@@ -407,8 +470,8 @@ __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, 
 			idx += static_cast<int64_t>(li) * g.stride[d];
 		}
 		if (ok) {
-			atb[idx] += static_cast<T>(cell_rhs[static_cast<long>(c) * NC + q]);
-			diag[idx] += blk[c * (NC * (NC + 1) / 2) + packed_index(q, q, NC)];
+			atb[idx] += cell_dr[static_cast<long>(c) * 2 * NC + q];
+			diag[idx] += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
 		}
 	}
 }
@@ -423,10 +486,10 @@ __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, 
 // 16-byte store per array.  Same cells in the same (colour) order as the generic kernel: bit-identical sums.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, const uint32_t* __restrict__ map,
-                                                             const T* __restrict__ blk, const double* __restrict__ cell_rhs,
-                                                             T* __restrict__ atb, T* __restrict__ diag)
+                                                             const T* __restrict__ cell_dr, T* __restrict__ atb,
+                                                             T* __restrict__ diag)
 {
-	constexpr int NC = 8, NB = 36;
+	constexpr int NC = 8;
 	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
 	const int groups = (ext0 + 3) / 4;  // per row; the thread index runs over (group, row, plane)
 	int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
@@ -468,8 +531,8 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, 
 			const uint32_t c = bz ? (by ? c11 : c10) : (by ? c01 : c00);
 			if (c == 0xFFFFFFFFu) { continue; }
 			const int q = bx | (by << 1) | (bz << 2);
-			a[j] += static_cast<T>(cell_rhs[static_cast<long>(c) * NC + q]);
-			dg[j] += blk[static_cast<long>(c) * NB + packed_index(q, q, NC)];
+			a[j] += cell_dr[static_cast<long>(c) * 2 * NC + q];
+			dg[j] += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
 		}
 	}
 	const int64_t idx = li[0] * g.stride[0] + li[1] * g.stride[1] + li[2] * g.stride[2];
@@ -491,8 +554,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_map(long ncell, const uint32_
 
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, const uint32_t* __restrict__ map,
-                                                            const T* __restrict__ blk,
-                                                            const double* __restrict__ cell_rhs,
+                                                            const T* __restrict__ cell_dr,
                                                             T* __restrict__ atb, T* __restrict__ diag)
 {
 	constexpr int NC = 1 << D;
@@ -534,8 +596,8 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, c
 		const uint32_t c = cidx[colour];
 		if (c == 0xFFFFFFFFu) { continue; }
 		const int q = cq[colour];
-		a += static_cast<T>(cell_rhs[static_cast<long>(c) * NC + q]);
-		dg += blk[static_cast<long>(c) * (NC * (NC + 1) / 2) + packed_index(q, q, NC)];
+		a += cell_dr[static_cast<long>(c) * 2 * NC + q];
+		dg += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
 	}
 	atb[idx]  = a;
 	diag[idx] = dg;
@@ -712,15 +774,15 @@ void assemble_dim(fi_ctx* c)
 		c->cells.nfac.alloc(sizeof(uint32_t) * ncell);
 	}
 	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
-	DevBuf& cell_rhs = c->scratch[13];
-	cell_rhs.alloc(sizeof(double) * NC * ncell);
+	DevBuf& cell_dr = c->scratch[13];
+	cell_dr.alloc(sizeof(T) * 2 * NC * ncell);
 	// cells with very many rows (coarse levels) are listed by the first kernel and summed by workgroups in the second
 	DevBuf& heavy = c->scratch[11];
 	heavy.alloc(sizeof(uint32_t) * (static_cast<size_t>(total / kHeavyRows) + 2));
 	FI_HIP_TRY(hipMemsetAsync(heavy.p, 0, sizeof(uint32_t), st));
 	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
 	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,
-	                   c->cells.blk.as<T>(), cell_rhs.as<double>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
+	                   c->cells.blk.as<T>(), cell_dr.as<T>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
 	                   D == 3 ? c->cells.mrow.as<T>() : static_cast<T*>(nullptr),
 	                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr), heavy.as<uint32_t>(), pack_min);
 	{
@@ -728,7 +790,7 @@ void assemble_dim(fi_ctx* c)
 		const int  grid = static_cast<int>(max_heavy < 2048 ? max_heavy : 2048);
 		hipLaunchKernelGGL((k_build_heavy<D, T>), dim3(grid), dim3(kThreads), 0, st, ncell, starts.as<uint32_t>(),
 		                   counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs, c->cells.blk.as<T>(),
-		                   cell_rhs.as<double>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
+		                   cell_dr.as<T>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
 		                   D == 3 ? c->cells.mrow.as<T>() : static_cast<T*>(nullptr),
 		                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr), heavy.as<uint32_t>(), pack_min);
 	}
@@ -745,17 +807,15 @@ void assemble_dim(fi_ctx* c)
 			const int64_t groups = static_cast<int64_t>((g.own_hi[0] - g.own_lo[0] + 3) / 4) * (g.own_hi[1] - g.own_lo[1]) *
 			                       (g.own_hi[2] - g.own_lo[2]);
 			hipLaunchKernelGGL((k_gather_cells3<T>), dim3(blocks_for(groups)), dim3(kThreads), 0, st, g, ncell, map.as<uint32_t>(),
-			                   c->cells.blk.as<T>(), cell_rhs.as<double>(), c->atb.as<T>(), c->diag.as<T>());
+			                   cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>());
 		} else {
 			hipLaunchKernelGGL((k_gather_cells<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, st, g, ncell,
-			                   map.as<uint32_t>(), c->cells.blk.as<T>(), cell_rhs.as<double>(), c->atb.as<T>(),
-			                   c->diag.as<T>());
+			                   map.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>());
 		}
 	} else {
 		for (int colour = 0; colour < NC; ++colour) {
 			hipLaunchKernelGGL((k_scatter_cells<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, g, ncell,
-			                   c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), cell_rhs.as<double>(),
-			                   c->atb.as<T>(), c->diag.as<T>(), colour);
+			                   c->cells.cell_id.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>(), colour);
 		}
 	}
 	FI_HIP_TRY(hipGetLastError());

@@ -756,8 +756,8 @@ __global__ __launch_bounds__(kThreads) void k_prolong2(LevelPair L, const T* __r
 }
 
 // Cubic interpolation for the coarse-to-fine START (not the V-cycle: its P must stay the transpose of R).  Vertex-centred
-// axis: a fine point between two coarse points takes (-1, 9, 9, -1) / 16 of the four nearest (indices clamped at the
-// lattice's ends), a coincident one the coarse value.  Cell-centred axis: a fine point sits a quarter of a coarse cell
+// axis: a fine point between two coarse points takes (-1, 9, 9, -1) / 16 of the four nearest (next to the lattice's ends,
+// where they do not fit, the mean of its two neighbours), a coincident one the coarse value.  Cell-centred axis: a fine point sits a quarter of a coarse cell
 // from its coarse point j -- the cubic through j-1 .. j+2 at +1/4 (mirrored at -1/4); where the four taps do not fit
 // (first and last two fine points) the linear taps of k_prolong.  3-D lattices; slabs need two ghost planes of the
 // coarse solution.
@@ -766,6 +766,14 @@ __device__ inline void cubic_taps(int f, int nc, int cc, int* idx, T* w)
 {
 	const int j = f >> 1;
 	if (!cc) {
+		if ((f & 1) && (j < 1 || j + 2 > nc - 1)) {
+			// next to an end the four taps do not fit: the mean of the two neighbours, like k_prolong (with clamped indices the
+			// weights (-1, 9, 9, -1) / 16 put 7/16 where a linear function needs 1/2 -- rounds 2 and early 3)
+			prolong_taps<T>(f, nc, 0, &idx[0], &idx[1], &w[0], &w[1]);
+			idx[2] = idx[3] = idx[0];
+			w[2] = w[3] = T(0);
+			return;
+		}
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const int v = j - 1 + k;
@@ -791,36 +799,94 @@ __device__ inline void cubic_taps(int f, int nc, int cc, int* idx, T* w)
 		w[2] = w[3] = T(0);
 	}
 }
+// The weights of fine point f on the WINDOW of five coarse points u0 .. u0+4 that the pair of fine points (2j, 2j+1)
+// draws on between them (u0 = j-2 cell-centred, j-1 vertex-centred): the four taps of cubic_taps, dropped into their slots
+// (a clamped index that occurs twice adds up).  Static indices only: everything stays in registers.
+template <typename T>
+__device__ inline void cubic_window(int f, int nc, int cc, int u0, bool live, T* W)
+{
+	int idx[4];
+	T   w[4];
+	cubic_taps<T>(f, nc, cc, idx, w);
+#pragma unroll
+	for (int s = 0; s < 5; ++s) {
+		T acc = T(0);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { acc += (idx[k] - u0 == s) ? w[k] : T(0); }
+		W[s] = live ? acc : T(0);
+	}
+}
+// A thread owns a 2 x 2 x 2 block of fine points: the 5 x 5 coarse rows around it are interpolated along x ONCE each (five
+// loads, both x parities) and then spread over the four (y, z) parities -- 125 loads for eight fine points instead of the
+// 64 per point of one thread per pair of points (256^3 from 128^3: 177 -> ... us).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine)
 {
-	const int t  = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
-	const int fx = 2 * t;
-	if (fx >= L.nf[0]) { return; }
-	const int fy = static_cast<int>(blockIdx.y), fz = static_cast<int>(blockIdx.z) + L.f_z0;  // global plane
-	int ie[4], io[4], iy[4], iz[4];
-	T   we[4], wo[4], wy[4], wz[4];
-	cubic_taps<T>(fx, L.nc[0], L.cc[0], ie, we);
-	cubic_taps<T>(fx + 1 < L.nf[0] ? fx + 1 : fx, L.nc[0], L.cc[0], io, wo);
-	cubic_taps<T>(fy, L.nc[1], L.cc[1], iy, wy);
-	cubic_taps<T>(fz, L.nc[2], L.cc[2], iz, wz);
+	const int px = (L.nf[0] + 1) / 2, py = (L.nf[1] + 1) / 2;
+	const int jz0 = L.f_z0 >> 1, jz1 = (L.f_z0 + L.f_planes - 1) >> 1;
+	int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (t >= static_cast<int64_t>(px) * py * (jz1 - jz0 + 1)) { return; }
+	const int jx = static_cast<int>(t % px);
+	t /= px;
+	const int jy = static_cast<int>(t % py), jz = jz0 + static_cast<int>(t / py);
+	const int ux = jx - (L.cc[0] ? 2 : 1), uy = jy - (L.cc[1] ? 2 : 1), uz = jz - (L.cc[2] ? 2 : 1);
+	T Wx[2][5], Wy[2][5], Wz[2][5];
+	bool live[3][2];
+#pragma unroll
+	for (int p = 0; p < 2; ++p) {
+		live[0][p] = 2 * jx + p < L.nf[0];
+		live[1][p] = 2 * jy + p < L.nf[1];
+		live[2][p] = 2 * jz + p >= L.f_z0 && 2 * jz + p < L.f_z0 + L.f_planes;  // (slabs: the owned planes only)
+		cubic_window<T>(live[0][p] ? 2 * jx + p : 2 * jx, L.nc[0], L.cc[0], ux, live[0][p], Wx[p]);
+		cubic_window<T>(live[1][p] ? 2 * jy + p : 2 * jy, L.nc[1], L.cc[1], uy, live[1][p], Wy[p]);
+		cubic_window<T>(live[2][p] ? 2 * jz + p : 2 * jz + 1 - p, L.nc[2], L.cc[2], uz, live[2][p], Wz[p]);
+	}
+	int xi[5];
+#pragma unroll
+	for (int s = 0; s < 5; ++s) {
+		const int v = ux + s;
+		xi[s] = v < 0 ? 0 : (v > L.nc[0] - 1 ? L.nc[0] - 1 : v);
+	}
 	const int64_t csy = L.nc[0], csz = static_cast<int64_t>(L.nc[0]) * L.nc[1];
-	T even = T(0), odd = T(0);
+	T acc[2][2][2];
 #pragma unroll
-	for (int kz = 0; kz < 4; ++kz) {
-		if (wz[kz] == T(0)) { continue; }
+	for (int q = 0; q < 8; ++q) { acc[q >> 2][(q >> 1) & 1][q & 1] = T(0); }
+	// Every load is unconditional (25 dependent round trips otherwise: 103 us at 256^3): a plane without weight -- it may
+	// lie beyond the slab's ghost planes -- is replaced by coarse plane jz, which every live parity draws on.
+	const int safe_z = (jz > L.nc[2] - 1 ? L.nc[2] - 1 : jz) - L.c_base;
 #pragma unroll
-		for (int ky = 0; ky < 4; ++ky) {
-			const T wyz = wy[ky] * wz[kz];
-			if (wyz == T(0)) { continue; }
-			const T* row = coarse + csz * (iz[kz] - L.c_base) + csy * iy[ky];  // slabs: two ghost planes hold the neighbours' values
-			even += wyz * (we[0] * row[ie[0]] + we[1] * row[ie[1]] + we[2] * row[ie[2]] + we[3] * row[ie[3]]);
-			odd += wyz * (wo[0] * row[io[0]] + wo[1] * row[io[1]] + wo[2] * row[io[2]] + wo[3] * row[io[3]]);
+	for (int sz = 0; sz < 5; ++sz) {
+		const int vz = uz + sz;
+		const int cz = (Wz[0][sz] == T(0) && Wz[1][sz] == T(0)) ? safe_z
+		                                                        : (vz < 0 ? 0 : (vz > L.nc[2] - 1 ? L.nc[2] - 1 : vz)) - L.c_base;
+#pragma unroll
+		for (int sy = 0; sy < 5; ++sy) {
+			const int vy = uy + sy;
+			const T* row = coarse + csz * cz + csy * (vy < 0 ? 0 : (vy > L.nc[1] - 1 ? L.nc[1] - 1 : vy));
+			const T v0 = row[xi[0]], v1 = row[xi[1]], v2 = row[xi[2]], v3 = row[xi[3]], v4 = row[xi[4]];
+			const T e = Wx[0][0] * v0 + Wx[0][1] * v1 + Wx[0][2] * v2 + Wx[0][3] * v3 + Wx[0][4] * v4;
+			const T o = Wx[1][0] * v0 + Wx[1][1] * v1 + Wx[1][2] * v2 + Wx[1][3] * v3 + Wx[1][4] * v4;
+#pragma unroll
+			for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+				for (int pyb = 0; pyb < 2; ++pyb) {
+					const T w = Wy[pyb][sy] * Wz[pz][sz];
+					acc[pz][pyb][0] += w * e;
+					acc[pz][pyb][1] += w * o;
+				}
+			}
 		}
 	}
-	const int64_t i = (static_cast<int64_t>(fz - L.f_base) * L.nf[1] + fy) * L.nf[0] + fx;
-	fine[i] = even;
-	if (fx + 1 < L.nf[0]) { fine[i + 1] = odd; }
+#pragma unroll
+	for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+		for (int pyb = 0; pyb < 2; ++pyb) {
+			if (!live[2][pz] || !live[1][pyb]) { continue; }
+			const int64_t i = (static_cast<int64_t>(2 * jz + pz - L.f_base) * L.nf[1] + (2 * jy + pyb)) * L.nf[0] + 2 * jx;
+			fine[i] = acc[pz][pyb][0];
+			if (live[0][1]) { fine[i + 1] = acc[pz][pyb][1]; }
+		}
+	}
 }
 
 template <typename T>
@@ -1456,9 +1522,12 @@ void cascade_guess(RankSet& R)
 			const bool cubic = L.ndim == 3 && (lf[i]->nranks == 1 || lc[i]->reach >= 2) && !test_switch("FI_LINEAR_START") &&
 			                   sizeof(T) * static_cast<size_t>(lc[i]->g.nloc) <= (32u << 20);
 			if (cubic) {
-				const int pairs = (L.nf[0] + 1) / 2;
-				hipLaunchKernelGGL((k_prolong3_cubic<T>), dim3((pairs + kThreads - 1) / kThreads, L.nf[1], L.f_planes), dim3(kThreads), 0,
-				                   lf[i]->stream, L, lc[i]->x.as<T>(), lf[i]->x.as<T>());
+				const int64_t blocks8 = static_cast<int64_t>((L.nf[0] + 1) / 2) * ((L.nf[1] + 1) / 2) *
+				                        (((L.f_z0 + L.f_planes - 1) >> 1) - (L.f_z0 >> 1) + 1);
+				if (L.f_planes > 0) {
+					hipLaunchKernelGGL((k_prolong3_cubic<T>), dim3(static_cast<unsigned>((blocks8 + kThreads - 1) / kThreads)), dim3(kThreads),
+					                   0, lf[i]->stream, L, lc[i]->x.as<T>(), lf[i]->x.as<T>());
+				}
 			} else {
 				launch_prolong<T>(L, lc[i]->x.as<T>(), lf[i]->x.as<T>(), 0, lf[i]->stream);
 			}
@@ -3726,6 +3795,11 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 		cascade_guess<T>(R);
 	} else {
 		load_owned<T>(c, c->x, guess, memory);
+	}
+	if (test_switch("FI_START_ONLY")) {  // (tests: the start guess itself, no iteration on the finest level)
+		c->stats.iterations = 0;
+		store_owned<T>(c, c->x, out, memory);
+		return;
 	}
 	if (c->mg_mode == 1 && (c->coarse || (c->twin && c->twin->coarse))) {
 		cg_run_mg<T>(R, max_iterations, tol);

@@ -1208,8 +1208,10 @@ __global__ __launch_bounds__(kThreads) void k_cell_records(int64_t n_row, int64_
 	if (i < n_row) {  // keys of kind 0 sort first
 		const uint32_t pp = pos[slot];
 		pos_row[i] = pp;
-		// row (pp >> 8) & 0xFF of the cell: the data rows of a cell with <= 8 rows are its factor rows (row 0 == row1)
-		const V* src = reinterpret_cast<const V*>(mrow + c * 64 + ((pp >> 8) & 0xFFu) * 8);
+		// row (pp >> 8) & 0xFF of the cell: the data rows of a cell with <= 8 rows are its factor rows; row 0 is row1 (the
+		// only place a single-row cell keeps it)
+		const uint32_t ridx = (pp >> 8) & 0xFFu;
+		const V* src = reinterpret_cast<const V*>(ridx ? mrow + c * 64 + ridx * 8 : row1 + c * 8);
 		V*       dst = reinterpret_cast<V*>(coef_row + i * 8);
 #pragma unroll
 		for (int k = 0; k < 8 / VX; ++k) { dst[k] = src[k]; }

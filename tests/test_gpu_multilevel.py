@@ -277,3 +277,44 @@ def test_cubic_start_changes_the_path_not_the_solution(oracle, fi, monkeypatch):
         its.append(it)
     monkeypatch.delenv("FI_LINEAR_START", raising=False)
     assert its[0] <= its[1] + 2
+
+
+@pytest.mark.parametrize("sizes", [[24, 20, 28], [25, 21, 29], [26, 21, 24], [17, 16, 15]])
+@pytest.mark.parametrize("levels", [1, 2])
+def test_start_guess_reproduces_a_linear_field(fi, monkeypatch, sizes, levels):
+    """The interpolation of the coarse-to-fine start on its own (FI_START_ONLY: no iteration on the finest level).  Data
+    sampled from a linear function under model_2 alone: every level's solution is that function at the level's own
+    points, and both interpolations -- trilinear and cubic, vertex- and cell-centred axes, the extrapolating end points --
+    reproduce a linear function exactly.  A wrong index or weight anywhere shows as an O(1) error."""
+    if min(sizes) // (2 ** levels) < 3:
+        levels = 1
+    rng = np.random.default_rng(5)
+    n = 4000
+    # (points two cells inside: a coarser cell-centred lattice ends half a fine cell inside the fine one, and a row whose
+    # cell sticks out of ITS lattice loses corners -- field_interpolation.cpp:19-44 -- and with them the linear function)
+    pos = np.stack([rng.uniform(2, s - 3, n) for s in sizes], axis=1).astype(np.float32)
+    coef = np.array([0.3, -0.2, 0.15])
+    val = (pos.astype(np.float64) @ coef + 1.5).astype(np.float32)
+    w = fi.Weights(model_2=0.5, data_gradient=0.0)
+    grid = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in sizes[::-1]], indexing="ij")   # z, y, x
+    exact = (coef[0] * grid[2] + coef[1] * grid[1] + coef[2] * grid[0] + 1.5).ravel()
+    monkeypatch.setenv("FI_START_ONLY", "1")
+    try:
+        for linear in (False, True):
+            if linear:
+                monkeypatch.setenv("FI_LINEAR_START", "1")
+            else:
+                monkeypatch.delenv("FI_LINEAR_START", raising=False)
+            f = fi.LatticeField(sizes, dtype="f64")
+            f.add_field_constraints(w)
+            f.set_levels(levels, 1e-11)
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+            f.assemble()
+            assert f.stats()["num_levels"] >= 2
+            x, it, rel = f.solve_cg(None, 0, 1e-10)
+            assert it == 0
+            err = np.abs(f.solution_f64() - exact).max() / np.abs(exact).max()
+            assert err <= 2e-5, (sizes, levels, linear, err)     # (fp32 positions and values: 1e-7 relative each)
+    finally:
+        monkeypatch.delenv("FI_START_ONLY", raising=False)
+        monkeypatch.delenv("FI_LINEAR_START", raising=False)
