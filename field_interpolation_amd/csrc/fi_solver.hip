@@ -1478,6 +1478,8 @@ void cascade_guess(RankSet& R)
 			for (fi_ctx* l : lc) {  // the levels solve the way the finest level does
 				l->poly_terms = root->poly_terms;
 				l->poly_ratio = root->poly_ratio;
+				if (const char* e = tuning_switch("FI_COARSE_TERMS")) { l->poly_terms = atoi(e); }
+				if (const char* e = tuning_switch("FI_COARSE_RATIO")) { l->poly_ratio = atof(e); }
 			}
 			// with the V-cycle preconditioner on, a level that has coarser levels below it is solved with it too (a full
 			// multigrid start): Jacobi-PCG needs thousands of iterations on the coarse levels of an SDF (config 3: 4 338,
