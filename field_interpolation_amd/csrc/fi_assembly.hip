@@ -484,35 +484,12 @@ __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, 
 // The same for 3-D lattices, four consecutive x points per thread: the 8 incident cells of the four points lie in 5
 // columns x 2 rows x 2 planes of the map (20 look-ups instead of 32, issued as 4 runs of 5), the sums go out as one
 // 16-byte store per array.  Same cells in the same (colour) order as the generic kernel: bit-identical sums.
-// The 32 (point, colour) terms of a thread with the parities of its first point as template arguments: which cell of
-// the table and which corner a term takes is then fixed at compile time (with the parities in registers every term paid
-// seven selects over the table: ~1 000 vector instructions per thread, and the kernel is bound by their issue -- neither
-// unconditional loads nor cache-friendlier workgroup shapes moved its 200 us at 256^3).
-template <typename T, int P0, int PY, int PZ>
-__device__ inline void gather_terms(const uint32_t (&cid)[2][2][5], const T* __restrict__ cell_dr, T* a, T* dg)
-{
-	constexpr int NC = 8;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		a[j]  = T(0);
-		dg[j] = T(0);
-#pragma unroll
-		for (int colour = 0; colour < NC; ++colour) {  // the generic kernel's order: by the parity of the cell's origin
-			const int bx = ((P0 + j) ^ colour) & 1, by = (PY ^ (colour >> 1)) & 1, bz = (PZ ^ (colour >> 2)) & 1;
-			const uint32_t c = cid[bz][by][bx ? j : j + 1];
-			if (c == 0xFFFFFFFFu) { continue; }
-			const int q = bx | (by << 1) | (bz << 2);
-			a[j] += cell_dr[static_cast<long>(c) * 2 * NC + q];
-			dg[j] += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
-		}
-	}
-}
-
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, const uint32_t* __restrict__ map,
                                                              const T* __restrict__ cell_dr, T* __restrict__ atb,
                                                              T* __restrict__ diag)
 {
+	constexpr int NC = 8;
 	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
 	const int groups = (ext0 + 3) / 4;  // per row; the thread index runs over (group, row, plane)
 	int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
@@ -541,16 +518,22 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, 
 		}
 	}
 	T a[4], dg[4];
-	// (a row of the lattice per 64 groups: the parities are wave-uniform wherever a row holds a multiple of 256 points)
-	switch ((lp[0] & 1) | ((lp[1] & 1) << 1) | ((lp[2] & 1) << 2)) {
-	case 0: gather_terms<T, 0, 0, 0>(cid, cell_dr, a, dg); break;
-	case 1: gather_terms<T, 1, 0, 0>(cid, cell_dr, a, dg); break;
-	case 2: gather_terms<T, 0, 1, 0>(cid, cell_dr, a, dg); break;
-	case 3: gather_terms<T, 1, 1, 0>(cid, cell_dr, a, dg); break;
-	case 4: gather_terms<T, 0, 0, 1>(cid, cell_dr, a, dg); break;
-	case 5: gather_terms<T, 1, 0, 1>(cid, cell_dr, a, dg); break;
-	case 6: gather_terms<T, 0, 1, 1>(cid, cell_dr, a, dg); break;
-	default: gather_terms<T, 1, 1, 1>(cid, cell_dr, a, dg); break;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		a[j]  = T(0);
+		dg[j] = T(0);
+#pragma unroll
+		for (int colour = 0; colour < NC; ++colour) {  // the generic kernel's order: by the parity of the cell's origin
+			const int bx = ((lp[0] + j) ^ colour) & 1, by = (lp[1] ^ (colour >> 1)) & 1, bz = (lp[2] ^ (colour >> 2)) & 1;
+			// selects over static indices (a runtime index would move the table to scratch memory)
+			const uint32_t c00 = bx ? cid[0][0][j] : cid[0][0][j + 1], c01 = bx ? cid[0][1][j] : cid[0][1][j + 1];
+			const uint32_t c10 = bx ? cid[1][0][j] : cid[1][0][j + 1], c11 = bx ? cid[1][1][j] : cid[1][1][j + 1];
+			const uint32_t c = bz ? (by ? c11 : c10) : (by ? c01 : c00);
+			if (c == 0xFFFFFFFFu) { continue; }
+			const int q = bx | (by << 1) | (bz << 2);
+			a[j] += cell_dr[static_cast<long>(c) * 2 * NC + q];
+			dg[j] += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
+		}
 	}
 	const int64_t idx = li[0] * g.stride[0] + li[1] * g.stride[1] + li[2] * g.stride[2];
 #pragma unroll
