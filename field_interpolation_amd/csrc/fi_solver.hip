@@ -693,39 +693,88 @@ __global__ __launch_bounds__(kThreads) void k_prolong(LevelPair L, const T* __re
 
 // The same for 3-D lattices with everything resolved at compile time (the generic kernel indexes its coordinate
 // arrays by the runtime axis: they live in scratch memory -- 1.15 ms per call at 512^3 against 0.3 ms here).  A thread
-// owns the fine points 2t and 2t+1 of a row.
+// owns a 2 x 2 x 2 block of fine points (2j, 2j+1 along every axis): between them they draw on the coarse points
+// j-1 .. j+1, a window of 3 x 3 rows that is interpolated along x once (three loads, both x parities) and then spread over
+// the four (y, z) parities -- and every thread of a workgroup has work (one thread per PAIR of points and a row per
+// workgroup left half of the threads idle at 256^3: 78 us for 142 MB).
+template <typename T>
+__device__ inline void linear_window(int f, int nc, int cc, int u0, bool live, T* W)
+{
+	int i0, i1;
+	T   w0, w1;
+	prolong_taps<T>(f, nc, cc, &i0, &i1, &w0, &w1);
+#pragma unroll
+	for (int s = 0; s < 3; ++s) { W[s] = live ? ((i0 - u0 == s ? w0 : T(0)) + (i1 - u0 == s ? w1 : T(0))) : T(0); }
+}
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine,
                                                         int mode)
 {
-	const int t  = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
-	const int fx = 2 * t;
-	if (fx >= L.nf[0]) { return; }
-	const int fy = static_cast<int>(blockIdx.y);
-	const int fz = static_cast<int>(blockIdx.z) + L.f_z0;  // global plane
-	int xe0, xe1, xo0, xo1, cy[2], cz[2];
-	T   we0, we1, wo0, wo1, wy[2], wz[2];
-	prolong_taps<T>(fx, L.nc[0], L.cc[0], &xe0, &xe1, &we0, &we1);
-	prolong_taps<T>(fx + 1 < L.nf[0] ? fx + 1 : fx, L.nc[0], L.cc[0], &xo0, &xo1, &wo0, &wo1);
-	prolong_taps<T>(fy, L.nc[1], L.cc[1], &cy[0], &cy[1], &wy[0], &wy[1]);
-	prolong_taps<T>(fz, L.nc[2], L.cc[2], &cz[0], &cz[1], &wz[0], &wz[1]);
+	const int px = (L.nf[0] + 1) / 2, py = (L.nf[1] + 1) / 2;
+	const int jz0 = L.f_z0 >> 1, jz1 = (L.f_z0 + L.f_planes - 1) >> 1;
+	int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (t >= static_cast<int64_t>(px) * py * (jz1 - jz0 + 1)) { return; }
+	const int jx = static_cast<int>(t % px);
+	t /= px;
+	const int jy = static_cast<int>(t % py), jz = jz0 + static_cast<int>(t / py);
+	const int ux = jx - 1, uy = jy - 1, uz = jz - 1;
+	T Wx[2][3], Wy[2][3], Wz[2][3];
+	bool live[3][2];
+#pragma unroll
+	for (int p = 0; p < 2; ++p) {
+		live[0][p] = 2 * jx + p < L.nf[0];
+		live[1][p] = 2 * jy + p < L.nf[1];
+		live[2][p] = 2 * jz + p >= L.f_z0 && 2 * jz + p < L.f_z0 + L.f_planes;  // (slabs: the owned planes only)
+		linear_window<T>(live[0][p] ? 2 * jx + p : 2 * jx, L.nc[0], L.cc[0], ux, live[0][p], Wx[p]);
+		linear_window<T>(live[1][p] ? 2 * jy + p : 2 * jy, L.nc[1], L.cc[1], uy, live[1][p], Wy[p]);
+		linear_window<T>(live[2][p] ? 2 * jz + p : 2 * jz + 1 - p, L.nc[2], L.cc[2], uz, live[2][p], Wz[p]);
+	}
+	int xi[3];
+#pragma unroll
+	for (int s = 0; s < 3; ++s) {
+		const int v = ux + s;
+		xi[s] = v < 0 ? 0 : (v > L.nc[0] - 1 ? L.nc[0] - 1 : v);
+	}
 	const int64_t csy = L.nc[0], csz = static_cast<int64_t>(L.nc[0]) * L.nc[1];
-	T even = T(0), odd = T(0);
+	T acc[2][2][2];
 #pragma unroll
-	for (int uz = 0; uz < 2; ++uz) {
-		const int64_t oz = csz * (cz[uz] - L.c_base);
+	for (int q = 0; q < 8; ++q) { acc[q >> 2][(q >> 1) & 1][q & 1] = T(0); }
+	// every load unconditional; a plane without weight (it may lie beyond the slab's ghost plane) is replaced by coarse
+	// plane jz, which every live parity draws on
+	const int safe_z = (jz > L.nc[2] - 1 ? L.nc[2] - 1 : jz) - L.c_base;
 #pragma unroll
-		for (int uy = 0; uy < 2; ++uy) {
-			const T wyz = wy[uy] * wz[uz];
-			if (wyz == T(0)) { continue; }
-			const T* row = coarse + oz + csy * cy[uy];
-			even += wyz * (we0 * row[xe0] + we1 * row[xe1]);
-			odd += wyz * (wo0 * row[xo0] + wo1 * row[xo1]);
+	for (int sz = 0; sz < 3; ++sz) {
+		const int vz = uz + sz;
+		const int cz = (Wz[0][sz] == T(0) && Wz[1][sz] == T(0)) ? safe_z
+		                                                        : (vz < 0 ? 0 : (vz > L.nc[2] - 1 ? L.nc[2] - 1 : vz)) - L.c_base;
+#pragma unroll
+		for (int sy = 0; sy < 3; ++sy) {
+			const int vy = uy + sy;
+			const T* row = coarse + csz * cz + csy * (vy < 0 ? 0 : (vy > L.nc[1] - 1 ? L.nc[1] - 1 : vy));
+			const T v0 = row[xi[0]], v1 = row[xi[1]], v2 = row[xi[2]];
+			const T e = Wx[0][0] * v0 + Wx[0][1] * v1 + Wx[0][2] * v2;
+			const T o = Wx[1][0] * v0 + Wx[1][1] * v1 + Wx[1][2] * v2;
+#pragma unroll
+			for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+				for (int pyb = 0; pyb < 2; ++pyb) {
+					const T w = Wy[pyb][sy] * Wz[pz][sz];
+					acc[pz][pyb][0] += w * e;
+					acc[pz][pyb][1] += w * o;
+				}
+			}
 		}
 	}
-	const int64_t i = (static_cast<int64_t>(fz - L.f_base) * L.nf[1] + fy) * L.nf[0] + fx;
-	fine[i] = mode ? fine[i] + even : even;
-	if (fx + 1 < L.nf[0]) { fine[i + 1] = mode ? fine[i + 1] + odd : odd; }
+#pragma unroll
+	for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+		for (int pyb = 0; pyb < 2; ++pyb) {
+			if (!live[2][pz] || !live[1][pyb]) { continue; }
+			const int64_t i = (static_cast<int64_t>(2 * jz + pz - L.f_base) * L.nf[1] + (2 * jy + pyb)) * L.nf[0] + 2 * jx;
+			fine[i] = mode ? fine[i] + acc[pz][pyb][0] : acc[pz][pyb][0];
+			if (live[0][1]) { fine[i + 1] = mode ? fine[i + 1] + acc[pz][pyb][1] : acc[pz][pyb][1]; }
+		}
+	}
 }
 // 2-D form (the generic kernel indexes its coordinate arrays by the runtime axis -- scratch memory: 127 us per call at
 // 4096^2 against the 25 us two lattice passes take).  A thread owns the fine points 2t and 2t+1 of a row; y is the
@@ -904,9 +953,12 @@ template <typename T>
 void launch_prolong(const LevelPair& L, const T* coarse, T* fine, int mode, hipStream_t st)
 {
 	if (L.ndim == 3) {
-		const int pairs = (L.nf[0] + 1) / 2;
-		hipLaunchKernelGGL((k_prolong3<T>), dim3((pairs + kThreads - 1) / kThreads, L.nf[1], L.f_planes), dim3(kThreads), 0, st, L,
-		                   coarse, fine, mode);
+		const int64_t blocks8 = static_cast<int64_t>((L.nf[0] + 1) / 2) * ((L.nf[1] + 1) / 2) *
+		                        (((L.f_z0 + L.f_planes - 1) >> 1) - (L.f_z0 >> 1) + 1);
+		if (L.f_planes > 0) {
+			hipLaunchKernelGGL((k_prolong3<T>), dim3(static_cast<unsigned>((blocks8 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
+			                   coarse, fine, mode);
+		}
 	} else if (L.ndim == 2) {
 		const int pairs = (L.nf[0] + 1) / 2;
 		hipLaunchKernelGGL((k_prolong2<T>), dim3((pairs + kThreads - 1) / kThreads, L.f_planes), dim3(kThreads), 0, st, L, coarse, fine,
@@ -1680,11 +1732,13 @@ __global__ __launch_bounds__(kThreads) void k_restrict2(LevelPair L, const T* __
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict3_xy(LevelPair L, int planes, const T* __restrict__ fine, T* __restrict__ tmp)
 {
-	const int cx = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
-	if (cx >= L.nc[0]) { return; }
-	const int cy = static_cast<int>(blockIdx.y);
-	const int fz = static_cast<int>(blockIdx.z);  // local plane
-	if (fz >= planes) { return; }
+	// one thread per (cx, cy, fine plane), the index flat (a row of 128 coarse points per 256-thread workgroup left half of
+	// the threads idle); all 25 loads unconditional -- an index without weight is clamped into the row by restrict_taps
+	int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (t >= static_cast<int64_t>(L.nc[0]) * L.nc[1] * planes) { return; }
+	const int cx = static_cast<int>(t % L.nc[0]);
+	t /= L.nc[0];
+	const int cy = static_cast<int>(t % L.nc[1]), fz = static_cast<int>(t / L.nc[1]);  // fz: local plane
 	int fx[kRTaps], fy[kRTaps];
 	T   wx[kRTaps], wy[kRTaps];
 	restrict_taps<T>(cx, L.nf[0], L.nc[0], L.cc[0], 0, fx, wx);
@@ -1693,13 +1747,10 @@ __global__ __launch_bounds__(kThreads) void k_restrict3_xy(LevelPair L, int plan
 	T acc = T(0);
 #pragma unroll
 	for (int k1 = 0; k1 < kRTaps; ++k1) {
-		if (wy[k1] == T(0)) { continue; }
 		const T* row = plane + static_cast<int64_t>(fy[k1]) * L.nf[0];
 		T r = T(0);
 #pragma unroll
-		for (int k0 = 0; k0 < kRTaps; ++k0) {
-			if (wx[k0] != T(0)) { r += wx[k0] * row[fx[k0]]; }
-		}
+		for (int k0 = 0; k0 < kRTaps; ++k0) { r += wx[k0] * row[fx[k0]]; }
 		acc += wy[k1] * r;
 	}
 	tmp[(static_cast<int64_t>(fz) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
@@ -1707,19 +1758,18 @@ __global__ __launch_bounds__(kThreads) void k_restrict3_xy(LevelPair L, int plan
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict3_z(LevelPair L, const T* __restrict__ tmp, T* __restrict__ coarse)
 {
-	const int cx = static_cast<int>(blockIdx.x * kThreads + threadIdx.x);
-	if (cx >= L.nc[0]) { return; }
-	const int cy = static_cast<int>(blockIdx.y);
-	const int cz = static_cast<int>(blockIdx.z) + L.c_z0;  // global plane
+	const int64_t cplane = static_cast<int64_t>(L.nc[0]) * L.nc[1];
+	const int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (t >= cplane * L.c_planes) { return; }
+	const int64_t o  = t % cplane;
+	const int     cz = static_cast<int>(t / cplane) + L.c_z0;  // global plane
 	int fz[kRTaps];
 	T   wz[kRTaps];
 	restrict_taps<T>(cz, L.nf[2], L.nc[2], L.cc[2], L.f_base, fz, wz);
-	const int64_t cplane = static_cast<int64_t>(L.nc[0]) * L.nc[1];
-	const int64_t o = static_cast<int64_t>(cy) * L.nc[0] + cx;
 	T acc = T(0);
 #pragma unroll
 	for (int k = 0; k < kRTaps; ++k) {
-		if (wz[k] != T(0)) { acc += wz[k] * tmp[fz[k] * cplane + o]; }
+		if (wz[k] != T(0)) { acc += wz[k] * tmp[fz[k] * cplane + o]; }  // (a plane without weight may lie outside the slab)
 	}
 	coarse[(static_cast<int64_t>(cz - L.c_base)) * cplane + o] = acc;
 }
@@ -1730,9 +1780,13 @@ template <typename T>
 void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t st, T* tmp = nullptr, int f_local_planes = 0)
 {
 	if (L.ndim == 3 && tmp && f_local_planes > 0 && !test_switch("FI_ONE_PASS_RESTRICT")) {
-		hipLaunchKernelGGL((k_restrict3_xy<T>), dim3((L.nc[0] + kThreads - 1) / kThreads, L.nc[1], f_local_planes), dim3(kThreads), 0, st,
-		                   L, f_local_planes, fine, tmp);
-		hipLaunchKernelGGL((k_restrict3_z<T>), owned_grid(L.nc, L.ndim, L.c_planes), dim3(kThreads), 0, st, L, tmp, coarse);
+		const int64_t n_xy = static_cast<int64_t>(L.nc[0]) * L.nc[1] * f_local_planes, n_z = static_cast<int64_t>(L.nc[0]) * L.nc[1] * L.c_planes;
+		hipLaunchKernelGGL((k_restrict3_xy<T>), dim3(static_cast<unsigned>((n_xy + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
+		                   f_local_planes, fine, tmp);
+		if (n_z > 0) {
+			hipLaunchKernelGGL((k_restrict3_z<T>), dim3(static_cast<unsigned>((n_z + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L, tmp,
+			                   coarse);
+		}
 		return;
 	}
 	if (L.ndim == 3) {
