@@ -368,11 +368,6 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
                        const unsigned short* scaling = nullptr,   // scaling: bfloat16 array (default: the context's dinv16)
                        int extend = 0);  // slabs, deep exchange: the step also covers `extend` ghost planes on either side
 int  stencil_cheb_partials_max(const fi_ctx* c);  // room for the partials of a step extended over the whole ghost zone
-// fi_cheb_pair.hip: the polynomial's second and third step in one launch (fp32 3-D contexts on one GPU)
-bool cheb_pair_available(const fi_ctx* c);
-int  cheb_pair_partials(const fi_ctx* c);
-void cheb_pair_step(fi_ctx* c, const void* z1, const void* r, void* z3, double c1A, double c2A, double zprev_scale, double c1B,
-                    double c2B, double* partial, const unsigned short* scaling = nullptr);
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 // z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the
 // marching kernel(s) over the lattice; z with valid ghost planes.  Dinv is the context's bfloat16 copy (dinv16).

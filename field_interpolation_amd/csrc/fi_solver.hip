@@ -1043,7 +1043,6 @@ void ensure_vectors(fi_ctx* c)
 	int nb = apply_num_partials(c);
 	if (nb < 4096) { nb = 4096; }  // also covers the plain kernels of the tile operator (fi_tile_pass)
 	if (stencil_cheb_available(c) && nb < stencil_cheb_partials_max(c)) { nb = stencil_cheb_partials_max(c); }
-	if (cheb_pair_available(c) && nb < cheb_pair_partials(c)) { nb = cheb_pair_partials(c); }
 	c->max_blocks = nb;
 	c->partial.alloc(sizeof(double) * 4 * nb);
 	c->vectors_ready = true;
@@ -3198,8 +3197,6 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	// polynomial; step k then also computes its 2 (d - 1 - k) nearest ghost planes -- the values the neighbour computes
 	// for its own planes, bit for bit -- so that no step waits for an exchange: 2 exchanges per outer iteration (p for the
 	// apply, r for the polynomial) instead of d.  FI_NO_DEEP_HALO: one exchange per step (tests: identical results).
-	// steps two and three of a 4-term polynomial as ONE launch (fi_cheb_pair.hip: z_2 never reaches memory)
-	const bool pair = single && terms == 4 && z0_on_load && sizeof(T) == 4 && cheb_pair_available(c0);
 	const int  deep_width = 2 * (terms - 1);
 	const bool deep = z0_on_load && c0->nranks > 1 && c0->halo >= deep_width && c0->min_slab >= deep_width &&
 	                  !test_switch("FI_NO_DEEP_HALO");
@@ -3212,7 +3209,6 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	auto region = [](fi_ctx* c, int k) { return c->partial.as<double>() + static_cast<size_t>(k) * c->max_blocks; };
 	auto slot2 = [](fi_ctx* c) { return (c->scal.as<CgScalars>() + 2)->sums; };
 	int n_exchanges = 0, n_reductions = 0;  // (statistics: what an outer iteration costs over slabs)
-	int n_paired = 0;
 	auto cross = [&](int nvec) {  // sums[0..nvec) of slot 2 over the slabs
 		if (R.size() > 1 || c0->nranks > 1) { ++n_reductions; }
 		if (R.size() > 1) {
@@ -3263,11 +3259,9 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		// the polynomial: z_{k+1} from z_k (ZA / ZB alternate; the result ends in `zfin`)
 		Vec zin = ZA, zout = ZB;
 		for (int k = 1; k < terms; ++k) {
-			// every 4th pass times one step, the steps in turn (first: 2.5 lattice passes, second: 3.5, the others 4.5; the
-			// paired launch of steps two and three: 3.5): the roofline figure is bytes over time of ALL sampled launches
-			const bool pair_now = pair && k == 2;
-			const int  launches = pair ? 2 : terms - 1;
-			const bool sample = phase == 1 && k == 1 + psamples % launches && c0->level == 0 && psamples < kPolySamples &&
+			// every 4th pass times one step, the steps in turn (first: 2.5 lattice passes, second: 3.5, the others 4.5): the
+			// roofline figure is bytes over time of ALL sampled steps
+			const bool sample = phase == 1 && k == 1 + psamples % (terms - 1) && c0->level == 0 && psamples < kPolySamples &&
 			                    (tag & 3) == 3 && !tuning_switch("FI_NO_SAMPLES");
 			const bool overlap = !deep && R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
 			const bool pro = z0_on_load && k == 1;
@@ -3287,20 +3281,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 				ptags.push_back(tag);
 				// z, z_prev, r in, z_new out + the bfloat16 scaling; the first step has no z_prev and (formed on load) reads r as
 				// its z; the second step's z_prev is recomputed from r
-				const double vecs = k == 1 ? (pro ? 2.0 : 3.0) : (k == 2 ? 3.0 : 4.0);  // (the pair: z_1, r in, z_3 out)
+				const double vecs = k == 1 ? (pro ? 2.0 : 3.0) : (k == 2 ? 3.0 : 4.0);
 				pbytes.push_back((static_cast<double>(sizeof(T)) * vecs + 2.0) * static_cast<double>(c0->g.nown));
-			}
-			if (pair_now) {
-				// steps two and three in one launch (fi_cheb_pair.hip): z_2 is never stored; z_3 lands in the vector step two
-				// would have written -- step two's z_prev is recomputed from r, so nothing else lives there
-				cheb_pair_step(c0, (c0->*zin).p, c0->r.p, (c0->*zout).p, c1s[1], c2s[1], 1.0 / theta, c1s[2], c2s[2], region(c0, 2));
-				++n_paired;
-				if (sample) {
-					FI_HIP_TRY(hipEventRecord(pev[2 * psamples + 1], st));
-					++psamples;
-				}
-				std::swap(zin, zout);
-				break;
 			}
 			for (fi_ctx* c : R) {
 				const void* zp = k == 1 ? nullptr : (c->*zout).p;
@@ -3334,7 +3316,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		if (!folded) {
 			for (fi_ctx* c : R) {
 				hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>() + 2, region(c, 1), nbf_of(c),
-				                   region(c, 2), terms > 1 ? (pair ? cheb_pair_partials(c) : stencil_cheb_partials(c)) : nbf_of(c),
+				                   region(c, 2), terms > 1 ? stencil_cheb_partials(c) : nbf_of(c),
 				                   phase == 0 ? region(c, 3) : static_cast<const double*>(nullptr), nbf_of(c));
 			}
 			cross(phase == 0 ? 3 : 2);
@@ -3343,7 +3325,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			const int64_t o = c->g.own_first;
 			const int     nbf = nbf_of(c);
 			CgScalars*    sc = c->scal.as<CgScalars>();
-			const int     nrz = terms > 1 ? (pair ? cheb_pair_partials(c) : stencil_cheb_partials(c)) : nbf;
+			const int     nrz = terms > 1 ? stencil_cheb_partials(c) : nbf;
 			auto go = [&](auto kernel) {
 				if (folded) {
 					hipLaunchKernelGGL(kernel, dim3(nbf), dim3(kThreads), 0, c->stream, c->g.nown, sc + 1, sc, tag, phase, region(c, 1), nbf,
@@ -3485,7 +3467,6 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		// (+ one exchange of p per full apply: every outer iteration, the start and each verification)
 		c->stats.halo_exchanges = c0->nranks > 1 ? n_exchanges + issued + 1 + h.restarts : 0;
 		c->stats.reductions     = n_reductions;
-		c->stats.paired_steps   = n_paired;
 		c->last_outer_iterations = h.iter;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = iter_base + h.iter;
@@ -3859,7 +3840,6 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 {
 	ensure_vectors(c);
 	c->stats.coarse_iterations = 0;
-	c->stats.paired_steps      = 0;
 	RankSet R{c};
 	struct Report {
 		fi_ctx* c; int* it; float* rel;

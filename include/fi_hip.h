@@ -101,7 +101,6 @@ typedef struct fi_stats {
 	int    operator_applies;   /* full operator applications + preconditioner steps of the last solve (finest level) */
 	int    halo_exchanges;     /* slabs: halo exchanges of the finest level during the last solve (polynomial PCG) */
 	int    reductions;         /* slabs: dot-product reductions across the ranks during the last solve (polynomial PCG) */
-	int    paired_steps;       /* launches of the last solve that ran two steps of the polynomial at once (fi_cheb_pair.hip) */
 } fi_stats;
 
 const char* fi_last_error(void);

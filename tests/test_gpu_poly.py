@@ -345,45 +345,3 @@ def test_single_reduction_recurrence_over_slabs(fi, monkeypatch, dtype, tol, siz
     one.assemble()
     x1, it1, _ = one.solve_cg(None, 0, tol)
     assert abs(its - it1) <= max(3, it1 // 12), (its, it1)
-
-
-@pytest.mark.parametrize("sizes,wkw", [
-    ([70, 45, 52], dict(model_2=0.5)),
-    ([37, 29, 41], dict(model_2=0.7, model_0=0.05)),
-    ([64, 16, 33], dict(model_1=0.4)),
-    ([66, 35, 30], dict(model_1=0.3, model_2=0.6)),
-    ([130, 20, 24], dict(model_2=1.0)),
-])
-def test_paired_steps_equal_two_launches(fi, monkeypatch, sizes, wkw):
-    """Steps two and three of the 4-term polynomial as ONE launch (fi_cheb_pair.hip; FI_PAIR_ALWAYS lifts the size
-    threshold) against the two launches of the marching kernel (FI_NO_PAIR): the same preconditioner up to fp32 rounding --
-    same iteration count (+-1), same solution, on lattices whose extents are no multiples of the 64 x 16 tile, with every
-    combination of model rows the kernel is instantiated for."""
-    rng = np.random.default_rng(17)
-    n = 3000
-    pos = np.stack([rng.uniform(-0.5, s - 0.5, n) for s in sizes], axis=1).astype(np.float32)
-    val = rng.normal(size=n).astype(np.float32)
-    w = fi.Weights(data_gradient=0.0, **{"model_2": 0.0, **wkw})
-    got = {}
-    for mode in ("pair", "two"):
-        if mode == "pair":
-            monkeypatch.setenv("FI_PAIR_ALWAYS", "1")
-            monkeypatch.delenv("FI_NO_PAIR", raising=False)
-        else:
-            monkeypatch.setenv("FI_NO_PAIR", "1")
-            monkeypatch.delenv("FI_PAIR_ALWAYS", raising=False)
-        f = fi.LatticeField(sizes, dtype="f32")
-        f.add_field_constraints(w)
-        f.set_polynomial(4, 30.0)
-        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
-        f.assemble()
-        x, it, rel = f.solve_cg(None, 0, 1e-6)
-        st = f.stats()
-        assert rel <= 1e-6 and f.true_residual() <= 2e-6
-        assert (st["paired_steps"] > 0) == (mode == "pair"), (mode, st["paired_steps"])
-        got[mode] = (x.astype(np.float64), it)
-    monkeypatch.delenv("FI_PAIR_ALWAYS", raising=False)
-    monkeypatch.delenv("FI_NO_PAIR", raising=False)
-    assert abs(got["pair"][1] - got["two"][1]) <= 1, (got["pair"][1], got["two"][1])
-    scale = np.abs(got["two"][0]).max()
-    assert np.abs(got["pair"][0] - got["two"][0]).max() <= 2e-4 * scale
