@@ -27,7 +27,8 @@ Prints ONE JSON line on rank 0 (see the task contract), including
                    region; N = 1 only)
   "accurate"       config 4, N = 1: the same step with the solver that meets the north-star's FIELD tolerance (fp64 CG +
                    fp32 V-cycle to --accurate-tol): value, ms_per_step, iterations, solution_rel_err <= 1e-5
-  "cold_ms_per_step" one step on a fresh context (allocation, power method, first assemble, first solve)
+  "cold_ms_per_step" one step on a fresh context (allocation, power method, first assemble, first solve);
+  "cold_pooled_ms_per_step" the same with the device blocks of a destroyed context (fi_memory_pool)
   "cpu_baseline"   the C++ oracle (restatement of the reference's triplets -> AtA -> BiCGSTAB path, fp32, one thread)
                    timed on a bounded sample of the same workload (rank 0, N = 1, config 4 only)
   "cpu_best_effort" the same rows solved by a matrix-free Jacobi-PCG with OpenMP on all host cores
@@ -398,17 +399,26 @@ def main():
         # (fi_set_model: 16 marching launches + 2 host reads per level), the first assemble and a solve whose first look at
         # the stop flag is not scheduled by a previous solve of the same problem.  The timed steps above amortise all
         # of that (a per-frame caller does too: bipolar_2d.cpp:730); this is what a one-shot caller pays.
-        torch.cuda.synchronize()
-        t0c = time.perf_counter()
-        cold = fi.LatticeField(wl["sizes"], dtype=wl["dtype"])
-        configure(cold, wl)
-        cold_out = torch.empty_like(d_out)
-        step(cold, out=cold_out)
-        torch.cuda.synchronize()
-        line["cold_ms_per_step"] = 1e3 * (time.perf_counter() - t0c)
-        line["cold_note"] = ("fresh context: allocation, the polynomial's power method, first assemble and first solve; "
+        def cold_step():
+            torch.cuda.synchronize()
+            t0c = time.perf_counter()
+            cold = fi.LatticeField(wl["sizes"], dtype=wl["dtype"])
+            configure(cold, wl)
+            cold_out = torch.empty_like(d_out)
+            step(cold, out=cold_out)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0c)
+            del cold, cold_out          # (its device blocks go to the library's pool: fi_memory_pool)
+            return ms
+
+        fi.memory_pool(0)               # nothing left over from earlier contexts of this process
+        line["cold_ms_per_step"] = cold_step()
+        # the same once more: what a caller pays that creates and destroys a context per solve (the reference's stateless
+        # solve_sparse_linear* used that way) once the pool holds the blocks of the context before
+        line["cold_pooled_ms_per_step"] = cold_step()
+        line["cold_note"] = ("fresh context: allocation, the polynomial's power method, first assemble and first solve "
+                             "(cold_pooled: the device blocks come from the pool a destroyed context leaves); "
                              "ms_per_step is the steady state of a caller that re-solves on one context")
-        del cold, cold_out
     if world == 1 and not args.no_accuracy:
         # the same inputs solved in fp64 to 1e-10 (V-cycle PCG where levels are available), outside the timed region
         x_run = d_out.cpu().numpy().astype(np.float64)

@@ -7,4 +7,4 @@ GPU; importing the API without the built library raises ImportError (no CPU fall
 from .api import (GradientKernel, LatticeField, LatticeGroup, SolveOptions, ValueKernel, Weights,  # noqa: F401
                   generate_error_map, jacobi_iterations, sdf_from_points, solve_sparse_linear_exact,
                   solve_sparse_linear_with_guess, solve_tiled_with_guess, upscale_field)
-from ._capi import FiError  # noqa: F401
+from ._capi import FiError, memory_pool  # noqa: F401

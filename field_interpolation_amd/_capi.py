@@ -18,7 +18,7 @@ SYMBOLS = [
     "fi_slab_range", "fi_slab_point_range", "fi_slab_partition", "fi_halo_width", "fi_comm_unique_id", "fi_comm_init", "fi_comm_init_host", "fi_comm_self_test", "fi_set_model", "fi_add_points", "fi_add_border_prior",
     "fi_add_rows_coo", "fi_assemble", "fi_clear_points", "fi_set_option", "fi_solve_cg", "fi_jacobi", "fi_tile_pass", "fi_error_map",
     "fi_get_solution_f64", "fi_true_residual", "fi_apply_AtA_f64", "fi_get_Atb_f64", "fi_get_diag_f64",
-    "fi_get_stats", "fi_time_apply", "fi_upscale_field",
+    "fi_get_stats", "fi_memory_pool", "fi_time_apply", "fi_upscale_field",
     "fi_group_create", "fi_group_destroy", "fi_group_size", "fi_group_rank", "fi_group_assemble",
     "fi_group_solve_cg", "fi_group_apply_AtA_f64", "fi_group_true_residual", "fi_group_get_solution_f64", "fi_group_tile_pass", "fi_group_error_map",
 ]
@@ -100,6 +100,7 @@ def lib():
     L.fi_get_diag_f64.argtypes = [vp, dp]
     L.fi_get_stats.argtypes = [vp, C.POINTER(FiStats)]
     L.fi_time_apply.argtypes = [vp, C.c_int, dp]
+    L.fi_memory_pool.argtypes = [C.c_longlong, C.POINTER(C.c_longlong)]
     L.fi_upscale_field.argtypes = [fp, C.c_int, ip, ip, fp, C.c_int]
     L.fi_group_create.argtypes = [C.POINTER(vp), C.c_int, ip, C.c_int, C.c_int]
     L.fi_group_destroy.argtypes = [vp]
@@ -128,3 +129,11 @@ def device_count():
     n = C.c_int(0)
     check(lib().fi_device_count(C.byref(n)))
     return n.value
+
+
+def memory_pool(keep_bytes=-1):
+    """fi_memory_pool: device memory of destroyed contexts kept for the next one, on the current device.  Frees it down
+    to keep_bytes (0: all of it; negative: nothing) and returns the bytes that stay cached."""
+    left = C.c_longlong(0)
+    check(lib().fi_memory_pool(int(keep_bytes), C.byref(left)))
+    return left.value

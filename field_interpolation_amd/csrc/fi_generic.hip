@@ -266,8 +266,7 @@ void grow(DevBuf& b, size_t used_bytes, size_t need_bytes, hipStream_t st)
 	n.alloc(cap);
 	if (used_bytes) { FI_HIP_TRY(hipMemcpyAsync(n.p, b.p, used_bytes, hipMemcpyDeviceToDevice, st)); }
 	FI_HIP_TRY(hipStreamSynchronize(st));
-	std::swap(b.p, n.p);
-	std::swap(b.bytes, n.bytes);
+	b.swap(n);
 }
 
 }  // namespace

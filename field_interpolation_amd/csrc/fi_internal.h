@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fi_hip.h"
@@ -51,18 +52,30 @@ struct Fail {
 	} while (0)
 
 // ---- device buffer --------------------------------------------------------------------------------
+// Device memory of destroyed contexts is kept for the next one (fi_pool.hip): hipMalloc / hipFree synchronise the device
+// and cost 50-500 us per block -- a 256^3 context holds ~60 blocks (first assemble + solve 14 ms against 8 warm, destroy
+// 16-24 ms).  A block enters the pool only while `pool_quiescent` is set: fi_ctx_destroy sets it after a device-wide
+// synchronisation, so nothing in flight can still touch a pooled block; every other release (a buffer that grows, a
+// temporary) is a plain hipFree, as before.  FI_NO_POOL: no pooling (tests).
+void*  pool_take(size_t capacity_wanted, size_t* capacity);  // a pooled block of at least / at most twice that capacity, or nullptr
+bool   pool_give(void* p, size_t capacity);                   // false: the pool is full or off, the caller frees the block
+size_t pool_trim(size_t keep_bytes);                          // frees pooled blocks down to keep_bytes; returns what stays
+extern thread_local bool pool_quiescent;
+
 struct DevBuf {
 	void*  p     = nullptr;
-	size_t bytes = 0;
+	size_t bytes = 0;  // usable bytes (the request); 64 zeroed bytes follow
+	size_t cap   = 0;  // bytes of the block
 	DevBuf() = default;
 	DevBuf(const DevBuf&) = delete;
 	DevBuf& operator=(const DevBuf&) = delete;
 	~DevBuf() { release(); }
 	void release()
 	{
-		if (p) { (void)hipFree(p); }
+		if (p && !(pool_quiescent && pool_give(p, cap))) { (void)hipFree(p); }
 		p     = nullptr;
 		bytes = 0;
+		cap   = 0;
 	}
 	// 64 zeroed bytes of slack behind every buffer: the tiled kernels read whole 16-byte groups, and the group at
 	// the end of a row whose length is not a multiple of the group reads on into the next row -- behind the very
@@ -72,9 +85,19 @@ struct DevBuf {
 		if (nbytes <= bytes && p) { return; }
 		release();
 		if (nbytes == 0) { nbytes = 16; }
-		FI_HIP_TRY(hipMalloc(&p, nbytes + 64));
+		p = pool_take(nbytes + 64, &cap);
+		if (!p) {
+			cap = nbytes + 64;
+			FI_HIP_TRY(hipMalloc(&p, cap));
+		}
 		FI_HIP_TRY(hipMemset(static_cast<char*>(p) + nbytes, 0, 64));
 		bytes = nbytes;
+	}
+	void swap(DevBuf& o)
+	{
+		std::swap(p, o.p);
+		std::swap(bytes, o.bytes);
+		std::swap(cap, o.cap);
 	}
 	template <typename T>
 	T* as() const { return static_cast<T*>(p); }

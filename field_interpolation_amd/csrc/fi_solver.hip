@@ -2212,8 +2212,7 @@ void swap_vectors(RankSet& R, Vec a, Vec b)
 {
 	if (a == b) { return; }
 	for (fi_ctx* c : R) {
-		std::swap((c->*a).p, (c->*b).p);
-		std::swap((c->*a).bytes, (c->*b).bytes);
+		(c->*a).swap(c->*b);
 	}
 }
 template <typename T>
@@ -3899,8 +3898,7 @@ void tile_pass_run(RankSet& R, int tile_size)  // x of every member: the guess o
 				fi_ctx* c = R[i];
 				c->tile_ts = 0;
 				if (swapped[i]) {
-					std::swap(c->atb.p, c->scratch[21].p);
-					std::swap(c->atb.bytes, c->scratch[21].bytes);
+					c->atb.swap(c->scratch[21]);
 				}
 			}
 		}
@@ -3917,8 +3915,7 @@ void tile_pass_run(RankSet& R, int tile_size)  // x of every member: the guess o
 		hipLaunchKernelGGL((k_tile_rhs<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
 		                   c->atb.as<T>() + o, c->q.as<T>() + o, c->r.as<T>() + o, c->x.as<T>() + o, rhs.as<T>() + o);
 		FI_HIP_TRY(hipGetLastError());
-		std::swap(c->atb.p, rhs.p);
-		std::swap(c->atb.bytes, rhs.bytes);
+		c->atb.swap(rhs);
 		restore.swapped[i] = true;
 	}
 	// contexts of materialised rows only (the drop-in's solve_tiled_with_guess): tiles without any entry keep the guess
@@ -4468,6 +4465,16 @@ int fi_ctx_destroy(fi_ctx* c)
 	if (!c) { return FI_OK; }
 	(void)hipSetDevice(c->device);
 	if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+	// the context's blocks go to the pool of fi_pool.hip: nothing on the device may still touch them (helper streams,
+	// the group's stream, a caller's stream the vectors were handed to)
+	struct Quiescent {
+		bool was;
+		Quiescent() : was(fi::pool_quiescent)
+		{
+			if (!was) { fi::pool_quiescent = hipDeviceSynchronize() == hipSuccess; }
+		}
+		~Quiescent() { fi::pool_quiescent = was; }
+	} quiescent;
 	for (auto* pb : c->pending) { delete pb; }
 	for (auto* pb : c->pending_pool) { delete pb; }
 	for (auto* b : c->batches) { delete b; }
@@ -4492,6 +4499,15 @@ int fi_ctx_destroy(fi_ctx* c)
 	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }
 	delete c;
 	return FI_OK;
+}
+
+int fi_memory_pool(long long keep_bytes, long long* cached_bytes)
+{
+	FI_API_BEGIN
+	const size_t keep = keep_bytes < 0 ? ~size_t(0) : static_cast<size_t>(keep_bytes);
+	const size_t left = fi::pool_trim(keep);
+	if (cached_bytes) { *cached_bytes = static_cast<long long>(left); }
+	FI_API_END
 }
 
 int fi_slab_partition(int planes, int rank, int nranks, int* lo, int* hi)

@@ -306,7 +306,11 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 }
 
 // Frees the device contexts this thread's stateless calls have cached (gpu_field.hpp).
-void clear_context_cache() { cache().clear(); }
+void clear_context_cache()
+{
+	cache().clear();
+	(void)fi_memory_pool(0, nullptr);  // and the device blocks the library keeps of destroyed contexts
+}
 
 namespace detail {
 

@@ -267,6 +267,11 @@ int fi_apply_AtA_f64(fi_ctx* ctx, const double* x, double* y); /* y = (A^T A) x 
 int fi_get_Atb_f64(fi_ctx* ctx, double* out);
 int fi_get_diag_f64(fi_ctx* ctx, double* out);
 int fi_get_stats(const fi_ctx* ctx, fi_stats* out);
+/* Device memory of destroyed contexts is kept (per device, at most 8 GiB) and handed to the next context: hipMalloc /
+ * hipFree synchronise the device and dominate the cost of a context that lives for one solve -- what a caller of the
+ * reference's stateless solve_sparse_linear* (sparse_linear.hpp:75-96) creates per call.  Frees pooled blocks of the
+ * CURRENT device down to keep_bytes (0: everything; negative: nothing) and reports what stays cached. */
+int fi_memory_pool(long long keep_bytes, long long* cached_bytes);
 /* Launches the AtA apply `reps` times on the context's stream between two HIP events. */
 int fi_time_apply(fi_ctx* ctx, int reps, double* ms_per_launch);
 

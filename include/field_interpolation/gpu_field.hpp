@@ -72,7 +72,8 @@ std::unique_ptr<GpuLatticeField> gpu_sdf_from_points(const std::vector<int>& siz
 
 // The stateless solver calls of sparse_linear.hpp keep device contexts between calls, keyed by shape and precision (at
 // most six, systems of up to 2^20 unknowns only; larger systems get a context per call): the per-frame caller's latency
-// (src/bipolar_2d.cpp:730).  This frees the calling thread's cached contexts (they are freed at thread exit otherwise).
+// (src/bipolar_2d.cpp:730).  This frees the calling thread's cached contexts (they are freed at thread exit otherwise)
+// and the device memory the library keeps of destroyed contexts (fi_memory_pool).
 void clear_context_cache();
 
 } // namespace field_interpolation

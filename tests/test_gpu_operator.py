@@ -387,3 +387,41 @@ def test_border_prior_is_refused_on_a_slab(fi):
     with pytest.raises(FiError) as e:
         f.add_border_prior(0.5)
     assert e.value.code == 5      # FI_ERR_UNSUPPORTED
+
+
+def test_memory_of_destroyed_contexts_is_reused(fi, monkeypatch):
+    """fi_memory_pool: the blocks of a destroyed context serve the next one (same answers, bit for bit -- a pooled block
+    is handed out only after the device-wide synchronisation of fi_ctx_destroy, and every buffer is written before it is
+    read); FI_NO_POOL frees them instead; trimming empties the pool."""
+    import gc
+    sizes = [48, 40, 36]
+    rng = np.random.default_rng(8)
+    pos = np.stack([rng.uniform(0, s - 1, 5000) for s in sizes], axis=1).astype(np.float32)
+    val = rng.normal(size=len(pos)).astype(np.float32)
+    w = fi.Weights(data_gradient=0.0)
+
+    def solve():
+        f = fi.LatticeField(sizes, dtype="f32")
+        f.add_field_constraints(w)
+        f.set_levels(1)
+        f.set_polynomial(4)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-5)
+        x = x.copy()
+        del f
+        gc.collect()
+        return x, it
+
+    assert fi.memory_pool(0) == 0
+    x0, it0 = solve()
+    held = fi.memory_pool()
+    assert held > 0                                    # the first context's blocks are in the pool now
+    x1, it1 = solve()                                  # ... and this one lives in them
+    assert it1 == it0 and np.array_equal(x0, x1)
+    assert fi.memory_pool() <= held * 1.05             # nothing new had to be allocated (sizes repeat)
+    assert fi.memory_pool(0) == 0
+    monkeypatch.setenv("FI_NO_POOL", "1")
+    x2, it2 = solve()
+    monkeypatch.delenv("FI_NO_POOL", raising=False)
+    assert fi.memory_pool() == 0 and it2 == it0 and np.array_equal(x0, x2)
