@@ -57,8 +57,9 @@ struct Fail {
 // 16-24 ms).  A block enters the pool only while `pool_quiescent` is set: fi_ctx_destroy sets it after a device-wide
 // synchronisation, so nothing in flight can still touch a pooled block; every other release (a buffer that grows, a
 // temporary) is a plain hipFree, as before.  FI_NO_POOL: no pooling (tests).
-void*  pool_take(size_t capacity_wanted, size_t* capacity);  // a pooled block of at least / at most twice that capacity, or nullptr
-bool   pool_give(void* p, size_t capacity);                   // false: the pool is full or off, the caller frees the block
+// (`used`: the bytes its last owner asked for -- the 64 bytes behind them are still zero, no kernel ever writes there)
+void*  pool_take(size_t capacity_wanted, size_t* capacity, size_t* used);  // a pooled block of at least / at most twice that capacity, or nullptr
+bool   pool_give(void* p, size_t capacity, size_t used);                   // false: the pool is full or off, the caller frees the block
 size_t pool_trim(size_t keep_bytes);                          // frees pooled blocks down to keep_bytes; returns what stays
 extern thread_local bool pool_quiescent;
 
@@ -72,7 +73,7 @@ struct DevBuf {
 	~DevBuf() { release(); }
 	void release()
 	{
-		if (p && !(pool_quiescent && pool_give(p, cap))) { (void)hipFree(p); }
+		if (p && !(pool_quiescent && pool_give(p, cap, bytes))) { (void)hipFree(p); }
 		p     = nullptr;
 		bytes = 0;
 		cap   = 0;
@@ -85,12 +86,13 @@ struct DevBuf {
 		if (nbytes <= bytes && p) { return; }
 		release();
 		if (nbytes == 0) { nbytes = 16; }
-		p = pool_take(nbytes + 64, &cap);
+		size_t used = 0;
+		p = pool_take(nbytes + 64, &cap, &used);
 		if (!p) {
 			cap = nbytes + 64;
 			FI_HIP_TRY(hipMalloc(&p, cap));
 		}
-		FI_HIP_TRY(hipMemset(static_cast<char*>(p) + nbytes, 0, 64));
+		if (used != nbytes) { FI_HIP_TRY(hipMemset(static_cast<char*>(p) + nbytes, 0, 64)); }
 		bytes = nbytes;
 	}
 	void swap(DevBuf& o)

@@ -15,7 +15,8 @@ thread_local bool pool_quiescent = false;
 namespace {
 constexpr size_t kPoolBytes = size_t(8) << 30;
 struct DevicePool {
-	std::multimap<size_t, void*> blocks;  // capacity -> block
+	struct Block { void* p; size_t used; };
+	std::multimap<size_t, Block> blocks;  // capacity -> block, and the bytes its last owner used
 	size_t bytes = 0;
 };
 std::mutex g_mutex;
@@ -23,7 +24,7 @@ std::map<int, DevicePool> g_pools;
 bool pool_off() { return test_switch("FI_NO_POOL") != nullptr; }
 }  // namespace
 
-void* pool_take(size_t capacity_wanted, size_t* capacity)
+void* pool_take(size_t capacity_wanted, size_t* capacity, size_t* used)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { return nullptr; }
@@ -33,14 +34,15 @@ void* pool_take(size_t capacity_wanted, size_t* capacity)
 	DevicePool& P = pit->second;
 	auto it = P.blocks.lower_bound(capacity_wanted);
 	if (it == P.blocks.end() || it->first > 2 * capacity_wanted) { return nullptr; }
-	void* p = it->second;
+	void* p = it->second.p;
 	*capacity = it->first;
+	*used     = it->second.used;
 	P.bytes -= it->first;
 	P.blocks.erase(it);
 	return p;
 }
 
-bool pool_give(void* p, size_t capacity)
+bool pool_give(void* p, size_t capacity, size_t used)
 {
 	if (!p || capacity == 0 || pool_off()) { return false; }
 	int dev = 0;
@@ -48,7 +50,7 @@ bool pool_give(void* p, size_t capacity)
 	std::lock_guard<std::mutex> lock(g_mutex);
 	DevicePool& P = g_pools[dev];
 	if (P.bytes + capacity > kPoolBytes) { return false; }
-	P.blocks.emplace(capacity, p);
+	P.blocks.emplace(capacity, DevicePool::Block{p, used});
 	P.bytes += capacity;
 	return true;
 }
@@ -63,7 +65,7 @@ size_t pool_trim(size_t keep_bytes)
 	DevicePool& P = pit->second;
 	while (P.bytes > keep_bytes && !P.blocks.empty()) {
 		auto it = std::prev(P.blocks.end());  // the largest first
-		(void)hipFree(it->second);
+		(void)hipFree(it->second.p);
 		P.bytes -= it->first;
 		P.blocks.erase(it);
 	}

@@ -29,6 +29,8 @@
 #include <cstdarg>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -3087,9 +3089,40 @@ void ensure_poly_vectors(fi_ctx* c)
 
 // largest eigenvalue of diag(A_model)^-1 A_model by the power method (16 steps through the marching kernel's epilogue,
 // unnormalised: growth <= 4^16): a property of the lattice and the model weights, kept until fi_set_model
+// ... and beyond the context: the estimate is a function of the lattice's extents, the model weights and the precision
+// alone, so a process keeps the ones it has computed (a context that lives for one solve paid 16 launches and two host
+// round trips per level for a number the context before it had already found: 0.8 ms of a 256^3 cold step).
+struct LambdaKey {
+	int   dtype, ndim, gn[3];
+	float w[3];
+	bool operator<(const LambdaKey& o) const { return std::memcmp(this, &o, sizeof(LambdaKey)) < 0; }
+};
+LambdaKey lambda_key(const fi_ctx* c)
+{
+	LambdaKey k;
+	std::memset(&k, 0, sizeof(k));  // (padding bytes take part in the comparison)
+	k.dtype = c->dtype;
+	k.ndim  = c->g.ndim;
+	for (int d = 0; d < 3; ++d) { k.gn[d] = c->g.gn[d]; }
+	k.w[0] = c->w.model_0;
+	k.w[1] = c->w.model_1;
+	k.w[2] = c->w.model_2;
+	return k;
+}
+std::mutex g_lambda_mutex;
+std::map<LambdaKey, double> g_lambda_cache;
+
 template <typename T>
 void estimate_poly_lambda(RankSet& R)
 {
+	if (!test_switch("FI_NO_LAMBDA_CACHE")) {
+		std::lock_guard<std::mutex> lock(g_lambda_mutex);
+		auto it = g_lambda_cache.find(lambda_key(R[0]));
+		if (it != g_lambda_cache.end()) {
+			for (fi_ctx* c : R) { c->poly_lambda = it->second; }
+			return;
+		}
+	}
 	for (fi_ctx* c : R) { ensure_poly_vectors<T>(c); }
 	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
 	for (fi_ctx* c : R) {
@@ -3123,6 +3156,11 @@ void estimate_poly_lambda(RankSet& R)
 	}
 	const double lambda = (sums[0] > 0 && sums[1] > 0 && std::isfinite(sums[1])) ? std::sqrt(sums[1] / sums[0]) : 4.0;
 	for (fi_ctx* c : R) { c->poly_lambda = lambda; }
+	if (sums[0] > 0 && sums[1] > 0 && std::isfinite(sums[1])) {
+		std::lock_guard<std::mutex> lock(g_lambda_mutex);
+		if (g_lambda_cache.size() > 4096) { g_lambda_cache.clear(); }
+		g_lambda_cache[lambda_key(R[0])] = lambda;
+	}
 }
 
 template <typename T>

@@ -345,3 +345,28 @@ def test_single_reduction_recurrence_over_slabs(fi, monkeypatch, dtype, tol, siz
     one.assemble()
     x1, it1, _ = one.solve_cg(None, 0, tol)
     assert abs(its - it1) <= max(3, it1 // 12), (its, it1)
+
+
+def test_bound_of_the_polynomial_is_remembered_per_lattice(fi, monkeypatch):
+    """The polynomial's eigenvalue bound depends on the lattice's extents and the model weights only; a process remembers
+    it (a context that lives for one solve would run the power method for a number already known).  Remembered or
+    recomputed (FI_NO_LAMBDA_CACHE): the same bits, so the same iterates."""
+    sizes = [44, 36, 40]
+    rng = np.random.default_rng(23)
+    pos = np.stack([rng.uniform(0, s - 1, 4000) for s in sizes], axis=1).astype(np.float32)
+    val = rng.normal(size=len(pos)).astype(np.float32)
+    w = fi.Weights(model_2=0.45, model_1=0.07, data_gradient=0.0)
+    got = []
+    for no_cache in (False, False, True):
+        if no_cache:
+            monkeypatch.setenv("FI_NO_LAMBDA_CACHE", "1")
+        f = fi.LatticeField(sizes, dtype="f32")
+        f.add_field_constraints(w)
+        f.set_polynomial(4, 30.0)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-6)
+        got.append((x.copy(), it))
+    monkeypatch.delenv("FI_NO_LAMBDA_CACHE", raising=False)
+    for x, it in got[1:]:
+        assert it == got[0][1] and np.array_equal(x, got[0][0])
