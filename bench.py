@@ -363,8 +363,9 @@ def main():
     # launches per outer iteration against one full apply), else the apply
     if acc["prec_n"] > 0 and wl["poly"] > 2:
         roof_main = roof("k_apply_march3d<EPI>: Chebyshev steps of the polynomial preconditioner = model-operator apply + "
-                         "three-term recurrence in the epilogue; ALL steps of the polynomial sampled in turn (first: r, bf16 "
-                         "scaling in, z out = 2.5 lattice passes; second 3.5; the others 4.5): byte-weighted mean, finest level",
+                         "three-term recurrence in the epilogue; ALL steps of the sampled polynomials, timed between one pair "
+                         "of HIP events per polynomial (first: r, bf16 scaling in, z out = 2.5 lattice passes; second 3.5; the "
+                         "others 4.5): bytes of all sampled launches over their time, launch_ms = the mean per launch, finest level",
                          st["prec_bytes"], prec_avg_ms, acc["prec_n"], tr("cheb"))
     else:
         roof_main = roof_apply

@@ -3296,10 +3296,13 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		// the polynomial: z_{k+1} from z_k (ZA / ZB alternate; the result ends in `zfin`)
 		Vec zin = ZA, zout = ZB;
 		for (int k = 1; k < terms; ++k) {
-			// every 4th pass times one step, the steps in turn (first: 2.5 lattice passes, second: 3.5, the others 4.5): the
-			// roofline figure is bytes over time of ALL sampled steps
-			const bool sample = phase == 1 && k == 1 + psamples % (terms - 1) && c0->level == 0 && psamples < kPolySamples &&
-			                    (tag & 3) == 3 && !tuning_switch("FI_NO_SAMPLES");
+			// every 4th pass is timed: ALL its steps between one pair of event records (first step: 2.5 lattice passes,
+			// second: 3.5, the others 4.5) -- a pair of records idles the stream for a few microseconds, which a single
+			// 45 us launch between them shows as 5 % (0.58 against the trace's 0.61), three launches as 2 %.  The roofline
+			// figure is bytes over time of all sampled launches; the statistics report the mean per launch.
+			const bool sample_pass = phase == 1 && c0->level == 0 && psamples < kPolySamples && (tag & 3) == 3 &&
+			                         !tuning_switch("FI_NO_SAMPLES");
+			const bool sample = sample_pass && k == 1, sample_end = sample_pass && k == terms - 1;
 			const bool overlap = !deep && R.size() == 1 && overlap_possible(c0) && c0->march.np_inner > 0;
 			const bool pro = z0_on_load && k == 1;
 			const Vec  zsrc = pro ? static_cast<Vec>(&fi_ctx::r) : zin;  // the vector whose ghost planes the step reads
@@ -3318,8 +3321,12 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 				ptags.push_back(tag);
 				// z, z_prev, r in, z_new out + the bfloat16 scaling; the first step has no z_prev and (formed on load) reads r as
 				// its z; the second step's z_prev is recomputed from r
-				const double vecs = k == 1 ? (pro ? 2.0 : 3.0) : (k == 2 ? 3.0 : 4.0);
-				pbytes.push_back((static_cast<double>(sizeof(T)) * vecs + 2.0) * static_cast<double>(c0->g.nown));
+				double bytes = 0;
+				for (int j = 1; j < terms; ++j) {
+					const double vecs = j == 1 ? (z0_on_load ? 2.0 : 3.0) : (j == 2 ? 3.0 : 4.0);
+					bytes += (static_cast<double>(sizeof(T)) * vecs + 2.0) * static_cast<double>(c0->g.nown);
+				}
+				pbytes.push_back(bytes);
 			}
 			for (fi_ctx* c : R) {
 				const void* zp = k == 1 ? nullptr : (c->*zout).p;
@@ -3343,7 +3350,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 					stencil_cheb_step(c, (c->*zin).p, zp, c->r.p, (c->*zout).p, c1s[k - 1], c2s[k - 1], region(c, 2), 0, zs, 0.0, nullptr, ext);
 				}
 			}
-			if (sample) {
+			if (sample_end) {
 				FI_HIP_TRY(hipEventRecord(pev[2 * psamples + 1], st));
 				++psamples;
 			}
@@ -3497,9 +3504,10 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 		c->stats.spmv_samples = used;
 		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
-		c->stats.prec_samples = pused;
-		c->stats.prec_ms_avg  = pused ? psum / pused : 0.0;
-		c->stats.prec_bytes   = pused ? pbsum / pused : 0.0;  // mean over the sampled steps: bytes / time is their byte-weighted rate
+		// per LAUNCH: a sample holds the terms - 1 steps of one polynomial; bytes / time is their byte-weighted rate
+		c->stats.prec_samples = pused * (terms - 1);
+		c->stats.prec_ms_avg  = pused ? psum / (pused * (terms - 1)) : 0.0;
+		c->stats.prec_bytes   = pused ? pbsum / (pused * (terms - 1)) : 0.0;
 		c->stats.operator_applies = (iter_base + h.iter + 1) * terms + h.restarts;
 		// (+ one exchange of p per full apply: every outer iteration, the start and each verification)
 		c->stats.halo_exchanges = c0->nranks > 1 ? n_exchanges + issued + 1 + h.restarts : 0;

@@ -97,7 +97,7 @@ typedef struct fi_stats {
 	int    coarse_iterations;  /* CG iterations spent on coarser levels by the last solve (cascade start) */
 	double prec_ms_avg;        /* mean duration of the sampled Chebyshev-step launches of the polynomial preconditioner */
 	int    prec_samples;
-	double prec_bytes;         /* mean algorithmic bytes of the sampled launches (the steps in turn: 2.5 / 3.5 / 4.5 lattice passes) */
+	double prec_bytes;         /* mean algorithmic bytes of the sampled launches (every step of the sampled polynomials: 2.5 / 3.5 / 4.5 lattice passes) */
 	int    operator_applies;   /* full operator applications + preconditioner steps of the last solve (finest level) */
 	int    halo_exchanges;     /* slabs: halo exchanges of the finest level during the last solve (polynomial PCG) */
 	int    reductions;         /* slabs: dot-product reductions across the ranks during the last solve (polynomial PCG) */
