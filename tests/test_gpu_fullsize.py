@@ -207,3 +207,39 @@ def test_config5_over_eight_slabs_keeps_all_levels(fi):
     x, it, rel = grp.solve_cg(None, 1000, 1e-6)
     assert rel <= 1e-6 and grp.true_residual() <= 1.5e-6
     assert abs(it - 25) <= 3, it
+
+
+def test_bench_line_contract_single_gpu():
+    """The one JSON line of bench.py at N = 1 (a reduced lattice so that the CPU baseline takes seconds): every field of
+    the measurement contract, `roofline` and `cpu_baseline` objects included, the accurate leg within the field tolerance
+    and the cold figures."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--side", "96", "--cpu-side", "32"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["unit"] == "lattice points/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 96 ** 3 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert d["config"]["true_rel_residual"] <= 1.5e-5
+    assert d["accurate"]["solution_rel_err"] <= 1e-5 and d["accurate"]["value"] > 0
+    assert d["cold_ms_per_step"] > 0 and d["cold_pooled_ms_per_step"] > 0
