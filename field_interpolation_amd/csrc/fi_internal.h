@@ -342,6 +342,8 @@ struct fi_ctx {
 	                                     // the finest level on `stream`
 	hipEvent_t  ev_level = nullptr;
 	hipStream_t level_stream2 = nullptr;  // mixed precision: the replica's coarser levels (a second helper thread)
+	hipStream_t build_stream = nullptr;   // a coarser level beyond the first: the stream (and thread) its assembly runs on
+	hipEvent_t  ev_build = nullptr;
 	hipEvent_t  ev_level2 = nullptr;
 	hipEvent_t  ev_ready = nullptr, ev_halo = nullptr;
 	fi::DevBuf group_scal;    // loop-back group: CgScalars* of every member (held by member 0)

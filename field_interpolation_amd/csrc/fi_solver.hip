@@ -4195,6 +4195,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 	}
 	int first_tail = 0;
 	const int nlevels = plan_levels(c, &first_tail);
+	std::vector<fi_ctx*> built;
 	for (int l = 1; l <= nlevels; ++l) {
 		// from first_tail on the levels are whole lattices that every rank assembles -- from ALL the data points, which
 		// fi_slab_point_range asks the caller for in that case -- and solves in full (fi_ctx::replicated)
@@ -4269,6 +4270,20 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		w.model_4 = fine->w.model_4 * std::sqrt(vol / 256.0f);
 		w.gradient_smoothness = fine->w.gradient_smoothness * std::sqrt(vol / 16.0f);
 		co->w = w;
+		built.push_back(co);
+		fine = co;
+	}
+	if (fine->coarse) {  // deeper levels left over from an earlier, larger request
+		fi_ctx_destroy(fine->coarse);
+		fine->coarse = nullptr;
+	}
+	// The levels are problems of their own, each a chain of small launches with host round trips for its list sizes:
+	// rows from the point batches, cells, lists, diagonal.  On a helper's stream (fi_assemble) the levels beyond the first
+	// get a thread and a stream each (config 3's assembly 3.7 -> 2.2 ms, config 5's 24.3 -> 21.1 ms, the accurate leg of
+	// config 4 16.2 -> 15.9 ms per step: there the fp64 finest level is the longest chain).  FI_SERIAL_LEVEL_CHAINS: one
+	// after the other (tests: the same bits).
+	auto assemble_level = [src](fi_ctx* co) {
+		const int   l  = co->level;
 		const float ps = 1.0f / static_cast<float>(1 << l), ns = static_cast<float>(1 << l);
 		for (auto* b : src->batches) {
 			const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
@@ -4288,11 +4303,63 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		co->assembled = true;
 		co->vectors_ready = co->vectors_ready && co->max_blocks >= apply_num_partials(co);
 		co->stats.num_unknowns = co->g.nown;
-		fine = co;
-	}
-	if (fine->coarse) {  // deeper levels left over from an earlier, larger request
-		fi_ctx_destroy(fine->coarse);
-		fine->coarse = nullptr;
+	};
+	const bool chains = build_stream != nullptr && built.size() > 1 && !test_switch("FI_SERIAL_LEVEL_CHAINS");
+	if (!chains) {
+		for (fi_ctx* co : built) { assemble_level(co); }
+	} else {
+		hipEvent_t go = nullptr;
+		FI_HIP_TRY(hipEventCreateWithFlags(&go, hipEventDisableTiming));
+		FI_HIP_TRY(hipEventRecord(go, build_stream));  // (behind the caller's wait for the point batches)
+		std::vector<std::thread> workers;
+		std::vector<int>         codes(built.size(), FI_OK);
+		std::vector<std::string> msgs(built.size());
+		for (size_t i = 1; i < built.size(); ++i) {
+			fi_ctx* co = built[i];
+			if (!co->build_stream) {
+				FI_HIP_TRY(hipStreamCreateWithFlags(&co->build_stream, hipStreamNonBlocking));
+				FI_HIP_TRY(hipEventCreateWithFlags(&co->ev_build, hipEventDisableTiming));
+			}
+			FI_HIP_TRY(hipStreamWaitEvent(co->build_stream, go, 0));
+			co->stream = co->build_stream;
+		}
+		auto guarded = [&](size_t i) {
+			try {
+				FI_HIP_TRY(hipSetDevice(c->device));
+				assemble_level(built[i]);
+			} catch (const Fail& f) {
+				codes[i] = f.code;
+				msgs[i]  = fi_last_error();
+			} catch (...) {
+				codes[i] = FI_ERR_HIP;
+				msgs[i]  = "unexpected exception while assembling a coarser level";
+			}
+		};
+		for (size_t i = 1; i < built.size(); ++i) {
+			try {
+				workers.emplace_back(guarded, i);
+			} catch (...) {  // no thread to be had: this one on the caller's thread, behind the first level
+				workers.emplace_back();
+			}
+		}
+		guarded(0);
+		for (size_t i = 1; i < built.size(); ++i) {
+			std::thread& t = workers[i - 1];
+			if (t.joinable()) { t.join(); } else { guarded(i); }
+		}
+		// the caller orders `build_stream` against the solver stream: the other chains end in it
+		for (size_t i = 1; i < built.size(); ++i) {
+			(void)hipEventRecord(built[i]->ev_build, built[i]->build_stream);
+			(void)hipStreamWaitEvent(build_stream, built[i]->ev_build, 0);
+		}
+		(void)hipEventDestroy(go);
+		for (size_t i = 0; i < built.size(); ++i) {
+			if (codes[i] != FI_OK) {
+				for (size_t k = 1; k < built.size(); ++k) { (void)hipStreamSynchronize(built[k]->build_stream); }
+				set_error("%s", msgs[i].c_str());
+				throw Fail{codes[i]};
+			}
+		}
 	}
 	for (fi_ctx* l = c->coarse; l; l = l->coarse) { l->stream = c->stream; }  // the caller orders the two streams
 	// smoother bounds of the V-cycle (a global power method over all slabs) are estimated by the next multigrid solve
@@ -4534,6 +4601,10 @@ int fi_ctx_destroy(fi_ctx* c)
 	if (c->level_stream) { (void)hipStreamDestroy(c->level_stream); }
 	if (c->ev_level) { (void)hipEventDestroy(c->ev_level); }
 	if (c->level_stream2) { (void)hipStreamDestroy(c->level_stream2); }
+	if (c->build_stream) {
+		(void)hipStreamDestroy(c->build_stream);
+		(void)hipEventDestroy(c->ev_build);
+	}
 	if (c->ev_level2) { (void)hipEventDestroy(c->ev_level2); }
 	if (c->comm_stream) {
 		(void)hipStreamDestroy(c->comm_stream);

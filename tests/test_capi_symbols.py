@@ -82,5 +82,5 @@ def test_shipped_library_has_no_timing_hooks():
                  b"FI_TIME_STEP", b"FI_NO_SAMPLES", b"FI_POLY_UNFOLDED", b"FI_DUMMY"):
         assert name not in blob, name
     for name in (b"FI_NO_FUSE", b"FI_NO_MARCH", b"FI_ZC", b"FI_SOLVE_TIMEOUT_S", b"FI_NO_FUSED_SMOOTHER", b"FI_NO_Z0_ON_LOAD",
-                 b"FI_SERIAL_LEVELS", b"FI_LINEAR_START", b"FI_START_ONLY", b"FI_NO_POOL", b"FI_NO_LAMBDA_CACHE"):                              # the switches the tests use are there
+                 b"FI_SERIAL_LEVELS", b"FI_LINEAR_START", b"FI_START_ONLY", b"FI_NO_POOL", b"FI_NO_LAMBDA_CACHE", b"FI_SERIAL_LEVEL_CHAINS"):                              # the switches the tests use are there
         assert name in blob, name

@@ -318,3 +318,40 @@ def test_start_guess_reproduces_a_linear_field(fi, monkeypatch, sizes, levels):
     finally:
         monkeypatch.delenv("FI_START_ONLY", raising=False)
         monkeypatch.delenv("FI_LINEAR_START", raising=False)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_level_chains_in_parallel_same_bits(fi, monkeypatch, mixed):
+    """The coarser levels beyond the first are assembled on a thread and a stream each (build_levels on a helper's
+    stream); FI_SERIAL_LEVEL_CHAINS builds them one after the other.  Same kernels on the same data: the solves are
+    bitwise equal, assemble after assemble (the levels' buffers and streams are reused), in fp32 and in the
+    mixed-precision form whose replica carries the levels."""
+    sizes = [96, 80, 88]
+    w = fi.Weights(model_2=0.5, data_gradient=0.0)
+    sols = {}
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("FI_SERIAL_LEVEL_CHAINS", "1")
+        else:
+            monkeypatch.delenv("FI_SERIAL_LEVEL_CHAINS", raising=False)
+        f = fi.LatticeField(sizes, dtype="f64" if mixed else "f32")
+        f.add_field_constraints(w)
+        f.set_levels(3, 1e-6 if mixed else 1e-5)
+        f.set_multigrid(True)
+        if mixed:
+            f.set_mixed_precision(True)
+        rng = np.random.default_rng(31)
+        out = []
+        for k in range(3):
+            pos = np.stack([rng.uniform(0, s - 1, 6000 + 700 * k) for s in sizes], axis=1).astype(np.float32)
+            val = rng.normal(size=len(pos)).astype(np.float32)
+            f.clear_points()
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+            f.assemble()
+            assert f.stats()["num_levels"] == 4
+            x, it, rel = f.solve_cg(None, 0, 1e-7 if mixed else 1e-5)
+            out.append((x.copy(), it))
+        sols[serial] = out
+    monkeypatch.delenv("FI_SERIAL_LEVEL_CHAINS", raising=False)
+    for a, b in zip(sols[False], sols[True]):
+        assert a[1] == b[1] and np.array_equal(a[0], b[0])
