@@ -84,6 +84,27 @@ __device__ inline void block_sum(double* v, double* out)  // out[] valid in thre
 	__syncthreads();
 }
 
+// two events around a timed region, destroyed on every way out of it
+struct EventPair {
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	EventPair()
+	{
+		FI_HIP_TRY(hipEventCreate(&e0));
+		if (hipEventCreate(&e1) != hipSuccess) {
+			(void)hipEventDestroy(e0);
+			e0 = nullptr;
+			FI_HIP_TRY(hipErrorOutOfMemory);
+		}
+	}
+	EventPair(const EventPair&) = delete;
+	EventPair& operator=(const EventPair&) = delete;
+	~EventPair()
+	{
+		if (e0) { (void)hipEventDestroy(e0); }
+		if (e1) { (void)hipEventDestroy(e1); }
+	}
+};
+
 inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
 
 // grid-stride launch width for the streaming vector kernels: 256 CUs x 8 blocks
@@ -1283,9 +1304,8 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	}
 	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
 
-	hipEvent_t e0, e1;
-	FI_HIP_TRY(hipEventCreate(&e0));
-	FI_HIP_TRY(hipEventCreate(&e1));
+	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
+	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
 	FI_HIP_TRY(hipEventRecord(e0, st));
 
 	CgScalars init{};
@@ -1454,8 +1474,6 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 
 	const CgScalars h = *c0->scal_host;
 	int used = samples;  // samples of iterations that actually ran (kernels of later iterations exited on the flag)
@@ -2616,9 +2634,8 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
 	}
 	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
-	hipEvent_t e0, e1;
-	FI_HIP_TRY(hipEventCreate(&e0));
-	FI_HIP_TRY(hipEventCreate(&e1));
+	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
+	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
 	FI_HIP_TRY(hipEventRecord(e0, st));
 	CgScalars init{};
 	init.tol2     = tolerance * tolerance;
@@ -2776,8 +2793,6 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 	const CgScalars h = *c0->scal_host;
 	int used = samples < h.iter ? samples : h.iter;
 	double sum_ms = 0;
@@ -3177,9 +3192,8 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	for (fi_ctx* c : R) { ensure_poly_vectors<T>(c); }
 	if (!(c0->poly_lambda > 0)) { estimate_poly_lambda<T>(R); }
 
-	hipEvent_t e0, e1;
-	FI_HIP_TRY(hipEventCreate(&e0));
-	FI_HIP_TRY(hipEventCreate(&e1));
+	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
+	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
 	FI_HIP_TRY(hipEventRecord(e0, st));
 
 	// Chebyshev interval and recurrence constants (the same polynomial as cheb_smooth).  The preconditioner is positive
@@ -3477,8 +3491,6 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 
 	const CgScalars h = *c0->scal_host;
 	int used = samples;
@@ -3665,9 +3677,8 @@ void cg_run_poly_sr(RankSet& R, int max_iterations, float tol)
 		}
 	}
 	if (!(c0->poly_lambda > 0)) { estimate_poly_lambda<T>(R); }
-	hipEvent_t e0, e1;
-	FI_HIP_TRY(hipEventCreate(&e0));
-	FI_HIP_TRY(hipEventCreate(&e1));
+	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
+	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
 	FI_HIP_TRY(hipEventRecord(e0, st));
 
 	double lam_scale = 1.0;
@@ -3830,8 +3841,6 @@ void cg_run_poly_sr(RankSet& R, int max_iterations, float tol)
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 	const CgScalars h = *c0->scal_host;
 	for (fi_ctx* c : R) {
 		c->stats.spmv_samples = 0;
@@ -4839,9 +4848,8 @@ int fi_assemble(fi_ctx* c)
 	FI_API_BEGIN
 	fi::check_ctx(c);
 	fi::bind_device(c);
-	hipEvent_t e0, e1;
-	FI_HIP_TRY(hipEventCreate(&e0));
-	FI_HIP_TRY(hipEventCreate(&e1));
+	fi::EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
+	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
 	FI_HIP_TRY(hipEventRecord(e0, c->stream));
 	// Ghost planes along the decomposed axis.  reach: the widest model stencil, at least the cell reach (1) -- the width of
 	// an exchange.  halo (planes stored): the reach, or the polynomial preconditioner's DEEP exchange: 2 (d - 1) planes of
@@ -5009,8 +5017,6 @@ int fi_assemble(fi_ctx* c)
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 	c->stats.assemble_ms  = ms;
 	c->stats.num_levels   = 1;
 	for (fi_ctx* l = c->coarse; l; l = l->coarse) { c->stats.num_levels += 1; }
@@ -5197,9 +5203,8 @@ int fi_time_apply(fi_ctx* c, int reps, double* ms_per_launch)
 	fi::ensure_vectors(c);
 	fi::CgScalars init{};
 	FI_HIP_TRY(hipMemcpyAsync(c->scal.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-	hipEvent_t e0, e1;
-	FI_HIP_TRY(hipEventCreate(&e0));
-	FI_HIP_TRY(hipEventCreate(&e1));
+	fi::EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
+	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
 	// timing builds: FI_TIME_STEP = 1 / 2 / 3 times that step of the polynomial preconditioner instead (operands: the
 	// solver's vectors as they are -- isolated launches, the numbers of profiles/r2_ablation.md)
 	const char* which = fi::tuning_switch("FI_TIME_STEP");
@@ -5225,8 +5230,6 @@ int fi_time_apply(fi_ctx* c, int reps, double* ms_per_launch)
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 	*ms_per_launch = ms / reps;
 	FI_API_END
 }
