@@ -4317,8 +4317,12 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 	if (!chains) {
 		for (fi_ctx* co : built) { assemble_level(co); }
 	} else {
-		hipEvent_t go = nullptr;
-		FI_HIP_TRY(hipEventCreateWithFlags(&go, hipEventDisableTiming));
+		struct Go {
+			hipEvent_t e = nullptr;
+			~Go() { if (e) { (void)hipEventDestroy(e); } }
+		} go_holder;
+		FI_HIP_TRY(hipEventCreateWithFlags(&go_holder.e, hipEventDisableTiming));
+		const hipEvent_t go = go_holder.e;
 		FI_HIP_TRY(hipEventRecord(go, build_stream));  // (behind the caller's wait for the point batches)
 		std::vector<std::thread> workers;
 		std::vector<int>         codes(built.size(), FI_OK);
@@ -4361,7 +4365,6 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 			(void)hipEventRecord(built[i]->ev_build, built[i]->build_stream);
 			(void)hipStreamWaitEvent(build_stream, built[i]->ev_build, 0);
 		}
-		(void)hipEventDestroy(go);
 		for (size_t i = 0; i < built.size(); ++i) {
 			if (codes[i] != FI_OK) {
 				for (size_t k = 1; k < built.size(); ++k) { (void)hipStreamSynchronize(built[k]->build_stream); }
