@@ -474,3 +474,43 @@ def test_context_lifecycles_do_not_leak(fi):
         cycle(i)
     free_b = free_bytes()
     assert free_a - free_b <= 16 * 2 ** 20, (free_a - free_b) / 2 ** 20
+
+
+def test_contexts_on_two_host_threads(fi):
+    """Contexts are independent: two host threads, each creating, solving and destroying its own contexts at the same
+    time (ctypes drops the interpreter lock during the calls), get the answers of the same work done one after the other,
+    bit for bit.  What they share is behind locks: the pool of device blocks, the remembered bounds of the polynomial."""
+    import threading
+
+    def work(seed, out):
+        rng = np.random.default_rng(seed)
+        res = []
+        for k in range(6):
+            sizes = [[40, 36, 44], [52, 48], [36, 40, 32]][(seed + k) % 3]
+            pos = np.stack([rng.uniform(0, s - 1, 2500) for s in sizes], axis=1).astype(np.float32)
+            val = rng.normal(size=len(pos)).astype(np.float32)
+            w = fi.Weights(data_gradient=0.0)
+            f = fi.LatticeField(sizes, dtype="f32" if k % 2 else "f64")
+            f.add_field_constraints(w)
+            f.set_levels(1)
+            if len(sizes) == 3:
+                f.set_polynomial(4)
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+            f.assemble()
+            x, it, rel = f.solve_cg(None, 0, 1e-5)
+            res.append((x.copy(), it))
+            del f
+        out[seed] = res
+
+    serial, parallel = {}, {}
+    for seed in (1, 2):
+        work(seed, serial)
+    threads = [threading.Thread(target=work, args=(seed, parallel)) for seed in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for seed in (1, 2):
+        assert len(parallel[seed]) == len(serial[seed])
+        for a, b in zip(serial[seed], parallel[seed]):
+            assert a[1] == b[1] and np.array_equal(a[0], b[0])
