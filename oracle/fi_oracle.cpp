@@ -1026,6 +1026,79 @@ int fio_solve_pcg(void* h, int ncols, const float* guess, int max_iterations, do
 	return 1;
 }
 
+// The fp64 Jacobi-PCG above on `threads` cores, for golden solutions at the benchmark's own size (tests/golden/
+// make_golden_fullsize.py): the explicit AtA of the reference's rows (sparse_linear.cpp:105-113), fp64 throughout.  AtA is
+// symmetric, so a stored column is also the row: y_j = sum_a val[a] x[idx[a]] is summed by ONE thread in stored order --
+// the iterates do not depend on the thread count; dot products stay serial.  A guess in fp64 (a restart from a stored
+// iterate) and a progress line every `report` iterations.  Test infrastructure only.
+int fio_solve_pcg_f64_mt(void* h, int ncols, const double* guess, int max_iterations, double tol, int threads, int report,
+                         double* out, int* iters, double* err)
+{
+	fio::Normal<double> ne;
+	if (!fio::build_normal<double>(static_cast<Field*>(h)->sys, ncols, false, &ne)) { return 0; }
+#ifdef _OPENMP
+	if (threads > 0) { omp_set_num_threads(threads); }
+#endif
+	const fio::Compressed<double>& M = ne.AtA;
+	const int n = ncols;
+	auto apply = [&](const std::vector<double>& v, std::vector<double>& y) {
+#pragma omp parallel for schedule(static)
+		for (int j = 0; j < n; ++j) {
+			double sum = 0;
+			for (int a = M.ptr[j]; a < M.ptr[j + 1]; ++a) { sum += M.val[a] * v[M.idx[a]]; }
+			y[j] = sum;
+		}
+	};
+	auto dot = [&](const std::vector<double>& a, const std::vector<double>& b) {
+		double sum = 0;
+		for (int i = 0; i < n; ++i) { sum += a[i] * b[i]; }
+		return sum;
+	};
+	const std::vector<double> inv = fio::jacobi_scaling(M);
+	std::vector<double> x(guess, guess + n), r(n), p(n), q(n), z(n);
+	if (max_iterations <= 0) { max_iterations = 2 * n; }
+	apply(x, q);
+	for (int i = 0; i < n; ++i) { r[i] = ne.Atb[i] - q[i]; }
+	const double rhs_sq = dot(ne.Atb, ne.Atb);
+	if (rhs_sq == 0) {
+		std::fill(out, out + n, 0.0);
+		*iters = 0;
+		*err   = 0;
+		return 1;
+	}
+	const double tol2 = tol * tol * rhs_sq;
+	for (int i = 0; i < n; ++i) { z[i] = inv[i] * r[i]; }
+	p = z;
+	double rz = dot(r, z), rr = dot(r, r);
+	int it = 0;
+	while (rr > tol2 && it < max_iterations) {
+		apply(p, q);
+		const double pq = dot(p, q);
+		if (!(pq > 0)) { break; }
+		const double a = rz / pq;
+#pragma omp parallel for schedule(static)
+		for (int i = 0; i < n; ++i) {
+			x[i] += a * p[i];
+			r[i] -= a * q[i];
+			z[i] = inv[i] * r[i];
+		}
+		const double rz_new = dot(r, z);
+		const double b = rz_new / rz;
+		rz = rz_new;
+#pragma omp parallel for schedule(static)
+		for (int i = 0; i < n; ++i) { p[i] = z[i] + b * p[i]; }
+		rr = dot(r, r);
+		++it;
+		if (report > 0 && it % report == 0) {
+			std::fprintf(stderr, "[fio_solve_pcg_f64_mt] %d iterations, relative residual %.3e\n", it, std::sqrt(rr / rhs_sq));
+		}
+	}
+	std::copy(x.begin(), x.end(), out);
+	*iters = it;
+	*err   = std::sqrt(rr / rhs_sq);
+	return 1;
+}
+
 // "Best-effort CPU" figure of SURVEY.md 8(d), NOT the reference's algorithm: Jacobi-PCG on the normal equations
 // without ever forming AtA -- q = A^T (A p) from the compressed rows and columns of the reference's own A
 // (sparse_linear.cpp:59-70 semantics: duplicates summed), fp32 storage, fp64 dot products, OpenMP over rows /
@@ -1194,6 +1267,19 @@ int fio_apply_normal_f64(void* h, int ncols, const double* x, double* y)
 	}
 	std::fill(y, y + ncols, 0.0);
 	for (const auto& e : f->sys.ent) { y[e.col] += static_cast<double>(e.val) * t[e.row]; }
+	return 1;
+}
+
+// y = A^T b in float64 from the rows themselves (sparse_linear.cpp:120 without the compressed matrix).
+int fio_apply_transpose_rhs_f64(void* h, int ncols, double* y)
+{
+	const Field* f = static_cast<Field*>(h);
+	const int nrows = static_cast<int>(f->sys.rhs.size());
+	std::fill(y, y + ncols, 0.0);
+	for (const auto& e : f->sys.ent) {
+		if (e.col < 0 || e.col >= ncols || e.row < 0 || e.row >= nrows) { return 0; }
+		y[e.col] += static_cast<double>(e.val) * static_cast<double>(f->sys.rhs[e.row]);
+	}
 	return 1;
 }
 

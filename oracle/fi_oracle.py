@@ -90,6 +90,7 @@ def lib():
         L.fio_solve_exact_f64.argtypes = [vp, C.c_int, dp]
         L.fio_solve_with_guess.argtypes = [vp, C.c_int, fp, C.c_int, C.c_float, fp, ip, fp]
         L.fio_solve_pcg.argtypes = [vp, C.c_int, fp, C.c_int, C.c_double, C.c_int, dp, ip, dp]
+        L.fio_solve_pcg_f64_mt.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp]
         L.fio_solve_pcg_rows_omp.argtypes = [vp, C.c_int, fp, C.c_int, C.c_double, C.c_int, fp, ip, dp, dp]
         L.fio_jacobi_iterations.argtypes = [vp, C.c_int, fp, C.c_int, C.c_float, fp]
         L.fio_solve_tiled_with_guess.argtypes = [vp, C.c_long, fp, C.c_int, ip, C.POINTER(SolveOptions),
@@ -97,6 +98,7 @@ def lib():
         L.fio_normal_equations_f64.restype = C.c_long
         L.fio_normal_equations_f64.argtypes = [vp, C.c_int, ip, ip, dp, dp, dp]
         L.fio_apply_normal_f64.argtypes = [vp, C.c_int, dp, dp]
+        L.fio_apply_transpose_rhs_f64.argtypes = [vp, C.c_int, dp]
         _LIB = L
     return _LIB
 
@@ -234,6 +236,17 @@ class LatticeField:
                                  C.byref(it), C.byref(err))
         return (out, it.value, err.value) if ok else None
 
+    def solve_pcg_f64_mt(self, guess=None, max_iterations=0, tol=0.0, threads=0, report=0):
+        """The fp64 Jacobi-PCG of solve_pcg on `threads` cores (row gathers over the symmetric AtA: the iterates do not
+        depend on the thread count), fp64 guess: golden solutions at benchmark sizes.  -> (x, iterations, residual)."""
+        n = self.num_unknowns
+        g = np.zeros(n, np.float64) if guess is None else np.ascontiguousarray(guess, np.float64)
+        out = np.empty(n, np.float64)
+        it, err = C.c_int(0), C.c_double(0)
+        ok = lib().fio_solve_pcg_f64_mt(self._h, n, _d(g), max_iterations, tol, threads, report, _d(out),
+                                        C.byref(it), C.byref(err))
+        return (out, it.value, err.value) if ok else None
+
     def solve_pcg_rows_omp(self, guess, max_iterations=0, tol=0.0, threads=0):
         """Jacobi-PCG on A^T(A x) from the compressed rows / columns of A, OpenMP on `threads` cores (0: all): the
         "best-effort CPU" figure of bench.py -- not the reference's algorithm.  Returns (x, iterations, relative
@@ -279,6 +292,15 @@ class LatticeField:
         xx = np.ascontiguousarray(x, np.float64)
         y = np.empty(n, np.float64)
         if not lib().fio_apply_normal_f64(self._h, n, _d(xx), _d(y)):
+            raise ValueError("index out of range")
+        return y
+
+
+    def apply_transpose_rhs(self, ncols=None):
+        """A^T b in float64 from the rows (no compressed matrix)."""
+        n = ncols or self.num_unknowns
+        y = np.empty(n, np.float64)
+        if not lib().fio_apply_transpose_rhs_f64(self._h, n, _d(y)):
             raise ValueError("index out of range")
         return y
 

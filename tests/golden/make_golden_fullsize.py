@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Golden solutions at the BENCHMARK's own sizes, made by the oracle in this (build) container -- VERDICT r3 item 3.
+
+  config 4 at 256^3 (1 M scattered noisy value constraints, model_2 = 0.5: bench.py's default workload, synth.config4 seed 3)
+  config 5's shape (SDF from oriented points, default Weights, synth.config5 seed 4) at the largest side the oracle's
+  Jacobi-PCG finishes in reasonable time (--side5, default 128)
+
+The oracle (oracle/fi_oracle.cpp: the reference's rows -> explicit AtA in fp64, sparse_linear.cpp:105-113) solves
+AtA x = Atb by fp64 Jacobi-PCG (fio_solve_pcg_f64_mt) to a relative residual <= --tol (1e-10); the iterate is re-checked
+through A^T(A x) from the rows themselves (fio_apply_normal_f64).  Stored under tests/golden/: every --stride-th point per
+axis of x (fp64), the whole field's sum, sum of squares and max |x| (a "checksum" of the full solution), iteration count
+and true residual.  The GPU tests (tests/test_gpu_fullsize_golden.py) and bench.py's solution_rel_err compare with the
+sample.  The inputs are NOT stored: field_interpolation_amd/synth.py regenerates them from the seed (counter-based RNG).
+
+Run:  python tests/golden/make_golden_fullsize.py [--which 4,5] [--threads 8]     (minutes to an hour of CPU)
+"""
+import argparse
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import numpy as np                                            # noqa: E402
+from field_interpolation_amd import synth                     # noqa: E402
+from oracle import fi_oracle as fo                            # noqa: E402
+
+
+def sample(x, sizes, stride):
+    g = x.reshape(sizes[::-1])                                # z, y, x (x fastest: field_interpolation.hpp:104-111)
+    sl = tuple(slice(0, None, stride) for _ in sizes)
+    return np.ascontiguousarray(g[sl])
+
+
+def store(name, sizes, x, stride, meta):
+    s = sample(x, sizes, stride)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, sizes=np.asarray(sizes, np.int32), stride=np.int32(stride), sample=s,
+                        field_sum=np.float64(x.sum()), field_sumsq=np.float64((x * x).sum()),
+                        field_maxabs=np.float64(np.abs(x).max()), **meta)
+    print("wrote %s (%d sample values, %d bytes)" % (path, s.size, os.path.getsize(path)), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="4,5")
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--tol", type=float, default=1e-10)
+    ap.add_argument("--side4", type=int, default=256)
+    ap.add_argument("--side5", type=int, default=128)
+    ap.add_argument("--stride", type=int, default=8)
+    ap.add_argument("--max-it", type=int, default=200000)
+    args = ap.parse_args()
+    which = [int(w) for w in args.which.split(",")]
+
+    if 4 in which:
+        side = args.side4
+        npts = int(round(1_000_000 * (side / 256.0) ** 3))
+        sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3)
+        t0 = time.perf_counter()
+        f = fo.LatticeField(sizes)
+        f.add_field_constraints(fo.Weights(model_2=w.model_2))
+        f.add_value_constraints(pos, val, w.data_pos)
+        print("config 4 at %d^3: %d rows, %d triplets (%.0f s)" % (side, f.num_rows, f.num_triplets,
+                                                                    time.perf_counter() - t0), flush=True)
+        x, it, rel = f.solve_pcg_f64_mt(None, args.max_it, args.tol, args.threads, 50)
+        print("  %d iterations, recurrence residual %.3e, %.0f s" % (it, rel, time.perf_counter() - t0), flush=True)
+        atb = f.apply_transpose_rhs()
+        tr = float(np.linalg.norm(atb - f.apply_normal(x)) / np.linalg.norm(atb))
+        print("  true residual through A^T(A x): %.3e" % tr, flush=True)
+        assert tr <= 2 * args.tol
+        store("config4_%d_oracle_f64.npz" % side, sizes, x, args.stride,
+              dict(iterations=np.int32(it), true_rel_residual=np.float64(tr), num_points=np.int32(npts), seed=np.int32(3),
+                   what="config 4 (synth.config4 seed 3), oracle fp64 Jacobi-PCG on the explicit AtA of the reference's rows"))
+        del f, x
+    if 5 in which:
+        side = args.side5
+        npts = int(round(5_000_000 * (side / 512.0) ** 2))
+        sizes, w, pos, nrm = synth.config5(side=side, num_points=npts, seed=4)
+        t0 = time.perf_counter()
+        f = fo.sdf_from_points(sizes, fo.Weights(), pos, nrm)
+        print("config-5 shape at %d^3: %d points, %d rows, %d triplets" % (side, npts, f.num_rows, f.num_triplets), flush=True)
+        x, it, rel = f.solve_pcg_f64_mt(None, args.max_it, args.tol, args.threads, 500)
+        print("  %d iterations, recurrence residual %.3e, %.0f s" % (it, rel, time.perf_counter() - t0), flush=True)
+        atb = f.apply_transpose_rhs()
+        tr = float(np.linalg.norm(atb - f.apply_normal(x)) / np.linalg.norm(atb))
+        print("  true residual through A^T(A x): %.3e" % tr, flush=True)
+        assert tr <= 2 * args.tol
+        store("config5_%d_oracle_f64.npz" % side, sizes, x, max(args.stride // 2, 1),
+              dict(iterations=np.int32(it), true_rel_residual=np.float64(tr), num_points=np.int32(npts), seed=np.int32(4),
+                   what="config 5's shape (synth.config5 seed 4, default Weights), oracle fp64 Jacobi-PCG on the explicit AtA"))
+
+
+if __name__ == "__main__":
+    main()
