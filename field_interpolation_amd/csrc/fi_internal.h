@@ -54,9 +54,11 @@ struct Fail {
 // ---- device buffer --------------------------------------------------------------------------------
 // Device memory of destroyed contexts is kept for the next one (fi_pool.hip): hipMalloc / hipFree synchronise the device
 // and cost 50-500 us per block -- a 256^3 context holds ~60 blocks (first assemble + solve 14 ms against 8 warm, destroy
-// 16-24 ms).  A block enters the pool only while `pool_quiescent` is set: fi_ctx_destroy sets it after a device-wide
-// synchronisation, so nothing in flight can still touch a pooled block; every other release (a buffer that grows, a
-// temporary) is a plain hipFree, as before.  FI_NO_POOL: no pooling (tests).
+// 16-24 ms).  A block enters the pool only while `pool_quiescent` is set: fi_ctx_destroy sets it after synchronising
+// every stream of the context (all work on a context's blocks is enqueued on its own streams; other streams and threads
+// of the device are not stalled), so nothing in flight can still touch a pooled block; every other release (a buffer that
+// grows, a temporary) is a plain hipFree, as before.  An allocation that runs out of memory empties the pool and tries
+// once more.  FI_NO_POOL: no pooling (tests).
 // (`used`: the bytes its last owner asked for -- the 64 bytes behind them are still zero, no kernel ever writes there)
 void*  pool_take(size_t capacity_wanted, size_t* capacity, size_t* used);  // a pooled block of at least / at most twice that capacity, or nullptr
 bool   pool_give(void* p, size_t capacity, size_t used);                   // false: the pool is full or off, the caller frees the block
@@ -90,7 +92,20 @@ struct DevBuf {
 		p = pool_take(nbytes + 64, &cap, &used);
 		if (!p) {
 			cap = nbytes + 64;
-			FI_HIP_TRY(hipMalloc(&p, cap));
+			hipError_t e = hipMalloc(&p, cap);
+			if (e == hipErrorOutOfMemory) {
+				// the pool may be what fills the device (blocks no request of this process fits any more, or memory another
+				// allocator of the process -- torch -- now wants): give everything back and ask once more
+				(void)hipGetLastError();
+				p = nullptr;
+				(void)pool_trim(0);
+				e = hipMalloc(&p, cap);
+			}
+			if (e != hipSuccess) {
+				p   = nullptr;
+				cap = 0;
+				FI_HIP_TRY(e);
+			}
 		}
 		if (used != nbytes) { FI_HIP_TRY(hipMemset(static_cast<char*>(p) + nbytes, 0, 64)); }
 		bytes = nbytes;
@@ -305,11 +320,23 @@ struct fi_ctx {
 	// polynomial in that operator is a convergent smoother of A whatever the data (f = mg_safe)
 	fi::DevBuf dinv16s;
 	bool       dinv16s_valid = false;
+	// The fp32 replica of a mixed-precision context whose data are value rows (fi_solver.hip, twin_assemble_lumped): its
+	// finest level runs on the LUMPED operator A~ = A_model + diag(dlump), dlump = the row sums of the data term (a value row
+	// a >= 0 has a a^T <= (sum a) diag(a): A <= A~, equal to second order on smooth fields).  No rows, no cells, no sort for
+	// the replica's finest level; CG on the exact fp64 operator takes the same number of iterations (tools/proto_lumped.py)
+	bool       lumped = false;
+	fi::DevBuf dlump;   // float[nloc]
 	bool       data_pinned = false;  // (levels of <= 2^16 points, set with dinv16s) every point's data diagonal reaches its model
 	                                 // diagonal: value rows that dense hold every smooth mode, and two sweeps of the polynomial
 	                                 // smoother solve such a coarsest level as well as an exact solve (tools/proto_cc.py)
 	double     mg_safe = 4.0;
 	int        mg_smoother = 1;   // 1: the polynomial in A_model + f diag(A_data) where the marching kernel runs it; 0: Chebyshev in A
+	// Data facts that decide which kernels AND WHICH COLLECTIVES a solve runs -- triplet rows anywhere (any_trip), gradient
+	// rows anywhere (value_rows_only is its negation) -- are agreed over the ranks at the start of fi_assemble (one
+	// all-reduce; a loop-back group decides over its members: facts_forced): a rank whose slab happens to hold no points
+	// would otherwise take another branch than its neighbours (poly_ok, poly_smoother_ok, the deep halo, `beside`)
+	bool       any_trip = false;
+	bool       facts_forced = false, forced_trip = false, forced_grad = false;
 	bool       value_rows_only = false;  // set by fi_assemble (levels and replicas: from the context that holds the points): no
 	                                     // gradient rows.  The polynomial smoother is used for such data only: a gradient row
 	                                     // a (+-w/4 on the cell's corners) makes a a^T large exactly where diag(a_i^2) is not --
@@ -401,6 +428,7 @@ void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 bool stencil_full_epi_available(const fi_ctx* c);
 void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a,
                        double c1, double c2);
+void stencil_lumped_residual(fi_ctx* c, const void* x, const void* b, void* out);  // out = b - (A_model + diag(dlump)) x
 
 // fi_stencil2d.hip: LDS-tiled kernel for 2-D lattices (model_0/1/2), called through the stencil_* entry points
 void tile2d_prepare(fi_ctx* c);

@@ -397,7 +397,7 @@ void safe_scaling_dim(fi_ctx* c)
 		weak = cnt.as<unsigned int>();
 	}
 	hipLaunchKernelGGL((k_safe_scaling<D, T>), dim3(blocks_for(g.nloc)), dim3(kThreads), 0, c->stream, g, mc, c->diag.as<T>(),
-	                   static_cast<T>(c->mg_safe), c->dinv16s.as<unsigned short>(), weak);
+	                   static_cast<T>(c->lumped ? 1.0 : c->mg_safe), c->dinv16s.as<unsigned short>(), weak);  // (lumped: diag - m IS the bound)
 	FI_HIP_TRY(hipGetLastError());
 	c->data_pinned = false;
 	if (weak) {

@@ -1167,7 +1167,7 @@ void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec, int width = 0)  // width pla
 // workgroups -- the caller then exchanges first and applies in one go.
 bool overlap_possible(const fi_ctx* c)
 {
-	return c->nranks > 1 && c->march.valid && c->march.n_inner > 0 && c->generic.ntrip == 0 && c->tile_ts == 0 &&
+	return c->nranks > 1 && c->march.valid && c->march.n_inner > 0 && !c->any_trip && c->generic.ntrip == 0 && c->tile_ts == 0 &&
 	       (c->cells.ncell == 0 || cells_fused(c)) && !test_switch("FI_NO_OVERLAP");
 }
 void exchange_begin(fi_ctx* c, void* v)
@@ -1510,6 +1510,7 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 }
 
 bool poly_ok(const fi_ctx* c);
+void remember_lambda(const fi_ctx* c);
 template <typename T>
 void cg_run_poly(RankSet& R, int max_iterations, float tol);
 template <typename T>
@@ -2335,7 +2336,7 @@ bool poly_smoother_ok(const RankSet& R)
 	for (const fi_ctx* c : R) {
 		// 3-D levels only: the 2-D tile kernel applies its cells in the same single launch, so the Chebyshev smoother in
 		// the full operator costs no more per step there and is the better smoother (config 3: 13 iterations against 38)
-		if (c->mg_smoother != 1 || !c->value_rows_only || !c->march.valid || !stencil_full_epi_available(c) || c->generic.ntrip != 0) {
+		if (c->mg_smoother != 1 || !c->value_rows_only || !c->march.valid || !stencil_full_epi_available(c) || c->generic.ntrip != 0 || c->any_trip) {
 			return false;
 		}
 	}
@@ -2403,9 +2404,18 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		return;
 	}
 	const bool poly = poly_smoother_ok<T>(R);
-	auto residual = [&]() {  // mg_r = b - A x
+	for (const fi_ctx* c : R) {
+		FI_REQUIRE(!c->lumped || poly, FI_ERR_UNSUPPORTED, "a lumped replica smooths with the polynomial only");
+	}
+	auto residual = [&]() {  // mg_r = b - A x (a lumped replica: its own operator, A_model + diag(dlump))
 		halo_exchange(R, x);
-		for (fi_ctx* c : R) { stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, true, c->mg_r.p, 0.0, 0.0, 0.0); }
+		for (fi_ctx* c : R) {
+			if (c->lumped) {
+				stencil_lumped_residual(c, (c->*x).p, (c->*b).p, c->mg_r.p);
+			} else {
+				stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, true, c->mg_r.p, 0.0, 0.0, 0.0);
+			}
+		}
 	};
 	auto post_smooth = [&]() {  // x += M (b - A x)
 		residual();
@@ -2735,7 +2745,10 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			for (fi_ctx* c : top) {
 				for (fi_ctx* l = c; l; l = l->coarse) {
 					if (l->lambda_max > 0) { l->lambda_max *= 1.5; }
-					if (l->poly_lambda > 0) { l->poly_lambda = (l->poly_lambda > 1.0 ? l->poly_lambda : 1.0) * 1.25; }
+					if (l->poly_lambda > 0) {
+						l->poly_lambda = (l->poly_lambda > 1.0 ? l->poly_lambda : 1.0) * 1.25;
+						remember_lambda(l);
+					}
 				}
 			}
 			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), 0); }
@@ -2825,7 +2838,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 
 // the polynomial preconditioner runs through the 3-D marching kernel; contexts it does not cover (1-D / 2-D lattices,
 // model_3 / model_4 / gradient_smoothness, rows given as triplets) keep the Jacobi diagonal
-bool poly_ok(const fi_ctx* c) { return c->poly_terms > 1 && stencil_cheb_available(c) && c->generic.ntrip == 0 && c->tile_ts == 0; }
+bool poly_ok(const fi_ctx* c) { return c->poly_terms > 1 && stencil_cheb_available(c) && c->generic.ntrip == 0 && !c->any_trip && c->tile_ts == 0; }
 
 // ---- CG preconditioned by a Chebyshev polynomial in Dinv (A_model + diag(A_data)) ---------------------------------
 // z = M r,  M = p_d(Dinv A~) Dinv  with  A~ = the model rows + the DIAGONAL of the data rows: symmetric positive definite
@@ -3126,6 +3139,15 @@ LambdaKey lambda_key(const fi_ctx* c)
 }
 std::mutex g_lambda_mutex;
 std::map<LambdaKey, double> g_lambda_cache;
+// a solve that found the bound too small has widened it (done == 2): the process-wide entry follows, so that the next
+// context of this lattice and model does not repeat the breakdown and the restart
+void remember_lambda(const fi_ctx* c)
+{
+	if (test_switch("FI_NO_LAMBDA_CACHE") || test_switch("FI_POLY_LAMBDA_SCALE") || !(c->poly_lambda > 0)) { return; }
+	std::lock_guard<std::mutex> lock(g_lambda_mutex);
+	double& v = g_lambda_cache[lambda_key(c)];
+	if (c->poly_lambda > v) { v = c->poly_lambda; }
+}
 
 template <typename T>
 void estimate_poly_lambda(RankSet& R)
@@ -3435,6 +3457,7 @@ void cg_run_poly(RankSet& R, int max_iterations, float tol)
 			--widenings_left;
 			iter_base += c0->scal_host->iter;
 			for (fi_ctx* c : R) { c->poly_lambda = (c->poly_lambda > 1.0 ? c->poly_lambda : 1.0) * 1.25; }
+			remember_lambda(c0);  // (the next context of this lattice and model starts from the widened bound)
 			set_interval();
 			init.max_iter = max_iterations > iter_base ? max_iterations - iter_base : 1;
 			reset_scalars(R, init);
@@ -4267,7 +4290,8 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		co->comm = tail ? nullptr : c->comm;
 		co->mg_smoother = c->mg_smoother;
 		co->mg_safe     = c->mg_safe;
-		co->value_rows_only = holds_value_rows_only(src);
+		co->value_rows_only = src->value_rows_only;  // (agreed over the ranks: fi_assemble)
+		co->any_trip        = src->any_trip;
 		co->stream = build_stream ? build_stream : c->stream;
 		co->defer_scaling_exchange = build_stream != nullptr;  // a helper thread never talks to the neighbours
 		const float vol = static_cast<float>(1 << D);
@@ -4383,6 +4407,63 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 // In three parts, so that fi_assemble can run the replica's finest level and the replica's coarser levels on two helper
 // threads beside the fp64 finest level: twin_prepare (the context; cheap, on the caller's thread), twin_assemble (rows +
 // finest level on `stream`), build_levels(c->twin, c, stream) and twin_finish.
+// The replica's finest level on the LUMPED operator (fi_ctx::lumped): value rows only, a 3-D lattice the marching kernel
+// covers, the V-cycle with the polynomial smoother.  FI_NO_LUMPED_TWIN: the replica assembles its own cells (tests).
+bool lumped_twin_wanted(const fi_ctx* c)
+{
+	if (test_switch("FI_NO_LUMPED_TWIN") || test_switch("FI_MG_FULL_SMOOTHER") || test_switch("FI_NO_MARCH")) { return false; }
+	const fi_weights& w = c->w;
+	return c->g.ndim == 3 && c->mg_mode == 1 && c->mg_smoother == 1 && c->levels_wanted > 0 && c->value_rows_only &&
+	       c->generic.ntrip == 0 && !c->any_trip && c->g.gn[0] >= 4 && !(w.model_3 > 0 || w.model_4 > 0 || w.gradient_smoothness > 0) &&
+	       (w.model_1 > 0 || w.model_2 > 0);
+}
+
+__global__ __launch_bounds__(kThreads) void k_fill_f64(int64_t n, double v, double* __restrict__ out)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		out[i] = v;
+	}
+}
+// dlump = max(A 1 - D w0^2, 0) (the model_0 rows [w0] are diagonal already and stay with the model part); the replica's
+// `diag` starts as dlump, k_model_diag adds the model diagonal
+__global__ __launch_bounds__(kThreads) void k_lumped_diag(int64_t n, const double* __restrict__ a1, double model0,
+                                                           float* __restrict__ dlump, float* __restrict__ diag)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const double v = a1[i] - model0;
+		const float  f = v > 0.0 ? static_cast<float>(v) : 0.0f;
+		dlump[i] = f;
+		diag[i]  = f;
+	}
+}
+
+// The lumped replica of an ASSEMBLED fp64 context, on the context's stream: row sums of the data term by one apply of the
+// fp64 operator to the vector of ones (every model row of order >= 1 sums to zero), then the replica's diagonal and scalings.
+void twin_assemble_lumped(fi_ctx* c)
+{
+	fi_ctx* t = c->twin;
+	t->stream = c->stream;
+	for (auto* pb : t->pending) { t->pending_pool.push_back(pb); }
+	t->pending.clear();
+	generic_clear(t);
+	assemble(t);  // no rows: atb and diag zeroed, no cells
+	const Geom& g = c->g;
+	t->dlump.alloc(sizeof(float) * g.nloc);
+	FI_HIP_TRY(hipMemsetAsync(t->dlump.p, 0, sizeof(float) * g.nloc, c->stream));
+	ensure_vectors(c);
+	FI_HIP_TRY(hipMemsetAsync(c->scal.p, 0, sizeof(CgScalars), c->stream));  // (the operator kernels exit at once while the stop flag of the last solve is up)
+	hipLaunchKernelGGL(k_fill_f64, dim3(stream_blocks(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc, 1.0, c->p.as<double>());
+	apply_AtA(c, c->p.p, c->q.p, nullptr);
+	const double w0 = c->w.model_0 > 0 ? static_cast<double>(c->w.model_0) : 0.0;
+	hipLaunchKernelGGL(k_lumped_diag, dim3(stream_blocks(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
+	                   c->q.as<double>() + g.own_first, g.ndim * w0 * w0, t->dlump.as<float>() + g.own_first,
+	                   t->diag.as<float>() + g.own_first);
+	FI_HIP_TRY(hipGetLastError());
+	generic_assemble(t);
+	stencil_prepare(t);
+	operator_prepare(t);
+}
+
 fi_ctx* twin_prepare(fi_ctx* c)
 {
 	if (c->level != 0) { return nullptr; }
@@ -4440,13 +4521,20 @@ fi_ctx* twin_prepare(fi_ctx* c)
 	t->min_slab        = c->min_slab;
 	t->poly_terms      = c->poly_terms;   // (the coarse-to-fine start on the replica solves its levels with them)
 	t->poly_ratio      = c->poly_ratio;
-	t->value_rows_only = holds_value_rows_only(c);
+	t->value_rows_only = c->value_rows_only;  // (agreed over the ranks: fi_assemble)
+	t->any_trip        = c->any_trip;
+	t->lumped          = lumped_twin_wanted(c);
 	return t;
 }
 
 void twin_assemble(fi_ctx* c, hipStream_t build_stream)
 {
 	fi_ctx* t = c->twin;
+	if (t->lumped) {  // (fi_assemble's helper threads never get here: the lumped form needs the assembled fp64 operator)
+		FI_REQUIRE(build_stream == nullptr, FI_ERR_STATE, "the lumped replica is built behind the fp64 level");
+		twin_assemble_lumped(c);
+		return;
+	}
 	if (build_stream) {
 		t->stream = build_stream;
 		t->defer_scaling_exchange = true;  // a helper thread never talks to the neighbours
@@ -4589,17 +4677,19 @@ int fi_ctx_destroy(fi_ctx* c)
 {
 	if (!c) { return FI_OK; }
 	(void)hipSetDevice(c->device);
-	if (c->stream) { (void)hipStreamSynchronize(c->stream); }
-	// the context's blocks go to the pool of fi_pool.hip: nothing on the device may still touch them (helper streams,
-	// the group's stream, a caller's stream the vectors were handed to)
+	// The context's blocks go to the pool of fi_pool.hip: nothing in flight may still touch them.  Everything that works on
+	// a context's blocks is enqueued on one of ITS streams (the solver stream -- a group's members share member 0's --, the
+	// helper streams of the assembly, the communication stream): those are drained, level by level as the recursion below
+	// reaches them; the rest of the device (other contexts, torch, other threads) is not stalled.
+	bool drained = true;
+	for (hipStream_t st : {c->stream, c->level_stream, c->level_stream2, c->build_stream, c->comm_stream}) {
+		if (st && hipStreamSynchronize(st) != hipSuccess) { drained = false; }
+	}
 	struct Quiescent {
 		bool was;
-		Quiescent() : was(fi::pool_quiescent)
-		{
-			if (!was) { fi::pool_quiescent = hipDeviceSynchronize() == hipSuccess; }
-		}
+		explicit Quiescent(bool ok) : was(fi::pool_quiescent) { fi::pool_quiescent = ok; }
 		~Quiescent() { fi::pool_quiescent = was; }
-	} quiescent;
+	} quiescent(drained);
 	for (auto* pb : c->pending) { delete pb; }
 	for (auto* pb : c->pending_pool) { delete pb; }
 	for (auto* b : c->batches) { delete b; }
@@ -4858,10 +4948,29 @@ int fi_assemble(fi_ctx* c)
 	// an exchange.  halo (planes stored): the reach, or the polynomial preconditioner's DEEP exchange: 2 (d - 1) planes of
 	// r travel once per polynomial and the steps run redundantly on the shrinking ghost zone (cg_run_poly) instead of one
 	// exchange per step -- 3-D lattices, 3 to 5 terms set before the assemble, slabs at least that thick on every rank.
+	// Data facts every rank must see alike (fi_ctx::any_trip): one all-reduce in front of everything they decide
+	{
+		bool trip = c->generic.ntrip != 0, grad = !fi::holds_value_rows_only(c);
+		if (c->facts_forced) {  // a loop-back group has looked at all its members
+			trip = c->forced_trip;
+			grad = c->forced_grad;
+		} else if (c->nranks > 1 && fi::comm_ready(c)) {
+			double* slot = (c->scal.as<fi::CgScalars>() + 2)->sums;
+			double  v[2] = {trip ? 1.0 : 0.0, grad ? 1.0 : 0.0};
+			FI_HIP_TRY(hipMemcpyAsync(slot, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+			fi::allreduce_sum(c, slot, 2);
+			FI_HIP_TRY(hipMemcpyAsync(v, slot, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+			FI_HIP_TRY(hipStreamSynchronize(c->stream));
+			trip = v[0] > 0.0;
+			grad = v[1] > 0.0;
+		}
+		c->any_trip        = trip;
+		c->value_rows_only = !grad && !trip;
+	}
 	const int reach = fi::model_reach(c->w);
 	const int want_reach = reach > 1 ? reach : 1;
 	int want_halo = want_reach;
-	if (c->nranks > 1 && c->g.ndim == 3 && c->poly_terms >= 3 && c->poly_terms <= 5 && c->generic.ntrip == 0 &&
+	if (c->nranks > 1 && c->g.ndim == 3 && c->poly_terms >= 3 && c->poly_terms <= 5 && !c->any_trip &&
 	    !fi::test_switch("FI_NO_DEEP_HALO")) {
 		const int deep = 2 * (c->poly_terms - 1);
 		const int thinnest = c->g.gn[2] / c->nranks;  // (the equal split: floor(G / n) is the thinnest slab)
@@ -4884,10 +4993,9 @@ int fi_assemble(fi_ctx* c)
 	// for list sizes; 256^3 with one coarser level: 2.05 -> 1.6 ms).  Contexts without triplet rows; the
 	// helper's failure is re-raised here.  The helper does no communication: over slabs the levels' exchange of the
 	// diagonal's ghost planes is done below, by this thread.
-	c->value_rows_only = fi::holds_value_rows_only(c);
 	// Mixed precision: the fp32 replica and ITS levels are the helper's work (the fp64 context keeps no levels of its own).
 	const bool mixed64 = c->mixed && c->dtype == FI_F64;
-	const bool beside = (c->levels_wanted > 0 || mixed64) && c->generic.ntrip == 0 && !fi::test_switch("FI_SERIAL_LEVELS");
+	const bool beside = (c->levels_wanted > 0 || mixed64) && !c->any_trip && !fi::test_switch("FI_SERIAL_LEVELS");
 	if (beside && mixed64) {  // (levels an earlier, unmixed assemble may have left on this context)
 		const int keep = c->levels_wanted;
 		c->levels_wanted = 0;
@@ -4926,9 +5034,12 @@ int fi_assemble(fi_ctx* c)
 				*msg  = "unexpected exception while building the coarser levels";
 			}
 		};
+		const bool lumped = mixed64 && c->twin && c->twin->lumped;
 		auto build = [&]() {
 			guarded([&]() {
-				if (mixed64) {
+				if (lumped) {
+					// (the replica's finest level needs the assembled fp64 operator: built below, by this thread)
+				} else if (mixed64) {
 					fi::twin_assemble(c, c->level_stream);
 				} else {
 					fi::build_levels(c, nullptr, c->level_stream);
@@ -4942,7 +5053,7 @@ int fi_assemble(fi_ctx* c)
 		};
 		std::thread helper, helper2;
 		try {
-			helper = std::thread(build);
+			if (!lumped) { helper = std::thread(build); }
 			if (mixed64) { helper2 = std::thread(build2); }
 		} catch (...) {  // no thread to be had: the levels are built below, after the finest level, on their stream
 		}
@@ -4959,7 +5070,7 @@ int fi_assemble(fi_ctx* c)
 			main_code = FI_ERR_HIP;
 			fi::set_error("unexpected exception while assembling the finest level");
 		}
-		if (helper.joinable()) { helper.join(); } else if (main_code == FI_OK) { build(); }
+		if (helper.joinable()) { helper.join(); } else if (main_code == FI_OK && !lumped) { build(); }
 		if (mixed64) {
 			if (helper2.joinable()) { helper2.join(); } else if (main_code == FI_OK) { build2(); }
 			if (helper_code == FI_OK && helper2_code != FI_OK) {
@@ -4993,6 +5104,10 @@ int fi_assemble(fi_ctx* c)
 		if (mixed64) {
 			FI_HIP_TRY(hipEventRecord(c->ev_level2, c->level_stream2));
 			FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_level2, 0));
+			if (lumped) {
+				c->twin->defer_scaling_exchange = true;  // (its share of the one exchange: operator_finish_ghosts below)
+				fi::twin_assemble_lumped(c);
+			}
 			fi::twin_finish(c);
 		}
 		// slabs: the levels' share of the assembly's one exchange (the diagonal's ghost planes), in level order on every rank
@@ -5328,6 +5443,18 @@ int fi_group_assemble(fi_group* g)
 {
 	FI_API_BEGIN
 	FI_REQUIRE(g != nullptr, FI_ERR_INVALID, "null group");
+	{  // the data facts a real decomposition agrees on by an all-reduce (fi_ctx::any_trip)
+		bool trip = false, grad = false;
+		for (fi_ctx* c : g->members) {
+			trip = trip || c->generic.ntrip != 0;
+			grad = grad || !fi::holds_value_rows_only(c);
+		}
+		for (fi_ctx* c : g->members) {
+			c->facts_forced = true;
+			c->forced_trip  = trip;
+			c->forced_grad  = grad;
+		}
+	}
 	for (fi_ctx* c : g->members) {
 		const int rc = fi_assemble(c);
 		if (rc != FI_OK) { return rc; }

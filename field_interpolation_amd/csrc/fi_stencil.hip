@@ -130,6 +130,9 @@ struct MarchCoef {
 //     mode 2 (every variant; smoother of the V-cycle, fi_solver.hip cheb_smooth): the same recurrence on the FULL
 //       operator, q = A z with the data cells: z_new = a z - c1 z_prev + c2 Dinv (r - q);
 //     mode 3 (every variant): the residual z_new = r - q.
+//     mode 4 (plain variant): the residual of the LUMPED operator A~ = A_model + diag(l), l = the row sums of the data term
+//       (fi_ctx::dlump, passed as z_prev): z_new = r - (A_model z + l z).  The fp32 replica of a mixed-precision context
+//       whose data are value rows runs its finest level on A~ (fi_solver.hip, twin_assemble_lumped): no cell records.
 // The fused (data cell) variant completes a plane one step late and runs its epilogue there; with the operands of the
 // epilogue it is register-allocated for two workgroups per CU (at three it would spill ~190 VGPRs).
 template <typename T>
@@ -609,6 +612,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		if (E.mode == 3) {
 #pragma unroll
 			for (int j = 0; j < VX; ++j) { pz[j] = rv[j] - q[j]; }
+		} else if (E.mode == 4) {  // the residual of the LUMPED operator: z_prev carries the lumped data diagonal
+#pragma unroll
+			for (int j = 0; j < VX; ++j) { pz[j] = rv[j] - (q[j] + zp[j] * zc[j]); }
 		} else {
 #pragma unroll
 			for (int j = 0; j < VX; ++j) { pz[j] = E.a * zc[j] - E.c1 * zp[j] + E.c2 * (dv[j] * (rv[j] - q[j])); }
@@ -1815,6 +1821,16 @@ void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	                 static_cast<float*>(znew), static_cast<float>(a), static_cast<float>(zprev ? c1 : 0.0),
 	                 static_cast<float>(c2), residual ? 3 : 2, 0.0f, 0.0f};
 	march_launch<float>(c, zf, nullptr, nullptr, &E);
+}
+
+// out = b - (A_model x + dlump x): the residual of the lumped operator of a replica without cell records (ChebEpi mode 4)
+void stencil_lumped_residual(fi_ctx* c, const void* x, const void* b, void* out)
+{
+	FI_REQUIRE(c->lumped && c->march.valid && c->dtype == FI_F32 && c->cells.ncell == 0, FI_ERR_UNSUPPORTED,
+	           "no lumped operator on this context");
+	ChebEpi<float> E{c->dlump.as<float>(), static_cast<const float*>(b), c->dinv16.as<unsigned short>(), static_cast<float*>(out),
+	                 0.0f, 0.0f, 0.0f, 4, 0.0f, 0.0f};
+	march_launch_epi<float>(c, static_cast<const float*>(x), E, nullptr);
 }
 
 bool stencil_apply_part(fi_ctx* c, const void* x, void* y, double* partial, int part)

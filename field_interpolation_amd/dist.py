@@ -39,10 +39,35 @@ def point_range(lo, hi, levels=0):
     return lo - 2.0 * cell, hi + (2.0 if levels > 0 else 1.0) * cell
 
 
-def points_of_slab(positions, ndim, lo, hi, levels=0):
+def has_replicated_tail(sizes, nranks, levels, reach=2):
+    """plan_levels of the library (fi_solver.hip): does a hierarchy of `levels` coarser levels over `nranks` slabs end in
+    REPLICATED levels (whole lattices on every rank, once a level's slabs would be thinner than max(reach, 4) planes)?
+    Such levels are assembled from ALL the points: fi_slab_point_range then returns everything."""
+    if nranks <= 1 or levels <= 0:
+        return False
+    n = [int(s) for s in sizes]
+    planes = n[-1]
+    lo = [(r * planes) // nranks for r in range(nranks)]
+    hi = [((r + 1) * planes) // nranks for r in range(nranks)]
+    for _ in range(int(levels)):
+        n = [(s + 1) // 2 for s in n]
+        if min(n) < 8:
+            return False
+        lo = [(v + 1) // 2 for v in lo]
+        hi = [(v + 1) // 2 for v in hi]
+        if min(h - l for l, h in zip(lo, hi)) < max(reach, 4):
+            return True
+    return False
+
+
+def points_of_slab(positions, ndim, lo, hi, levels=0, sizes=None, nranks=1, reach=2):
     """Boolean mask of the points a rank owning planes [lo, hi) of the slowest axis has to upload, for a context
-    with `levels` coarser levels (FI_OPT_LEVELS)."""
+    with `levels` coarser levels (FI_OPT_LEVELS).  With `sizes` and `nranks` the replicated tail of the hierarchy is
+    honoured like fi_slab_point_range does: every point when the deepest levels are whole lattices on every rank.
+    (LatticeField.point_range() asks the library itself and is the rule to prefer.)"""
     z = np.asarray(positions, np.float32).reshape(-1, ndim)[:, ndim - 1]
+    if sizes is not None and has_replicated_tail(sizes, nranks, levels, reach):
+        return np.ones(len(z), bool)
     zlo, zhi = point_range(lo, hi, levels)
     return (z >= zlo) & (z < zhi)
 

@@ -196,3 +196,22 @@ def test_points_of_slab_covers_the_cells_of_every_coarse_level():
             total = sum(int(fdist.points_of_slab(pos, 3, *fdist.slab_range(planes, r, nranks), levels).sum())
                         for r in range(nranks))
             assert total <= len(pos) * (1.0 + 4.0 * nranks * 2.0 ** levels / planes) + 1
+
+
+def test_replicated_tail_rule_of_the_point_filter():
+    """dist.points_of_slab mirrors fi_slab_point_range: once the deepest levels of a slab hierarchy are replicated (whole
+    lattices on every rank) every rank has to upload every point.  (The library's own answer is compared with this rule
+    on the GPU: tests/test_gpu_slabs.py.)"""
+    from field_interpolation_amd import dist as fdist
+    pos = np.random.default_rng(0).uniform(0, 63, size=(500, 3)).astype(np.float32)
+    # 64 planes over 4 ranks: level 1 -> 8 planes per slab, level 2 -> 4, level 3 -> 2 < 4: replicated from level 3 on
+    assert not fdist.has_replicated_tail([64, 64, 64], 4, 2)
+    assert fdist.has_replicated_tail([64, 64, 64], 4, 3)
+    assert not fdist.has_replicated_tail([64, 64, 64], 1, 3)
+    assert not fdist.has_replicated_tail([64, 64, 64], 8, 0)
+    lo, hi = fdist.slab_range(64, 1, 4)
+    part = fdist.points_of_slab(pos, 3, lo, hi, 2, sizes=[64, 64, 64], nranks=4)
+    assert 0 < part.sum() < len(pos)
+    assert fdist.points_of_slab(pos, 3, lo, hi, 3, sizes=[64, 64, 64], nranks=4).all()
+    # levels that do not exist (an axis below 8 points) cannot be replicated
+    assert not fdist.has_replicated_tail([16, 16, 16], 2, 5)

@@ -355,3 +355,50 @@ def test_level_chains_in_parallel_same_bits(fi, monkeypatch, mixed):
     monkeypatch.delenv("FI_SERIAL_LEVEL_CHAINS", raising=False)
     for a, b in zip(sols[False], sols[True]):
         assert a[1] == b[1] and np.array_equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("sizes,n", [([40, 36, 44], 3000), ([33, 30, 35], 20000)])
+def test_lumped_replica_of_value_row_data(oracle, fi, monkeypatch, sizes, n):
+    """Mixed precision on value rows: the fp32 replica's finest level runs on the LUMPED operator A_model + diag(row sums of
+    the data term) -- no rows, cells or sort for it (fi_solver.hip, twin_assemble_lumped) -- while CG itself iterates on the
+    exact fp64 operator.  Same solution as the oracle's, about the iterations of the replica that assembles its own cells
+    (FI_NO_LUMPED_TWIN), sparse data and dense (several rows per cell); a re-assemble with other points follows."""
+    rng = np.random.default_rng(31)
+    w = fi.Weights(model_2=0.5)
+    pos = np.stack([rng.uniform(-0.5, s - 0.5, n) for s in sizes], axis=1).astype(np.float32)
+    val = (np.sin(pos[:, 0] * 0.3) + 0.1 * rng.normal(size=n)).astype(np.float32)
+    fo = oracle.LatticeField(sizes)
+    fo.add_field_constraints(oracle.Weights(model_2=0.5))
+    fo.add_value_constraints(pos, val, w.data_pos)
+    x_ref = fo.solve_exact_f64() if int(np.prod(sizes)) <= 40000 else None
+    its = {}
+    for lumped in (True, False):
+        if lumped:
+            monkeypatch.delenv("FI_NO_LUMPED_TWIN", raising=False)
+        else:
+            monkeypatch.setenv("FI_NO_LUMPED_TWIN", "1")
+        f = fi.LatticeField(sizes, dtype="f64")
+        f.add_field_constraints(w)
+        f.set_levels(2, 1e-5)
+        f.set_multigrid(True)
+        f.set_mixed_precision(True)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-9)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.01e-9
+        its[lumped] = it
+        sol = f.solution_f64()
+        if x_ref is not None:
+            assert rel_inf(sol, x_ref) <= 1e-6
+        else:
+            AtA, atb, _ = fo.normal_equations()
+            assert np.linalg.norm(atb - AtA @ sol) <= 2e-9 * np.linalg.norm(atb)
+        if lumped:      # other points on the same context: the replica follows
+            pos2 = pos[: n // 2] + np.float32(0.25)
+            f.clear_points()
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos2, None, None, values=val[: n // 2])
+            f.assemble()
+            x2, it2, rel2 = f.solve_cg(None, 0, 1e-9)
+            assert f.stats()["converged"] == 1 and f.true_residual() <= 1.01e-9 and it2 <= 2 * it + 4
+    monkeypatch.delenv("FI_NO_LUMPED_TWIN", raising=False)
+    assert its[True] <= its[False] + max(3, its[False] // 3), its

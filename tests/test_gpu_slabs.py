@@ -231,3 +231,22 @@ def test_replicated_tail_of_a_slab_hierarchy(fi, monkeypatch, dtype, mixed):
     assert rc <= tol and itc > itg + itg // 2, (itc, itg)
     lo, hi = cut.members[3].point_range()
     assert -100 < lo < hi < 200
+
+
+@pytest.mark.parametrize("sizes,nranks", [([64, 64, 64], 4), ([64, 64, 64], 8), ([48, 40, 96], 3), ([32, 32, 32], 2)])
+def test_python_point_filter_follows_the_library_rule(fi, sizes, nranks):
+    """dist.points_of_slab must keep every point once the hierarchy ends in replicated levels, as
+    fi_slab_point_range does -- compared level count by level count with the library's own answer."""
+    from field_interpolation_amd import dist as fdist
+    for levels in range(0, 5):
+        grp = fi.LatticeGroup(sizes, nranks, dtype="f32")
+        grp.add_field_constraints(fi.Weights())
+        grp.set_levels(levels, 1e-4)
+        lo, hi = grp.members[nranks - 1].point_range()
+        everything = lo < -1e30 and hi > 1e30
+        assert everything == fdist.has_replicated_tail(sizes, nranks, levels), (sizes, nranks, levels, lo, hi)
+        if not everything:
+            sl = fdist.slab_range(sizes[2], nranks - 1, nranks)
+            plo, phi = fdist.point_range(sl[0], sl[1], levels)
+            assert plo <= lo + 1e-3 and phi >= hi - 1e-3      # the Python margin covers the library's
+        del grp

@@ -91,6 +91,21 @@ def test_four_processes_with_a_replicated_tail():
         assert res["max_diff"] <= (5e-2 if res["tol"] >= 1e-6 else 1e-4), res
 
 
+def test_a_rank_without_points_runs_the_same_collectives():
+    """the data facts that choose kernels and collectives (gradient rows, triplet rows) are agreed over the ranks
+    at the start of fi_assemble.  Rank 1 receives ZERO points here; without the agreement it would pick the polynomial
+    smoother / the polynomial PCG / the deep halo while rank 0 does not, and the run would hang or diverge."""
+    results = _worker_results(FI_WORKER_CASES="lopsided")
+    assert len(results) == 4
+    for res in results:
+        it = res["iterations"]
+        assert res["points_kept"][1] == 0 and res["points_kept"][0] == res["points"], res
+        assert it[0] == it[1], res
+        assert abs(it[0] - res["iterations_one"]) <= max(3, res["iterations_one"] // 10), res
+        assert max(res["rel"]) <= res["tol"] and max(res["true_rel"]) <= 1.5 * res["tol"], res
+        assert res["max_diff"] <= (5e-2 if res["tol"] >= 1e-6 else 1e-4), res
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_on_one_gpu(scaling):
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--side", "64", "--cpu-side", "0",

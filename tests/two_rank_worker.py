@@ -90,6 +90,31 @@ if os.environ.get("FI_WORKER_CASES") == "tail":
         print("RESULTS " + json.dumps(results), flush=True)
     dist.destroy_process_group()
     sys.exit(0)
+if os.environ.get("FI_WORKER_CASES") == "lopsided":
+    # ALL the data sit in rank 0's half: rank 1 is handed zero points.  What a rank holds must not decide which collectives
+    # it runs (fi_assemble agrees on the data facts first): oriented points (gradient rows -> the Chebyshev smoother in A
+    # on every rank), the kLinearInterpolation gradient kernel (triplet rows -> no polynomial, no deep halo on any rank),
+    # and value rows through the lumped replica of the mixed-precision solve.
+    rng = np.random.default_rng(11)
+    sizes = [32, 32, 64]
+    d = rng.normal(size=(1500, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    lpos = (np.array([15.5, 15.5, 10.0]) + 6.0 * d + rng.normal(scale=0.2, size=d.shape)).astype(np.float32)
+    lnrm = d.astype(np.float32)
+    lval = rng.normal(size=len(lpos)).astype(np.float32)
+    results.append(run("lopsided SDF, V-cycle PCG f64 mixed (2 levels)", sizes, fi.Weights(), lpos, lnrm, None, "f64", 1e-8, levels=2,
+                       multigrid=True, mixed=True))
+    wl = fi.Weights(gradient_kernel=fi.GradientKernel.kLinearInterpolation)
+    results.append(run("lopsided, gradient kLinearInterpolation, polynomial asked for, f32", sizes, wl, lpos, lnrm, None, "f32", 1e-5,
+                       levels=1, poly=4))
+    results.append(run("lopsided value rows, V-cycle PCG f64 mixed (lumped replica)", sizes, fi.Weights(), lpos, None, lval, "f64", 1e-8,
+                       levels=2, multigrid=True, mixed=True))
+    results.append(run("lopsided value rows, cascade + polynomial PCG f32", sizes, fi.Weights(), lpos, None, lval, "f32", 1e-5, levels=1,
+                       poly=4))
+    if rank == 0:
+        print("RESULTS " + json.dumps(results), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0)
 sizes, w, pos, val = synth.config4(side=48, num_points=6591, seed=3)
 results.append(run("config4 48^3 cascade(2 levels) + polynomial PCG f32", sizes, w, pos, None, val, "f32", 1e-5, levels=2, poly=4))
 results.append(run("config4 48^3 Jacobi-PCG f64", sizes, w, pos, None, val, "f64", 1e-9))
