@@ -15,7 +15,7 @@ ERR_NAMES = {1: "FI_ERR_INVALID", 2: "FI_ERR_HIP", 3: "FI_ERR_STATE", 4: "FI_ERR
 # every symbol include/fi_hip.h declares
 SYMBOLS = [
     "fi_last_error", "fi_device_count", "fi_ctx_create", "fi_ctx_create_slab", "fi_ctx_destroy",
-    "fi_slab_range", "fi_slab_point_range", "fi_slab_partition", "fi_halo_width", "fi_comm_unique_id", "fi_comm_init", "fi_comm_init_host", "fi_comm_self_test", "fi_set_model", "fi_add_points", "fi_add_border_prior",
+    "fi_slab_range", "fi_slab_point_range", "fi_slab_partition", "fi_halo_width", "fi_comm_unique_id", "fi_comm_init", "fi_comm_init_host", "fi_comm_info", "fi_comm_self_test", "fi_set_model", "fi_add_points", "fi_add_border_prior",
     "fi_add_rows_coo", "fi_assemble", "fi_clear_points", "fi_set_option", "fi_solve_cg", "fi_jacobi", "fi_tile_pass", "fi_error_map",
     "fi_get_solution_f64", "fi_true_residual", "fi_apply_AtA_f64", "fi_get_Atb_f64", "fi_get_diag_f64",
     "fi_get_stats", "fi_memory_pool", "fi_time_apply", "fi_upscale_field",
@@ -80,6 +80,7 @@ def lib():
     L.fi_halo_width.argtypes = [C.POINTER(FiWeights), ip]
     L.fi_comm_unique_id.argtypes = [vp]
     L.fi_comm_init.argtypes = [vp, vp]
+    L.fi_comm_info.argtypes = [vp, C.POINTER(C.c_long)]
     L.fi_comm_init_host.argtypes = [vp, C.c_char_p, C.c_int]
     L.fi_set_model.argtypes = [vp, C.POINTER(FiWeights)]
     L.fi_add_points.argtypes = [vp, C.c_long, fp, fp, fp, fp, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int]

@@ -227,6 +227,15 @@ class LatticeField:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(_capi.lib().fi_comm_init(self._h, buf))
 
+    def comm_info(self):
+        """fi_comm_info: what the slab transport looks like from inside -- the ranks RCCL itself counts (ncclCommCount), this
+        rank's index and device there, the kind of transport, ghost planes per exchange and their bytes."""
+        out = (C.c_long * 7)()
+        check(_capi.lib().fi_comm_info(self._h, out))
+        kind = {0: "none", 1: "rccl", 2: "host-staged test transport"}.get(out[3], "?")
+        return {"ranks": out[0], "rank": out[1], "device": out[2], "transport": kind, "halo_planes": out[4],
+                "halo_planes_stored": out[5], "plane_bytes": out[6], "halo_bytes_per_exchange": out[4] * out[6]}
+
     def comm_init_host(self, name, create):
         """fi_comm_init_host: the host-staged TEST transport for ranks that share one GPU."""
         check(_capi.lib().fi_comm_init_host(self._h, name.encode(), 1 if create else 0))

@@ -69,6 +69,10 @@ struct Rccl {
 	ncclResult_t (*GroupStart)() = nullptr;
 	ncclResult_t (*GroupEnd)() = nullptr;
 	const char* (*GetErrorString)(ncclResult_t) = nullptr;
+	// diagnostics (fi_comm_info): optional -- a library without them reports -1
+	ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+	ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+	ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 Rccl& rccl()
@@ -97,6 +101,9 @@ Rccl& rccl()
 	t.GroupStart     = reinterpret_cast<decltype(t.GroupStart)>(sym("ncclGroupStart"));
 	t.GroupEnd       = reinterpret_cast<decltype(t.GroupEnd)>(sym("ncclGroupEnd"));
 	t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(sym("ncclGetErrorString"));
+	t.CommCount      = reinterpret_cast<decltype(t.CommCount)>(dlsym(t.handle, "ncclCommCount"));
+	t.CommUserRank   = reinterpret_cast<decltype(t.CommUserRank)>(dlsym(t.handle, "ncclCommUserRank"));
+	t.CommCuDevice   = reinterpret_cast<decltype(t.CommCuDevice)>(dlsym(t.handle, "ncclCommCuDevice"));
 	r = t;
 	return r;
 }
@@ -399,6 +406,36 @@ int fi_comm_init(fi_ctx* c, const void* unique_id128)
 			c->comm->comm = nullptr;
 		}
 		FI_NCCL_TRY(fi::rccl().CommInitRank(&c->comm->comm, c->nranks, id, c->rank));
+	} catch (const fi::Fail& f) {
+		return f.code;
+	}
+	return FI_OK;
+}
+
+int fi_comm_info(const fi_ctx* c, long out[7])
+{
+	try {
+		FI_REQUIRE(c != nullptr && out != nullptr, FI_ERR_INVALID, "null argument");
+		for (int i = 0; i < 7; ++i) { out[i] = 0; }
+		out[4] = c->nranks > 1 ? c->reach : 0;
+		out[5] = c->nranks > 1 ? c->halo : 0;
+		int64_t plane = 1;
+		for (int d = 0; d + 1 < c->g.ndim; ++d) { plane *= c->g.gn[d]; }
+		out[6] = static_cast<long>(plane * (c->dtype == FI_F64 ? 8 : 4));
+		if (!c->comm) { return FI_OK; }
+		if (c->comm->comm) {
+			fi::Rccl& r = fi::rccl();
+			int v = -1;
+			out[0] = (r.CommCount && r.CommCount(c->comm->comm, &v) == ncclSuccess) ? v : -1;
+			out[1] = (r.CommUserRank && r.CommUserRank(c->comm->comm, &v) == ncclSuccess) ? v : -1;
+			out[2] = (r.CommCuDevice && r.CommCuDevice(c->comm->comm, &v) == ncclSuccess) ? v : -1;
+			out[3] = 1;
+		} else if (c->comm->host) {
+			out[0] = c->nranks;
+			out[1] = c->rank;
+			out[2] = c->device;
+			out[3] = 2;
+		}
 	} catch (const fi::Fail& f) {
 		return f.code;
 	}

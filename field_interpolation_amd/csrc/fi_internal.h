@@ -385,6 +385,10 @@ struct fi_ctx {
 	fi_stats   stats{};
 	std::vector<hipEvent_t> ev;       // sampled events around AtA applies
 	std::vector<hipEvent_t> ev_prec;  // ... around Chebyshev steps of the polynomial preconditioner
+	// V-cycle PCG: the finest level's pre-smoothing chains (the polynomial's launches from zero) are timed for the first
+	// prec_budget cycles of a solve; prec_taken pairs of ev_prec are valid, prec_chain_bytes = algorithmic bytes of one chain
+	int        prec_budget = 0, prec_taken = 0, prec_chain_launches = 0;
+	double     prec_chain_bytes = 0;
 };
 
 namespace fi {

@@ -2345,7 +2345,7 @@ bool poly_smoother_ok(const RankSet& R)
 
 // z = M r through the work vectors za / zb; returns the one that holds the result (ghost planes not exchanged)
 template <typename T>
-Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb)
+Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr, int* chain_launches = nullptr)
 {
 	fi_ctx* c0 = R[0];
 	const int    terms = mg_poly_terms();
@@ -2364,6 +2364,14 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb)
 			                   static_cast<T>(1.0 / theta));
 		}
 	}
+	if (chain_bytes) {  // z, z_prev, r in, z_new out + the bfloat16 scaling; the first step has no z_prev (formed on load: no z
+		*chain_bytes = 0;   // either), the second recomputes its z_prev from r: 2.5 / 3.5 / 4.5 lattice passes in fp32
+		for (int j = 1; j < terms; ++j) {
+			const double vecs = j == 1 ? (pro ? 2.0 : 3.0) : (j == 2 ? 3.0 : 4.0);
+			*chain_bytes += (static_cast<double>(sizeof(T)) * vecs + 2.0) * static_cast<double>(c0->g.nown);
+		}
+	}
+	if (chain_launches) { *chain_launches = terms - 1; }
 	Vec zin = za, zout = zb;
 	double rho = 1.0 / sigma;
 	for (int k = 1; k < terms; ++k) {
@@ -2443,7 +2451,18 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	// the parts are summed over the ranks (the one collective of the tail), the interpolation needs no exchange
 	const bool junction = Rc[0]->replicated && !R[0]->replicated && R[0]->nranks > 1;
 	if (poly) {
-		swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d));  // x = M b
+		// x = M b.  The finest level's chain is timed for the first cycles of a solve (cg_run_mg sets the budget): all its
+		// launches between one pair of event records, like the polynomial PCG's samples
+		fi_ctx* c0 = R[0];
+		const bool sample = c0->level == 0 && c0->prec_budget > 0 && static_cast<int>(c0->ev_prec.size()) >= 2 * (c0->prec_taken + 1);
+		if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev_prec[2 * c0->prec_taken], c0->stream)); }
+		swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d, sample ? &c0->prec_chain_bytes : nullptr,
+		                                 sample ? &c0->prec_chain_launches : nullptr));
+		if (sample) {
+			FI_HIP_TRY(hipEventRecord(c0->ev_prec[2 * c0->prec_taken + 1], c0->stream));
+			++c0->prec_taken;
+			--c0->prec_budget;
+		}
 		residual();
 		halo_exchange(R, &fi_ctx::mg_r);
 		for (size_t i = 0; i < R.size(); ++i) {
@@ -2662,6 +2681,16 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	}
 	int samples = 0;
 	const bool mixed = !Tw.empty();
+	fi_ctx* const prec_ctx = mixed ? Tw[0] : c0;  // the context whose finest-level smoother chains are timed (vcycle)
+	if (prec_ctx->level == 0 && !(mixed ? replicated_copies(Tw) : replicated_copies(R))) {
+		while (static_cast<int>(prec_ctx->ev_prec.size()) < 2 * kPolySamples) {
+			hipEvent_t e;
+			FI_HIP_TRY(hipEventCreate(&e));
+			prec_ctx->ev_prec.push_back(e);
+		}
+		prec_ctx->prec_budget = kPolySamples;
+		prec_ctx->prec_taken  = 0;
+	}
 	auto dot = [&](Vec a, Vec b) {
 		for (fi_ctx* c : R) {
 			hipLaunchKernelGGL((k_dot<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, a), vown<T>(c, b),
@@ -2814,13 +2843,28 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		FI_HIP_TRY(hipEventElapsedTime(&t, c0->ev[2 * k], c0->ev[2 * k + 1]));
 		sum_ms += t;
 	}
+	// the timed smoother chains of cycles that ran (cycle k belongs to iteration k: the first one to the start)
+	int pused = 0, plaunch = 0;
+	double psum = 0;
+	prec_ctx->prec_budget = 0;
+	if (prec_ctx->level == 0) {
+		const int ran = prec_ctx->prec_taken < h.iter + 1 ? prec_ctx->prec_taken : h.iter + 1;
+		for (int k = 0; k < ran; ++k) {
+			float t = 0;
+			FI_HIP_TRY(hipEventElapsedTime(&t, prec_ctx->ev_prec[2 * k], prec_ctx->ev_prec[2 * k + 1]));
+			psum += t;
+			++pused;
+		}
+		plaunch = prec_ctx->prec_chain_launches;
+	}
 	for (fi_ctx* c : R) {
 		c->stats.spmv_samples = used;
 		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
 		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
-		c->stats.prec_samples = 0;
-		c->stats.prec_ms_avg  = 0.0;
-		c->stats.prec_bytes   = 0.0;
+		// per LAUNCH, like the polynomial PCG's figures: a sample holds the launches of one chain
+		c->stats.prec_samples = pused * plaunch;
+		c->stats.prec_ms_avg  = pused && plaunch ? psum / (pused * plaunch) : 0.0;
+		c->stats.prec_bytes   = pused && plaunch ? prec_ctx->prec_chain_bytes / plaunch : 0.0;
 		c->stats.operator_applies = h.iter + 1 + h.restarts;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;

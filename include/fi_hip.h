@@ -143,6 +143,13 @@ int fi_comm_self_test(int device, long count);
  * fi_comm_init.  Halo planes of the CG search direction and the dot products then travel over xGMI. */
 int fi_comm_unique_id(void* out128);
 int fi_comm_init(fi_ctx* ctx, const void* unique_id128);
+/* What the transport of a slab context looks like from the inside (a bench line can then show that RCCL really carried N
+ * ranks): out[0] = ranks the communicator counts (ncclCommCount; the test transport: its segment's; 0: no transport),
+ * out[1] = this rank's index in it (ncclCommUserRank), out[2] = the HIP device the communicator is bound to
+ * (ncclCommCuDevice), out[3] = 1 RCCL / 2 host-staged test transport / 0 none, out[4] = ghost planes one exchange moves
+ * to each neighbour (the stencil reach), out[5] = ghost planes stored (the polynomial's deep exchange moves that many
+ * once per polynomial), out[6] = bytes of one lattice plane in the context's precision. */
+int fi_comm_info(const fi_ctx* ctx, long out[7]);
 /* TEST transport for ranks that share one GPU (RCCL refuses two ranks on one device): the halo planes and the dot
  * products travel through the POSIX shared-memory segment `name` ("/...") by host copies, behind the same two internal
  * operations (exchange_halo, allreduce_sum) the RCCL path implements.  Rank 0 passes create = 1 BEFORE the other ranks

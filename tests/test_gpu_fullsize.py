@@ -211,8 +211,8 @@ def test_config5_over_eight_slabs_keeps_all_levels(fi):
 
 def test_bench_line_contract_single_gpu():
     """The one JSON line of bench.py at N = 1 (a reduced lattice so that the CPU baseline takes seconds): every field of
-    the measurement contract, `roofline` and `cpu_baseline` objects included, the accurate leg within the field tolerance
-    and the cold figures."""
+    the measurement contract, the `roofline*` and `cpu_baseline` objects included; the headline is the solver that meets
+    the field tolerance (fp64 CG + fp32 V-cycle), the fp32 residual-1e-5 mode sits in `fast`; and the cold figures."""
     import json
     import os
     import subprocess
@@ -228,7 +228,8 @@ def test_bench_line_contract_single_gpu():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["unit"] == "lattice points/s"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "lattice points/s"
+    assert d["scaling"] == "strong"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 96 ** 3 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     rf = d["roofline"]
@@ -240,6 +241,13 @@ def test_bench_line_contract_single_gpu():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
-    assert d["config"]["true_rel_residual"] <= 1.5e-5
-    assert d["accurate"]["solution_rel_err"] <= 1e-5 and d["accurate"]["value"] > 0
+    for name in ("roofline_apply", "roofline_assembly"):
+        assert d[name]["bound"] == "hbm" and 0 < d[name]["frac"] < 1 and d[name]["algorithmic_bytes"] > 0, name
+    assert "double" in d["roofline_apply"]["kernel"]
+    assert d["config"]["true_rel_residual"] <= 1.01 * 1e-7 and "V-cycle PCG" in d["config"]["solver"]
+    # the headline meets the north-star's field tolerance (here against an fp64 GPU solve: the oracle's committed sample
+    # covers 256^3 -- tests/test_gpu_fullsize_golden.py), the fast mode does not claim to
+    assert d["solution_rel_err"] <= 1e-5 and d["config"]["field_tolerance_met"] is True
+    assert d["fast"]["dtype"] == "f32" and d["fast"]["value"] > d["value"] and d["fast"]["true_rel_residual"] <= 1.5e-5
+    assert d["fast"]["solution_rel_err"] > d["solution_rel_err"]
     assert d["cold_ms_per_step"] > 0 and d["cold_pooled_ms_per_step"] > 0

@@ -114,7 +114,12 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == scaling
     assert line["config"]["parallelism"] == "slab2"
-    assert line["config"]["true_rel_residual"] <= 1.5e-5
+    # the headline solver over two slabs: fp64 CG + fp32 V-cycle (the lumped replica, levels over slabs), to 1e-7
+    assert line["dtype"] == "f64" and "V-cycle PCG" in line["config"]["solver"]
+    assert line["config"]["true_rel_residual"] <= 1.5e-7
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["transport"].startswith("host-staged")
+    assert sorted(r[1] for r in line["config"]["ranks_seen_by_rccl"]) == [0, 1]
+    assert line["config"]["halo_bytes_per_exchange_and_neighbour"] == 2 * 64 * 64 * 8
     assert ("64x64x128" if scaling == "weak" else "64x64x64") in line["config"]["workload"]
     assert line["value"] > 0
 
@@ -122,8 +127,8 @@ def test_bench_two_ranks_on_one_gpu(scaling):
 def test_bench_four_ranks_strong_scaling_on_one_gpu():
     """bench.py --gpus 4 in its default form (strong: the configuration's own lattice split 4 ways, 16 planes of a 64^3
     lattice per rank, one coarser level of 8 planes per rank) through the real orchestration."""
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--side", "64", "--cpu-side", "0"],
-                  nproc=4)
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--side", "64", "--cpu-side", "0",
+                   "--fast"], nproc=4)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["config"]["parallelism"] == "slab4"
