@@ -304,12 +304,17 @@ class LatticeField:
         if ratio is not None:
             check(_capi.lib().fi_set_option(self._h, 7, float(ratio)))
 
-    def set_mg_smoother(self, polynomial=True, safe_factor=None):
-        """FI_OPT_MG_SMOOTHER / FI_OPT_MG_SAFE_FACTOR: the V-cycle's smoother on fp32 3-D levels -- the polynomial in
-        A_model + f diag(A_data) (default) or the Chebyshev polynomial in the full operator."""
+    def set_mg_smoother(self, polynomial=True, safe_factor=None, terms=None, ratio=None):
+        """FI_OPT_MG_SMOOTHER / FI_OPT_MG_SAFE_FACTOR / FI_OPT_MG_TERMS / FI_OPT_MG_RATIO: the V-cycle's smoother on fp32 3-D
+        levels -- the polynomial in A_model + f diag(A_data) (default; `terms` terms over [hi / ratio, hi]) or the Chebyshev
+        polynomial in the full operator."""
         check(_capi.lib().fi_set_option(self._h, 8, 1.0 if polynomial else 0.0))
         if safe_factor is not None:
             check(_capi.lib().fi_set_option(self._h, 9, float(safe_factor)))
+        if terms is not None:
+            check(_capi.lib().fi_set_option(self._h, 10, float(terms)))
+        if ratio is not None:
+            check(_capi.lib().fi_set_option(self._h, 11, float(ratio)))
         self._dirty = True
 
     def jacobi(self, guess, num_iterations, weight):
@@ -431,9 +436,9 @@ class LatticeGroup:
         for m in self.members:
             m.set_polynomial(terms, ratio)
 
-    def set_mg_smoother(self, polynomial=True, safe_factor=None):
+    def set_mg_smoother(self, polynomial=True, safe_factor=None, terms=None, ratio=None):
         for m in self.members:
-            m.set_mg_smoother(polynomial, safe_factor)
+            m.set_mg_smoother(polynomial, safe_factor, terms, ratio)
 
     def assemble(self):
         check(_capi.lib().fi_group_assemble(self._g))

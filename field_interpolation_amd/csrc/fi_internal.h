@@ -330,6 +330,8 @@ struct fi_ctx {
 	                                 // diagonal: value rows that dense hold every smooth mode, and two sweeps of the polynomial
 	                                 // smoother solve such a coarsest level as well as an exact solve (tools/proto_cc.py)
 	double     mg_safe = 4.0;
+	int        mg_terms = 5;      // the polynomial smoother: terms and interval ratio (FI_OPT_MG_TERMS / FI_OPT_MG_RATIO)
+	double     mg_pratio = 30.0;
 	int        mg_smoother = 1;   // 1: the polynomial in A_model + f diag(A_data) where the marching kernel runs it; 0: Chebyshev in A
 	// Data facts that decide which kernels AND WHICH COLLECTIVES a solve runs -- triplet rows anywhere (any_trip), gradient
 	// rows anywhere (value_rows_only is its negation) -- are agreed over the ranks at the start of fi_assemble (one

@@ -2328,7 +2328,8 @@ void cheb_smooth(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_z
 //     pre  (from zero):  x = M b                                   d - 1 plain launches of (2.5 .. 4.5) lattice passes
 //     post:              x += M (b - A x)                          one full apply with the residual epilogue + the same
 // against 2 d launches of the fused (data-cell) kernel with the epilogue for the Chebyshev smoother in A itself.
-int    mg_poly_terms() { const char* e = tuning_switch("FI_MG_TERMS"); return e && atoi(e) > 0 ? atoi(e) : 4; }
+int    mg_poly_terms(const fi_ctx* c) { const char* e = tuning_switch("FI_MG_TERMS"); return e && atoi(e) > 0 ? atoi(e) : c->mg_terms; }
+double mg_poly_ratio(const fi_ctx* c) { const char* e = tuning_switch("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : c->mg_pratio; }
 template <typename T>
 bool poly_smoother_ok(const RankSet& R)
 {
@@ -2348,9 +2349,9 @@ template <typename T>
 Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr, int* chain_launches = nullptr)
 {
 	fi_ctx* c0 = R[0];
-	const int    terms = mg_poly_terms();
+	const int    terms = mg_poly_terms(c0);
 	const double lam = c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0;
-	const double hi = 1.1 * lam, lo = hi / mg_ratio();
+	const double hi = 1.1 * lam, lo = hi / mg_poly_ratio(c0);
 	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
 	const bool single = R.size() == 1 && c0->nranks == 1;
 	bool ghosts_scaled = true;
@@ -4334,6 +4335,8 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		co->comm = tail ? nullptr : c->comm;
 		co->mg_smoother = c->mg_smoother;
 		co->mg_safe     = c->mg_safe;
+		co->mg_terms    = c->mg_terms;
+		co->mg_pratio   = c->mg_pratio;
 		co->value_rows_only = src->value_rows_only;  // (agreed over the ranks: fi_assemble)
 		co->any_trip        = src->any_trip;
 		co->stream = build_stream ? build_stream : c->stream;
@@ -4562,6 +4565,8 @@ fi_ctx* twin_prepare(fi_ctx* c)
 	t->mg_mode         = c->mg_mode;
 	t->mg_smoother     = c->mg_smoother;
 	t->mg_safe         = c->mg_safe;
+	t->mg_terms        = c->mg_terms;
+	t->mg_pratio       = c->mg_pratio;
 	t->min_slab        = c->min_slab;
 	t->poly_terms      = c->poly_terms;   // (the coarse-to-fine start on the replica solves its levels with them)
 	t->poly_ratio      = c->poly_ratio;
@@ -5237,6 +5242,16 @@ int fi_set_option(fi_ctx* c, int option, double value)
 	case FI_OPT_MG_SAFE_FACTOR:
 		FI_REQUIRE(value >= 1.0 && value <= 64.0, FI_ERR_INVALID, "FI_OPT_MG_SAFE_FACTOR must be 1..64");
 		c->mg_safe = value;
+		c->assembled = false;
+		break;
+	case FI_OPT_MG_TERMS:
+		FI_REQUIRE(value >= 2 && value <= 16, FI_ERR_INVALID, "FI_OPT_MG_TERMS must be 2..16");
+		c->mg_terms = static_cast<int>(value);
+		c->assembled = false;  // the levels take the setting when they are built
+		break;
+	case FI_OPT_MG_RATIO:
+		FI_REQUIRE(value > 1.0 && value <= 1000.0, FI_ERR_INVALID, "FI_OPT_MG_RATIO must be in (1, 1000]");
+		c->mg_pratio = value;
 		c->assembled = false;
 		break;
 	default: FI_REQUIRE(false, FI_ERR_INVALID, "unknown option %d", option);

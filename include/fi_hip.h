@@ -241,6 +241,13 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * level (the only smoother of 2-D / fp64 levels).  Both give symmetric positive definite preconditioners. */
 #define FI_OPT_MG_SMOOTHER 8
 #define FI_OPT_MG_SAFE_FACTOR 9
+/* FI_OPT_MG_TERMS (default 5, 2..16) and FI_OPT_MG_RATIO (default 30, (1, 1000]): the polynomial smoother's number of
+ * terms (terms - 1 launches of the plain marching kernel per smoothing pass) and the ratio of its interval [hi / ratio, hi].
+ * Measured on config 4 (fp64 CG + fp32 V-cycle to a field within 1e-5; profiles/r4_ablation.md): 4 terms / ratio 10 (the
+ * setting of round 3) 7 iterations at 256^3 and 8 at 512^3, 5 / 30 five and six -- each cycle 8 % dearer, the solve 20 %
+ * cheaper. */
+#define FI_OPT_MG_TERMS 10
+#define FI_OPT_MG_RATIO 11
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */

@@ -64,6 +64,18 @@ if cfg == 4 and os.path.exists(gpath):
     s = int(g["stride"])
     got = f.solution_f64().reshape(sizes[::-1])[::s, ::s, ::s]
     err = float(np.abs(got - g["sample"]).max() / float(g["field_maxabs"]))
+if os.environ.get("PHASES") == "1":   # host-side wall time of each call of a step (synchronised in between)
+    acc = [0.0, 0.0, 0.0, 0.0]
+    for _ in range(reps):
+        torch.cuda.synchronize(); t = [time.perf_counter()]
+        f.clear_points(); torch.cuda.synchronize(); t.append(time.perf_counter())
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient if d_nrm is not None else 0.0, w.gradient_kernel, d_pos, d_nrm, None,
+                     values=d_val); torch.cuda.synchronize(); t.append(time.perf_counter())
+        f.assemble(); torch.cuda.synchronize(); t.append(time.perf_counter())
+        f.solve_cg(d_zero if zero else None, 0, tol, out=d_out); torch.cuda.synchronize(); t.append(time.perf_counter())
+        for k in range(4):
+            acc[k] += (t[k + 1] - t[k]) * 1e3 / reps
+    print("phases (host wall, ms): clear %.3f  add_points %.3f  assemble %.3f  solve %.3f  sum %.3f" % (*acc, sum(acc)), flush=True)
 print("%s: %.2f ms/step = %.3g pts/s  iters %d (coarse %d)  asm %.2f solve %.2f ms  true_rel %.2e  field_err(oracle) %.2e"
       % (os.environ.get("NAME", "acc"), ms, n / ms * 1e3, st["iterations"], st["coarse_iterations"], st["assemble_ms"],
          st["solve_ms"], f.true_residual(), err), flush=True)
