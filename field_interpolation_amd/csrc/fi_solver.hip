@@ -1776,6 +1776,50 @@ __global__ __launch_bounds__(kThreads) void k_restrict3_xy(LevelPair L, int plan
 	}
 	tmp[(static_cast<int64_t>(fz) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
 }
+// The same pass through LDS: a workgroup owns 64 x 8 coarse points of one fine plane and stages the 132 x 20 fine values
+// they gather from with coalesced loads (the flat kernel's 25 loads per thread have a stride of two fine points between
+// neighbouring lanes: 61 us from 256^3 to 128^3 for 84 MB, against 25 us here).  Same taps, same order of summation:
+// the same bits.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_restrict3_xy_tiled(LevelPair L, int planes, const T* __restrict__ fine, T* __restrict__ tmp)
+{
+	constexpr int CX = 64, CY = 8, FW = 2 * CX + 4, FH = 2 * CY + 4, PW = FW + 1;
+	__shared__ T tile[FH][PW];
+	const int cx0 = static_cast<int>(blockIdx.x) * CX, cy0 = static_cast<int>(blockIdx.y) * CY, fz = static_cast<int>(blockIdx.z);
+	const int fx0 = 2 * cx0 - 2, fy0 = 2 * cy0 - 2;
+	const T* plane = fine + static_cast<int64_t>(fz) * L.nf[0] * L.nf[1];
+	for (int i = threadIdx.x; i < FW * FH; i += kThreads) {
+		const int row = i / FW, col = i - row * FW;
+		int gx = fx0 + col, gy = fy0 + row;
+		gx = gx < 0 ? 0 : (gx >= L.nf[0] ? L.nf[0] - 1 : gx);  // (clamped values only ever meet taps without weight)
+		gy = gy < 0 ? 0 : (gy >= L.nf[1] ? L.nf[1] - 1 : gy);
+		tile[row][col] = plane[static_cast<int64_t>(gy) * L.nf[0] + gx];
+	}
+	__syncthreads();
+	const int tx = threadIdx.x % CX, ty = threadIdx.x / CX;  // ty: 0 .. 3, two coarse rows per thread
+	const int cx = cx0 + tx;
+	if (cx >= L.nc[0]) { return; }
+	int fx[kRTaps];
+	T   wx[kRTaps];
+	restrict_taps<T>(cx, L.nf[0], L.nc[0], L.cc[0], fx0, fx, wx);
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int cy = cy0 + ty + 4 * h;
+		if (cy >= L.nc[1]) { continue; }
+		int fy[kRTaps];
+		T   wy[kRTaps];
+		restrict_taps<T>(cy, L.nf[1], L.nc[1], L.cc[1], fy0, fy, wy);
+		T acc = T(0);
+#pragma unroll
+		for (int k1 = 0; k1 < kRTaps; ++k1) {
+			T r = T(0);
+#pragma unroll
+			for (int k0 = 0; k0 < kRTaps; ++k0) { r += wx[k0] * tile[fy[k1]][fx[k0]]; }
+			acc += wy[k1] * r;
+		}
+		tmp[(static_cast<int64_t>(fz) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
+	}
+}
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict3_z(LevelPair L, const T* __restrict__ tmp, T* __restrict__ coarse)
 {
@@ -1802,8 +1846,13 @@ void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t s
 {
 	if (L.ndim == 3 && tmp && f_local_planes > 0 && !test_switch("FI_ONE_PASS_RESTRICT")) {
 		const int64_t n_xy = static_cast<int64_t>(L.nc[0]) * L.nc[1] * f_local_planes, n_z = static_cast<int64_t>(L.nc[0]) * L.nc[1] * L.c_planes;
-		hipLaunchKernelGGL((k_restrict3_xy<T>), dim3(static_cast<unsigned>((n_xy + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
-		                   f_local_planes, fine, tmp);
+		if (L.nc[0] >= 32 && f_local_planes <= 65535 && !test_switch("FI_FLAT_RESTRICT")) {
+			hipLaunchKernelGGL((k_restrict3_xy_tiled<T>), dim3((L.nc[0] + 63) / 64, (L.nc[1] + 7) / 8, f_local_planes), dim3(kThreads), 0, st,
+			                   L, f_local_planes, fine, tmp);
+		} else {
+			hipLaunchKernelGGL((k_restrict3_xy<T>), dim3(static_cast<unsigned>((n_xy + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
+			                   f_local_planes, fine, tmp);
+		}
 		if (n_z > 0) {
 			hipLaunchKernelGGL((k_restrict3_z<T>), dim3(static_cast<unsigned>((n_z + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L, tmp,
 			                   coarse);
@@ -2085,6 +2134,38 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 	}
 }
 
+// r = b - q with the partials of r.r and b.b in the same pass (the start and the verification of V-cycle PCG on an
+// undivided lattice: k_sub + two k_dot + their one-block sums were five launches and three more lattice passes)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_resid_norms(int64_t n, const T* __restrict__ b, const T* __restrict__ q, T* __restrict__ r,
+                                                           double* __restrict__ partial_rr, double* __restrict__ partial_bb)
+{
+	double acc[2] = {0, 0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T bi = b[i];
+		const T ri = bi - q[i];
+		r[i] = ri;
+		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
+		acc[1] += static_cast<double>(bi) * static_cast<double>(bi);
+	}
+	double out[2];
+	block_sum<2>(acc, out);
+	if (threadIdx.x == 0) {
+		partial_rr[blockIdx.x] = out[0];
+		partial_bb[blockIdx.x] = out[1];
+	}
+}
+// b.b into sums[2] (where kMgInitRr expects it), in front of k_mg_logic(kMgInitRr) on the same stream
+__global__ __launch_bounds__(kThreads) void k_sum_to_slot2(CgScalars* sc, const double* __restrict__ partial, int count)
+{
+	double acc[1] = {0};
+	for (int i = threadIdx.x; i < count; i += kThreads) { acc[0] += partial[i]; }
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { sc->sums[2] = out[0]; }
+}
+
 int mg_degree() { const char* e = tuning_switch("FI_MG_DEGREE"); return e && atoi(e) > 0 ? atoi(e) : 4; }  // config 3 / 5: degree 2 -> 4 halves the solve time
 double mg_ratio() { const char* e = tuning_switch("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : 10.0; }
 
@@ -2328,7 +2409,15 @@ void cheb_smooth(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_z
 //     pre  (from zero):  x = M b                                   d - 1 plain launches of (2.5 .. 4.5) lattice passes
 //     post:              x += M (b - A x)                          one full apply with the residual epilogue + the same
 // against 2 d launches of the fused (data-cell) kernel with the epilogue for the Chebyshev smoother in A itself.
-int    mg_poly_terms(const fi_ctx* c) { const char* e = tuning_switch("FI_MG_TERMS"); return e && atoi(e) > 0 ? atoi(e) : c->mg_terms; }
+int    mg_poly_terms(const fi_ctx* c)
+{
+	if (c->level > 0) {
+		const char* ec = tuning_switch("FI_MG_COARSE_TERMS");
+		if (ec && atoi(ec) > 1) { return atoi(ec); }
+	}
+	const char* e = tuning_switch("FI_MG_TERMS");
+	return e && atoi(e) > 0 ? atoi(e) : c->mg_terms;
+}
 double mg_poly_ratio(const fi_ctx* c) { const char* e = tuning_switch("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : c->mg_pratio; }
 template <typename T>
 bool poly_smoother_ok(const RankSet& R)
@@ -2738,6 +2827,14 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	// residual -- the usual outcome -- costs one operator application, not a cycle.)
 	auto restart = [&]() -> int {
 		apply_all(R, X, Q, false);
+		if (R.size() == 1 && c0->nranks == 1) {  // undivided lattice: one pass for r, r.r and b.b
+			double* prr = c0->partial.as<double>();
+			double* pbb = prr + static_cast<size_t>(c0->max_blocks);
+			hipLaunchKernelGGL((k_resid_norms<T>), dim3(nbv(c0)), dim3(kThreads), 0, st, c0->g.nown, vown<T>(c0, B), vown<T>(c0, Q),
+			                   vown<T>(c0, Rv), prr, pbb);
+			hipLaunchKernelGGL(k_sum_to_slot2, dim3(1), dim3(kThreads), 0, st, sc0, pbb, nbv(c0));
+			mg_reduce(R, nbv, kMgInitRr);
+		} else {
 		for (fi_ctx* c : R) {
 			hipLaunchKernelGGL((k_sub<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, B), vown<T>(c, Q),
 			                   vown<T>(c, Rv));
@@ -2747,6 +2844,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
 		dot(Rv, Rv);
 		mg_reduce(R, nbv, kMgInitRr);
+		}
 		const int flag = read_flag();
 		if (flag) { return flag; }
 		precondition<T>(R, Tw, Rv, Z, false);
@@ -4380,6 +4478,12 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		generic_assemble(co);
 		stencil_prepare(co);
 		operator_prepare(co);
+		// the polynomial smoother's scaling (and whether the data pin a small level) with the level's assembly, on its chain's
+		// stream, instead of at the head of the first solve (undivided levels: over slabs the ghost planes' diagonal comes later)
+		if (co->dtype == FI_F32 && co->g.ndim == 3 && co->mg_smoother == 1 && co->value_rows_only && !co->any_trip &&
+		    co->march.valid && co->nranks == 1 && !test_switch("FI_MG_FULL_SMOOTHER")) {
+			prepare_safe_scaling(co);
+		}
 		co->assembled = true;
 		co->vectors_ready = co->vectors_ready && co->max_blocks >= apply_num_partials(co);
 		co->stats.num_unknowns = co->g.nown;
@@ -5119,6 +5223,20 @@ int fi_assemble(fi_ctx* c)
 			main_code = FI_ERR_HIP;
 			fi::set_error("unexpected exception while assembling the finest level");
 		}
+		// The lumped replica needs nothing but the finest level this thread has just assembled: built here, on the solver
+		// stream, while the helpers are still busy with the coarser levels (0.3 ms of a 256^3 assemble).  No communication
+		// (its share of the assembly's one exchange comes with operator_finish_ghosts below).
+		if (lumped && main_code == FI_OK) {
+			try {
+				c->twin->defer_scaling_exchange = true;
+				fi::twin_assemble_lumped(c);
+			} catch (const fi::Fail& f) {
+				main_code = f.code;
+			} catch (...) {
+				main_code = FI_ERR_HIP;
+				fi::set_error("unexpected exception while building the lumped replica");
+			}
+		}
 		if (helper.joinable()) { helper.join(); } else if (main_code == FI_OK && !lumped) { build(); }
 		if (mixed64) {
 			if (helper2.joinable()) { helper2.join(); } else if (main_code == FI_OK) { build2(); }
@@ -5153,10 +5271,6 @@ int fi_assemble(fi_ctx* c)
 		if (mixed64) {
 			FI_HIP_TRY(hipEventRecord(c->ev_level2, c->level_stream2));
 			FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_level2, 0));
-			if (lumped) {
-				c->twin->defer_scaling_exchange = true;  // (its share of the one exchange: operator_finish_ghosts below)
-				fi::twin_assemble_lumped(c);
-			}
 			fi::twin_finish(c);
 		}
 		// slabs: the levels' share of the assembly's one exchange (the diagonal's ghost planes), in level order on every rank
