@@ -35,6 +35,8 @@
 #include <thread>
 
 #include "fi_internal.h"
+#include "fi_transfer.h"
+#include "fi_tail.h"
 
 namespace fi {
 
@@ -623,16 +625,6 @@ __global__ __launch_bounds__(kThreads) void k_upscale(UpscaleArgs a, int64_t nla
 //   cell-centred (even fine extent): coarse point j sits between fine 2j and 2j+1; fine 2j takes 3/4 of coarse j and
 //     1/4 of j-1, fine 2j+1 takes 3/4 of j and 1/4 of j+1; the first and the last fine point extrapolate (5/4, -1/4).
 // One thread per fine point; mode 0: fine = P coarse, mode 1: fine += P coarse.
-struct LevelPair {
-	int ndim;
-	int nf[3], nc[3];  // GLOBAL extents of the fine and the coarse lattice
-	int cc[3];         // the axis was halved cell-centred
-	// slabs (slowest axis L = ndim-1): the kernels walk `f_planes` owned fine planes starting at global plane
-	// f_z0 / `c_planes` owned coarse planes from c_z0; local storage of either level starts at global plane *_base
-	int f_z0, f_planes, f_base;
-	int c_z0, c_planes, c_base;
-};
-
 LevelPair level_pair(const fi_ctx* fine, const fi_ctx* coarse)
 {
 	LevelPair L{};
@@ -660,27 +652,6 @@ LevelPair level_pair(const fi_ctx* fine, const fi_ctx* coarse)
 		if (L.c_planes < 0) { L.c_planes = 0; }
 	}
 	return L;
-}
-
-// the two coarse points fine index f interpolates from along one axis, and their weights
-template <typename T>
-__device__ inline void prolong_taps(int f, int nc, int cc, int* i0, int* i1, T* w0, T* w1)
-{
-	const int j = f >> 1;
-	if (cc) {
-		const int nb = (f & 1) ? j + 1 : j - 1;
-		const bool in = nb >= 0 && nb < nc;
-		*i0 = j;
-		*i1 = in ? nb : ((f & 1) ? j - 1 : j + 1);
-		*w0 = in ? T(0.75) : T(1.25);
-		*w1 = in ? T(0.25) : T(-0.25);
-	} else {
-		const int c0 = j > nc - 1 ? nc - 1 : j;
-		*i0 = c0;
-		*i1 = c0 + 1 < nc ? c0 + 1 : c0;
-		*w1 = (f & 1) ? T(0.5) : T(0);
-		*w0 = T(1) - *w1;
-	}
 }
 
 template <typename T>
@@ -1574,9 +1545,16 @@ void cascade_guess(RankSet& R)
 				int64_t n_level = 1;
 				for (int d = 0; d < 3; ++d) { n_level *= lc[0]->g.gn[d]; }
 				const int cap_mg = n_level <= (1LL << 22) ? 40 : 8;
-				cg_run<T>(lc, 48, ltol);
-				int coarse_it = lc[0]->stats.iterations;
-				if (!lc[0]->stats.converged) {
+				// (oriented points: the 48 cheap steps never finish a level -- 144 launches per level for nothing, a tenth of
+				// config 3's step -- so those levels go straight to the V-cycle)
+				int coarse_it = 0;
+				bool finished = false;
+				if (lc[0]->value_rows_only) {
+					cg_run<T>(lc, 48, ltol);
+					coarse_it = lc[0]->stats.iterations;
+					finished  = lc[0]->stats.converged != 0;
+				}
+				if (!finished) {
 					cg_run_mg<T>(lc, cap_mg, ltol);
 					coarse_it += lc[0]->stats.iterations;
 				}
@@ -1623,38 +1601,6 @@ void cascade_guess(RankSet& R)
 // (weight 1/2; the last coarse point also takes the full weight of a fine point beyond it).  Cell-centred axis: fine
 // 2c-1 .. 2c+2 with (1/4, 3/4, 3/4, 1/4); the end points' extrapolation puts 5/4 of fine 0 on coarse 0 and -1/4 of it on
 // coarse 1 (mirrored at the other end): five taps.  Indices are relative to `base` and clamped where the weight is 0.
-constexpr int kRTaps = 5;
-template <typename T>
-__device__ inline void restrict_taps(int c, int nf, int nc, int cc, int base, int* f, T* w)
-{
-	if (cc) {
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int ff = 2 * c - 1 + k;
-			const bool in = ff >= 0 && ff < nf;
-			T ww = (k == 1 || k == 2) ? T(0.75) : T(0.25);
-			if (in && (ff == 0 || ff == nf - 1)) { ww = T(1.25); }  // c == 0 / c == nc - 1: the extrapolated end point
-			f[k] = (in ? ff : 2 * c) - base;
-			w[k] = in ? ww : T(0);
-		}
-		const bool lo = c == 1, hi = c == nc - 2;  // (extents >= 8: never both)
-		f[4] = (lo ? 0 : (hi ? nf - 1 : 2 * c)) - base;
-		w[4] = (lo || hi) ? T(-0.25) : T(0);
-	} else {
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			const int ff = 2 * c + k - 1;
-			const bool in = ff >= 0 && ff < nf;
-			T ww = (k == 1) ? T(1) : T(0.5);
-			if (k == 2 && c + 1 >= nc && in) { ww = T(1); }  // fine point 2c+1 when coarse c+1 does not exist
-			f[k] = (in ? ff : 2 * c) - base;
-			w[k] = in ? ww : T(0);
-		}
-		f[3] = f[4] = 2 * c - base;
-		w[3] = w[4] = T(0);
-	}
-}
-
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, const T* __restrict__ fine, T* __restrict__ coarse)
 {
@@ -2485,6 +2431,161 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 	return zin;
 }
 
+// ---- the V-cycle of the hierarchy's tail as a program of the small-level engine (fi_tail.h) ----------------------------
+// The same cycle as vcycle() below -- the same smoothers with the same constants, the same transfers -- written out as the
+// stages of ONE cooperative launch.  Vectors: rhs b and result x as the caller names them on the top level, mg_b / mg_x
+// below; work vectors mg_r (residual), mg_d and q (the polynomials' iterates: x itself is only ever the final target of a
+// stage, never an intermediate, so the program's pointers stay valid from cycle to cycle).
+template <typename T>
+bool poly_smoother_ok(const RankSet& R);
+
+struct TailProgram {
+	std::vector<TailOp> ops;
+	std::vector<fi_ctx*> chain;
+	bool ok = true;
+
+	void op(int kind, int level, const float* a, const float* b, const float* c, float* out, float* acc, const unsigned short* scale,
+	        double s0 = 0, double s1 = 0, double s2 = 0)
+	{
+		ops.push_back(TailOp{kind, level, a, b, c, out, acc, scale, static_cast<float>(s0), static_cast<float>(s1), static_cast<float>(s2), 0});
+	}
+	// target (+)= M r: the polynomial in A_model + f diag(A_data) (poly_chain); out: target of the last step, acc: accumulate
+	void poly_ops(int l, const float* r, float* out, float* acc)
+	{
+		fi_ctx* c = chain[l];
+		const int    terms = mg_poly_terms(c);
+		const double lam = c->poly_lambda > 1.0 ? c->poly_lambda : 1.0;
+		const double hi = 1.1 * lam, lo = hi / mg_poly_ratio(c);
+		const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+		const unsigned short* sc = c->dinv16s.as<unsigned short>();
+		float* W[2] = {c->mg_d.as<float>(), c->q.as<float>()};
+		if (terms < 2) { ok = false; return; }
+		op(kTailScale, l, r, nullptr, nullptr, W[0], nullptr, sc, 1.0 / theta);
+		int cur = 0;
+		double rho = 1.0 / sigma;
+		for (int k = 1; k < terms; ++k) {
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+			const bool   last = k == terms - 1;
+			op(kTailPolyStep, l, W[cur], k == 1 ? nullptr : W[1 - cur], r, last ? out : W[1 - cur], last ? acc : nullptr, sc, 1.0 + c1,
+			   k == 1 ? 0.0 : c1, c2);
+			cur = 1 - cur;
+			rho = rho_new;
+		}
+	}
+	// degree-k Chebyshev smoothing in the full operator (cheb_smooth_fused): x starts at zero / at its present value
+	void cheb_ops(int l, const float* b, float* x, int degree, double ratio, bool from_zero)
+	{
+		fi_ctx* c = chain[l];
+		const double hi = 1.1 * c->lambda_max, lo = hi / ratio;
+		const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+		const unsigned short* sc = c->dinv16.as<unsigned short>();
+		float* W[2] = {c->mg_d.as<float>(), c->mg_r.as<float>()};
+		if (degree < 2 || !(c->lambda_max > 0)) { ok = false; return; }
+		const float* zk = nullptr;    // x_k
+		const float* zp = nullptr;    // x_{k-1} (null: zero, or no such term)
+		int steps = degree - 1;       // recurrence steps after the first term
+		if (from_zero) {
+			op(kTailScale, l, b, nullptr, nullptr, W[0], nullptr, sc, 1.0 / theta);   // x_1 = Dinv b / theta
+			zk = W[0];
+		} else {
+			op(kTailChebStep, l, x, nullptr, b, W[0], nullptr, sc, 1.0, 0.0, 1.0 / theta);  // x_1 = x_0 + Dinv (b - A x_0) / theta
+			zk = W[0];
+			zp = x;
+		}
+		double rho = 1.0 / sigma;
+		for (int k = 1; k <= steps; ++k) {
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+			const bool   last = k == steps;
+			float* out = last ? x : (zk == W[0] ? W[1] : W[0]);   // (x_{k-1}'s buffer may be overwritten: it is read at the point itself only)
+			op(kTailChebStep, l, zk, zp, b, out, nullptr, sc, 1.0 + c1, zp ? c1 : 0.0, c2);
+			zp = zk;
+			zk = out;
+			rho = rho_new;
+		}
+	}
+	void residual(int l, const float* x, const float* b, float* out) { op(kTailResidual, l, x, nullptr, b, out, nullptr, nullptr); }
+
+	void cycle(int l, const float* b, float* x)
+	{
+		fi_ctx* c = chain[l];
+		RankSet one{c};
+		const bool last = l + 1 == static_cast<int>(chain.size());
+		const bool poly = poly_smoother_ok<float>(one);
+		const int    deg = mg_degree();
+		const double ratio = mg_ratio();
+		float* r = c->mg_r.as<float>();
+		if (c->lumped) { ok = false; return; }
+		if (last) {
+			if (poly && c->dinv16s_valid && c->data_pinned && !test_switch("FI_MG_COARSEST_CHEB")) {
+				poly_ops(l, b, x, nullptr);
+				residual(l, x, b, r);
+				poly_ops(l, r, nullptr, x);
+			} else {
+				cheb_ops(l, b, x, 4 * deg + 4, 10.0 * ratio, true);
+			}
+			return;
+		}
+		fi_ctx* co = chain[l + 1];
+		if (poly) {
+			poly_ops(l, b, x, nullptr);
+		} else {
+			cheb_ops(l, b, x, deg, ratio, true);
+		}
+		residual(l, x, b, r);
+		op(kTailRestrict, l, r, nullptr, nullptr, co->mg_b.as<float>(), nullptr, nullptr);
+		cycle(l + 1, co->mg_b.as<float>(), co->mg_x.as<float>());
+		op(kTailProlongAdd, l, co->mg_x.as<float>(), nullptr, nullptr, x, nullptr, nullptr);
+		if (poly) {
+			residual(l, x, b, r);
+			poly_ops(l, r, nullptr, x);
+		} else {
+			cheb_ops(l, b, x, deg, ratio, false);
+		}
+	}
+};
+
+// x = V(b) on the tail that starts at R's level, in one launch; false: the level is not the engine's (the caller recurses)
+template <typename T>
+bool tail_vcycle(RankSet& R, Vec b, Vec x)
+{
+	if (sizeof(T) != 4 || R.size() != 1) { return false; }
+	fi_ctx* c = R[0];
+	if (c->level == 0 || !c->tail_ok || c->nranks != 1) { return false; }
+	const void* bp = (c->*b).p;
+	const void* xp = (c->*x).p;
+	if (!c->tail_prog_valid || c->tail_prog_b != bp || c->tail_prog_x != xp) {
+		TailProgram P;
+		for (fi_ctx* l = c; l; l = l->coarse) { P.chain.push_back(l); }
+		P.cycle(0, static_cast<const float*>(bp), static_cast<float*>(const_cast<void*>(xp)));
+		if (!P.ok || P.ops.empty()) {
+			c->tail_ok = false;  // (a setting the engine does not cover: the tiled kernels run this hierarchy)
+			return false;
+		}
+		std::vector<unsigned char> blob(sizeof(TailLevel) * kTailMaxLevels + sizeof(TailOp) * P.ops.size());
+		TailLevel* lv = reinterpret_cast<TailLevel*>(blob.data());
+		int64_t widest = 0;
+		for (size_t k = 0; k < P.chain.size(); ++k) {
+			lv[k] = tail_level_of(P.chain[k]);
+			if (k + 1 < P.chain.size()) { lv[k].to_coarse = level_pair(P.chain[k], P.chain[k + 1]); }
+			widest = lv[k].nn > widest ? lv[k].nn : widest;
+		}
+		std::memcpy(blob.data() + sizeof(TailLevel) * kTailMaxLevels, P.ops.data(), sizeof(TailOp) * P.ops.size());
+		c->tail_prog.alloc(blob.size());
+		FI_HIP_TRY(hipMemcpyAsync(c->tail_prog.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+		FI_HIP_TRY(hipStreamSynchronize(c->stream));  // (the host buffer dies here)
+		c->tail_nlev       = static_cast<int>(P.chain.size());
+		c->tail_nops       = static_cast<int>(P.ops.size());
+		c->tail_widest     = widest;
+		c->tail_prog_b     = bp;
+		c->tail_prog_x     = xp;
+		c->tail_prog_valid = true;
+	}
+	tail_run(c, c->tail_prog.p, c->tail_nlev, c->tail_nops, c->tail_widest);
+	return true;
+}
+
 // x = V(b) on the level of R.  Over slabs every level is a slab decomposition of its own (coarse plane k lives
 // with fine plane 2k): restriction reads one ghost plane of the fine residual, interpolation one of the coarse
 // correction.
@@ -2495,6 +2596,7 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		for_each_copy(R, [&](RankSet& one) { vcycle<T>(one, b, x); });
 		return;
 	}
+	if (tail_vcycle<T>(R, b, x)) { return; }  // the small-level engine: this level and all below it in one launch
 	const int deg = mg_degree();
 	const double ratio = mg_ratio();
 	if (tuning_switch("FI_MG_POLY")) {  // experiment: the polynomial alone as the preconditioner, no coarse correction
@@ -2872,6 +2974,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			RankSet top = mixed ? Tw : R;
 			for (fi_ctx* c : top) {
 				for (fi_ctx* l = c; l; l = l->coarse) {
+					l->tail_prog_valid = false;  // (the small-level engine's program carries the smoothers' constants)
 					if (l->lambda_max > 0) { l->lambda_max *= 1.5; }
 					if (l->poly_lambda > 0) {
 						l->poly_lambda = (l->poly_lambda > 1.0 ? l->poly_lambda : 1.0) * 1.25;
@@ -4484,6 +4587,8 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		    co->march.valid && co->nranks == 1 && !test_switch("FI_MG_FULL_SMOOTHER")) {
 			prepare_safe_scaling(co);
 		}
+		co->tail_prog_valid = false;
+		if (tail_level_supported(co)) { tail_build_operator(co); }  // the small-level engine's view of the data rows
 		co->assembled = true;
 		co->vectors_ready = co->vectors_ready && co->max_blocks >= apply_num_partials(co);
 		co->stats.num_unknowns = co->g.nown;
@@ -4549,6 +4654,17 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 		}
 	}
 	for (fi_ctx* l = c->coarse; l; l = l->coarse) { l->stream = c->stream; }  // the caller orders the two streams
+	// the tail of the hierarchy the small-level engine runs (fi_tail.h): from the coarsest level up while the levels qualify
+	{
+		std::vector<fi_ctx*> chain;
+		for (fi_ctx* l = c->coarse; l; l = l->coarse) { chain.push_back(l); }
+		bool ok = true;
+		for (size_t k = chain.size(); k-- > 0;) {
+			ok = ok && tail_level_supported(chain[k]) && static_cast<int>(chain.size() - k) <= kTailMaxLevels;
+			chain[k]->tail_ok = ok;
+			chain[k]->tail_prog_valid = false;
+		}
+	}
 	// smoother bounds of the V-cycle (a global power method over all slabs) are estimated by the next multigrid solve
 	for (fi_ctx* l = c; l; l = l->coarse) { l->lambda_max = 0; }
 }
