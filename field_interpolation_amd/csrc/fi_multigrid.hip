@@ -1,0 +1,1239 @@
+// fi_multigrid.hip -- the coarse-to-fine start (src/sdf_field.cpp:272-288 generalised to several levels), the smoothers,
+// the V-cycle and V-cycle preconditioned CG (fp64 CG around an fp32 V-cycle in mixed precision).
+#include "fi_solver_internal.h"
+
+namespace fi {
+
+// Coarse-to-fine start (the reference's own remedy for large lattices: solve a coarser lattice, upscale, use
+// as the guess -- src/sdf_field.cpp:272-288, README.md "My resolution is huge"): every coarser level is
+// solved from the interpolated solution of the level below it, to a loose tolerance; x of `c` receives the
+// interpolated guess.  All on the device.
+template <typename T>
+void cascade_guess(RankSet& R)
+{
+	// chains[l] = the level-l contexts of all members
+	std::vector<RankSet> chains;
+	{
+		RankSet cur = R;
+		for (;;) {
+			chains.push_back(cur);
+			RankSet next;
+			for (fi_ctx* c : cur) {
+				if (c->coarse) { next.push_back(c->coarse); }
+			}
+			if (next.size() != cur.size()) { break; }
+			cur = next;
+		}
+	}
+	for (auto& lev : chains) {
+		for (fi_ctx* c : lev) { ensure_vectors(c); }
+	}
+	for (fi_ctx* c : chains.back()) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
+	fi_ctx* root = R[0];
+	for (size_t k = chains.size(); k-- > 1;) {
+		RankSet& lc = chains[k];
+		RankSet& lf = chains[k - 1];
+		try {
+			for (fi_ctx* l : lc) {  // the levels solve the way the finest level does
+				l->poly_terms = root->poly_terms;
+				l->poly_ratio = root->poly_ratio;
+				if (const char* e = tuning_switch("FI_COARSE_TERMS")) { l->poly_terms = atoi(e); }
+				if (const char* e = tuning_switch("FI_COARSE_RATIO")) { l->poly_ratio = atof(e); }
+			}
+			// with the V-cycle preconditioner on, a level that has coarser levels below it is solved with it too (a full
+			// multigrid start): Jacobi-PCG needs thousands of iterations on the coarse levels of an SDF (config 3: 4 338,
+			// most of the solve's wall time)
+			const bool mg = root->mg_mode == 1 && lc[0]->coarse && !test_switch("FI_CASCADE_NO_MG");
+			for (fi_ctx* l : lc) { l->mg_mode = root->mg_mode; }
+			for_each_copy(lc, [&](RankSet& lc) {  // (the copies of a replicated level: each on its own)
+			if (poly_ok(lc[0])) {
+				cg_run_poly<T>(lc, 0, static_cast<float>(root->coarse_tol));
+			} else if (mg) {
+				// Data-rich levels (config 4) are done after a few dozen cheap Jacobi-PCG steps; where that is not enough the
+				// V-cycle takes over from the iterate.  A start guess is worth a bounded effort, and fp32 levels cannot go
+				// below ~1e-5 anyway (the recurrence stalls there: 29 000 iterations without reaching 1e-6 at 48^3).
+				const double floor_tol = sizeof(T) == 4 ? 1e-5 : 0.0;
+				const float  ltol = static_cast<float>(root->coarse_tol > floor_tol ? root->coarse_tol : floor_tol);
+				// (measured, tools/r3_sweep_cascade.sh: config 3 wants its levels converged -- 13 fine iterations at 4096^2
+				// instead of 19 / 26 with 8 / 4 cycles per level --, config 5's 256^3 level is not worth more than 8 cycles:
+				// 439 -> 396 ms per step)
+				int64_t n_level = 1;
+				for (int d = 0; d < 3; ++d) { n_level *= lc[0]->g.gn[d]; }
+				const int cap_mg = n_level <= (1LL << 22) ? 40 : 8;
+				// (oriented points: the 48 cheap steps never finish a level -- 144 launches per level for nothing, a tenth of
+				// config 3's step -- so those levels go straight to the V-cycle)
+				int coarse_it = 0;
+				bool finished = false;
+				if (lc[0]->value_rows_only) {
+					cg_run<T>(lc, 48, ltol);
+					coarse_it = lc[0]->stats.iterations;
+					finished  = lc[0]->stats.converged != 0;
+				}
+				if (!finished) {
+					cg_run_mg<T>(lc, cap_mg, ltol);
+					coarse_it += lc[0]->stats.iterations;
+				}
+				for (fi_ctx* l : lc) { l->stats.iterations = coarse_it; }
+			} else {
+				cg_run<T>(lc, 0, static_cast<float>(root->coarse_tol));
+			}
+			});
+		} catch (const Fail& f) {
+			if (f.code != FI_ERR_BREAKDOWN) { throw; }  // a coarse level without data: keep what it has
+		}
+		root->stats.coarse_iterations += lc[0]->stats.iterations;
+		halo_exchange(lc, &fi_ctx::x);  // interpolation reads one coarse plane beyond the slab
+		for (size_t i = 0; i < lf.size(); ++i) {
+			const LevelPair L = level_pair(lf[i], lc[i]);
+			// cubic where the coarse vector stays in cache (64 taps per pair of fine points): 256^3 from 128^3 20 -> 19
+			// outer iterations; at 512^3 the kernel would cost more than the start it improves
+			const bool cubic = L.ndim == 3 && (lf[i]->nranks == 1 || lc[i]->reach >= 2) && !test_switch("FI_LINEAR_START") &&
+			                   sizeof(T) * static_cast<size_t>(lc[i]->g.nloc) <= (32u << 20);
+			if (cubic) {
+				launch_prolong_cubic<T>(L, lc[i]->x.as<T>(), lf[i]->x.as<T>(), lf[i]->stream);
+			} else {
+				launch_prolong<T>(L, lc[i]->x.as<T>(), lf[i]->x.as<T>(), 0, lf[i]->stream);
+			}
+		}
+		FI_HIP_TRY(hipGetLastError());
+	}
+}
+
+// r = b - q (q may be null: r = b);  d = alpha * Dinv r;  x = zero_x ? d : x + d
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cheb_init(int64_t n, const T* __restrict__ b, const T* __restrict__ q,
+                                                         const T* __restrict__ dinv, T* __restrict__ r,
+                                                         T* __restrict__ d, T* __restrict__ x, T alpha, int zero_x)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T ri = q ? b[i] - q[i] : b[i];
+		const T di = alpha * dinv[i] * ri;
+		r[i] = ri;
+		d[i] = di;
+		x[i] = zero_x ? di : x[i] + di;
+	}
+}
+
+// r = r_in - q;  d = c1 d + c2 Dinv r;  x = x_in + d.  Passes that nobody would read are skipped: r_in is the
+// right-hand side itself on the first step of a smoother that started from zero (then x_in is d: x == d so far),
+// and the last step of a polynomial stores neither r nor d.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cheb_iter(int64_t n, const T* __restrict__ q, const T* __restrict__ dinv,
+                                                         const T* r_in, T* r, T* d, const T* x_in, T* x, T c1, T c2,
+                                                         int store_rd)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T ri = r_in[i] - q[i];
+		const T d0 = d[i];
+		const T di = c1 * d0 + c2 * dinv[i] * ri;
+		const T xi = (x_in == d ? d0 : x_in[i]) + di;
+		if (store_rd) {
+			r[i] = ri;
+			d[i] = di;
+		}
+		x[i] = xi;
+	}
+}
+
+// start of a smoother from zero: d = alpha Dinv b (x == d and r == b are not stored; a polynomial of degree 1
+// stores x instead)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_cheb_first(int64_t n, const T* __restrict__ b, const T* __restrict__ dinv,
+                                                          T* __restrict__ d, T alpha)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		d[i] = alpha * dinv[i] * b[i];
+	}
+}
+
+
+// r = b - q
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_sub(int64_t n, const T* __restrict__ b, const T* __restrict__ q,
+                                                   T* __restrict__ r)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		r[i] = b[i] - q[i];
+	}
+}
+
+// power method: v = Dinv q, partial of v.v
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_power_step(int64_t n, const T* __restrict__ q, const T* __restrict__ dinv,
+                                                          T* __restrict__ v, double* __restrict__ partial)
+{
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T w = dinv[i] * q[i];
+		v[i] = w;
+		acc[0] += static_cast<double>(w) * static_cast<double>(w);
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+
+
+// CG with a preconditioner: r -= alpha q, x += alpha p (p is still the direction of this step), partial r.r
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, const CgScalars* __restrict__ sc, const T* __restrict__ p,
+                                                       const T* __restrict__ q, T* __restrict__ x, T* __restrict__ r,
+                                                       double* __restrict__ partial)
+{
+	if (sc->done) { return; }
+	const T alpha = static_cast<T>(sc->alpha);
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += alpha * p[i];
+		const T ri = r[i] - alpha * q[i];
+		r[i] = ri;
+		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+
+// partial of a.b
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_dot(int64_t n, const T* __restrict__ a, const T* __restrict__ b,
+                                                   double* __restrict__ partial)
+{
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		acc[0] += static_cast<double>(a[i]) * static_cast<double>(b[i]);
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+
+// p = z + beta p
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_mg_direction(int64_t n, const CgScalars* __restrict__ sc,
+                                                            const T* __restrict__ z, T* __restrict__ p, int first)
+{
+	const T beta = first ? T(0) : static_cast<T>(sc->beta);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		p[i] = z[i] + beta * p[i];
+	}
+}
+
+// Mixed precision (CG in fp64, V-cycle on the fp32 replica): the fp32 copy of the residual leaves k_mg_step with the
+// update itself, and the fp64 copy of z = V(r) is never formed -- r.z and the new direction read the fp32 result.
+// Per step 3 fp64 lattice passes less than k_mg_step + k_to_twin + k_from_twin + k_dot + k_mg_direction.
+__global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgScalars* __restrict__ sc,
+                                                             const double* __restrict__ p, const double* __restrict__ q,
+                                                             double* __restrict__ x, double* __restrict__ r,
+                                                             float* __restrict__ r32, double* __restrict__ partial)
+{
+	if (sc->done) { return; }
+	const double alpha = sc->alpha;
+	const double inv = 1.0 / mixed_scale(sc);  // sc->rr is still the previous norm: k_mg_logic(kMgResid) records this scale
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += alpha * p[i];
+		const double ri = r[i] - alpha * q[i];
+		r[i]   = ri;
+		r32[i] = static_cast<float>(ri * inv);
+		acc[0] += ri * ri;
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+// partial of r . (s z32)
+__global__ __launch_bounds__(kThreads) void k_dot_mixed(int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ r,
+                                                         const float* __restrict__ z32, double* __restrict__ partial)
+{
+	const double s = twin_scale(sc);
+	double acc[1] = {0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		acc[0] += r[i] * (s * static_cast<double>(z32[i]));
+	}
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
+}
+// p = s z32 + beta p
+__global__ __launch_bounds__(kThreads) void k_mg_direction_mixed(int64_t n, const CgScalars* __restrict__ sc,
+                                                                  const float* __restrict__ z32, double* __restrict__ p, int first)
+{
+	const double beta = first ? 0.0 : sc->beta;
+	const double s = twin_scale(sc);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		p[i] = s * static_cast<double>(z32[i]) + beta * p[i];
+	}
+}
+
+// r = b - q with the partials of r.r and b.b in the same pass (the start and the verification of V-cycle PCG on an
+// undivided lattice: k_sub + two k_dot + their one-block sums were five launches and three more lattice passes)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_resid_norms(int64_t n, const T* __restrict__ b, const T* __restrict__ q, T* __restrict__ r,
+                                                           double* __restrict__ partial_rr, double* __restrict__ partial_bb)
+{
+	double acc[2] = {0, 0};
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const T bi = b[i];
+		const T ri = bi - q[i];
+		r[i] = ri;
+		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
+		acc[1] += static_cast<double>(bi) * static_cast<double>(bi);
+	}
+	double out[2];
+	block_sum<2>(acc, out);
+	if (threadIdx.x == 0) {
+		partial_rr[blockIdx.x] = out[0];
+		partial_bb[blockIdx.x] = out[1];
+	}
+}
+// b.b into sums[2] (where kMgInitRr expects it), in front of k_mg_logic(kMgInitRr) on the same stream
+__global__ __launch_bounds__(kThreads) void k_sum_to_slot2(CgScalars* sc, const double* __restrict__ partial, int count)
+{
+	double acc[1] = {0};
+	for (int i = threadIdx.x; i < count; i += kThreads) { acc[0] += partial[i]; }
+	double out[1];
+	block_sum<1>(acc, out);
+	if (threadIdx.x == 0) { sc->sums[2] = out[0]; }
+}
+
+int mg_degree() { const char* e = tuning_switch("FI_MG_DEGREE"); return e && atoi(e) > 0 ? atoi(e) : 4; }  // config 3 / 5: degree 2 -> 4 halves the solve time
+double mg_ratio() { const char* e = tuning_switch("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : 10.0; }
+
+template <typename T>
+void mg_alloc(fi_ctx* c)
+{
+	ensure_vectors(c);
+	const size_t bytes = sizeof(T) * c->g.nloc;
+	const bool fresh = c->mg_b.bytes < bytes;
+	c->mg_b.alloc(bytes);
+	c->mg_x.alloc(bytes);
+	c->mg_r.alloc(bytes);
+	c->mg_d.alloc(bytes);
+	if (fresh) {  // ghost planes outside the lattice are never written: keep them finite
+		FI_HIP_TRY(hipMemsetAsync(c->mg_b.p, 0, bytes, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->mg_x.p, 0, bytes, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->mg_r.p, 0, bytes, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->mg_d.p, 0, bytes, c->stream));
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_add_vec(int64_t n, const T* __restrict__ d, T* __restrict__ x)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += d[i];
+	}
+}
+
+// Sum of vector `v` (whole lattices: the replicated level below a slab level) over the ranks, in place: every rank has
+// restricted its slab's residual into its own coarse planes, the others are zero.
+template <typename T>
+void sum_over_ranks(RankSet& Rfine, RankSet& Rc, DevBuf fi_ctx::*v)
+{
+	const int64_t n = Rc[0]->g.nloc;
+	if (Rc.size() > 1) {  // loop-back group: add up into member 0 in member order, copy back
+		fi_ctx* c0 = Rc[0];
+		for (size_t m = 1; m < Rc.size(); ++m) {
+			hipLaunchKernelGGL((k_add_vec<T>), dim3(stream_blocks(n)), dim3(kThreads), 0, c0->stream, n, (Rc[m]->*v).as<T>(), (c0->*v).as<T>());
+		}
+		for (size_t m = 1; m < Rc.size(); ++m) {
+			FI_HIP_TRY(hipMemcpyAsync((Rc[m]->*v).p, (c0->*v).p, sizeof(T) * n, hipMemcpyDeviceToDevice, c0->stream));
+		}
+	} else if (Rfine[0]->nranks > 1) {
+		allreduce_sum_vec(Rfine[0], (Rc[0]->*v).p, n, sizeof(T) == 8);
+	}
+}
+
+RankSet coarse_of(const RankSet& R)
+{
+	RankSet r;
+	for (fi_ctx* c : R) { r.push_back(c->coarse); }
+	return r;
+}
+
+void apply_all(RankSet& R, Vec in, Vec out, bool partials)
+{
+	halo_exchange(R, in);
+	for (fi_ctx* c : R) { apply_AtA(c, (c->*in).p, (c->*out).p, partials ? c->partial.as<double>() : nullptr); }
+}
+
+
+// largest eigenvalue of Dinv*AtA by the power method (10 steps, unnormalised: growth <= 8^10, fine in fp32)
+template <typename T>
+void estimate_lambda(RankSet& R)
+{
+	for (fi_ctx* c : R) { mg_alloc<T>(c); }
+	CgScalars init{};
+	reset_scalars(R, init);
+	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	for (fi_ctx* c : R) {
+		hipLaunchKernelGGL((k_seed<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, global_first(c),
+		                   vown<T>(c, &fi_ctx::mg_d));
+	}
+	const int steps = 10;
+	double sums[2] = {0, 0};
+	for (int k = 0; k < steps; ++k) {
+		apply_all(R, &fi_ctx::mg_d, &fi_ctx::q, false);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_power_step<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, &fi_ctx::q),
+			                   vown<T>(c, &fi_ctx::dinv), vown<T>(c, &fi_ctx::mg_d), c->partial.as<double>());
+		}
+		if (k >= steps - 2) {  // |v|^2 after the last two steps, summed over all slabs
+			reduce_phase(R, 1, nbv, nbv, -1);
+			fi_ctx* c0 = R[0];
+			FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, c0->scal.p, sizeof(CgScalars), hipMemcpyDeviceToHost, c0->stream));
+			FI_HIP_TRY(hipStreamSynchronize(c0->stream));
+			sums[k - (steps - 2)] = c0->scal_host->sums[0];
+		}
+	}
+	const double lambda = (sums[0] > 0 && sums[1] > 0) ? std::sqrt(sums[1] / sums[0]) : 2.0;
+	for (fi_ctx* c : R) { c->lambda_max = lambda; }
+}
+
+// The smoother through the marching kernel's epilogue (fi_stencil.hip, ChebEpi mode 2): the same polynomial written as
+// a three-term recurrence in the iterates themselves,
+//     x_{k+1} = (1 + c1) x_k - c1 x_{k-1} + c2 Dinv (b - A x_k),   c1 = rho_k rho_{k-1}, c2 = 2 rho_k / delta
+// (d_k = x_{k+1} - x_k of the form below), so that a step is ONE launch that reads x_k, x_{k-1}, b, Dinv and the cell
+// records and writes x_{k+1}: 5 lattice passes instead of the 10 of apply + k_cheb_iter.  The iterates rotate through
+// x, mg_d and mg_r; the buffer that ends up holding the result is swapped into x.
+bool smooth_fused_ok(const RankSet& R)  // (stencil_full_epi_available knows which precisions a context's kernel covers)
+{
+	if (test_switch("FI_NO_FUSED_SMOOTHER")) { return false; }  // tests compare the two forms of the smoother
+	for (const fi_ctx* c : R) {
+		if (!stencil_full_epi_available(c)) { return false; }
+	}
+	return true;
+}
+void swap_vectors(RankSet& R, Vec a, Vec b)
+{
+	if (a == b) { return; }
+	for (fi_ctx* c : R) {
+		(c->*a).swap(c->*b);
+	}
+}
+template <typename T>
+void cheb_smooth_fused(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_zero)
+{
+	const double hi = 1.1 * R[0]->lambda_max, lo = hi / ratio;
+	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	const Vec ring[3] = {x, &fi_ctx::mg_d, &fi_ctx::mg_r};
+	int cur = 0, prev = -1;  // ring positions of x_k and x_{k-1} (-1: x_{k-1} = 0, or the first step of a smoother that starts at x)
+	auto step = [&](double a, double c1, double c2) {
+		const int next = prev < 0 ? (cur + 1) % 3 : 3 - cur - prev;
+		halo_exchange(R, ring[cur]);
+		for (fi_ctx* c : R) {
+			stencil_full_step(c, (c->*ring[cur]).p, prev < 0 ? nullptr : (c->*ring[prev]).p, (c->*b).p, false,
+			                  (c->*ring[next]).p, a, c1, c2);
+		}
+		prev = cur;
+		cur  = next;
+	};
+	bool have_prev = false;  // x_{k-1} is a vector (not the zero start)
+	if (from_zero) {
+		for (fi_ctx* c : R) {  // x_1 = Dinv b / theta
+			hipLaunchKernelGGL((k_cheb_first16<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   vown<T>(c, b), c->dinv16.as<unsigned short>() + c->g.own_first, vown<T>(c, x),
+			                   static_cast<T>(1.0 / theta));
+		}
+	} else {
+		step(1.0, 0.0, 1.0 / theta);  // x_1 = x_0 + Dinv (b - A x_0) / theta
+		have_prev = true;
+	}
+	double rho = 1.0 / sigma;
+	for (int k = 1; k < degree; ++k) {
+		const double rho_new = 1.0 / (2.0 * sigma - rho);
+		const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+		if (!have_prev) { prev = -1; }  // x_0 = 0: its term drops out, a = 1 + c1 stays
+		step(1.0 + c1, c1, c2);
+		have_prev = true;
+		rho = rho_new;
+	}
+	swap_vectors(R, x, ring[cur]);
+}
+
+// degree-k Chebyshev smoothing of AtA x = b on [lmax/ratio, 1.1 lmax]; from_zero: x starts at 0
+template <typename T>
+void cheb_smooth(RankSet& R, Vec b, Vec x, int degree, double ratio, bool from_zero)
+{
+	if (smooth_fused_ok(R)) {
+		cheb_smooth_fused<T>(R, b, x, degree, ratio, from_zero);
+		return;
+	}
+	const double hi = 1.1 * R[0]->lambda_max, lo = hi / ratio;
+	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	auto nbv = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	if (from_zero) {
+		// x == d and r == b until the first update: only d is written (straight into x when the polynomial ends here)
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_cheb_first<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
+			                   vown<T>(c, &fi_ctx::dinv), degree > 1 ? vown<T>(c, &fi_ctx::mg_d) : vown<T>(c, x),
+			                   static_cast<T>(1.0 / theta));
+		}
+	} else {
+		apply_all(R, x, &fi_ctx::q, false);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_cheb_init<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
+			                   vown<T>(c, &fi_ctx::q), vown<T>(c, &fi_ctx::dinv), vown<T>(c, &fi_ctx::mg_r),
+			                   vown<T>(c, &fi_ctx::mg_d), vown<T>(c, x), static_cast<T>(1.0 / theta), 0);
+		}
+	}
+	double rho = 1.0 / sigma;
+	for (int k = 1; k < degree; ++k) {
+		const double rho_new = 1.0 / (2.0 * sigma - rho);
+		apply_all(R, &fi_ctx::mg_d, &fi_ctx::q, false);
+		const bool first = from_zero && k == 1, last = k == degree - 1;
+		for (fi_ctx* c : R) {
+			T* d = vown<T>(c, &fi_ctx::mg_d);
+			T* r = vown<T>(c, &fi_ctx::mg_r);
+			hipLaunchKernelGGL((k_cheb_iter<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, &fi_ctx::q),
+			                   vown<T>(c, &fi_ctx::dinv), first ? static_cast<const T*>(vown<T>(c, b)) : static_cast<const T*>(r), r,
+			                   d, first ? static_cast<const T*>(d) : static_cast<const T*>(vown<T>(c, x)), vown<T>(c, x),
+			                   static_cast<T>(rho_new * rho), static_cast<T>(2.0 * rho_new / delta), last ? 0 : 1);
+		}
+		rho = rho_new;
+	}
+}
+
+// ---- the V-cycle's polynomial smoother ----------------------------------------------------------------------------
+// M = p_d(D^-1 A^) D^-1 with A^ = A_model + f diag(A_data), D = diag(A^): the polynomial of cg_run_poly's preconditioner
+// (same kernel, same recurrence: fi_stencil.hip ChebEpi mode 0) over an operator that BOUNDS the full one -- a cell's
+// block is sum a a^T <= 2^D diag(a_i^2), so with f = 2^D, A <= A^ and the spectrum of M A stays below 1 + eps < 2: a
+// convergent smoother whatever the data; f = mg_safe = 4 is the measured optimum (tools/proto_cc.py: 11 / 11 / 13
+// iterations for f = 2 / 4 / 8 on config 4, f = 1 diverges on dense data).  A smoothing pass is
+//     pre  (from zero):  x = M b                                   d - 1 plain launches of (2.5 .. 4.5) lattice passes
+//     post:              x += M (b - A x)                          one full apply with the residual epilogue + the same
+// against 2 d launches of the fused (data-cell) kernel with the epilogue for the Chebyshev smoother in A itself.
+int    mg_poly_terms(const fi_ctx* c)
+{
+	if (c->level > 0) {
+		const char* ec = tuning_switch("FI_MG_COARSE_TERMS");
+		if (ec && atoi(ec) > 1) { return atoi(ec); }
+	}
+	const char* e = tuning_switch("FI_MG_TERMS");
+	return e && atoi(e) > 0 ? atoi(e) : c->mg_terms;
+}
+double mg_poly_ratio(const fi_ctx* c) { const char* e = tuning_switch("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : c->mg_pratio; }
+template <typename T>
+bool poly_smoother_ok(const RankSet& R)
+{
+	if (sizeof(T) != 4 || test_switch("FI_MG_FULL_SMOOTHER")) { return false; }  // tests compare the two smoothers
+	for (const fi_ctx* c : R) {
+		// 3-D levels only: the 2-D tile kernel applies its cells in the same single launch, so the Chebyshev smoother in
+		// the full operator costs no more per step there and is the better smoother (config 3: 13 iterations against 38)
+		if (c->mg_smoother != 1 || !c->value_rows_only || !c->march.valid || !stencil_full_epi_available(c) || c->generic.ntrip != 0 || c->any_trip) {
+			return false;
+		}
+	}
+	return true;
+}
+
+// z = M r through the work vectors za / zb; returns the one that holds the result (ghost planes not exchanged)
+template <typename T>
+Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr, int* chain_launches = nullptr)
+{
+	fi_ctx* c0 = R[0];
+	const int    terms = mg_poly_terms(c0);
+	const double lam = c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0;
+	const double hi = 1.1 * lam, lo = hi / mg_poly_ratio(c0);
+	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+	const bool single = R.size() == 1 && c0->nranks == 1;
+	bool ghosts_scaled = true;
+	for (const fi_ctx* c : R) { ghosts_scaled = ghosts_scaled && c->scaling_ghosts; }
+	const bool pro = (single || ghosts_scaled) && terms > 2 && c0->march.valid && !test_switch("FI_NO_Z0_ON_LOAD");
+	auto region2 = [](fi_ctx* c) { return c->partial.as<double>() + 2 * static_cast<size_t>(c->max_blocks); };
+	if (!pro) {
+		for (fi_ctx* c : R) {  // z_0 = Dinv r / theta
+			hipLaunchKernelGGL((k_cheb_first16<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   vown<T>(c, r), c->dinv16s.as<unsigned short>() + c->g.own_first, vown<T>(c, za),
+			                   static_cast<T>(1.0 / theta));
+		}
+	}
+	if (chain_bytes) {  // z, z_prev, r in, z_new out + the bfloat16 scaling; the first step has no z_prev (formed on load: no z
+		*chain_bytes = 0;   // either), the second recomputes its z_prev from r: 2.5 / 3.5 / 4.5 lattice passes in fp32
+		for (int j = 1; j < terms; ++j) {
+			const double vecs = j == 1 ? (pro ? 2.0 : 3.0) : (j == 2 ? 3.0 : 4.0);
+			*chain_bytes += (static_cast<double>(sizeof(T)) * vecs + 2.0) * static_cast<double>(c0->g.nown);
+		}
+	}
+	if (chain_launches) { *chain_launches = terms - 1; }
+	Vec zin = za, zout = zb;
+	double rho = 1.0 / sigma;
+	for (int k = 1; k < terms; ++k) {
+		const double rho_new = 1.0 / (2.0 * sigma - rho);
+		const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+		const bool   first_on_load = pro && k == 1;
+		halo_exchange(R, first_on_load ? r : zin);
+		for (fi_ctx* c : R) {
+			const unsigned short* sc = c->dinv16s.as<unsigned short>();
+			if (first_on_load) {
+				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc);
+			} else {
+				// the second step's z_prev is z_0 = Dinv r / theta, recomputed from r and the scaling
+				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0,
+				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc);
+			}
+		}
+		std::swap(zin, zout);
+		rho = rho_new;
+	}
+	return zin;
+}
+
+// ---- the V-cycle of the hierarchy's tail as a program of the small-level engine (fi_tail.h) ----------------------------
+// The same cycle as vcycle() below -- the same smoothers with the same constants, the same transfers -- written out as the
+// stages of ONE cooperative launch.  Vectors: rhs b and result x as the caller names them on the top level, mg_b / mg_x
+// below; work vectors mg_r (residual), mg_d and q (the polynomials' iterates: x itself is only ever the final target of a
+// stage, never an intermediate, so the program's pointers stay valid from cycle to cycle).
+template <typename T>
+bool poly_smoother_ok(const RankSet& R);
+
+struct TailProgram {
+	std::vector<TailOp> ops;
+	std::vector<fi_ctx*> chain;
+	bool ok = true;
+
+	void op(int kind, int level, const float* a, const float* b, const float* c, float* out, float* acc, const unsigned short* scale,
+	        double s0 = 0, double s1 = 0, double s2 = 0)
+	{
+		ops.push_back(TailOp{kind, level, a, b, c, out, acc, scale, static_cast<float>(s0), static_cast<float>(s1), static_cast<float>(s2), 0});
+	}
+	// target (+)= M r: the polynomial in A_model + f diag(A_data) (poly_chain); out: target of the last step, acc: accumulate
+	void poly_ops(int l, const float* r, float* out, float* acc)
+	{
+		fi_ctx* c = chain[l];
+		const int    terms = mg_poly_terms(c);
+		const double lam = c->poly_lambda > 1.0 ? c->poly_lambda : 1.0;
+		const double hi = 1.1 * lam, lo = hi / mg_poly_ratio(c);
+		const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+		const unsigned short* sc = c->dinv16s.as<unsigned short>();
+		float* W[2] = {c->mg_d.as<float>(), c->q.as<float>()};
+		if (terms < 2) { ok = false; return; }
+		op(kTailScale, l, r, nullptr, nullptr, W[0], nullptr, sc, 1.0 / theta);
+		int cur = 0;
+		double rho = 1.0 / sigma;
+		for (int k = 1; k < terms; ++k) {
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+			const bool   last = k == terms - 1;
+			op(kTailPolyStep, l, W[cur], k == 1 ? nullptr : W[1 - cur], r, last ? out : W[1 - cur], last ? acc : nullptr, sc, 1.0 + c1,
+			   k == 1 ? 0.0 : c1, c2);
+			cur = 1 - cur;
+			rho = rho_new;
+		}
+	}
+	// degree-k Chebyshev smoothing in the full operator (cheb_smooth_fused): x starts at zero / at its present value
+	void cheb_ops(int l, const float* b, float* x, int degree, double ratio, bool from_zero)
+	{
+		fi_ctx* c = chain[l];
+		const double hi = 1.1 * c->lambda_max, lo = hi / ratio;
+		const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+		const unsigned short* sc = c->dinv16.as<unsigned short>();
+		float* W[2] = {c->mg_d.as<float>(), c->mg_r.as<float>()};
+		if (degree < 2 || !(c->lambda_max > 0)) { ok = false; return; }
+		const float* zk = nullptr;    // x_k
+		const float* zp = nullptr;    // x_{k-1} (null: zero, or no such term)
+		int steps = degree - 1;       // recurrence steps after the first term
+		if (from_zero) {
+			op(kTailScale, l, b, nullptr, nullptr, W[0], nullptr, sc, 1.0 / theta);   // x_1 = Dinv b / theta
+			zk = W[0];
+		} else {
+			op(kTailChebStep, l, x, nullptr, b, W[0], nullptr, sc, 1.0, 0.0, 1.0 / theta);  // x_1 = x_0 + Dinv (b - A x_0) / theta
+			zk = W[0];
+			zp = x;
+		}
+		double rho = 1.0 / sigma;
+		for (int k = 1; k <= steps; ++k) {
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+			const bool   last = k == steps;
+			float* out = last ? x : (zk == W[0] ? W[1] : W[0]);   // (x_{k-1}'s buffer may be overwritten: it is read at the point itself only)
+			op(kTailChebStep, l, zk, zp, b, out, nullptr, sc, 1.0 + c1, zp ? c1 : 0.0, c2);
+			zp = zk;
+			zk = out;
+			rho = rho_new;
+		}
+	}
+	void residual(int l, const float* x, const float* b, float* out) { op(kTailResidual, l, x, nullptr, b, out, nullptr, nullptr); }
+
+	void cycle(int l, const float* b, float* x)
+	{
+		fi_ctx* c = chain[l];
+		RankSet one{c};
+		const bool last = l + 1 == static_cast<int>(chain.size());
+		const bool poly = poly_smoother_ok<float>(one);
+		const int    deg = mg_degree();
+		const double ratio = mg_ratio();
+		float* r = c->mg_r.as<float>();
+		if (c->lumped) { ok = false; return; }
+		if (last) {
+			if (poly && c->dinv16s_valid && c->data_pinned && !test_switch("FI_MG_COARSEST_CHEB")) {
+				poly_ops(l, b, x, nullptr);
+				residual(l, x, b, r);
+				poly_ops(l, r, nullptr, x);
+			} else {
+				cheb_ops(l, b, x, 4 * deg + 4, 10.0 * ratio, true);
+			}
+			return;
+		}
+		fi_ctx* co = chain[l + 1];
+		if (poly) {
+			poly_ops(l, b, x, nullptr);
+		} else {
+			cheb_ops(l, b, x, deg, ratio, true);
+		}
+		residual(l, x, b, r);
+		op(kTailRestrict, l, r, nullptr, nullptr, co->mg_b.as<float>(), nullptr, nullptr);
+		cycle(l + 1, co->mg_b.as<float>(), co->mg_x.as<float>());
+		op(kTailProlongAdd, l, co->mg_x.as<float>(), nullptr, nullptr, x, nullptr, nullptr);
+		if (poly) {
+			residual(l, x, b, r);
+			poly_ops(l, r, nullptr, x);
+		} else {
+			cheb_ops(l, b, x, deg, ratio, false);
+		}
+	}
+};
+
+// x = V(b) on the tail that starts at R's level, in one launch; false: the level is not the engine's (the caller recurses)
+template <typename T>
+bool tail_vcycle(RankSet& R, Vec b, Vec x)
+{
+	if (sizeof(T) != 4 || R.size() != 1) { return false; }
+	fi_ctx* c = R[0];
+	if (c->level == 0 || !c->tail_ok || c->nranks != 1) { return false; }
+	const void* bp = (c->*b).p;
+	const void* xp = (c->*x).p;
+	if (!c->tail_prog_valid || c->tail_prog_b != bp || c->tail_prog_x != xp) {
+		TailProgram P;
+		for (fi_ctx* l = c; l; l = l->coarse) { P.chain.push_back(l); }
+		P.cycle(0, static_cast<const float*>(bp), static_cast<float*>(const_cast<void*>(xp)));
+		if (!P.ok || P.ops.empty()) {
+			c->tail_ok = false;  // (a setting the engine does not cover: the tiled kernels run this hierarchy)
+			return false;
+		}
+		std::vector<unsigned char> blob(sizeof(TailLevel) * kTailMaxLevels + sizeof(TailOp) * P.ops.size());
+		TailLevel* lv = reinterpret_cast<TailLevel*>(blob.data());
+		int64_t widest = 0;
+		for (size_t k = 0; k < P.chain.size(); ++k) {
+			lv[k] = tail_level_of(P.chain[k]);
+			if (k + 1 < P.chain.size()) { lv[k].to_coarse = level_pair(P.chain[k], P.chain[k + 1]); }
+			widest = lv[k].nn > widest ? lv[k].nn : widest;
+		}
+		std::memcpy(blob.data() + sizeof(TailLevel) * kTailMaxLevels, P.ops.data(), sizeof(TailOp) * P.ops.size());
+		c->tail_prog.alloc(blob.size());
+		FI_HIP_TRY(hipMemcpyAsync(c->tail_prog.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+		FI_HIP_TRY(hipStreamSynchronize(c->stream));  // (the host buffer dies here)
+		c->tail_nlev       = static_cast<int>(P.chain.size());
+		c->tail_nops       = static_cast<int>(P.ops.size());
+		c->tail_widest     = widest;
+		c->tail_prog_b     = bp;
+		c->tail_prog_x     = xp;
+		c->tail_prog_valid = true;
+	}
+	tail_run(c, c->tail_prog.p, c->tail_nlev, c->tail_nops, c->tail_widest);
+	return true;
+}
+
+// x = V(b) on the level of R.  Over slabs every level is a slab decomposition of its own (coarse plane k lives
+// with fine plane 2k): restriction reads one ghost plane of the fine residual, interpolation one of the coarse
+// correction.
+template <typename T>
+void vcycle(RankSet& R, Vec b, Vec x)
+{
+	if (replicated_copies(R)) {  // the replicated tail in a loop-back group: every member's copy on its own
+		for_each_copy(R, [&](RankSet& one) { vcycle<T>(one, b, x); });
+		return;
+	}
+	if (tail_vcycle<T>(R, b, x)) { return; }  // the small-level engine: this level and all below it in one launch
+	const int deg = mg_degree();
+	const double ratio = mg_ratio();
+	if (tuning_switch("FI_MG_POLY")) {  // experiment: the polynomial alone as the preconditioner, no coarse correction
+		cheb_smooth<T>(R, b, x, deg, ratio, true);
+		return;
+	}
+	const bool poly = poly_smoother_ok<T>(R);
+	for (const fi_ctx* c : R) {
+		FI_REQUIRE(!c->lumped || poly, FI_ERR_UNSUPPORTED, "a lumped replica smooths with the polynomial only");
+	}
+	auto residual = [&]() {  // mg_r = b - A x (a lumped replica: its own operator, A_model + diag(dlump))
+		halo_exchange(R, x);
+		for (fi_ctx* c : R) {
+			if (c->lumped) {
+				stencil_lumped_residual(c, (c->*x).p, (c->*b).p, c->mg_r.p);
+			} else {
+				stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, true, c->mg_r.p, 0.0, 0.0, 0.0);
+			}
+		}
+	};
+	auto post_smooth = [&]() {  // x += M (b - A x)
+		residual();
+		const Vec d = poly_chain<T>(R, &fi_ctx::mg_r, &fi_ctx::mg_d, &fi_ctx::q);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_add_vec<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, d),
+			                   vown<T>(c, x));
+		}
+	};
+	if (!R[0]->coarse) {
+		// coarsest level: two sweeps of the polynomial smoother where the data pin every point (fi_ctx::data_pinned: config
+		// 4 -- as good as an exact solve there, tools/proto_cc.py, and 7 launches instead of 20); else a longer polynomial
+		// over a wider band, in the full operator: an SDF's coarsest level still has weakly held global modes (97 instead of
+		// 37 iterations on the 40 x 32 x 48 test problem with the sweeps).
+		if (poly && R[0]->dinv16s_valid && R[0]->data_pinned && !test_switch("FI_MG_COARSEST_CHEB")) {
+			swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d));
+			post_smooth();
+			return;
+		}
+		cheb_smooth<T>(R, b, x, 4 * deg + 4, 10.0 * ratio, true);
+		return;
+	}
+	RankSet Rc = coarse_of(R);
+	// a slab level above the replicated tail: every rank restricts into its own coarse planes of the WHOLE coarse lattice,
+	// the parts are summed over the ranks (the one collective of the tail), the interpolation needs no exchange
+	const bool junction = Rc[0]->replicated && !R[0]->replicated && R[0]->nranks > 1;
+	if (poly) {
+		// x = M b.  The finest level's chain is timed for the first cycles of a solve (cg_run_mg sets the budget): all its
+		// launches between one pair of event records, like the polynomial PCG's samples
+		fi_ctx* c0 = R[0];
+		const bool sample = c0->level == 0 && c0->prec_budget > 0 && static_cast<int>(c0->ev_prec.size()) >= 2 * (c0->prec_taken + 1);
+		if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev_prec[2 * c0->prec_taken], c0->stream)); }
+		swap_vectors(R, x, poly_chain<T>(R, b, x, &fi_ctx::mg_d, sample ? &c0->prec_chain_bytes : nullptr,
+		                                 sample ? &c0->prec_chain_launches : nullptr));
+		if (sample) {
+			FI_HIP_TRY(hipEventRecord(c0->ev_prec[2 * c0->prec_taken + 1], c0->stream));
+			++c0->prec_taken;
+			--c0->prec_budget;
+		}
+		residual();
+		halo_exchange(R, &fi_ctx::mg_r);
+		for (size_t i = 0; i < R.size(); ++i) {
+			const LevelPair L = level_pair(R[i], Rc[i]);
+			if (junction) { FI_HIP_TRY(hipMemsetAsync(Rc[i]->mg_b.p, 0, sizeof(T) * Rc[i]->g.nloc, R[i]->stream)); }
+			launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream, vbase<T>(R[i], &fi_ctx::q),
+			                   R[i]->g.n[2]);
+		}
+		if (junction) { sum_over_ranks<T>(R, Rc, &fi_ctx::mg_b); }
+		vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
+		halo_exchange(Rc, &fi_ctx::mg_x);
+		for (size_t i = 0; i < R.size(); ++i) {
+			const LevelPair L = level_pair(R[i], Rc[i]);
+			launch_prolong<T>(L, vbase<T>(Rc[i], &fi_ctx::mg_x), vbase<T>(R[i], x), 1, R[i]->stream);
+		}
+		post_smooth();
+		return;
+	}
+	cheb_smooth<T>(R, b, x, deg, ratio, true);
+	if (smooth_fused_ok(R)) {  // mg_r = b - A x in one launch
+		halo_exchange(R, x);
+		for (fi_ctx* c : R) { stencil_full_step(c, (c->*x).p, nullptr, (c->*b).p, true, c->mg_r.p, 0.0, 0.0, 0.0); }
+	} else {
+		apply_all(R, x, &fi_ctx::q, false);
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_sub<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, b),
+			                   vown<T>(c, &fi_ctx::q), vown<T>(c, &fi_ctx::mg_r));
+		}
+	}
+	halo_exchange(R, &fi_ctx::mg_r);
+	for (size_t i = 0; i < R.size(); ++i) {
+		const LevelPair L = level_pair(R[i], Rc[i]);
+		if (junction) { FI_HIP_TRY(hipMemsetAsync(Rc[i]->mg_b.p, 0, sizeof(T) * Rc[i]->g.nloc, R[i]->stream)); }
+		launch_restrict<T>(L, vbase<T>(R[i], &fi_ctx::mg_r), vbase<T>(Rc[i], &fi_ctx::mg_b), R[i]->stream, vbase<T>(R[i], &fi_ctx::q),
+		                   R[i]->g.n[2]);
+	}
+	if (junction) { sum_over_ranks<T>(R, Rc, &fi_ctx::mg_b); }
+	vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
+	halo_exchange(Rc, &fi_ctx::mg_x);
+	for (size_t i = 0; i < R.size(); ++i) {
+		const LevelPair L = level_pair(R[i], Rc[i]);
+		launch_prolong<T>(L, vbase<T>(Rc[i], &fi_ctx::mg_x), vbase<T>(R[i], x), 1, R[i]->stream);
+	}
+	cheb_smooth<T>(R, b, x, deg, ratio, false);
+}
+
+// work vectors, cleared stop flags and smoother bounds for every level below (and including) R
+template <typename T>
+void mg_prepare(RankSet& R, bool clear_finest)
+{
+	RankSet lev = R;
+	bool finest = true;
+	while (!lev.empty() && lev[0]) {
+		for (fi_ctx* l : lev) {
+			mg_alloc<T>(l);
+			if (!finest || clear_finest) {  // the operator kernels of a level exit early while ITS stop flag is up
+				FI_HIP_TRY(hipMemsetAsync(l->scal.p, 0, sizeof(CgScalars), l->stream));  // (no host source that could go out of scope)
+			}
+		}
+		finest = false;
+		if (!lev[0]->coarse) { break; }
+		lev = coarse_of(lev);
+	}
+	// smoother bounds.  Levels that smooth with the polynomial in A_model + f diag(A_data) (poly_smoother_ok): the bound of
+	// the model operator (a number of the lattice and the weights: kept across assembles) and the scaling array.  The
+	// others (Chebyshev in the full operator; the coarsest level always): power method on Dinv A, once per assemble.
+	if (!R[0]->coarse) { return; }
+	std::vector<RankSet> chain;
+	for (RankSet l = R;; l = coarse_of(l)) {
+		chain.push_back(l);
+		if (!l[0]->coarse) { break; }
+	}
+	for (size_t k = chain.size(); k-- > 0;) {
+		RankSet& l = chain[k];
+		const bool coarsest = k + 1 == chain.size();
+		bool poly_level = poly_smoother_ok<T>(l);
+		if (poly_level) {
+			for (fi_ctx* c : l) {
+				if (!c->dinv16s_valid) { prepare_safe_scaling(c); }  // (also says whether the data pin a small level)
+			}
+			// the coarsest level: the polynomial only where the data hold every point at least as firmly as the model
+			// couples it -- an SDF's coarsest level keeps weakly held global modes and needs the long Chebyshev polynomial in A
+			if (coarsest) {
+				for (const fi_ctx* c : l) { poly_level = poly_level && c->data_pinned && !test_switch("FI_MG_COARSEST_CHEB"); }
+				if (!poly_level) {
+					for (fi_ctx* c : l) { c->data_pinned = false; }
+				}
+			}
+		}
+		if (poly_level) {
+			if (!(l[0]->poly_lambda > 0)) { for_each_copy(l, [&](RankSet& s) { estimate_poly_lambda<T>(s); }); }
+		} else if (!(l[0]->lambda_max > 0)) {
+			// Every level estimates its own bound.  (Rounds 1-2 let the finest level -- 8x the work -- take the estimate of
+			// the level below it: the coarse replicas weigh data against model differently, and a stress case with
+			// nearest-neighbour gradient rows, tests/stress_solve.py seed 5039, stagnated at 2e-3 for 60 000 iterations under
+			// a smoother whose interval was too short.  Levels that smooth with the polynomial need no estimate at all.)
+			for_each_copy(l, [&](RankSet& s) { estimate_lambda<T>(s); });
+		}
+	}
+}
+
+__global__ __launch_bounds__(kThreads) void k_to_twin(int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ r,
+                                                       float* __restrict__ r32)
+{
+	const double inv = 1.0 / twin_scale(sc);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		r32[i] = static_cast<float>(r[i] * inv);
+	}
+}
+
+// z = V(r).  Mixed precision (Tw: the fp32 replicas): the V-cycle reads the replica's r and leaves z in the replica's
+// mg_x, scaled by CgScalars::tscale -- `have_r32`: k_mg_step_mixed has already written the fp32 residual; the fp64 copy
+// of z is not formed (k_dot_mixed / k_mg_direction_mixed read the fp32 one).
+template <typename T>
+void precondition(RankSet& R, RankSet& Tw, Vec r, Vec z, bool have_r32)
+{
+	vcycle<T>(R, r, z);
+}
+template <>
+void precondition<double>(RankSet& R, RankSet& Tw, Vec r, Vec z, bool have_r32)
+{
+	if (Tw.empty()) {
+		vcycle<double>(R, r, z);
+		return;
+	}
+	if (!have_r32) {
+		for (size_t i = 0; i < R.size(); ++i) {
+			fi_ctx* c = R[i];
+			fi_ctx* t = Tw[i];
+			hipLaunchKernelGGL(k_to_twin, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   c->scal.as<CgScalars>(), vown<double>(c, r), vown<float>(t, &fi_ctx::r));
+		}
+	}
+	vcycle<float>(Tw, &fi_ctx::r, &fi_ctx::mg_x);
+}
+
+// coarse-to-fine start on the fp32 replicas of FI_F64 contexts (mixed precision), widened into x
+__global__ __launch_bounds__(kThreads) void k_widen(int64_t n, const float* __restrict__ src, double* __restrict__ dst)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		dst[i] = static_cast<double>(src[i]);
+	}
+}
+void twin_cascade_guess(RankSet& R)
+{
+	RankSet Tw;
+	for (fi_ctx* c : R) {
+		ensure_vectors(c->twin);
+		c->twin->stats.coarse_iterations = 0;
+		Tw.push_back(c->twin);
+	}
+	cascade_guess<float>(Tw);
+	for (fi_ctx* c : R) {
+		fi_ctx* t = c->twin;
+		FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->g.nloc, c->stream));
+		hipLaunchKernelGGL(k_widen, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+		                   t->x.as<float>() + t->g.own_first, c->x.as<double>() + c->g.own_first);
+		c->stats.coarse_iterations = t->stats.coarse_iterations;
+	}
+	FI_HIP_TRY(hipGetLastError());
+}
+
+// V-cycle preconditioned CG on the finest level; x of every member holds the guess on entry
+template <typename T>
+void cg_run_mg(RankSet& R, int max_iterations, float tol)
+{
+	fi_ctx* c0 = R[0];
+	hipStream_t st = c0->stream;
+	// mixed precision: the V-cycle runs on the fp32 replicas (RankSet Tw), CG itself stays in T = double
+	RankSet Tw;
+	if (sizeof(T) == 8 && c0->twin && c0->twin->coarse) {
+		for (fi_ctx* c : R) { Tw.push_back(c->twin); }
+		mg_prepare<float>(Tw, true);
+	} else {
+		mg_prepare<T>(R, false);
+	}
+	if (max_iterations <= 0) {
+		const int64_t dflt = 2 * static_cast<int64_t>(c0->g.gn[0]) * c0->g.gn[1] * c0->g.gn[2];
+		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
+	}
+	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
+	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
+	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
+	FI_HIP_TRY(hipEventRecord(e0, st));
+	CgScalars init{};
+	init.tol2     = tolerance * tolerance;
+	init.max_iter = max_iterations;
+	reset_scalars(R, init);
+	CgScalars* sc0 = c0->scal.as<CgScalars>();
+	auto nbv      = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
+	auto nb_apply = [](fi_ctx* c) { return apply_num_partials(c); };
+	const Vec X = &fi_ctx::x, Rv = &fi_ctx::r, P = &fi_ctx::p, Q = &fi_ctx::q, Z = &fi_ctx::mg_x, B = &fi_ctx::atb;
+	while (static_cast<int>(c0->ev.size()) < 2 * kMaxSamples) {
+		hipEvent_t e;
+		FI_HIP_TRY(hipEventCreate(&e));
+		c0->ev.push_back(e);
+	}
+	int samples = 0;
+	const bool mixed = !Tw.empty();
+	fi_ctx* const prec_ctx = mixed ? Tw[0] : c0;  // the context whose finest-level smoother chains are timed (vcycle)
+	if (prec_ctx->level == 0 && !(mixed ? replicated_copies(Tw) : replicated_copies(R))) {
+		while (static_cast<int>(prec_ctx->ev_prec.size()) < 2 * kPolySamples) {
+			hipEvent_t e;
+			FI_HIP_TRY(hipEventCreate(&e));
+			prec_ctx->ev_prec.push_back(e);
+		}
+		prec_ctx->prec_budget = kPolySamples;
+		prec_ctx->prec_taken  = 0;
+	}
+	auto dot = [&](Vec a, Vec b) {
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_dot<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, a), vown<T>(c, b),
+			                   c->partial.as<double>());
+		}
+	};
+	auto dot_rz = [&]() {  // partials of r . z
+		if constexpr (std::is_same<T, double>::value) {
+			if (mixed) {
+				for (size_t i = 0; i < R.size(); ++i) {
+					fi_ctx* c = R[i];
+					hipLaunchKernelGGL(k_dot_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+					                   vown<double>(c, Rv), vown<float>(Tw[i], &fi_ctx::mg_x), c->partial.as<double>());
+				}
+				return;
+			}
+		}
+		dot(Rv, Z);
+	};
+	auto direction = [&](int first) {
+		if constexpr (std::is_same<T, double>::value) {
+			if (mixed) {
+				for (size_t i = 0; i < R.size(); ++i) {
+					fi_ctx* c = R[i];
+					hipLaunchKernelGGL(k_mg_direction_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+					                   c->scal.as<CgScalars>(), vown<float>(Tw[i], &fi_ctx::mg_x), vown<double>(c, P), first);
+				}
+				return;
+			}
+		}
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_mg_direction<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   c->scal.as<CgScalars>(), vown<T>(c, Z), vown<T>(c, P), first);
+		}
+	};
+
+	auto read_flag = [&]() {
+		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+		return c0->scal_host->done;
+	};
+	// r = b - A x, rr (b.b on the first call) and the stop test on it; unless that ends the solve: z = V(r), p = z, rz.
+	// Returns the stop flag.  (The flag is read BEFORE the V-cycle is spent: a verification that confirms the recurrence's
+	// residual -- the usual outcome -- costs one operator application, not a cycle.)
+	auto restart = [&]() -> int {
+		apply_all(R, X, Q, false);
+		if (R.size() == 1 && c0->nranks == 1) {  // undivided lattice: one pass for r, r.r and b.b
+			double* prr = c0->partial.as<double>();
+			double* pbb = prr + static_cast<size_t>(c0->max_blocks);
+			hipLaunchKernelGGL((k_resid_norms<T>), dim3(nbv(c0)), dim3(kThreads), 0, st, c0->g.nown, vown<T>(c0, B), vown<T>(c0, Q),
+			                   vown<T>(c0, Rv), prr, pbb);
+			hipLaunchKernelGGL(k_sum_to_slot2, dim3(1), dim3(kThreads), 0, st, sc0, pbb, nbv(c0));
+			mg_reduce(R, nbv, kMgInitRr);
+		} else {
+		for (fi_ctx* c : R) {
+			hipLaunchKernelGGL((k_sub<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, B), vown<T>(c, Q),
+			                   vown<T>(c, Rv));
+		}
+		dot(B, B);
+		reduce_phase(R, 1, nbv, nbv, -1);  // -> sums[0]
+		for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_sum2, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
+		dot(Rv, Rv);
+		mg_reduce(R, nbv, kMgInitRr);
+		}
+		const int flag = read_flag();
+		if (flag) { return flag; }
+		precondition<T>(R, Tw, Rv, Z, false);
+		dot_rz();
+		mg_reduce(R, nbv, kMgInitRz);
+		direction(1);
+		return 0;
+	};
+	int done = restart();
+
+	double limit_s = 600.0;
+	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
+	const auto wall0 = std::chrono::steady_clock::now();
+	bool timed_out = false;
+	int restarts_left = c0->verify_residual ? 3 : 0;
+	int widenings_left = 2;
+	// One look at the stop flag per iteration, right behind the residual update: the V-cycle of an iteration that has just
+	// converged is not launched.
+	for (;;) {
+		if (done == 2 && widenings_left > 0 && std::isfinite(c0->scal_host->rr) && std::isfinite(c0->scal_host->pq)) {
+			// r.V(r) <= 0 with finite numbers: a smoother's interval is too short for its level (the bounds are power-method
+			// estimates: lower bounds with 10 % headroom) and the V-cycle is not positive definite.  Widen every level's
+			// interval and go on from the last iterate.
+			--widenings_left;
+			RankSet top = mixed ? Tw : R;
+			for (fi_ctx* c : top) {
+				for (fi_ctx* l = c; l; l = l->coarse) {
+					l->tail_prog_valid = false;  // (the small-level engine's program carries the smoothers' constants)
+					if (l->lambda_max > 0) { l->lambda_max *= 1.5; }
+					if (l->poly_lambda > 0) {
+						l->poly_lambda = (l->poly_lambda > 1.0 ? l->poly_lambda : 1.0) * 1.25;
+						remember_lambda(l);
+					}
+				}
+			}
+			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>(), 0); }
+			done = restart();
+			continue;
+		}
+		if (done) {
+			if (done != 1 || restarts_left <= 0) { break; }
+			--restarts_left;  // recurrence converged: check b - A x, continue from it if it misses the tolerance
+			for (fi_ctx* c : R) { hipLaunchKernelGGL(k_bump_restarts, dim3(1), dim3(1), 0, c->stream, c->scal.as<CgScalars>()); }
+			done = restart();
+			continue;
+		}
+		if (timed_out_anywhere(R, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > limit_s)) {
+			timed_out = true;
+			break;
+		}
+		const bool sample = samples < kMaxSamples;
+		halo_exchange(R, P);
+		if (sample) { FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples], st)); }
+		for (fi_ctx* c : R) { apply_AtA(c, c->p.p, c->q.p, c->partial.as<double>()); }
+		if (sample) {
+			FI_HIP_TRY(hipEventRecord(c0->ev[2 * samples + 1], st));
+			++samples;
+		}
+		mg_reduce(R, nb_apply, kMgAlpha);
+		bool stepped = false;
+		if constexpr (std::is_same<T, double>::value) {
+			if (mixed) {
+				for (size_t i = 0; i < R.size(); ++i) {
+					fi_ctx* c = R[i];
+					hipLaunchKernelGGL(k_mg_step_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+					                   vown<double>(c, P), vown<double>(c, Q), vown<double>(c, X), vown<double>(c, Rv),
+					                   vown<float>(Tw[i], &fi_ctx::r), c->partial.as<double>());
+				}
+				stepped = true;
+			}
+		}
+		if (!stepped) {
+			for (fi_ctx* c : R) {
+				hipLaunchKernelGGL((k_mg_step<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+				                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>());
+			}
+		}
+		mg_reduce(R, nbv, kMgResid);
+		done = read_flag();
+		if (done) { continue; }
+		precondition<T>(R, Tw, Rv, Z, stepped);
+		dot_rz();
+		mg_reduce(R, nbv, kMgBeta);
+		direction(0);
+		FI_HIP_TRY(hipGetLastError());
+	}
+	FI_HIP_TRY(hipEventRecord(e1, st));
+	FI_HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	const CgScalars h = *c0->scal_host;
+	int used = samples < h.iter ? samples : h.iter;
+	double sum_ms = 0;
+	for (int k = 0; k < used; ++k) {
+		float t = 0;
+		FI_HIP_TRY(hipEventElapsedTime(&t, c0->ev[2 * k], c0->ev[2 * k + 1]));
+		sum_ms += t;
+	}
+	// the timed smoother chains of cycles that ran (cycle k belongs to iteration k: the first one to the start)
+	int pused = 0, plaunch = 0;
+	double psum = 0;
+	prec_ctx->prec_budget = 0;
+	if (prec_ctx->level == 0) {
+		const int ran = prec_ctx->prec_taken < h.iter + 1 ? prec_ctx->prec_taken : h.iter + 1;
+		for (int k = 0; k < ran; ++k) {
+			float t = 0;
+			FI_HIP_TRY(hipEventElapsedTime(&t, prec_ctx->ev_prec[2 * k], prec_ctx->ev_prec[2 * k + 1]));
+			psum += t;
+			++pused;
+		}
+		plaunch = prec_ctx->prec_chain_launches;
+	}
+	for (fi_ctx* c : R) {
+		c->stats.spmv_samples = used;
+		c->stats.spmv_ms_avg  = used ? sum_ms / used : 0.0;
+		c->stats.spmv_bytes   = apply_algorithmic_bytes(c);
+		// per LAUNCH, like the polynomial PCG's figures: a sample holds the launches of one chain
+		c->stats.prec_samples = pused * plaunch;
+		c->stats.prec_ms_avg  = pused && plaunch ? psum / (pused * plaunch) : 0.0;
+		c->stats.prec_bytes   = pused && plaunch ? prec_ctx->prec_chain_bytes / plaunch : 0.0;
+		c->stats.operator_applies = h.iter + 1 + h.restarts;
+		c->stats.solve_ms     = ms;
+		c->stats.iterations   = h.iter;
+		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
+		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
+		c->stats.restarts     = h.restarts;
+		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
+		if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
+	}
+	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);
+	FI_REQUIRE(!timed_out, FI_ERR_TIMEOUT, "solve stopped by the wall-clock guard (FI_SOLVE_TIMEOUT_S = %g s) after %d iterations, "
+	           "relative residual %g", limit_s, h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0);
+}
+
+
+
+// ---- explicit instantiations (declared in fi_solver_internal.h) ----
+template void cascade_guess<float>(RankSet&);
+template void cascade_guess<double>(RankSet&);
+template void cg_run_mg<float>(RankSet&, int, float);
+template void cg_run_mg<double>(RankSet&, int, float);
+template void mg_alloc<float>(fi_ctx*);
+template void mg_alloc<double>(fi_ctx*);
+
+}  // namespace fi
