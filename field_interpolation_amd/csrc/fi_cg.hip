@@ -596,7 +596,10 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 			timed_out = true;
 			break;
 		}
-		for (int k = 0; k < kCheckEvery; ++k) {
+		// (a coarser level of a coarse-to-fine start is done within a few steps: shorter bursts between two looks at the flag
+		// leave fewer launches behind that only find the flag up -- 31 of 48 iterations of config 4's three levels)
+		const int burst = c0->level > 0 ? kCheckEvery / 2 : kCheckEvery;
+		for (int k = 0; k < burst; ++k) {
 			++issued;
 			// every 4th apply is timed: an event record is a barrier packet of its own in the queue
 			const bool sample = c0->level == 0 && samples < 8 && (issued & 3) == 1;  // event pairs cost the stream ~11 us each

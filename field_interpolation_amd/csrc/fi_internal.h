@@ -180,6 +180,7 @@ struct MarchParams {
 	int     tx, ty;          // tile extent in x and y (lattice points)
 	int     txt;             // threads along x (32: wide tiles, 16: 64 x 16)
 	int     dbg;             // timing experiments only (FI_DBG): 1 = no halo loads, 2 = no stores
+	int     dense_min;       // a layer with more records than this is scattered by all four waves (fi_stencil.hip)
 	int64_t plane;           // nx * ny
 };
 

@@ -348,6 +348,7 @@ void twin_assemble_lumped(fi_ctx* c)
 	generic_assemble(t);
 	stencil_prepare(t);
 	operator_prepare(t);
+	if (t->nranks == 1) { prepare_safe_scaling(t); }  // (the smoother's scaling with the assembly; slabs: after the ghost planes' exchange)
 }
 
 fi_ctx* twin_prepare(fi_ctx* c)

@@ -85,8 +85,16 @@ constexpr int kThreads = 256;
 // Tile shapes (threads along x; a thread owns VX points): 32 -> 128 x 8 tiles in fp32 (512-byte runs per row: 7 %
 // faster than 64 x 16 at 512^3, equal at 256^3), 16 -> 64 x 16 for lattices a wide tile would mostly overhang
 // (64^3 levels of the cascade: half of every 128-wide tile would be idle).  Chosen per context by march_setup.
-#ifndef FI_DENSE_MIN
-#define FI_DENSE_MIN 64u  // a layer with more records than this is scattered by all four waves (a band each)
+// A layer with more records than MarchParams::dense_min is scattered by all four waves (a band each), a sparser one by ONE
+// wave while the others skip the code.  Swept in round 4 on the isolated apply of config 4 (60-67 records per layer and
+// tile: right at the threshold; profiles/r4_ablation.md section 6), 256^3 fp32 / fp64: 8: 52.2 / 140.3 us, 16: 52.2 / 140.8,
+// 32: 52.8 / 132.2, 64: 51.4-52.2 / 103.8-105.9, 128: 58.5 / 106.4, 256: 58.3 / 105.3 (512^3 fp32: 381 / 381 / 381 / 374-381 /
+// 436 / 437 us).  64 it stays, for row records and for packed blocks (an SDF: 64 is best there too).
+#ifndef FI_DENSE_MIN_ROWS
+#define FI_DENSE_MIN_ROWS 64
+#endif
+#ifndef FI_DENSE_MIN_PACK
+#define FI_DENSE_MIN_PACK 64
 #endif
 constexpr int kR       = 2;   // halo rows/cols kept in LDS
 
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	// cell): the other waves skip the code, which matters because the kernel is instruction-issue bound.  That
 	// wave prefetches the layer's row records 4 steps ahead.  Denser layers: every wave takes its band, direct loads.
 	auto layer_dense = [&](int layer) {
-		return (uni(layR[layer * 4 + 4]) - uni(layR[layer * 4])) + (uni(layB[layer * 4 + 4]) - uni(layB[layer * 4])) > FI_DENSE_MIN;
+		return (uni(layR[layer * 4 + 4]) - uni(layR[layer * 4])) + (uni(layB[layer * 4 + 4]) - uni(layB[layer * 4])) > static_cast<uint32_t>(P.dense_min);
 	};
 	// Every wave issues the record loads of the next layer in every step, unconditionally (clamped index):
 	// loads that cross a step must sit in straight-line code, or the compiler's s_waitcnt bookkeeping gives up
@@ -814,7 +822,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 			} else if (band == (s & 3)) {
 				const int o = (s + 1) * 4;
 				if (pf.ok) { row_apply(pf.pos, pf.a, b0, b1, b0, b1, true); }
-				cells_scatter(0u, 0u, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
+				// (row records beyond the 64 prefetched ones -- dense_min may lie above 64 -- are loaded here)
+				const uint32_t re = uni(layR[o + 4]), rs = uni(layR[o]) + 64u;
+				cells_scatter(rs < re ? rs : re, re, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
 			}
 			FI_STAMP(s, 4);
 			prefetch_rows(s + 1 + PR, pf);
@@ -1118,6 +1128,7 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 	P->chunks = (nz_own + P->zc - 1) / P->zc;
 	P->nwg    = P->tiles_x * P->tiles_y * P->chunks;
 	P->plane  = static_cast<int64_t>(P->nx) * P->ny;
+	P->dense_min = c->cells.pack ? FI_DENSE_MIN_PACK : FI_DENSE_MIN_ROWS;
 	P->dbg    = 0;
 #if defined(FI_TIMING_BUILD) || defined(FI_STAMPS)
 	P->dbg    = tuning_switch("FI_DBG") ? atoi(tuning_switch("FI_DBG")) : 0;

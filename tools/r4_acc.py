@@ -38,6 +38,8 @@ f.add_field_constraints(w)
 f.set_levels(levels, ctol)
 f.set_multigrid(True)
 f.set_mixed_precision(True)
+if os.environ.get("POLY"):
+    f.set_polynomial(int(os.environ["POLY"]), float(os.environ.get("POLY_RATIO", "30")))
 
 
 def step():
