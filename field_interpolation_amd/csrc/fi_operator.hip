@@ -158,11 +158,16 @@ __device__ inline void atomic_add(T* p, T v)
 
 // y[corners] += B x[corners] for every occupied cell.  Inputs may sit on ghost planes; outputs go to
 // owned points only.  fp32/fp64 hardware atomics (global_atomic_add_f32 / _f64, no CAS loop).
+// colour >= 0: only the cells whose origin has that parity pattern (bit d = parity along axis d), with plain
+// read-add-write instead of atomics: two cells of one colour are at least two apart along some axis and share no corner, so a
+// launch per colour, 2^D launches in colour order, forms every sum in the same order on every run -- bitwise reproducible,
+// which the atomic form (colour < 0: FI_CELLS_ATOMIC, tests) is not.  The path of the contexts the tiled kernels do not
+// cover (1-D lattices, model_3 / model_4, gradient_smoothness: field_interpolation.cpp:282-315) and of the tile operator.
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell, const uint32_t* __restrict__ cell_id,
                                                            const T* __restrict__ blk, const T* __restrict__ x,
                                                            T* __restrict__ y, double* __restrict__ partial,
-                                                           const int* __restrict__ done, int ts)
+                                                           const int* __restrict__ done, int ts, int colour)
 {
 	if (done && *done) { return; }
 	constexpr int NC = 1 << D;
@@ -171,10 +176,13 @@ __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell,
 	     c += static_cast<int64_t>(gridDim.x) * kThreads) {
 		uint32_t id = cell_id[c];
 		int l[3] = {0, 0, 0};
+		int col = 0;
 		for (int d = 0; d < D; ++d) {
 			l[d] = static_cast<int>(id % static_cast<uint32_t>(g.cn[d]));
 			id /= static_cast<uint32_t>(g.cn[d]);
+			col |= (l[d] & 1) << d;
 		}
+		if (colour >= 0 && col != colour) { continue; }
 		int64_t idx[NC];
 		bool    in[NC], own[NC];
 		T       xv[NC];
@@ -204,14 +212,14 @@ __global__ __launch_bounds__(kThreads) void k_apply_cells(Geom g, int64_t ncell,
 				if (ts > 0 && tid[i] != tid[j]) { continue; }
 				s += blk[c * (NC * (NC + 1) / 2) + e] * xv[j];
 			}
-			atomic_add(&y[idx[i]], s);
+			if (colour >= 0) { y[idx[i]] += s; } else { atomic_add(&y[idx[i]], s); }
 			contrib += static_cast<double>(xv[i]) * static_cast<double>(s);
 		}
 		(void)in;
 	}
 	if (partial) {
 		const double s = block_sum(contrib);
-		if (threadIdx.x == 0) { partial[blockIdx.x] = s; }
+		if (threadIdx.x == 0) { partial[blockIdx.x] = colour > 0 ? partial[blockIdx.x] + s : s; }  // (the colours' launches follow each other on the stream)
 	}
 }
 
@@ -449,6 +457,8 @@ void safe_scaling_dim(fi_ctx* c)
 	c->dinv16s_valid = true;
 }
 
+int cells_partials(const fi_ctx* c) { return capped_blocks(c->cells.ncell); }  // partials of the untiled path's cell kernel
+
 template <int D, typename T>
 void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 {
@@ -467,9 +477,12 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 	}
 	if (c->cells.ncell > 0 && (ts > 0 || !cells_fused(c))) {
 		nb_cells = capped_blocks(c->cells.ncell);
-		hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(nb_cells), dim3(kThreads), 0, c->stream, g,
-		                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), x, y,
-		                   partial ? partial + nb_model : nullptr, done, ts);
+		const int first = test_switch("FI_CELLS_ATOMIC") ? -1 : 0, last = first < 0 ? -1 : (1 << D) - 1;  // (tests compare the two forms)
+		for (int colour = first; colour <= last; ++colour) {
+			hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(nb_cells), dim3(kThreads), 0, c->stream, g,
+			                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->cells.blk.as<T>(), x, y,
+			                   partial ? partial + nb_model : nullptr, done, ts, colour);
+		}
 	}
 	if (ts > 0) {
 		generic_apply_tile(c, x, y, partial ? partial + nb_model + nb_cells : nullptr, ts);
@@ -487,12 +500,12 @@ size_t elem_size(const fi_ctx* c) { return c->dtype == FI_F64 ? sizeof(double) :
 int apply_num_partials(const fi_ctx* c)
 {
 	if (c->tile_ts > 0) {
-		return capped_blocks(c->g.nown) + (c->cells.ncell > 0 ? capped_blocks(c->cells.ncell) : 0) + generic_num_partials(c);
+		return capped_blocks(c->g.nown) + (c->cells.ncell > 0 ? cells_partials(c) : 0) + generic_num_partials(c);
 	}
 	int nb_model = stencil_partials(c);
 	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
 	int n = nb_model + generic_num_partials(c);
-	if (!cells_fused(c) && c->cells.ncell > 0) { n += capped_blocks(c->cells.ncell); }
+	if (!cells_fused(c) && c->cells.ncell > 0) { n += cells_partials(c); }
 	return n;
 }
 

@@ -514,3 +514,32 @@ def test_contexts_on_two_host_threads(fi):
         assert len(parallel[seed]) == len(serial[seed])
         for a, b in zip(serial[seed], parallel[seed]):
             assert a[1] == b[1] and np.array_equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("sizes,kw", [([40, 33, 29], dict(model_3=0.7, model_2=0.3)), ([37, 41, 30], dict(model_4=0.4, gradient_smoothness=0.3)),
+                                      ([300, 200], dict(model_3=0.5, model_1=0.2)), ([5000], dict(model_2=0.5, model_4=0.1))])
+def test_wide_stencils_are_bitwise_reproducible(oracle, fi, monkeypatch, dtype, sizes, kw):
+    """model_3 / model_4 / gradient_smoothness (field_interpolation.cpp:282-315) and 1-D lattices run the untiled kernels;
+    their data cells are applied colour by colour (k_apply_cells: 2^D launches, cells of one parity share no corner), not by
+    the atomic scatter of rounds 1-3 (FI_CELLS_ATOMIC) whose sums depend on the order the hardware retires the additions in.
+    The same operator as the oracle's explicit AtA, the same bits on every apply, equal to the atomic form up to rounding;
+    the tile operator of fi_tile_pass takes the same path."""
+    rng = np.random.default_rng(17)
+    n = int(0.3 * np.prod(sizes))
+    pos, nrm, pw, val = random_points(rng, sizes, n, margin=0.4)
+    w = fi.Weights(**kw)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, pw, None, dtype=dtype)
+    _check_operator(fo, fg, dtype)
+    x = rng.normal(size=int(np.prod(sizes)))
+    y = fg.apply_AtA(x)
+    for _ in range(3):
+        np.testing.assert_array_equal(y, fg.apply_AtA(x))
+    monkeypatch.setenv("FI_CELLS_ATOMIC", "1")
+    ya = fg.apply_AtA(x)
+    monkeypatch.delenv("FI_CELLS_ATOMIC")
+    assert np.abs(ya - y).max() <= (1e-12 if dtype == "f64" else 2e-5) * np.abs(y).max()
+    if len(sizes) > 1:
+        g = rng.normal(size=int(np.prod(sizes))).astype(np.float32)
+        t1, t2 = fg.tile_pass(g, 8), fg.tile_pass(g, 8)
+        np.testing.assert_array_equal(t1, t2)
