@@ -21,6 +21,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "fi_internal.h"
+#include "fi_sort.h"
 
 namespace fi {
 
@@ -718,10 +719,10 @@ void assemble_dim(fi_ctx* c)
 	int end_bit = 1;
 	while ((1ull << end_bit) <= invalid) { ++end_bit; }
 	size_t tb = 0;
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
+	FI_HIP_TRY(sort_pairs_u32(nullptr, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
 	                                              row_sorted.as<uint32_t>(), static_cast<int>(total), 0, end_bit, st));
 	tmp.alloc(tb);
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
+	FI_HIP_TRY(sort_pairs_u32(tmp.p, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
 	                                              row_sorted.as<uint32_t>(), static_cast<int>(total), 0, end_bit, st));
 	// runs of equal keys = occupied cells (+ one run of invalid rows at the end)
 	size_t tb2 = 0;

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "fi_internal.h"
+#include "fi_sort.h"
 #include "fi_stencil_common.h"
 
 namespace fi {
@@ -226,6 +227,66 @@ __global__ void k_iota32(uint32_t* v, int64_t n)
 	if (i < n) { v[i] = static_cast<uint32_t>(i); }
 }
 
+// Workgroups with and without cells, both lists in ascending order, and everything the host wants to read back, in ONE
+// single-block launch (round 3: a classification kernel, two stream compactions of three launches each and a packing
+// kernel -- eight launches for a few thousand flags).  out: [0..1] the two counts, [2..3] row / block records, [4..5]
+// distinct cells per kind (sum of the 64 counter pairs), then one flag byte per workgroup.
+__global__ __launch_bounds__(1024) void k_classify_pack(int nwg, int per_wg, const uint32_t* __restrict__ lay_row,
+                                                         const uint32_t* __restrict__ lay_blk, const uint32_t* __restrict__ n_row,
+                                                         const uint32_t* __restrict__ n_blk, const uint32_t* __restrict__ uniq64,
+                                                         uint32_t* __restrict__ wg_cells, uint32_t* __restrict__ wg_plain,
+                                                         uint8_t* __restrict__ out)
+{
+	using Scan = hipcub::BlockScan<int, 1024>;
+	__shared__ typename Scan::TempStorage tmp;
+	__shared__ int base_with, base_without;
+	if (threadIdx.x == 0) {
+		base_with    = 0;
+		base_without = 0;
+	}
+	__syncthreads();
+	for (int w0 = 0; w0 < nwg; w0 += 1024) {
+		const int wg = w0 + static_cast<int>(threadIdx.x);
+		bool any = false;
+		if (wg < nwg) {
+			const int64_t a = static_cast<int64_t>(wg) * per_wg, b = a + per_wg;
+			any = lay_row[b] > lay_row[a] || lay_blk[b] > lay_blk[a];
+			out[24 + wg] = any ? 1 : 0;
+		}
+		const int flag = (wg < nwg && any) ? 1 : 0;
+		int pos = 0, total = 0;
+		Scan(tmp).ExclusiveSum(flag, pos, total);
+		const int live = nwg - w0 < 1024 ? nwg - w0 : 1024;  // workgroups of this chunk
+		if (wg < nwg) {
+			if (any) {
+				wg_cells[base_with + pos] = static_cast<uint32_t>(wg);
+			} else {
+				wg_plain[base_without + (static_cast<int>(threadIdx.x) - pos)] = static_cast<uint32_t>(wg);
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			base_with += total;
+			base_without += live - total;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		uint32_t* head = reinterpret_cast<uint32_t*>(out);
+		uint32_t a = 0, b = 0;
+		for (int w = 0; w < 64; ++w) {
+			a += uniq64[2 * w];
+			b += uniq64[2 * w + 1];
+		}
+		head[0] = static_cast<uint32_t>(base_with);
+		head[1] = static_cast<uint32_t>(base_without);
+		head[2] = *n_row;
+		head[3] = *n_blk;
+		head[4] = a;
+		head[5] = b;
+	}
+}
+
 // 1 for a workgroup whose lists (all its layers, both record kinds) hold at least one cell
 __global__ __launch_bounds__(kThreads) void k_classify_wg(int nwg, int per_wg, const uint32_t* __restrict__ lay_row,
                                                            const uint32_t* __restrict__ lay_blk, uint32_t* __restrict__ ids,
@@ -291,11 +352,11 @@ void build_cell_lists(fi_ctx* c)
 		int key_bits = 1;
 		while ((1LL << key_bits) < 2 * nbuckets) { ++key_bits; }
 		size_t tb = 0;
-		FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
+		FI_HIP_TRY(sort_pairs_u32(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
 		                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
 		                                              static_cast<int>(nslots), 0, key_bits, st));
 		tmp.alloc(tb);
-		FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
+		FI_HIP_TRY(sort_pairs_u32(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
 		                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
 		                                              static_cast<int>(nslots), 0, key_bits, st));
 	}
@@ -306,30 +367,15 @@ void build_cell_lists(fi_ctx* c)
 	                   nbuckets, bound, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>());
 	// workgroups with and without cells (march_launch): classified here, read back with the totals below
 	const int nwg = P.nwg;
-	DevBuf &ids = c->scratch[27], &has = c->scratch[28], &has_not = c->scratch[29], &nsel = c->scratch[30];  // pos / slot_sorted are still live
-	ids.alloc(sizeof(uint32_t) * nwg);
-	has.alloc(nwg);
-	has_not.alloc(nwg);
-	nsel.alloc(sizeof(int) * 2);
 	m.wg_cells.alloc(sizeof(uint32_t) * nwg);
 	m.wg_plain.alloc(sizeof(uint32_t) * nwg);
-	hipLaunchKernelGGL(k_classify_wg, dim3((nwg + kThreads - 1) / kThreads), dim3(kThreads), 0, st, nwg, (P.zc + 1) * 4,
-	                   m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), ids.as<uint32_t>(), has.as<uint8_t>(),
-	                   has_not.as<uint8_t>());
-	size_t tb3 = 0;
-	FI_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
-	                                         nsel.as<int>(), nwg, st));
-	tmp.alloc(tb3);
-	FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has.as<uint8_t>(), m.wg_cells.as<uint32_t>(),
-	                                         nsel.as<int>(), nwg, st));
-	FI_HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, tb3, ids.as<uint32_t>(), has_not.as<uint8_t>(),
-	                                         m.wg_plain.as<uint32_t>(), nsel.as<int>() + 1, nwg, st));
-	// everything the host needs in ONE copy (five separate ones cost ~15 us each): the two selection counts, the record
-	// totals, the distinct cells per kind, and the per-workgroup flags
+	// everything the host needs in ONE copy: the two selection counts, the record totals, the distinct cells per kind, and
+	// the per-workgroup flags
 	DevBuf& pack = c->scratch[34];
 	pack.alloc(24 + static_cast<size_t>(nwg));
-	hipLaunchKernelGGL(k_pack_readback, dim3(1), dim3(kThreads), 0, st, nwg, nsel.as<int>(), m.lay_row.as<uint32_t>() + nbuckets,
-	                   m.lay_blk.as<uint32_t>() + nbuckets, count.as<uint32_t>(), has.as<uint8_t>(), pack.as<uint8_t>());
+	hipLaunchKernelGGL(k_classify_pack, dim3(1), dim3(1024), 0, st, nwg, (P.zc + 1) * 4, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
+	                   m.lay_row.as<uint32_t>() + nbuckets, m.lay_blk.as<uint32_t>() + nbuckets, count.as<uint32_t>(),
+	                   m.wg_cells.as<uint32_t>(), m.wg_plain.as<uint32_t>(), pack.as<uint8_t>());
 	std::vector<uint8_t> h_pack(24 + static_cast<size_t>(nwg));
 	FI_HIP_TRY(hipMemcpyAsync(h_pack.data(), pack.p, h_pack.size(), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
