@@ -183,8 +183,8 @@ def workload(args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)  # (a context's first two assembles still allocate)
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json configuration: 2, 3, 4 (default) or 5")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="--gpus N: strong (default) = the configuration's own lattice split N ways, the form BASELINE "
