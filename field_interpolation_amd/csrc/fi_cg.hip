@@ -568,9 +568,20 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	const bool folded_set = !folded && !tuning_switch("FI_NO_FOLD");  // slabs: the same kernels behind a reduction over the rank set
 	int issued = 0;         // CG steps enqueued so far (the device runs step k only while it is not done)
 	int restarts_left = c0->verify_residual ? 3 : 0;
+	// Coarser levels of a coarse-to-fine start (launches of 2-25 us: the host issues them no faster than the GPU retires
+	// them): the first look at the stop flag comes when this level's previous solve had finished -- a re-assembled problem
+	// changes little -- and the look right behind the initialisation is skipped (kernels of a finished solve exit at once).
+	// Config 4's three levels: 48 iterations issued for 22 needed -> 25, four looks less per solve.
+	int looks = 0;
 	for (;;) {
-		FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
-		FI_HIP_TRY(hipStreamSynchronize(st));
+		const bool skip_look = looks == 0 && c0->level > 0 && c0->last_cg_iterations > 0;
+		++looks;
+		if (!skip_look) {
+			FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+			FI_HIP_TRY(hipStreamSynchronize(st));
+		} else {
+			c0->scal_host->done = 0;
+		}
 		if (c0->scal_host->done) {
 			// The recurrence residual met the tolerance.  In fp32 it drifts away from b - A x over hundreds of
 			// steps, so the true residual is evaluated once; if it misses the tolerance CG restarts from it
@@ -598,7 +609,11 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		}
 		// (a coarser level of a coarse-to-fine start is done within a few steps: shorter bursts between two looks at the flag
 		// leave fewer launches behind that only find the flag up -- 31 of 48 iterations of config 4's three levels)
-		const int burst = c0->level > 0 ? kCheckEvery / 2 : kCheckEvery;
+		int burst = kCheckEvery;
+		if (c0->level > 0) {
+			burst = kCheckEvery / 2;
+			if (c0->last_cg_iterations > 0) { burst = looks == 1 ? (c0->last_cg_iterations < 64 ? c0->last_cg_iterations : 64) : 2; }
+		}
 		for (int k = 0; k < burst; ++k) {
 			++issued;
 			// every 4th apply is timed: an event record is a barrier packet of its own in the queue
@@ -715,6 +730,7 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		c->stats.operator_applies = h.iter + 1 + h.restarts;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
+		c->last_cg_iterations = timed_out ? 0 : h.iter;  // the same on every rank: the scalars are sums over all of them
 		// with the verified stop on, "converged" means b - A x itself met the tolerance (done == 5); a recurrence
 		// that converged while the true residual stagnated above it (fp32 on an ill-conditioned system) is not
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
