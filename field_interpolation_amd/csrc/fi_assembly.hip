@@ -34,11 +34,23 @@ __host__ __device__ inline int packed_index(int i, int j, int nc)  // i <= j
 	return i * nc - (i * (i - 1)) / 2 + (j - i);
 }
 
+// sum of row q of the symmetric block: the cell's share of (A_data 1)(corner q) -- what the lumped replica of a
+// mixed-precision context puts on its diagonal (fi_levels.hip twin_assemble_lumped)
+template <int NC>
+__device__ inline double block_row_sum(const double* B, int q)
+{
+	double s = 0.0;
+#pragma unroll
+	for (int j = 0; j < NC; ++j) { s += B[q <= j ? packed_index(q, j, NC) : packed_index(j, q, NC)]; }
+	return s;
+}
+
 struct EmitArgs {
 	Geom  g;
 	float vw, gw;
 	int   vk, gk;
 	int   has_nrm, has_pw, has_val;
+	int   rows_per_point;        // 1 + D, or 1 when the batch has no gradient rows (no normals or a zero gradient weight)
 	uint32_t invalid_key;
 	float pos_scale, nrm_scale;  // 1 on the caller's lattice; 1/2^l and 2^l on coarser levels
 };
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 	}
 	const float w     = a.has_pw ? pw[i] : 1.0f;
 	const float value = a.has_val ? val[i] : 0.0f;
-	const long  slot0 = i * (1 + D);
+	const long  slot0 = i * a.rows_per_point;
 
 	// cell of the point: floor(pos) per axis (multilerp :29-32, cell_index :115)
 	int   cell[D];
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 	}
 
 	// ---- gradient rows ------------------------------------------------------------------------
+	if (a.rows_per_point == 1) { return; }
 	for (int d = 0; d < D; ++d) {
 		const long slot = slot0 + 1 + d;
 		uint32_t k = a.invalid_key;
@@ -211,6 +224,7 @@ __global__ void k_iota(uint32_t* v, long n)
 	if (i < n) { v[i] = static_cast<uint32_t>(i); }
 }
 
+constexpr int kRec = 3;  // the cell's record for the sums over the lattice points: [A^T b | diagonal | row sums] x 2^D corners
 constexpr uint32_t kHeavyRows = 192;  // cells with more rows are summed by a whole workgroup (k_build_heavy)
 
 // everything after the sums of a cell: block, first row, rhs, factor rows
@@ -236,8 +250,9 @@ __device__ inline void finish_cell(long c, long ncell, uint32_t s, uint32_t m, d
 	// eight entries strewn over the 144-byte block (256^3, 1 M cells: the gather 372 -> ... us)
 	if (DIRECT) {
 		for (int q = 0; q < NC; ++q) {
-			cell_dr[static_cast<long>(c) * 2 * NC + q]      = static_cast<T>(gvec[q]);
-			cell_dr[static_cast<long>(c) * 2 * NC + NC + q] = static_cast<T>(B[packed_index(q, q, NC)]);
+			cell_dr[static_cast<long>(c) * kRec * NC + q]      = static_cast<T>(gvec[q]);
+			cell_dr[static_cast<long>(c) * kRec * NC + NC + q] = static_cast<T>(B[packed_index(q, q, NC)]);
+			cell_dr[static_cast<long>(c) * kRec * NC + 2 * NC + q] = static_cast<T>(block_row_sum<NC>(B, q));
 		}
 	}
 
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 	// the block in ROUNDS parts (fp64 3-D: two halves of 18, 64 KB of static LDS is the limit), then record + first row
 	constexpr int ROUNDS = (D == 3 && sizeof(T) == 8) ? 2 : 1;
 	constexpr int EPR    = NB / ROUNDS;
-	constexpr int ST1 = EPR | 1, ST2 = 3 * NC + 1;  // odd strides: a column of the tile spreads over the banks
+	constexpr int ST1 = EPR | 1, ST2 = kRec * NC + 1;  // odd strides: a column of the tile spreads over the banks
 	__shared__ T tile[kThreads * (ST1 > ST2 ? ST1 : ST2)];
 	const long c0 = static_cast<long>(blockIdx.x) * kThreads;
 	const long c  = c0 + threadIdx.x;
@@ -374,16 +389,20 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 	for (int q = 0; q < NC; ++q) {
 		tile[threadIdx.x * ST2 + q]          = static_cast<T>(gvec[q]);
 		tile[threadIdx.x * ST2 + NC + q]     = static_cast<T>(B[packed_index(q, q, NC)]);
-		tile[threadIdx.x * ST2 + 2 * NC + q] = first[q];
+		tile[threadIdx.x * ST2 + 2 * NC + q] = static_cast<T>(block_row_sum<NC>(B, q));
 	}
 	__syncthreads();
-	for (int i = threadIdx.x; i < nb * 2 * NC; i += kThreads) {
-		const int cell = i / (2 * NC), e = i - cell * 2 * NC;
-		cell_dr[c0 * 2 * NC + i] = tile[cell * ST2 + e];
+	for (int i = threadIdx.x; i < nb * kRec * NC; i += kThreads) {
+		const int cell = i / (kRec * NC), e = i - cell * kRec * NC;
+		cell_dr[c0 * kRec * NC + i] = tile[cell * ST2 + e];
 	}
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < NC; ++q) { tile[threadIdx.x * (NC + 1) + q] = first[q]; }
+	__syncthreads();
 	for (int i = threadIdx.x; i < nb * NC; i += kThreads) {
 		const int cell = i / NC, e = i - cell * NC;
-		row1[c0 * NC + i] = tile[cell * ST2 + 2 * NC + e];
+		row1[c0 * NC + i] = tile[cell * (NC + 1) + e];
 	}
 	if (mine) {
 		finish_cell<D, T, false>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_dr, nrow, row1, mrow, nfac, pack_min);
@@ -447,7 +466,8 @@ __global__ __launch_bounds__(kThreads) void k_build_heavy(long ncell, const uint
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, const uint32_t* __restrict__ cell_id,
                                                              const T* __restrict__ cell_dr,
-                                                             T* __restrict__ atb, T* __restrict__ diag, int colour)
+                                                             T* __restrict__ atb, T* __restrict__ diag,
+                                                             float* __restrict__ lump, int colour)
 {
 	constexpr int NC = 1 << D;
 	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
@@ -471,8 +491,9 @@ __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, 
 			idx += static_cast<int64_t>(li) * g.stride[d];
 		}
 		if (ok) {
-			atb[idx] += cell_dr[static_cast<long>(c) * 2 * NC + q];
-			diag[idx] += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
+			atb[idx] += cell_dr[static_cast<long>(c) * kRec * NC + q];
+			diag[idx] += cell_dr[static_cast<long>(c) * kRec * NC + NC + q];
+			if (lump) { lump[idx] += static_cast<float>(cell_dr[static_cast<long>(c) * kRec * NC + 2 * NC + q]); }
 		}
 	}
 }
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter_cells(Geom g, long ncell, 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, const uint32_t* __restrict__ map,
                                                              const T* __restrict__ cell_dr, T* __restrict__ atb,
-                                                             T* __restrict__ diag)
+                                                             T* __restrict__ diag, float* __restrict__ lump)
 {
 	constexpr int NC = 8;
 	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
@@ -519,10 +540,12 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, 
 		}
 	}
 	T a[4], dg[4];
+	float lp4[4];
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		a[j]  = T(0);
 		dg[j] = T(0);
+		lp4[j] = 0.0f;
 #pragma unroll
 		for (int colour = 0; colour < NC; ++colour) {  // the generic kernel's order: by the parity of the cell's origin
 			const int bx = ((lp[0] + j) ^ colour) & 1, by = (lp[1] ^ (colour >> 1)) & 1, bz = (lp[2] ^ (colour >> 2)) & 1;
@@ -532,8 +555,9 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, 
 			const uint32_t c = bz ? (by ? c11 : c10) : (by ? c01 : c00);
 			if (c == 0xFFFFFFFFu) { continue; }
 			const int q = bx | (by << 1) | (bz << 2);
-			a[j] += cell_dr[static_cast<long>(c) * 2 * NC + q];
-			dg[j] += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
+			a[j] += cell_dr[static_cast<long>(c) * kRec * NC + q];
+			dg[j] += cell_dr[static_cast<long>(c) * kRec * NC + NC + q];
+			if (lump) { lp4[j] += static_cast<float>(cell_dr[static_cast<long>(c) * kRec * NC + 2 * NC + q]); }
 		}
 	}
 	const int64_t idx = li[0] * g.stride[0] + li[1] * g.stride[1] + li[2] * g.stride[2];
@@ -542,7 +566,176 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, 
 		if (j < nvalid) {
 			atb[idx + j]  = a[j];
 			diag[idx + j] = dg[j];
+			if (lump) { lump[idx + j] = lp4[j]; }
 		}
+	}
+}
+
+// ---- the same sums for 3-D lattices, by TILES of lattice points in LDS ------------------------------------------------
+// One workgroup owns 64 x 4 x 2 owned points: it collects the cells that touch them (the cells are sorted by extended id,
+// x fastest: k_row_bounds gives the range of every (y, z) row of cells, a tile looks at 5 x 3 rows), orders them by the
+// parity colour of their origin, adds their records to the tile's accumulators colour after colour -- within a colour no
+// two cells share a corner -- and stores the tile with full lines.  The same sums in the same order as the 2^D colour
+// launches and the gather launch: the same bits.  No cell map, no zeroing of the arrays, and the time follows the occupied
+// cells, not the look-ups (256^3 fp64, 6 % of the cells occupied: gather 310 us + map 45 us + zeroing 42 us -> ... us).
+__global__ __launch_bounds__(kThreads) void k_row_bounds(int64_t nrows, uint32_t row_len, long ncell,
+                                                          const uint32_t* __restrict__ cell_id, uint32_t* __restrict__ bound)
+{
+	const int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (r > nrows) { return; }
+	const uint64_t key = static_cast<uint64_t>(r) * row_len;  // first index with cell_id >= key
+	long lo = 0, hi = ncell;
+	while (lo < hi) {
+		const long mid = (lo + hi) >> 1;
+		if (static_cast<uint64_t>(cell_id[mid]) < key) { lo = mid + 1; } else { hi = mid; }
+	}
+	bound[r] = static_cast<uint32_t>(lo);
+}
+
+constexpr int kTileX = 64, kTileY = 4, kTileZ = 2;
+constexpr int kTileCells = (kTileX + 1) * (kTileY + 1) * (kTileZ + 1);  // 975: every cell of the tile's 5 x 3 rows
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_tile_sums3(Geom g, const uint32_t* __restrict__ row_bound,
+                                                          const uint32_t* __restrict__ cell_id, const T* __restrict__ cell_dr,
+                                                          T* __restrict__ atb, T* __restrict__ diag, float* __restrict__ lump)
+{
+	constexpr int NC = 8;
+	constexpr int NP = kTileX * kTileY * kTileZ;
+	__shared__ T        acc_b[NP], acc_d[NP];
+	__shared__ float    acc_l[NP];
+	__shared__ uint32_t list_cell[kTileCells], list_loc[kTileCells];
+	__shared__ int      ncol[NC], base[NC + 1], fill[NC];
+	const int tid = threadIdx.x;
+	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
+	const int x0 = static_cast<int>(blockIdx.x) * kTileX, y0 = static_cast<int>(blockIdx.y) * kTileY,
+	          z0 = static_cast<int>(blockIdx.z) * kTileZ;  // first owned point of the tile (owned-relative)
+	// the same point on the extended cell grid: a point at lp is corner b of the cell with origin lp - b
+	const int lp0[3] = {g.own_lo[0] + x0 + g.off[0] - g.coff[0], g.own_lo[1] + y0 + g.off[1] - g.coff[1],
+	                    g.own_lo[2] + z0 + g.off[2] - g.coff[2]};
+	for (int i = tid; i < NP; i += kThreads) {
+		acc_b[i] = T(0);
+		acc_d[i] = T(0);
+		acc_l[i] = 0.0f;
+	}
+	if (tid < NC) {
+		ncol[tid] = 0;
+		fill[tid] = 0;
+	}
+	__syncthreads();
+	// the tile's cells: rows (ly, lz) = lp0 - 1 .. lp0 + tile - 1, within a row lx = lp0x - 1 .. lp0x + 63.  The rows' ranges
+	// first (one round of loads), then two passes over ALL their cells at once, a cell per thread and trip: count by colour,
+	// then place (the order within a colour is free: its cells touch distinct points).  Every wave walking its own rows one
+	// after the other was a chain of eight dependent rounds of loads: 19 us per tile.
+	constexpr int ROWS = (kTileY + 1) * (kTileZ + 1);
+	__shared__ uint32_t row_first[ROWS], row_key[ROWS], row_at[ROWS + 1];
+	if (tid < ROWS) {
+		const int ry = tid % (kTileY + 1), rz = tid / (kTileY + 1);
+		const int ly = lp0[1] - 1 + ry, lz = lp0[2] - 1 + rz;
+		uint32_t s = 0, e = 0, key0 = 0;
+		if (ly >= 0 && ly < g.cn[1] && lz >= 0 && lz < g.cn[2]) {
+			const uint32_t row = static_cast<uint32_t>(lz) * static_cast<uint32_t>(g.cn[1]) + static_cast<uint32_t>(ly);
+			key0 = row * static_cast<uint32_t>(g.cn[0]);
+			s = row_bound[row];
+			e = row_bound[row + 1];
+		}
+		row_first[tid] = s;
+		row_key[tid]   = key0;
+		row_at[tid + 1] = e - s;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t a = 0;
+		row_at[0] = 0;
+		for (int r = 0; r < ROWS; ++r) {
+			a += row_at[r + 1];
+			row_at[r + 1] = a;
+		}
+	}
+	__syncthreads();
+	const uint32_t in_rows = row_at[ROWS];
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		for (uint32_t k = tid; k < in_rows; k += kThreads) {
+			int r = 0;
+#pragma unroll
+			for (int j = 1; j < ROWS; ++j) { r += row_at[j] <= k ? 1 : 0; }
+			const uint32_t i = row_first[r] + (k - row_at[r]);
+			const int ry = r % (kTileY + 1), rz = r / (kTileY + 1);
+			const int ly = lp0[1] - 1 + ry, lz = lp0[2] - 1 + rz;
+			const int lx = static_cast<int>(cell_id[i] - row_key[r]);
+			const int cx = lx - (lp0[0] - 1);  // 0 .. 64 inside the tile's reach
+			if (cx < 0 || cx > kTileX) { continue; }
+			const int colour = (lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2);
+			if (pass == 0) {
+				atomicAdd(&ncol[colour], 1);
+			} else {
+				const int at = base[colour] + atomicAdd(&fill[colour], 1);
+				list_cell[at] = i;
+				list_loc[at]  = static_cast<uint32_t>(cx) | (static_cast<uint32_t>(ry) << 8) | (static_cast<uint32_t>(rz) << 12) |
+				                (static_cast<uint32_t>(colour) << 16);
+			}
+		}
+		__syncthreads();
+		if (pass == 0) {
+			if (tid == 0) {
+				int a = 0;
+				for (int k = 0; k < NC; ++k) {
+					base[k] = a;
+					a += ncol[k];
+				}
+				base[NC] = a;
+			}
+			__syncthreads();
+		}
+	}
+	const int total = base[NC];
+	// chunks of one entry per thread: the record comes into registers in one round of loads, then the colours of the chunk
+	// one after another (the list is in colour order, so are the chunks)
+	for (int c0 = 0; c0 < total; c0 += kThreads) {
+		const int  i    = c0 + tid;
+		const bool live = i < total;
+		T        rb[NC], rd[NC];
+		float    rl[NC];
+		uint32_t loc = 0;
+		if (live) {
+			const long c = list_cell[i];
+			loc = list_loc[i];
+#pragma unroll
+			for (int q = 0; q < NC; ++q) {
+				rb[q] = cell_dr[c * kRec * NC + q];
+				rd[q] = cell_dr[c * kRec * NC + NC + q];
+				rl[q] = lump ? static_cast<float>(cell_dr[c * kRec * NC + 2 * NC + q]) : 0.0f;
+			}
+		}
+		const int last = c0 + kThreads < total ? c0 + kThreads - 1 : total - 1;
+		const int col_lo = static_cast<int>(list_loc[c0] >> 16), col_hi = static_cast<int>(list_loc[last] >> 16);
+		for (int colour = col_lo; colour <= col_hi; ++colour) {
+			if (live && static_cast<int>(loc >> 16) == colour) {
+				const int cx = static_cast<int>(loc & 0xFFu), ry = static_cast<int>((loc >> 8) & 0xFu), rz = static_cast<int>((loc >> 12) & 0xFu);
+#pragma unroll
+				for (int q = 0; q < NC; ++q) {
+					const int px = cx - 1 + (q & 1), py = ry - 1 + ((q >> 1) & 1), pz = rz - 1 + ((q >> 2) & 1);
+					if (px >= 0 && px < kTileX && py >= 0 && py < kTileY && pz >= 0 && pz < kTileZ) {
+						const int p = (pz * kTileY + py) * kTileX + px;
+						acc_b[p] += rb[q];
+						acc_d[p] += rd[q];
+						acc_l[p] += rl[q];
+					}
+				}
+			}
+			__syncthreads();
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < NP; i += kThreads) {
+		const int px = i % kTileX, py = (i / kTileX) % kTileY, pz = i / (kTileX * kTileY);
+		if (x0 + px >= ext0 || y0 + py >= ext1 || z0 + pz >= ext2) { continue; }
+		const int64_t idx = (g.own_lo[0] + x0 + px) * g.stride[0] + (g.own_lo[1] + y0 + py) * g.stride[1] +
+		                    (g.own_lo[2] + z0 + pz) * g.stride[2];
+		atb[idx]  = acc_b[i];
+		diag[idx] = acc_d[i];
+		if (lump) { lump[idx] = acc_l[i]; }
 	}
 }
 
@@ -556,7 +749,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_map(long ncell, const uint32_
 template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, const uint32_t* __restrict__ map,
                                                             const T* __restrict__ cell_dr,
-                                                            T* __restrict__ atb, T* __restrict__ diag)
+                                                            T* __restrict__ atb, T* __restrict__ diag, float* __restrict__ lump)
 {
 	constexpr int NC = 1 << D;
 	int64_t o = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
@@ -592,16 +785,19 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, c
 		cq[colour]   = q;
 	}
 	T a = T(0), dg = T(0);  // both arrays are zero when this kernel runs (assemble): written, not accumulated
+	float lp1 = 0.0f;
 #pragma unroll
 	for (int colour = 0; colour < NC; ++colour) {
 		const uint32_t c = cidx[colour];
 		if (c == 0xFFFFFFFFu) { continue; }
 		const int q = cq[colour];
-		a += cell_dr[static_cast<long>(c) * 2 * NC + q];
-		dg += cell_dr[static_cast<long>(c) * 2 * NC + NC + q];
+		a += cell_dr[static_cast<long>(c) * kRec * NC + q];
+		dg += cell_dr[static_cast<long>(c) * kRec * NC + NC + q];
+		if (lump) { lp1 += static_cast<float>(cell_dr[static_cast<long>(c) * kRec * NC + 2 * NC + q]); }
 	}
 	atb[idx]  = a;
 	diag[idx] = dg;
+	if (lump) { lump[idx] = lp1; }
 }
 
 // {number of runs, key of the last run, length of the last run}
@@ -629,7 +825,9 @@ void emit_rows_dim(fi_ctx* c, long n, const float* pos, const float* nrm, const 
 		pb = new Pending();
 	}
 	c->pending.push_back(pb);
-	pb->nrows = n * (1 + D);
+	// value rows only: one row per point (the rows the sort, the run lengths and the blocks walk: 4 M -> 1 M on config 4)
+	const int rows_per_point = (nrm != nullptr && gw != 0.0f) ? 1 + D : 1;
+	pb->nrows = n * rows_per_point;
 	pb->key.alloc(sizeof(uint32_t) * pb->nrows);
 	pb->coef.alloc(sizeof(float) * pb->nrows * NC);
 	pb->rhs.alloc(sizeof(float) * pb->nrows);
@@ -640,6 +838,7 @@ void emit_rows_dim(fi_ctx* c, long n, const float* pos, const float* nrm, const 
 	a.vk = vk;
 	a.gk = gk;
 	a.has_nrm = nrm != nullptr;
+	a.rows_per_point = rows_per_point;
 	a.has_pw  = pw != nullptr;
 	a.has_val = val != nullptr;
 	a.pos_scale = pos_scale;
@@ -664,8 +863,18 @@ void assemble_dim(fi_ctx* c)
 	// operator arrays over local storage
 	c->atb.alloc(sizeof(T) * g.nloc);
 	c->diag.alloc(sizeof(T) * g.nloc);
-	FI_HIP_TRY(hipMemsetAsync(c->atb.p, 0, sizeof(T) * g.nloc, st));
-	FI_HIP_TRY(hipMemsetAsync(c->diag.p, 0, sizeof(T) * g.nloc, st));
+	// (zeroed below, once the path of the sums over the lattice points is known: the gather writes every owned point itself)
+	// row sums of the data term for the lumped replica of a mixed-precision context (fi_assemble asks: want_lump)
+	float* lump = nullptr;
+	if (c->want_lump) {
+		c->lump.alloc(sizeof(float) * g.nloc);
+		lump = c->lump.as<float>();
+	}
+	auto zero_operator = [&]() {
+		FI_HIP_TRY(hipMemsetAsync(c->atb.p, 0, sizeof(T) * g.nloc, st));
+		FI_HIP_TRY(hipMemsetAsync(c->diag.p, 0, sizeof(T) * g.nloc, st));
+		if (lump) { FI_HIP_TRY(hipMemsetAsync(lump, 0, sizeof(float) * g.nloc, st)); }
+	};
 
 	long total = 0;
 	for (auto* pb : c->pending) { total += pb->nrows; }
@@ -673,7 +882,10 @@ void assemble_dim(fi_ctx* c)
 	c->cells.nb    = NB;
 	c->stats.num_data_rows = 0;
 	c->stats.num_cells     = 0;
-	if (total == 0) { return; }
+	if (total == 0) {
+		zero_operator();
+		return;
+	}
 	FI_REQUIRE(total < (1L << 31), FI_ERR_UNSUPPORTED, "more than 2^31 data rows in one context");
 
 	// gather the batches into one row table (single batch: used in place)
@@ -743,7 +955,10 @@ void assemble_dim(fi_ctx* c)
 	FI_HIP_TRY(hipMemcpyAsync(h_tail, tail3.p, sizeof(h_tail), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
 	const uint32_t h_runs = h_tail[0];
-	if (h_runs == 0) { return; }
+	if (h_runs == 0) {
+		zero_operator();
+		return;
+	}
 	const uint32_t h_last_key = h_tail[1], h_last_count = h_tail[2];
 	long ncell   = h_runs;
 	long invalid_rows = 0;
@@ -753,7 +968,10 @@ void assemble_dim(fi_ctx* c)
 	}
 	c->stats.num_data_rows = total - invalid_rows;
 	c->stats.num_cells     = ncell;
-	if (ncell == 0) { return; }
+	if (ncell == 0) {
+		zero_operator();
+		return;
+	}
 	size_t tb3 = 0;
 	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(),
 	                                            static_cast<int>(h_runs), st));
@@ -776,7 +994,7 @@ void assemble_dim(fi_ctx* c)
 	}
 	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
 	DevBuf& cell_dr = c->scratch[13];
-	cell_dr.alloc(sizeof(T) * 2 * NC * ncell);
+	cell_dr.alloc(sizeof(T) * kRec * NC * ncell);
 	// cells with very many rows (coarse levels) are listed by the first kernel and summed by workgroups in the second
 	DevBuf& heavy = c->scratch[11];
 	heavy.alloc(sizeof(uint32_t) * (static_cast<size_t>(total / kHeavyRows) + 2));
@@ -798,7 +1016,28 @@ void assemble_dim(fi_ctx* c)
 	FI_HIP_TRY(hipGetLastError());
 	int64_t ncells_ext = 1;
 	for (int d = 0; d < D; ++d) { ncells_ext *= g.cn[d]; }
-	if (static_cast<int64_t>(ncell) * 64 >= ncells_ext && ncells_ext < (1LL << 32) && !test_switch("FI_NO_GATHER")) {
+	// One launch over the POINTS (dense cell map, 2^D look-ups per point) on small lattices, 2^D launches over the CELLS
+	// elsewhere: the gather costs by the lattice (256^3 fp64: 310 us alone on the GPU, 6 % of the cells occupied), the
+	// scatter by the occupied cells (8 launches of ~8 us there); below ~64^3 the launches outweigh the look-ups.
+	int64_t gather_max = 1 << 18;
+	if (const char* e = tuning_switch("FI_GATHER_MAX")) { gather_max = atoll(e); }
+	if (test_switch("FI_GATHER_ALWAYS")) { gather_max = 1LL << 32; }
+	const bool gather = static_cast<int64_t>(ncell) * 64 >= ncells_ext && ncells_ext < (1LL << 32) && ncells_ext <= gather_max &&
+	                    !test_switch("FI_NO_GATHER");
+	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
+	const bool tiles = D == 3 && !test_switch("FI_NO_GATHER") && !test_switch("FI_NO_TILE_SUMS") && ncells_ext < (1LL << 32) &&
+	                   (ext1 + kTileY - 1) / kTileY <= 65535 && (ext2 + kTileZ - 1) / kTileZ <= 65535;
+	if (!(gather || tiles) || g.nown != g.nloc) { zero_operator(); }
+	if (tiles) {
+		const int64_t nrows = static_cast<int64_t>(g.cn[1]) * g.cn[2];
+		DevBuf& rb = c->scratch[24];
+		rb.alloc(sizeof(uint32_t) * (nrows + 1));
+		hipLaunchKernelGGL(k_row_bounds, dim3(blocks_for(nrows + 1)), dim3(kThreads), 0, st, nrows, static_cast<uint32_t>(g.cn[0]), ncell,
+		                   c->cells.cell_id.as<uint32_t>(), rb.as<uint32_t>());
+		hipLaunchKernelGGL((k_tile_sums3<T>), dim3((ext0 + kTileX - 1) / kTileX, (ext1 + kTileY - 1) / kTileY, (ext2 + kTileZ - 1) / kTileZ),
+		                   dim3(kThreads), 0, st, g, rb.as<uint32_t>(), c->cells.cell_id.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(),
+		                   c->diag.as<T>(), lump);
+	} else if (gather) {
 		DevBuf& map = c->scratch[24];
 		map.alloc(sizeof(uint32_t) * ncells_ext);
 		FI_HIP_TRY(hipMemsetAsync(map.p, 0xFF, sizeof(uint32_t) * ncells_ext, st));
@@ -808,15 +1047,15 @@ void assemble_dim(fi_ctx* c)
 			const int64_t groups = static_cast<int64_t>((g.own_hi[0] - g.own_lo[0] + 3) / 4) * (g.own_hi[1] - g.own_lo[1]) *
 			                       (g.own_hi[2] - g.own_lo[2]);
 			hipLaunchKernelGGL((k_gather_cells3<T>), dim3(blocks_for(groups)), dim3(kThreads), 0, st, g, ncell, map.as<uint32_t>(),
-			                   cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>());
+			                   cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>(), lump);
 		} else {
 			hipLaunchKernelGGL((k_gather_cells<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, st, g, ncell,
-			                   map.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>());
+			                   map.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>(), lump);
 		}
 	} else {
 		for (int colour = 0; colour < NC; ++colour) {
 			hipLaunchKernelGGL((k_scatter_cells<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, g, ncell,
-			                   c->cells.cell_id.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>(), colour);
+			                   c->cells.cell_id.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(), c->diag.as<T>(), lump, colour);
 		}
 	}
 	FI_HIP_TRY(hipGetLastError());

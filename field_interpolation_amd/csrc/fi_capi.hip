@@ -472,6 +472,7 @@ int fi_assemble(fi_ctx* c)
 	// diagonal's ghost planes is done below, by this thread.
 	// Mixed precision: the fp32 replica and ITS levels are the helper's work (the fp64 context keeps no levels of its own).
 	const bool mixed64 = c->mixed && c->dtype == FI_F64;
+	c->want_lump = mixed64 && fi::lumped_twin_wanted(c);  // (the assembly forms the replica's diagonal beside A^T b)
 	const bool beside = (c->levels_wanted > 0 || mixed64) && !c->any_trip && !fi::test_switch("FI_SERIAL_LEVELS");
 	if (beside && mixed64) {  // (levels an earlier, unmixed assemble may have left on this context)
 		const int keep = c->levels_wanted;

@@ -327,6 +327,10 @@ struct fi_ctx {
 	// the replica's finest level; CG on the exact fp64 operator takes the same number of iterations (tools/proto_lumped.py)
 	bool       lumped = false;
 	fi::DevBuf dlump;   // float[nloc]
+	// on the fp64 context of such a pair: the row sums of ITS data term, formed by the assembly beside A^T b and the
+	// diagonal (fi_assembly.hip: a third entry of every cell's record) when fi_assemble sets want_lump
+	bool       want_lump = false;
+	fi::DevBuf lump;    // float[nloc]
 	bool       data_pinned = false;  // (levels of <= 2^16 points, set with dinv16s) every point's data diagonal reaches its model
 	                                 // diagonal: value rows that dense hold every smooth mode, and two sweeps of the polynomial
 	                                 // smoother solve such a coarsest level as well as an exact solve (tools/proto_cc.py)

@@ -304,27 +304,23 @@ bool lumped_twin_wanted(const fi_ctx* c)
 	       (w.model_1 > 0 || w.model_2 > 0);
 }
 
-__global__ __launch_bounds__(kThreads) void k_fill_f64(int64_t n, double v, double* __restrict__ out)
+// the replica's dlump and the start of its `diag` (k_model_diag adds the model diagonal) from the row sums the fp64
+// level's assembly formed (non-negative for the interpolation kernels; clamped like every bound of the smoother)
+__global__ __launch_bounds__(kThreads) void k_lumped_diag(int64_t n, const float* __restrict__ sums, float* __restrict__ dlump,
+                                                           float* __restrict__ diag)
 {
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		out[i] = v;
-	}
-}
-// dlump = max(A 1 - D w0^2, 0) (the model_0 rows [w0] are diagonal already and stay with the model part); the replica's
-// `diag` starts as dlump, k_model_diag adds the model diagonal
-__global__ __launch_bounds__(kThreads) void k_lumped_diag(int64_t n, const double* __restrict__ a1, double model0,
-                                                           float* __restrict__ dlump, float* __restrict__ diag)
-{
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		const double v = a1[i] - model0;
-		const float  f = v > 0.0 ? static_cast<float>(v) : 0.0f;
+		const float v = sums[i];
+		const float f = v > 0.0f ? v : 0.0f;
 		dlump[i] = f;
 		diag[i]  = f;
 	}
 }
 
-// The lumped replica of an ASSEMBLED fp64 context, on the context's stream: row sums of the data term by one apply of the
-// fp64 operator to the vector of ones (every model row of order >= 1 sums to zero), then the replica's diagonal and scalings.
+// The lumped replica of an ASSEMBLED fp64 context, on the context's stream.  dlump = the row sums of the data term,
+// (A_data 1): every cell's record carries its share (the row sums of its block) and the assembly adds them up over the
+// lattice points with A^T b and the diagonal -- no pass of its own (until round 4's last build: an apply of the fp64
+// operator to a vector of ones, 0.2 ms of the 256^3 assemble's critical path).
 void twin_assemble_lumped(fi_ctx* c)
 {
 	fi_ctx* t = c->twin;
@@ -334,16 +330,11 @@ void twin_assemble_lumped(fi_ctx* c)
 	generic_clear(t);
 	assemble(t);  // no rows: atb and diag zeroed, no cells
 	const Geom& g = c->g;
+	FI_REQUIRE(c->want_lump && c->lump.p, FI_ERR_STATE, "the lumped replica needs the row sums of the fp64 level's assembly");
 	t->dlump.alloc(sizeof(float) * g.nloc);
-	FI_HIP_TRY(hipMemsetAsync(t->dlump.p, 0, sizeof(float) * g.nloc, c->stream));
-	ensure_vectors(c);
-	FI_HIP_TRY(hipMemsetAsync(c->scal.p, 0, sizeof(CgScalars), c->stream));  // (the operator kernels exit at once while the stop flag of the last solve is up)
-	hipLaunchKernelGGL(k_fill_f64, dim3(stream_blocks(g.nloc)), dim3(kThreads), 0, c->stream, g.nloc, 1.0, c->p.as<double>());
-	apply_AtA(c, c->p.p, c->q.p, nullptr);
-	const double w0 = c->w.model_0 > 0 ? static_cast<double>(c->w.model_0) : 0.0;
+	if (g.nown != g.nloc) { FI_HIP_TRY(hipMemsetAsync(t->dlump.p, 0, sizeof(float) * g.nloc, c->stream)); }
 	hipLaunchKernelGGL(k_lumped_diag, dim3(stream_blocks(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
-	                   c->q.as<double>() + g.own_first, g.ndim * w0 * w0, t->dlump.as<float>() + g.own_first,
-	                   t->diag.as<float>() + g.own_first);
+	                   c->lump.as<float>() + g.own_first, t->dlump.as<float>() + g.own_first, t->diag.as<float>() + g.own_first);
 	FI_HIP_TRY(hipGetLastError());
 	generic_assemble(t);
 	stencil_prepare(t);

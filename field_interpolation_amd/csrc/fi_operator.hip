@@ -356,34 +356,49 @@ ModelCoef<T> make_coef(const fi_weights& w)
 // The same for 3-D lattices without gradient_smoothness, a row of x per workgroup row: the y and z parts of the model
 // diagonal are uniform over the workgroup, no 64-bit divisions per point (256^3 fp64: 203 -> ... us, the kernel was
 // bound by its index arithmetic, not by the 436 MB it moves).  Same sums in the same order: the same bits.
+constexpr int kDiagRows = 4;  // rows of x per workgroup (256^3: 65 536 workgroups of one row each were bound by their dispatch)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_model_diag3(Geom g, ModelCoef<T> mc, T* __restrict__ diag, T* __restrict__ dinv,
                                                           unsigned short* __restrict__ d16)
 {
-	const int ext0 = g.own_hi[0] - g.own_lo[0];
+	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1];
 	const int x = static_cast<int>(blockIdx.x) * kThreads + threadIdx.x;
 	if (x >= ext0) { return; }
-	const int li[3] = {g.own_lo[0] + x, g.own_lo[1] + static_cast<int>(blockIdx.y), g.own_lo[2] + static_cast<int>(blockIdx.z)};
-	const int64_t idx = li[0] * g.stride[0] + li[1] * g.stride[1] + li[2] * g.stride[2];
-	T acc = 0;
+	const int lx = g.own_lo[0] + x, lz = g.own_lo[2] + static_cast<int>(blockIdx.z);
+	const int y0 = static_cast<int>(blockIdx.y) * kDiagRows;
+	T in[kDiagRows];
 #pragma unroll
-	for (int d = 0; d < 3; ++d) {  // (d = 0, 1, 2 in this order, like k_model_diag)
-		const int c = li[d] + g.off[d], n = g.gn[d];
-		if (mc.on[0]) { acc += mc.w0sq; }
-		for (int k = 1; k <= 4; ++k) {
-			if (!mc.on[k]) { continue; }
-			for (int m = 0; m <= k; ++m) {
-				const int a = c - m;
-				if (a >= 0 && a + k < n) { acc += mc.c[k][m] * mc.c[k][m]; }
+	for (int j = 0; j < kDiagRows; ++j) {
+		const int64_t idx = lx * g.stride[0] + (g.own_lo[1] + y0 + j) * g.stride[1] + lz * g.stride[2];
+		in[j] = y0 + j < ext1 ? diag[idx] : T(0);
+	}
+#pragma unroll
+	for (int j = 0; j < kDiagRows; ++j) {
+		if (y0 + j >= ext1) { break; }
+		const int ly = g.own_lo[1] + y0 + j;
+		const int64_t idx = lx * g.stride[0] + ly * g.stride[1] + lz * g.stride[2];
+		// (sum of the terms in the order d = 0, 1, 2, term by term as before: a running sum, not a sum of three parts)
+		T acc = 0;
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			const int li = d == 0 ? lx : (d == 1 ? ly : lz);
+			const int c = li + g.off[d], n = g.gn[d];
+			if (mc.on[0]) { acc += mc.w0sq; }
+			for (int k = 1; k <= 4; ++k) {
+				if (!mc.on[k]) { continue; }
+				for (int m = 0; m <= k; ++m) {
+					const int a = c - m;
+					if (a >= 0 && a + k < n) { acc += mc.c[k][m] * mc.c[k][m]; }
+				}
 			}
 		}
-	}
-	const T d = diag[idx] + acc;
-	diag[idx] = d;
-	if (dinv) {
-		const T v = (d != T(0)) ? T(1) / d : T(1);
-		dinv[idx] = v;
-		d16[idx]  = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
+		const T d = in[j] + acc;
+		diag[idx] = d;
+		if (dinv) {
+			const T v = (d != T(0)) ? T(1) / d : T(1);
+			dinv[idx] = v;
+			d16[idx]  = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
+		}
 	}
 }
 
@@ -397,8 +412,8 @@ void prepare_dim(fi_ctx* c)
 	const bool whole = g.nown == g.nloc;  // no ghost planes: every local point is an owned one
 	const int ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
 	if (D == 3 && !mc.on[5] && ext1 <= 65535 && ext2 <= 65535) {
-		hipLaunchKernelGGL((k_model_diag3<T>), dim3((g.own_hi[0] - g.own_lo[0] + kThreads - 1) / kThreads, ext1, ext2), dim3(kThreads), 0,
-		                   c->stream, g, mc, c->diag.as<T>(), whole ? c->dinv.as<T>() : static_cast<T*>(nullptr),
+		hipLaunchKernelGGL((k_model_diag3<T>), dim3((g.own_hi[0] - g.own_lo[0] + kThreads - 1) / kThreads, (ext1 + kDiagRows - 1) / kDiagRows, ext2),
+		                   dim3(kThreads), 0, c->stream, g, mc, c->diag.as<T>(), whole ? c->dinv.as<T>() : static_cast<T*>(nullptr),
 		                   whole ? c->dinv16.as<unsigned short>() : static_cast<unsigned short*>(nullptr));
 	} else
 	hipLaunchKernelGGL((k_model_diag<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g, mc,

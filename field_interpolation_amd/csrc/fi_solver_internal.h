@@ -528,6 +528,7 @@ void build_levels(fi_ctx* c, fi_ctx* src = nullptr, hipStream_t build_stream = n
 fi_ctx* twin_prepare(fi_ctx* c);
 void twin_assemble(fi_ctx* c, hipStream_t build_stream);
 void twin_assemble_lumped(fi_ctx* c);
+bool lumped_twin_wanted(const fi_ctx* c);
 void twin_finish(fi_ctx* c);
 void build_twin(fi_ctx* c);
 // fi_capi.hip

@@ -249,21 +249,24 @@ def test_gather_assembly_same_bits_as_colour_launches(fi, dtype, monkeypatch):
     """A^T b and diag(A^T A) by the gather launch (dense cell map, cells visited in colour order) and by the 2^D
     parity-colour scatter launches: the same sums in the same order, bit for bit (3-D and 2-D)."""
     rng = np.random.default_rng(9)
-    for sizes, n in (([40, 36, 28], 9000), ([90, 70], 2500)):
+    for sizes, n in (([40, 36, 28], 9000), ([150, 37, 19], 60000), ([90, 70], 2500)):
         pos, nrm, pw, val = random_points(rng, sizes, n)
         got = []
-        for no_gather in (False, True):
-            if no_gather:
-                monkeypatch.setenv("FI_NO_GATHER", "1")
-            else:
-                monkeypatch.delenv("FI_NO_GATHER", raising=False)
+        for switch in (None, "FI_NO_TILE_SUMS", "FI_NO_GATHER"):   # 3-D: LDS tiles of points / gather launch / colour launches
+            monkeypatch.delenv("FI_NO_GATHER", raising=False)
+            monkeypatch.delenv("FI_NO_TILE_SUMS", raising=False)
+            if switch:
+                monkeypatch.setenv(switch, "1")
             f = fi.LatticeField(sizes, dtype=dtype)
             f.add_field_constraints(fi.Weights(model_1=0.2))
             f.add_points(1.0, fi.ValueKernel.kLinearInterpolation, 1.0, fi.GradientKernel.kCellEdges, pos, nrm, pw, values=val)
             f.assemble()
             got.append((f.Atb().copy(), f.diag().copy()))
-        np.testing.assert_array_equal(got[0][0], got[1][0])
-        np.testing.assert_array_equal(got[0][1], got[1][1])
+        for other in got[1:]:
+            np.testing.assert_array_equal(got[0][0], other[0])
+            np.testing.assert_array_equal(got[0][1], other[1])
+    monkeypatch.delenv("FI_NO_GATHER", raising=False)
+    monkeypatch.delenv("FI_NO_TILE_SUMS", raising=False)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
