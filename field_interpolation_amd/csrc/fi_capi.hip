@@ -460,6 +460,7 @@ int fi_assemble(fi_ctx* c)
 		int sizes[3] = {c->g.gn[0], c->g.gn[1], c->g.gn[2]};
 		fi::compute_geom(c, c->g.ndim, sizes);
 		c->vectors_ready = false;
+		c->vectors_stale = true;
 	}
 	if (c->nranks > 1) {
 		FI_REQUIRE(c->slab_hi - c->slab_lo >= c->reach, FI_ERR_UNSUPPORTED,

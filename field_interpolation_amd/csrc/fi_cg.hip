@@ -287,6 +287,7 @@ void compute_geom(fi_ctx* c, int ndim, const int* sizes)
 	Geom& g = c->g;
 	g = Geom{};
 	g.ndim = ndim;
+	c->vectors_stale = true;  // (ghost planes may have moved)
 	const int L = ndim - 1;
 	for (int d = 0; d < 3; ++d) {
 		g.gn[d]     = d < ndim ? sizes[d] : 1;
@@ -338,14 +339,22 @@ void ensure_vectors(fi_ctx* c)
 	if (c->vectors_ready) { return; }
 	const size_t es = elem_size(c);
 	const Geom&  g  = c->g;
-	c->x.alloc(es * g.nloc);
-	c->r.alloc(es * g.nloc);
-	c->p.alloc(es * g.nloc);
-	c->q.alloc(es * g.nloc);
-	FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, es * g.nloc, c->stream));
-	FI_HIP_TRY(hipMemsetAsync(c->r.p, 0, es * g.nloc, c->stream));
-	FI_HIP_TRY(hipMemsetAsync(c->p.p, 0, es * g.nloc, c->stream));
-	FI_HIP_TRY(hipMemsetAsync(c->q.p, 0, es * g.nloc, c->stream));
+	// zeroed when they are new or the local geometry has changed (ghost planes outside the lattice are never written and
+	// must stay finite); a re-assembled problem of the same shape keeps them (every solve writes all it reads: 4 fills of
+	// 134 MB = 80 us per step of a 256^3 fp64 context)
+	const size_t need = es * g.nloc;
+	const bool fresh = c->vectors_stale || c->x.bytes < need || c->r.bytes < need || c->p.bytes < need || c->q.bytes < need;
+	c->x.alloc(need);
+	c->r.alloc(need);
+	c->p.alloc(need);
+	c->q.alloc(need);
+	if (fresh) {
+		FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, need, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->r.p, 0, need, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->p.p, 0, need, c->stream));
+		FI_HIP_TRY(hipMemsetAsync(c->q.p, 0, need, c->stream));
+	}
+	c->vectors_stale = false;
 	int nb = apply_num_partials(c);
 	if (nb < 4096) { nb = 4096; }  // also covers the plain kernels of the tile operator (fi_tile_pass)
 	if (stencil_cheb_available(c) && nb < stencil_cheb_partials_max(c)) { nb = stencil_cheb_partials_max(c); }
@@ -770,6 +779,7 @@ void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 		return;
 	}
 	if (c->mg_mode == 1 && (c->coarse || (c->twin && c->twin->coarse))) {
+		c->predictable_start = !guess;
 		cg_run_mg<T>(R, max_iterations, tol);
 	} else if (poly_ok(c)) {
 		cg_run_poly_or_jacobi<T>(R, max_iterations, tol);

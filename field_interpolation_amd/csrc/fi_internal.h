@@ -285,6 +285,7 @@ struct fi_ctx {
 	bool       model_set = false;
 	bool       assembled = false;
 	bool       vectors_ready = false;
+	bool       vectors_stale = true;   // the solver vectors must be zeroed before their next use (new, or the local geometry changed)
 	hipStream_t stream = nullptr;
 
 	std::vector<fi::Pending*> pending;
@@ -360,6 +361,9 @@ struct fi_ctx {
 	int        poly_terms = 0;    // > 1: CG preconditioned by a Chebyshev polynomial of that many terms (cg_run_poly)
 	double     poly_ratio = 10.0; // the polynomial's interval is [hi / ratio, hi], hi = 1.1 * poly_lambda
 	double     poly_lambda = 0;   // largest eigenvalue of diag(A_model)^-1 A_model (power method, once per model)
+	int        last_mg_iterations = 0;     // of the previous V-cycle PCG solve of this context, its tolerance, and whether the
+	double     last_mg_tol = 0;            // solve about to run starts the way that one did (no caller's guess): cg_run_mg
+	bool       predictable_start = false;
 	int        last_cg_iterations = 0;     // of the previous Jacobi-PCG solve of this context (coarser levels: first look at the stop flag)
 	int        last_outer_iterations = 0;  // of the previous polynomial-PCG solve of this context (first look at the stop flag)
 	int        mg_mode = 0;       // 0: Jacobi-PCG (+ cascade start when levels exist); 1: V-cycle preconditioned CG

@@ -70,6 +70,7 @@ void cascade_guess(RankSet& R)
 					finished  = lc[0]->stats.converged != 0;
 				}
 				if (!finished) {
+					for (fi_ctx* l : lc) { l->predictable_start = true; }  // (from the level below or the 48 steps above)
 					cg_run_mg<T>(lc, cap_mg, ltol);
 					coarse_it += lc[0]->stats.iterations;
 				}
@@ -863,23 +864,45 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	cheb_smooth<T>(R, b, x, deg, ratio, false);
 }
 
+struct ScalarRecords {
+	CgScalars* p[16];
+	int        n = 0;
+};
+__global__ __launch_bounds__(64) void k_clear_scalars(ScalarRecords recs)
+{
+	uint32_t* w = reinterpret_cast<uint32_t*>(recs.p[blockIdx.x]);
+	for (unsigned int i = threadIdx.x; i < sizeof(CgScalars) / 4; i += 64) { w[i] = 0u; }
+}
+
 // work vectors, cleared stop flags and smoother bounds for every level below (and including) R
 template <typename T>
 void mg_prepare(RankSet& R, bool clear_finest)
 {
 	RankSet lev = R;
 	bool finest = true;
+	ScalarRecords recs;
+	hipStream_t recs_stream = nullptr;
+	auto flush = [&]() {  // one launch for the records of up to 16 levels on one stream (was: a fill per level)
+		if (recs.n > 0) {
+			hipLaunchKernelGGL(k_clear_scalars, dim3(recs.n), dim3(64), 0, recs_stream, recs);
+			FI_HIP_TRY(hipGetLastError());
+		}
+		recs.n = 0;
+	};
 	while (!lev.empty() && lev[0]) {
 		for (fi_ctx* l : lev) {
 			mg_alloc<T>(l);
 			if (!finest || clear_finest) {  // the operator kernels of a level exit early while ITS stop flag is up
-				FI_HIP_TRY(hipMemsetAsync(l->scal.p, 0, sizeof(CgScalars), l->stream));  // (no host source that could go out of scope)
+				if (recs.n == 16 || (recs.n > 0 && l->stream != recs_stream)) { flush(); }
+				recs_stream = l->stream;
+				recs.p[recs.n++] = l->scal.as<CgScalars>();
 			}
 		}
 		finest = false;
 		if (!lev[0]->coarse) { break; }
 		lev = coarse_of(lev);
 	}
+	flush();
 	// smoother bounds.  Levels that smooth with the polynomial in A_model + f diag(A_data) (poly_smoother_ok): the bound of
 	// the model operator (a number of the lattice and the weights: kept across assembles) and the scaling array.  The
 	// others (Chebyshev in the full operator; the coarsest level always): power method on Dinv A, once per assemble.
@@ -1072,6 +1095,13 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	// r = b - A x, rr (b.b on the first call) and the stop test on it; unless that ends the solve: z = V(r), p = z, rz.
 	// Returns the stop flag.  (The flag is read BEFORE the V-cycle is spent: a verification that confirms the recurrence's
 	// residual -- the usual outcome -- costs one operator application, not a cycle.)
+	// A solve that starts like the previous one of this context (coarse-to-fine or zero start, the same tolerance) most
+	// likely takes as many iterations: no look at the stop flag before that count -- a look is a copy and a host round
+	// trip of 25-40 us in front of every V-cycle.  Should the solve be over earlier, the fp64 kernels exit on the flag and
+	// the cycles in between are wasted, nothing else; from the predicted count on every iteration looks again.
+	const int predicted = (c0->predictable_start && c0->last_mg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS")) ? c0->last_mg_iterations : 0;
+	int  steps = 0;
+	bool first_restart = true;
 	auto restart = [&]() -> int {
 		apply_all(R, X, Q, false);
 		if (R.size() == 1 && c0->nranks == 1) {  // undivided lattice: one pass for r, r.r and b.b
@@ -1092,7 +1122,9 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		dot(Rv, Rv);
 		mg_reduce(R, nbv, kMgInitRr);
 		}
-		const int flag = read_flag();
+		const bool look = !(first_restart && predicted > 0);
+		first_restart = false;
+		const int flag = look ? read_flag() : 0;
 		if (flag) { return flag; }
 		precondition<T>(R, Tw, Rv, Z, false);
 		dot_rz();
@@ -1170,7 +1202,8 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			}
 		}
 		mg_reduce(R, nbv, kMgResid);
-		done = read_flag();
+		++steps;
+		done = steps < predicted ? 0 : read_flag();
 		if (done) { continue; }
 		precondition<T>(R, Tw, Rv, Z, stepped);
 		dot_rz();
@@ -1215,6 +1248,8 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		c->stats.operator_applies = h.iter + 1 + h.restarts;
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
+		c->last_mg_iterations = timed_out || h.done == 2 ? 0 : h.iter;  // (the same on every rank: the scalars are sums over all)
+		c->last_mg_tol        = tolerance;
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
 		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
 		c->stats.restarts     = h.restarts;
