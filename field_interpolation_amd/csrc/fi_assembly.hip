@@ -1029,11 +1029,8 @@ void assemble_dim(fi_ctx* c)
 	                   (ext1 + kTileY - 1) / kTileY <= 65535 && (ext2 + kTileZ - 1) / kTileZ <= 65535;
 	if (!(gather || tiles) || g.nown != g.nloc) { zero_operator(); }
 	if (tiles) {
-		const int64_t nrows = static_cast<int64_t>(g.cn[1]) * g.cn[2];
 		DevBuf& rb = c->scratch[24];
-		rb.alloc(sizeof(uint32_t) * (nrows + 1));
-		hipLaunchKernelGGL(k_row_bounds, dim3(blocks_for(nrows + 1)), dim3(kThreads), 0, st, nrows, static_cast<uint32_t>(g.cn[0]), ncell,
-		                   c->cells.cell_id.as<uint32_t>(), rb.as<uint32_t>());
+		(void)cell_row_bounds(c);
 		hipLaunchKernelGGL((k_tile_sums3<T>), dim3((ext0 + kTileX - 1) / kTileX, (ext1 + kTileY - 1) / kTileY, (ext2 + kTileZ - 1) / kTileZ),
 		                   dim3(kThreads), 0, st, g, rb.as<uint32_t>(), c->cells.cell_id.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(),
 		                   c->diag.as<T>(), lump);
@@ -1196,6 +1193,23 @@ int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val)
 	return nb;
 }
 
+// 3-D: where every (y, z) row of cells starts in the sorted cell ids: bound[lz * cn1 + ly], one more entry at the end.
+// Formed once per assembly, on the context's stream (the sums over the lattice points and the fused kernel's lists use it).
+const uint32_t* cell_row_bounds(fi_ctx* c)
+{
+	const Geom& g = c->g;
+	DevBuf& rb = c->scratch[24];
+	if (!c->row_bounds_valid) {
+		const int64_t nrows = static_cast<int64_t>(g.cn[1]) * g.cn[2];
+		rb.alloc(sizeof(uint32_t) * (nrows + 1));
+		hipLaunchKernelGGL(k_row_bounds, dim3(blocks_for(nrows + 1)), dim3(kThreads), 0, c->stream, nrows, static_cast<uint32_t>(g.cn[0]),
+		                   static_cast<long>(c->cells.ncell), c->cells.cell_id.as<uint32_t>(), rb.as<uint32_t>());
+		FI_HIP_TRY(hipGetLastError());
+		c->row_bounds_valid = true;
+	}
+	return rb.as<uint32_t>();
+}
+
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val, float vw,
                      int vk, float gw, int gk, float pos_scale, float nrm_scale)
 {
@@ -1208,6 +1222,7 @@ void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, cons
 
 void assemble(fi_ctx* c)
 {
+	c->row_bounds_valid = false;
 	const bool f64 = c->dtype == FI_F64;
 	switch (c->g.ndim) {
 	case 1: f64 ? assemble_dim<1, double>(c) : assemble_dim<1, float>(c); break;

@@ -330,6 +330,7 @@ struct fi_ctx {
 	fi::DevBuf dlump;   // float[nloc]
 	// on the fp64 context of such a pair: the row sums of ITS data term, formed by the assembly beside A^T b and the
 	// diagonal (fi_assembly.hip: a third entry of every cell's record) when fi_assemble sets want_lump
+	bool       row_bounds_valid = false;  // scratch[24] holds cell_row_bounds() of the current cells
 	bool       want_lump = false;
 	fi::DevBuf lump;    // float[nloc]
 	bool       data_pinned = false;  // (levels of <= 2^16 points, set with dinv16s) every point's data diagonal reaches its model
@@ -485,6 +486,7 @@ void generic_error_map(fi_ctx* c, const void* x, void* out);             // out 
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val,
                      float vw, int vk, float gw, int gk, float pos_scale = 1.0f, float nrm_scale = 1.0f);
 void assemble(fi_ctx* c);
+const uint32_t* cell_row_bounds(fi_ctx* c);  // 3-D, after assemble(): first sorted cell of every (y, z) row of cells
 // border prior (src/sdf_field.cpp:218-246): coordinates of the lattice's border points and their distance to the nearest
 // data point added so far, as device buffers; returns their number
 int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val);

@@ -133,6 +133,222 @@ __global__ __launch_bounds__(kThreads) void k_cell_members(MarchParams P, Geom g
 	}
 }
 
+// ---- the same lists WITHOUT a sort (round 4) -----------------------------------------------------------------------------
+// The cells are sorted by extended id -- z, y, x -- and a list is (workgroup, layer, band of origin rows): for each of the
+// band's <= 5 origin rows the cells with x origin tile_x * tx - 1 .. tile_x * tx + tx - 1, a contiguous RANGE of the sorted
+// cells; the ranges one after the other are the list in the order the stable sort by (key, slot) produced.  With
+//   kinds[c]   records cell c contributes to a list it is a member of: (row records | block records << 32)
+//   P[c]       exclusive prefix sums of kinds over the sorted cells
+//   seg        where the x range of every tile starts and ends in every (y, z) row of cells (k_seg_bounds)
+// a list's record counts are differences of P at its ranges' ends (k_list_count, a thread per list), the lists' bounds an
+// exclusive scan of the counts, and a cell's record goes to bound + records of the band's earlier rows + P[c] - P[range
+// start] (k_list_fill, a thread per cell as in k_cell_members).  Replaces: membership count + scan + round trip +
+// membership write + iota + radix sort of 1.15 M pairs (3 passes, 7 fills) + bounds by binary search + record copy --
+// 27 calls and two host round trips per level -> 13 and one.
+__device__ inline bool pair_cell(const MarchParams& P, int cx, int cy, int zz)
+{
+	const int nz_own = P.own_z1 - P.own_z0;
+	const int mx = ((cx >= 0 && cx / P.tx < P.tiles_x) ? 1 : 0) + (((cx + 1) % P.tx == 0 && (cx + 1) / P.tx < P.tiles_x) ? 1 : 0);
+	const int my = ((cy >= 0 && cy / P.ty < P.tiles_y) ? 1 : 0) + (((cy + 1) % P.ty == 0 && (cy + 1) / P.ty < P.tiles_y) ? 1 : 0);
+	const int mz = ((zz >= 0 && zz < nz_own) ? 1 : 0) + ((zz + 1 >= 0 && zz + 1 < nz_own && (zz + 1) % P.zc == 0) ? 1 : 0);
+	return mx * my * mz <= 4;  // a two-row cell with more memberships stays a block record (k_cell_members)
+}
+
+__global__ __launch_bounds__(kThreads) void k_cell_kinds(MarchParams P, Geom g, int64_t ncell, const uint32_t* __restrict__ cell_id,
+                                                          const uint32_t* __restrict__ nrow, unsigned long long* __restrict__ kinds,
+                                                          uint32_t* __restrict__ uniq)
+{
+	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	const bool live = c < ncell;
+	const uint32_t rows_c = live ? nrow[c] : 0u;
+	// distinct cells of each kind (statistics): one atomic per wave, spread over 64 counter pairs on lines of their own
+	const unsigned long long rows = __ballot(live && rows_c == 1u), blks = __ballot(live && rows_c != 1u);
+	if ((threadIdx.x & 63) == 0) {
+		const int w = (blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) & 63;
+		if (rows) { atomicAdd(&uniq[kCountStride * w], static_cast<uint32_t>(__popcll(rows))); }
+		if (blks) { atomicAdd(&uniq[kCountStride * w + 1], static_cast<uint32_t>(__popcll(blks))); }
+	}
+	if (c > ncell) { return; }
+	if (c == ncell) {  // (the scan runs over ncell + 1 entries: P[ncell] = all records)
+		kinds[c] = 0ull;
+		return;
+	}
+	uint32_t id = cell_id[c];
+	const int cx = static_cast<int>(id % static_cast<uint32_t>(g.cn[0])) + g.coff[0];
+	id /= static_cast<uint32_t>(g.cn[0]);
+	const int cy = static_cast<int>(id % static_cast<uint32_t>(g.cn[1])) + g.coff[1];
+	id /= static_cast<uint32_t>(g.cn[1]);
+	const int zz = static_cast<int>(id) + g.coff[2] - P.zoff - P.own_z0;
+	const bool pair = rows_c == 2u && pair_cell(P, cx, cy, zz);
+	kinds[c] = (rows_c == 1u || pair) ? (pair ? 2ull : 1ull) : (1ull << 32);
+}
+
+// seg[(row * (tiles_x + 1) + t) * 2 + {0, 1}]: first cell of row `row` with x origin >= t * tx - 1 / >= t * tx (extended-local
+// rows: row = lz * cn1 + ly).  Tile t's cells in the row: [seg[.. t ..][0], seg[.. t + 1 ..][1]).
+__global__ __launch_bounds__(kThreads) void k_seg_bounds(MarchParams P, Geom g, int64_t nrows, const uint32_t* __restrict__ row_bound,
+                                                          const uint32_t* __restrict__ cell_id, uint32_t* __restrict__ seg)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	const int per = P.tiles_x + 1;
+	if (i >= nrows * per) { return; }
+	const int64_t row = i / per;
+	const int     t   = static_cast<int>(i % per);
+	const uint32_t key0 = static_cast<uint32_t>(row) * static_cast<uint32_t>(g.cn[0]);
+	const uint32_t a = row_bound[row], b = row_bound[row + 1];
+#pragma unroll
+	for (int which = 0; which < 2; ++which) {
+		int lx = t * P.tx - 1 + which - g.coff[0];  // first extended-local x of interest
+		if (lx < 0) { lx = 0; }
+		uint32_t lo = a, hi = b;
+		if (lx >= g.cn[0]) {
+			lo = b;
+		} else {
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (cell_id[mid] < key0 + static_cast<uint32_t>(lx)) { lo = mid + 1; } else { hi = mid; }
+			}
+		}
+		seg[i * 2 + which] = lo;
+	}
+}
+
+// the sorted-cell range of (tile_x, extended-local row ly of plane lz), empty when the row does not exist
+__device__ inline void tile_row_range(const MarchParams& P, const Geom& g, const uint32_t* __restrict__ seg, int tile_x, int ly, int lz,
+                                      uint32_t* s, uint32_t* e)
+{
+	*s = 0;
+	*e = 0;
+	if (ly < 0 || ly >= g.cn[1] || lz < 0 || lz >= g.cn[2]) { return; }
+	const int64_t row = static_cast<int64_t>(lz) * g.cn[1] + ly;
+	const int64_t i   = row * (P.tiles_x + 1) + tile_x;
+	*s = seg[i * 2];
+	*e = seg[(i + 1) * 2 + 1];
+	if (*e < *s) { *e = *s; }
+}
+
+// counts[b] = row records of list b, counts[nbuckets + b] = block records
+__global__ __launch_bounds__(kThreads) void k_list_count(MarchParams P, Geom g, int64_t nbuckets, const uint32_t* __restrict__ seg,
+                                                          const unsigned long long* __restrict__ pre, uint32_t* __restrict__ counts)
+{
+	const int64_t b = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (b >= nbuckets) { return; }
+	const int per_wg = (P.zc + 1) * 4;
+	const int wg = static_cast<int>(b / per_wg), rem = static_cast<int>(b % per_wg);
+	const int layer = rem / 4, band = rem % 4;
+	const int tiles_xy = P.tiles_x * P.tiles_y;
+	const int chunk = wg / tiles_xy, txy = wg % tiles_xy;
+	const int tile_y = txy / P.tiles_x, tile_x = txy % P.tiles_x;
+	const int nz_own = P.own_z1 - P.own_z0;
+	const int zz = chunk * P.zc + layer - 1;  // plane of the origins, relative to the first owned plane (layer 0: the one below the chunk)
+	unsigned long long n = 0;
+	if (layer >= 1 ? (zz >= 0 && zz < nz_own) : (zz + 1 >= 0 && zz + 1 < nz_own)) {
+		const int lz = zz + P.zoff + P.own_z0 - g.coff[2];
+		for (int r = 0; r <= P.ty; ++r) {
+			if (r * 4 / (P.ty + 1) != band) { continue; }
+			uint32_t s, e;
+			tile_row_range(P, g, seg, tile_x, tile_y * P.ty + r - 1 - g.coff[1], lz, &s, &e);
+			n += pre[e] - pre[s];
+		}
+	}
+	counts[b]            = static_cast<uint32_t>(n & 0xFFFFFFFFull);
+	counts[nbuckets + b] = static_cast<uint32_t>(n >> 32);
+}
+
+// the lists' bounds in the kernel's form from the scan of the counts: row records from 0, block records from 0
+__global__ __launch_bounds__(kThreads) void k_list_layout(int64_t nbuckets, const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ first, uint32_t* __restrict__ lay_row,
+                                                           uint32_t* __restrict__ lay_blk)
+{
+	const int64_t b = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (b > nbuckets) { return; }
+	const uint32_t rows_all = first[nbuckets];  // = all row records: the block records' scan starts there
+	if (b < nbuckets) {
+		lay_row[b] = first[b];
+		lay_blk[b] = first[nbuckets + b] - rows_all;
+	} else {
+		lay_row[b] = rows_all;
+		lay_blk[b] = first[2 * nbuckets - 1] + counts[2 * nbuckets - 1] - rows_all;
+	}
+}
+
+// one thread per cell: its records into every list it is a member of (the memberships of k_cell_members)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_list_fill(MarchParams P, Geom g, int64_t ncell, const uint32_t* __restrict__ seg,
+                                                         const unsigned long long* __restrict__ pre, const uint32_t* __restrict__ cell_id,
+                                                         const uint32_t* __restrict__ nrow, const uint32_t* __restrict__ lay_row,
+                                                         const uint32_t* __restrict__ lay_blk, const T* __restrict__ row1,
+                                                         const T* __restrict__ mrow, const uint32_t* __restrict__ nfac,
+                                                         uint32_t* __restrict__ pos_row, uint32_t* __restrict__ pos_blk,
+                                                         T* __restrict__ coef_row, T* __restrict__ coef_blk)
+{
+	using V = typename VecOf<T>::V;
+	constexpr int VX = VecOf<T>::VX;
+	const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c >= ncell) { return; }
+	uint32_t id = cell_id[c];
+	const int lx = static_cast<int>(id % static_cast<uint32_t>(g.cn[0]));
+	id /= static_cast<uint32_t>(g.cn[0]);
+	const int ly = static_cast<int>(id % static_cast<uint32_t>(g.cn[1]));
+	id /= static_cast<uint32_t>(g.cn[1]);
+	const int lz = static_cast<int>(id);
+	const int cx = lx + g.coff[0], cy = ly + g.coff[1];
+	const int zz = lz + g.coff[2] - P.zoff - P.own_z0;
+	const int nz_own = P.own_z1 - P.own_z0;
+	const unsigned long long mine = pre[c + 1] - pre[c];
+	const bool     as_rows = (mine & 0xFFFFFFFFull) != 0;
+	const uint32_t nrec    = as_rows ? static_cast<uint32_t>(mine) : 1u;  // 1, or 2 for a pair
+	const unsigned long long pc = pre[c];
+
+	const bool x_ok[2] = {cx >= 0 && cx / P.tx < P.tiles_x, (cx + 1) % P.tx == 0 && (cx + 1) / P.tx < P.tiles_x};
+	const int  x_ti[2] = {cx >= 0 ? cx / P.tx : 0, (cx + 1) / P.tx};
+	const int  x_tc[2] = {cx >= 0 ? cx % P.tx : 0, -1};
+	const bool y_ok[2] = {cy >= 0 && cy / P.ty < P.tiles_y, (cy + 1) % P.ty == 0 && (cy + 1) / P.ty < P.tiles_y};
+	const int  y_ti[2] = {cy >= 0 ? cy / P.ty : 0, (cy + 1) / P.ty};
+	const int  y_tc[2] = {cy >= 0 ? cy % P.ty : 0, -1};
+	const bool z_ok[2] = {zz >= 0 && zz < nz_own, zz + 1 >= 0 && zz + 1 < nz_own && (zz + 1) % P.zc == 0};
+	const int  z_tk[2] = {zz >= 0 ? zz / P.zc : 0, (zz + 1) / P.zc};
+	const int  z_tl[2] = {zz >= 0 ? zz % P.zc + 1 : 0, 0};
+	const uint32_t kf = as_rows ? 0u : nfac[c];
+	for (int m = 0; m < 8; ++m) {
+		const int a = m >> 2, b = (m >> 1) & 1, d = m & 1;
+		if (!(z_ok[a] && y_ok[b] && x_ok[d])) { continue; }
+		const int     wg     = (z_tk[a] * P.tiles_y + y_ti[b]) * P.tiles_x + x_ti[d];
+		const int     r      = y_tc[b] + 1;
+		const int     band   = r * 4 / (P.ty + 1);
+		const int64_t bucket = (static_cast<int64_t>(wg) * (P.zc + 1) + z_tl[a]) * 4 + band;
+		// records of the list in front of this cell's: the band's earlier rows, then the cells before it in its own row's range
+		unsigned long long before = 0;
+		for (int rr = r - 1; rr >= 0 && rr * 4 / (P.ty + 1) == band; --rr) {
+			uint32_t s, e;
+			tile_row_range(P, g, seg, x_ti[d], ly - (r - rr), lz, &s, &e);
+			before += pre[e] - pre[s];
+		}
+		{
+			uint32_t s, e;
+			tile_row_range(P, g, seg, x_ti[d], ly, lz, &s, &e);
+			before += pc - pre[s];
+		}
+		const uint32_t pp = static_cast<uint32_t>(x_tc[d] + 1) | (static_cast<uint32_t>(r) << 16);
+		if (as_rows) {
+			int64_t at = static_cast<int64_t>(lay_row[bucket]) + static_cast<int64_t>(before & 0xFFFFFFFFull);
+			for (uint32_t ridx = 0; ridx < nrec; ++ridx, ++at) {
+				pos_row[at] = pp | (ridx << 8);
+				const V* src = reinterpret_cast<const V*>(ridx ? mrow + c * 64 + ridx * 8 : row1 + c * 8);
+				V*       dst = reinterpret_cast<V*>(coef_row + at * 8);
+#pragma unroll
+				for (int v = 0; v < 8 / VX; ++v) { dst[v] = src[v]; }
+			}
+		} else {
+			const int64_t at = static_cast<int64_t>(lay_blk[bucket]) + static_cast<int64_t>(before >> 32);
+			pos_blk[at] = pp | (kf << 8);
+			const V* src = reinterpret_cast<const V*>(mrow + c * 64);
+			V*       dst = reinterpret_cast<V*>(coef_blk + at * 64);
+			const uint32_t nvec = (kf == 0xFFu ? 36u : kf * 8u) / VX;  // 255: the packed block (fp64 contexts)
+			for (uint32_t v = 0; v < nvec; ++v) { dst[v] = src[v]; }
+		}
+	}
+}
+
 // the host's view of the lists in one buffer: [0..1] workgroups with / without cells, [2..3] row / block records,
 // [4..5] distinct cells per kind (sum of the 64 counter pairs), then one flag byte per workgroup
 __global__ __launch_bounds__(kThreads) void k_pack_readback(int nwg, const int* __restrict__ nsel, const uint32_t* __restrict__ n_row,
@@ -317,92 +533,139 @@ void build_cell_lists(fi_ctx* c)
 	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1) * 4;  // (workgroup, layer, band of origin rows)
 	FI_REQUIRE(ncell * 8 < (1LL << 31) && 2 * nbuckets < (1LL << 31), FI_ERR_UNSUPPORTED, "too many data cells for one context");
 	hipStream_t st = c->stream;
-	DevBuf &count = c->scratch[14], &key = c->scratch[15], &pos = c->scratch[16], &slot_in = c->scratch[17],
-	       &key_sorted = c->scratch[18], &slot_sorted = c->scratch[19], &tmp = c->scratch[20], &nslot = c->scratch[31],
-	       &first = c->scratch[32], &cell_of = c->scratch[33];
-	count.alloc(sizeof(uint32_t) * (2 * nbuckets + 2 + kCountWords));  // distinct cells per kind (64 pairs), then the list bounds
-	nslot.alloc(sizeof(uint32_t) * (ncell + 1));
-	first.alloc(sizeof(uint32_t) * (ncell + 1));
+	const int nwg = P.nwg;
 	m.lay_row.alloc(sizeof(uint32_t) * (nbuckets + 1));
 	m.lay_blk.alloc(sizeof(uint32_t) * (nbuckets + 1));
-	FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * kCountWords, st));
-	const int nb = static_cast<int>((ncell + kThreads - 1) / kThreads);
-	hipLaunchKernelGGL(k_cell_members<false>, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
-	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), nslot.as<uint32_t>(),
-	                   static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
-	                   static_cast<uint32_t*>(nullptr), count.as<uint32_t>());
-	size_t tb0 = 0;
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
-	tmp.alloc(tb0);
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
-	hipLaunchKernelGGL(k_slot_total, dim3(1), dim3(1), 0, st, ncell, first.as<uint32_t>(), nslot.as<uint32_t>(),
-	                   first.as<uint32_t>() + ncell);
-	uint32_t h_slots = 0;
-	FI_HIP_TRY(hipMemcpyAsync(&h_slots, first.as<uint32_t>() + ncell, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	FI_HIP_TRY(hipStreamSynchronize(st));  // the sort below is sized by it
-	const int64_t nslots = h_slots;
-	key.alloc(sizeof(uint32_t) * (nslots + 1));
-	pos.alloc(sizeof(uint32_t) * (nslots + 1));
-	cell_of.alloc(sizeof(uint32_t) * (nslots + 1));
-	slot_in.alloc(sizeof(uint32_t) * (nslots + 1));
-	key_sorted.alloc(sizeof(uint32_t) * (nslots + 1));
-	slot_sorted.alloc(sizeof(uint32_t) * (nslots + 1));
-	hipLaunchKernelGGL(k_cell_members<true>, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
-	                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), static_cast<uint32_t*>(nullptr),
-	                   first.as<uint32_t>(), key.as<uint32_t>(), pos.as<uint32_t>(), cell_of.as<uint32_t>(), count.as<uint32_t>());
-	if (nslots > 0) {
-		hipLaunchKernelGGL(k_iota32, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-		                   slot_in.as<uint32_t>(), nslots);
-		// only the bits the keys have take part (256^3: 18 bits = 3 radix passes instead of 4)
-		int key_bits = 1;
-		while ((1LL << key_bits) < 2 * nbuckets) { ++key_bits; }
-		size_t tb = 0;
-		FI_HIP_TRY(sort_pairs_u32(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
-		                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-		                                              static_cast<int>(nslots), 0, key_bits, st));
-		tmp.alloc(tb);
-		FI_HIP_TRY(sort_pairs_u32(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
-		                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-		                                              static_cast<int>(nslots), 0, key_bits, st));
-	}
-	uint32_t* bound = count.as<uint32_t>() + kCountWords;  // [2 * nbuckets + 1]
-	hipLaunchKernelGGL(k_list_bounds, dim3(static_cast<int>((2 * nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-	                   st, nslots, 2 * nbuckets, key_sorted.as<uint32_t>(), bound);
-	hipLaunchKernelGGL(k_split_bounds, dim3(static_cast<int>((nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-	                   nbuckets, bound, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>());
-	// workgroups with and without cells (march_launch): classified here, read back with the totals below
-	const int nwg = P.nwg;
 	m.wg_cells.alloc(sizeof(uint32_t) * nwg);
 	m.wg_plain.alloc(sizeof(uint32_t) * nwg);
 	// everything the host needs in ONE copy: the two selection counts, the record totals, the distinct cells per kind, and
 	// the per-workgroup flags
 	DevBuf& pack = c->scratch[34];
 	pack.alloc(24 + static_cast<size_t>(nwg));
-	hipLaunchKernelGGL(k_classify_pack, dim3(1), dim3(1024), 0, st, nwg, (P.zc + 1) * 4, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
-	                   m.lay_row.as<uint32_t>() + nbuckets, m.lay_blk.as<uint32_t>() + nbuckets, count.as<uint32_t>(),
-	                   m.wg_cells.as<uint32_t>(), m.wg_plain.as<uint32_t>(), pack.as<uint8_t>());
 	std::vector<uint8_t> h_pack(24 + static_cast<size_t>(nwg));
-	FI_HIP_TRY(hipMemcpyAsync(h_pack.data(), pack.p, h_pack.size(), hipMemcpyDeviceToHost, st));
-	FI_HIP_TRY(hipStreamSynchronize(st));
+	if (!test_switch("FI_LISTS_BY_SORT")) {
+		// ---- lists as ranges of the sorted cells (no sort) ----
+		DevBuf &uniq = c->scratch[14], &counts_d = c->scratch[15], &first_d = c->scratch[16], &kinds = c->scratch[17],
+		       &pre = c->scratch[18], &seg = c->scratch[19], &tmp = c->scratch[20];
+		const uint32_t* row_bound = cell_row_bounds(c);
+		const int64_t nrows = static_cast<int64_t>(c->g.cn[1]) * c->g.cn[2];
+		const int64_t nseg  = nrows * (P.tiles_x + 1);
+		uniq.alloc(sizeof(uint32_t) * kCountWords);
+		counts_d.alloc(sizeof(uint32_t) * (2 * nbuckets + 1));
+		first_d.alloc(sizeof(uint32_t) * (2 * nbuckets + 1));
+		kinds.alloc(sizeof(unsigned long long) * (ncell + 1));
+		pre.alloc(sizeof(unsigned long long) * (ncell + 1));
+		seg.alloc(sizeof(uint32_t) * 2 * (nseg + 1));
+		FI_HIP_TRY(hipMemsetAsync(uniq.p, 0, sizeof(uint32_t) * kCountWords, st));
+		hipLaunchKernelGGL(k_cell_kinds, dim3(static_cast<int>((ncell + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, c->g, ncell,
+		                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), kinds.as<unsigned long long>(), uniq.as<uint32_t>());
+		size_t tb0 = 0;
+		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb0, kinds.as<unsigned long long>(), pre.as<unsigned long long>(),
+		                                            static_cast<int>(ncell + 1), st));
+		tmp.alloc(tb0);
+		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb0, kinds.as<unsigned long long>(), pre.as<unsigned long long>(),
+		                                            static_cast<int>(ncell + 1), st));
+		hipLaunchKernelGGL(k_seg_bounds, dim3(static_cast<int>((nseg + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, c->g, nrows,
+		                   row_bound, c->cells.cell_id.as<uint32_t>(), seg.as<uint32_t>());
+		const int nbb = static_cast<int>((nbuckets + 1 + kThreads - 1) / kThreads);
+		hipLaunchKernelGGL(k_list_count, dim3(nbb), dim3(kThreads), 0, st, P, c->g, nbuckets, seg.as<uint32_t>(),
+		                   pre.as<unsigned long long>(), counts_d.as<uint32_t>());
+		size_t tb1 = 0;
+		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, counts_d.as<uint32_t>(), first_d.as<uint32_t>(),
+		                                            static_cast<int>(2 * nbuckets), st));
+		tmp.alloc(tb1 > tb0 ? tb1 : tb0);
+		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb1, counts_d.as<uint32_t>(), first_d.as<uint32_t>(),
+		                                            static_cast<int>(2 * nbuckets), st));
+		hipLaunchKernelGGL(k_list_layout, dim3(nbb), dim3(kThreads), 0, st, nbuckets, counts_d.as<uint32_t>(), first_d.as<uint32_t>(),
+		                   m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>());
+		hipLaunchKernelGGL(k_classify_pack, dim3(1), dim3(1024), 0, st, nwg, (P.zc + 1) * 4, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
+		                   m.lay_row.as<uint32_t>() + nbuckets, m.lay_blk.as<uint32_t>() + nbuckets, uniq.as<uint32_t>(),
+		                   m.wg_cells.as<uint32_t>(), m.wg_plain.as<uint32_t>(), pack.as<uint8_t>());
+		FI_HIP_TRY(hipMemcpyAsync(h_pack.data(), pack.p, h_pack.size(), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+	} else {
+		// ---- the same lists by a radix sort of (list key, slot) pairs: the form of rounds 1-3, kept for the comparison ----
+		DevBuf &count = c->scratch[14], &key = c->scratch[15], &pos = c->scratch[16], &slot_in = c->scratch[17],
+		       &key_sorted = c->scratch[18], &slot_sorted = c->scratch[19], &tmp = c->scratch[20], &nslot = c->scratch[31],
+		       &first = c->scratch[32], &cell_of = c->scratch[33];
+		count.alloc(sizeof(uint32_t) * (2 * nbuckets + 2 + kCountWords));  // distinct cells per kind (64 pairs), then the list bounds
+		nslot.alloc(sizeof(uint32_t) * (ncell + 1));
+		first.alloc(sizeof(uint32_t) * (ncell + 1));
+		FI_HIP_TRY(hipMemsetAsync(count.p, 0, sizeof(uint32_t) * kCountWords, st));
+		const int nb = static_cast<int>((ncell + kThreads - 1) / kThreads);
+		hipLaunchKernelGGL(k_cell_members<false>, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
+		                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), nslot.as<uint32_t>(),
+		                   static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+		                   static_cast<uint32_t*>(nullptr), count.as<uint32_t>());
+		size_t tb0 = 0;
+		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
+		tmp.alloc(tb0);
+		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
+		hipLaunchKernelGGL(k_slot_total, dim3(1), dim3(1), 0, st, ncell, first.as<uint32_t>(), nslot.as<uint32_t>(),
+		                   first.as<uint32_t>() + ncell);
+		uint32_t h_slots = 0;
+		FI_HIP_TRY(hipMemcpyAsync(&h_slots, first.as<uint32_t>() + ncell, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));  // the sort below is sized by it
+		const int64_t nslots = h_slots;
+		key.alloc(sizeof(uint32_t) * (nslots + 1));
+		pos.alloc(sizeof(uint32_t) * (nslots + 1));
+		cell_of.alloc(sizeof(uint32_t) * (nslots + 1));
+		slot_in.alloc(sizeof(uint32_t) * (nslots + 1));
+		key_sorted.alloc(sizeof(uint32_t) * (nslots + 1));
+		slot_sorted.alloc(sizeof(uint32_t) * (nslots + 1));
+		hipLaunchKernelGGL(k_cell_members<true>, dim3(nb), dim3(kThreads), 0, st, P, c->g, ncell, nbuckets,
+		                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), static_cast<uint32_t*>(nullptr),
+		                   first.as<uint32_t>(), key.as<uint32_t>(), pos.as<uint32_t>(), cell_of.as<uint32_t>(), count.as<uint32_t>());
+		if (nslots > 0) {
+			hipLaunchKernelGGL(k_iota32, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+			                   slot_in.as<uint32_t>(), nslots);
+			int key_bits = 1;  // only the bits the keys have take part
+			while ((1LL << key_bits) < 2 * nbuckets) { ++key_bits; }
+			size_t tb = 0;
+			FI_HIP_TRY(sort_pairs_u32(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(), slot_in.as<uint32_t>(),
+			                          slot_sorted.as<uint32_t>(), static_cast<int>(nslots), 0, key_bits, st));
+			tmp.alloc(tb);
+			FI_HIP_TRY(sort_pairs_u32(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(), slot_in.as<uint32_t>(),
+			                          slot_sorted.as<uint32_t>(), static_cast<int>(nslots), 0, key_bits, st));
+		}
+		uint32_t* bound = count.as<uint32_t>() + kCountWords;  // [2 * nbuckets + 1]
+		hipLaunchKernelGGL(k_list_bounds, dim3(static_cast<int>((2 * nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+		                   st, nslots, 2 * nbuckets, key_sorted.as<uint32_t>(), bound);
+		hipLaunchKernelGGL(k_split_bounds, dim3(static_cast<int>((nbuckets + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+		                   nbuckets, bound, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>());
+		hipLaunchKernelGGL(k_classify_pack, dim3(1), dim3(1024), 0, st, nwg, (P.zc + 1) * 4, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
+		                   m.lay_row.as<uint32_t>() + nbuckets, m.lay_blk.as<uint32_t>() + nbuckets, count.as<uint32_t>(),
+		                   m.wg_cells.as<uint32_t>(), m.wg_plain.as<uint32_t>(), pack.as<uint8_t>());
+		FI_HIP_TRY(hipMemcpyAsync(h_pack.data(), pack.p, h_pack.size(), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipStreamSynchronize(st));
+	}
 	uint32_t head[6];
 	memcpy(head, h_pack.data(), sizeof(head));
 	const int counts[2] = {static_cast<int>(head[0]), static_cast<int>(head[1])};
-	const uint32_t totals[2] = {head[2], head[3]}, uniq[2] = {head[4], head[5]};
+	const uint32_t totals[2] = {head[2], head[3]}, uniq_cells[2] = {head[4], head[5]};
 	const uint8_t* h_has = h_pack.data() + 24;
 	m.n_row = totals[0];
 	m.n_blk = totals[1];
-	m.cells_row = uniq[0];
-	m.cells_blk = uniq[1];
+	m.cells_row = uniq_cells[0];
+	m.cells_blk = uniq_cells[1];
 	m.pos_row.alloc(sizeof(uint32_t) * (m.n_row + 1));
 	m.pos_blk.alloc(sizeof(uint32_t) * (m.n_blk + 1));
 	m.coef_row.alloc(sizeof(T) * 8 * (m.n_row + 1));
 	m.coef_blk.alloc(sizeof(T) * 64 * (m.n_blk + 1));
 	const int64_t n_all = m.n_row + m.n_blk;
 	if (n_all > 0) {
-		hipLaunchKernelGGL((k_cell_records<T>), dim3(static_cast<int>((n_all + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-		                   st, m.n_row, n_all, slot_sorted.as<uint32_t>(), pos.as<uint32_t>(), cell_of.as<uint32_t>(), c->cells.row1.as<T>(),
-		                   c->cells.mrow.as<T>(), c->cells.nfac.as<uint32_t>(), m.pos_row.as<uint32_t>(),
-		                   m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(), m.coef_blk.as<T>());
+		if (!test_switch("FI_LISTS_BY_SORT")) {
+			hipLaunchKernelGGL((k_list_fill<T>), dim3(static_cast<int>((ncell + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, c->g,
+			                   ncell, c->scratch[19].as<uint32_t>(), c->scratch[18].as<unsigned long long>(), c->cells.cell_id.as<uint32_t>(),
+			                   c->cells.nrow.as<uint32_t>(), m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), c->cells.row1.as<T>(),
+			                   c->cells.mrow.as<T>(), c->cells.nfac.as<uint32_t>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(),
+			                   m.coef_row.as<T>(), m.coef_blk.as<T>());
+		} else {
+			hipLaunchKernelGGL((k_cell_records<T>), dim3(static_cast<int>((n_all + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+			                   st, m.n_row, n_all, c->scratch[19].as<uint32_t>(), c->scratch[16].as<uint32_t>(), c->scratch[33].as<uint32_t>(),
+			                   c->cells.row1.as<T>(), c->cells.mrow.as<T>(), c->cells.nfac.as<uint32_t>(), m.pos_row.as<uint32_t>(),
+			                   m.pos_blk.as<uint32_t>(), m.coef_row.as<T>(), m.coef_blk.as<T>());
+		}
 	}
 	FI_HIP_TRY(hipGetLastError());
 	{

@@ -333,6 +333,58 @@ def test_two_row_cells_on_tile_and_chunk_seams(oracle, fi, dtype, monkeypatch):
     assert np.abs(fg.Atb() - atb).max() <= TOL[dtype] * np.abs(atb).max()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["dense", "seams", "surface", "tiles of 16 rows"])
+def test_lists_from_cell_ranges_equal_the_sorted_lists(fi, dtype, case, monkeypatch):
+    """The fused kernel's per-(workgroup, layer, band) record lists are read off the sorted cells as ranges (no sort,
+    round 4); FI_LISTS_BY_SORT builds them the way rounds 1-3 did, by a stable radix sort of (list key, slot) pairs.
+    Same lists in the same order: the operator's output must agree bit for bit -- dense data (packed blocks), two-row
+    cells on tile / chunk seams (record pairs), surface data (split launches), tiles of 16 rows (5 origin rows per band)."""
+    rng = np.random.default_rng(33)
+    val = None
+    nrm = None
+    w = fi.Weights()
+    if case == "dense":
+        sizes = [68, 35, 21]
+        pos = np.stack([rng.uniform(-1.2, s + 0.2, 60000) for s in sizes], 1).astype(np.float32)
+        nrm = rng.normal(size=(len(pos), 3)).astype(np.float32)
+        monkeypatch.setenv("FI_ZC", "8")
+    elif case == "seams":
+        sizes = [258, 17, 26]
+        monkeypatch.setenv("FI_ZC", "8")
+        cells = np.array([(cx, cy, cz) for cz in (6, 7, 8, 15, 22, 23) for cy in (6, 7, 8, 14, 15)
+                          for cx in list(range(120, 136)) + [126, 127, 128, 255, 256]], np.float32)
+        two = np.repeat(cells, 2, axis=0) + rng.uniform(0.05, 0.95, (2 * len(cells), 3)).astype(np.float32)
+        one = np.stack([rng.uniform(-1, s, 4000) for s in sizes], 1).astype(np.float32)
+        pos = np.concatenate([two, one])
+        val = rng.normal(size=len(pos)).astype(np.float32)
+        w = fi.Weights(model_2=0.7)
+    elif case == "surface":
+        from util import sphere_points
+        sizes = [70, 33, 90]
+        pos, nrm = sphere_points(rng, [21, 21, 21], 3000, noise=0.2)
+        pos = (pos + np.array([30.0, 6.0, 50.0])).astype(np.float32)
+    else:
+        sizes = [30, 48, 19]              # (narrow in x: the tile shape of 16 rows overhangs the lattice least)
+        pos = np.stack([rng.uniform(-1.2, s + 0.2, 30000) for s in sizes], 1).astype(np.float32)
+        val = rng.normal(size=len(pos)).astype(np.float32)
+    x = rng.normal(size=int(np.prod(sizes)))
+    got = []
+    for by_sort in (False, True):
+        if by_sort:
+            monkeypatch.setenv("FI_LISTS_BY_SORT", "1")
+        else:
+            monkeypatch.delenv("FI_LISTS_BY_SORT", raising=False)
+        f = fi.LatticeField(sizes, dtype=dtype)
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient if nrm is not None else 0.0, w.gradient_kernel, pos, nrm, None,
+                     values=val)
+        got.append((f.apply_AtA(x).copy(), f.stats()["spmv_bytes"]))
+    monkeypatch.delenv("FI_LISTS_BY_SORT", raising=False)
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    assert got[0][1] == got[1][1]          # (the distinct cells per kind behind the algorithmic bytes)
+
+
 @pytest.mark.parametrize("sizes,dtype", [([30, 26], "f64"), ([30, 26], "f32"), ([12, 10, 9], "f64"), ([40], "f64")])
 def test_border_prior_equals_the_reference_rows(oracle, fi, sizes, dtype):
     """src/sdf_field.cpp:218-246: every border lattice point gets add_equation(Weight{w}, Rhs{d}, {{index, 1.0f}}) with
