@@ -218,12 +218,6 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 	}
 }
 
-__global__ void k_iota(uint32_t* v, long n)
-{
-	const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-	if (i < n) { v[i] = static_cast<uint32_t>(i); }
-}
-
 constexpr int kRec = 3;  // the cell's record for the sums over the lattice points: [A^T b | diagonal | row sums] x 2^D corners
 constexpr uint32_t kHeavyRows = 192;  // cells with more rows are summed by a whole workgroup (k_build_heavy)
 
@@ -407,6 +401,108 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 	if (mine) {
 		finish_cell<D, T, false>(c, ncell, s, m, B, gvec, sorted_row, coef, blk, cell_dr, nrow, row1, mrow, nfac, pack_min);
 	}
+}
+
+// 3-D: EIGHT lanes per cell, lane j owns column j of the symmetric 8 x 8 block (8 + 1 fp64 accumulators instead of 44 in
+// one thread: 142-154 VGPRs and 38-51 KB of LDS held k_build_blocks at 3 waves per SIMD, each walking a chain of dependent
+// loads -- 165 us for the 970 k cells of config 4's fp64 level, 60 us for 30 k cells of ~30 rows on its 32^3 level).  The
+// same products summed in the same order, the Cholesky factor of a many-row cell by the same recurrence with the columns
+// spread over the lanes (values of row i of U travel by 8-wide shuffles): the same bits as k_build_blocks + finish_cell.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_build_blocks3(long ncell, const uint32_t* __restrict__ start,
+                                                             const uint32_t* __restrict__ count,
+                                                             const uint32_t* __restrict__ sorted_row,
+                                                             const float* __restrict__ coef, const float* __restrict__ rhs,
+                                                             T* __restrict__ blk, T* __restrict__ cell_dr,
+                                                             uint32_t* __restrict__ nrow, T* __restrict__ row1,
+                                                             T* __restrict__ mrow, uint32_t* __restrict__ nfac,
+                                                             uint32_t* __restrict__ heavy, uint32_t pack_min, int write_blk)
+{
+	constexpr int NC = 8, NB = 36;
+	const long t = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+	const long c = t >> 3;
+	const int  j = static_cast<int>(t & 7);
+	if (c >= ncell) { return; }  // (whole groups of 8 lanes: the shuffles below stay inside a live group)
+	const uint32_t s = start[c], m = count[c];
+	bool mine = true;
+	if (m > kHeavyRows) {  // coarse levels put 10^4..10^6 rows into one cell: a workgroup's job (k_build_heavy fills the slots)
+		if (j == 0) { heavy[1 + atomicAdd(&heavy[0], 1u)] = static_cast<uint32_t>(c); }
+		mine = false;
+	}
+	double col[NC];  // col[i] = B[i][j]
+	double g = 0.0;
+#pragma unroll
+	for (int i = 0; i < NC; ++i) { col[i] = 0.0; }
+	T first = T(0);
+	if (mine) {
+		for (uint32_t r = 0; r < m; ++r) {
+			const long   row = sorted_row[s + r];
+			const float4 lo = *reinterpret_cast<const float4*>(coef + row * NC), hi = *reinterpret_cast<const float4*>(coef + row * NC + 4);
+			const float  fj = coef[row * NC + j];
+			const double aj = static_cast<double>(fj);
+			const double a[NC] = {static_cast<double>(lo.x), static_cast<double>(lo.y), static_cast<double>(lo.z), static_cast<double>(lo.w),
+			                      static_cast<double>(hi.x), static_cast<double>(hi.y), static_cast<double>(hi.z), static_cast<double>(hi.w)};
+			if (r == 0) { first = static_cast<T>(fj); }
+#pragma unroll
+			for (int i = 0; i < NC; ++i) { col[i] += a[i] * aj; }
+			g += aj * static_cast<double>(rhs[row]);
+		}
+	}
+	// block (upper triangle, packed), the record of the sums over the lattice points, the first row
+	double dj = 0.0, sum = 0.0;
+#pragma unroll
+	for (int i = 0; i < NC; ++i) {
+		if (i <= j && write_blk) { blk[c * NB + packed_index(i, j, NC)] = static_cast<T>(col[i]); }
+		if (i == j) { dj = col[i]; }
+		sum += col[i];  // row sum of the symmetric block, entries in the order 0 .. 7 (block_row_sum)
+	}
+	cell_dr[c * kRec * NC + j]          = static_cast<T>(g);
+	cell_dr[c * kRec * NC + NC + j]     = static_cast<T>(dj);
+	cell_dr[c * kRec * NC + 2 * NC + j] = static_cast<T>(sum);
+	row1[c * NC + j] = first;
+	if (j == 0) { nrow[c] = m; }
+	if (!mine) { return; }
+	// factor rows for the fused kernel (finish_cell)
+	uint32_t k = 0;
+	if (m <= static_cast<uint32_t>(NC) && m < pack_min) {
+		for (uint32_t r = 0; r < m && m > 1; ++r) {
+			const long row = sorted_row[s + r];
+			mrow[(c * NC + r) * NC + j] = static_cast<T>(coef[row * NC + j]);
+		}
+		k = m;
+	} else if (sizeof(T) == 8 || pack_min <= static_cast<uint32_t>(NC)) {
+#pragma unroll
+		for (int i = 0; i < NC; ++i) {
+			if (i <= j) { mrow[c * NC * NC + packed_index(i, j, NC)] = static_cast<T>(col[i]); }
+		}
+		k = 0xFFu;
+	} else {
+		double dmax = dj;
+#pragma unroll
+		for (int o = 1; o < NC; o <<= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o, NC)); }
+		const double tiny = 1e-14 * dmax;
+		double u[NC];  // u[i] = U[i][j]
+#pragma unroll
+		for (int i = 0; i < NC; ++i) {
+			// row i of U: U[i][j] = (B[i][j] - sum_{t<i} U[t][i] U[t][j]) / U[i][i]; every lane forms the pivot from lane i's values
+			double piv = __shfl(col[i], i, NC);
+			double v   = col[i];
+#pragma unroll
+			for (int tt = 0; tt < i; ++tt) {
+				const double uti = __shfl(u[tt], i, NC);
+				piv -= uti * uti;
+				v -= uti * u[tt];
+			}
+			const bool   live = piv > tiny;
+			const double inv  = live ? 1.0 / sqrt(piv) : 0.0;
+			u[i] = j == i ? (live ? sqrt(piv) : 0.0) : (j > i ? v * inv : 0.0);
+			if (live) {  // (uniform over the group)
+				mrow[(c * NC + k) * NC + j] = static_cast<T>(u[i]);
+				++k;
+			}
+		}
+	}
+	if (j == 0) { nfac[c] = k; }
 }
 
 // One workgroup per heavy cell: threads stride over the cell's rows, then a fixed-shape tree (wave shuffles,
@@ -918,24 +1014,22 @@ void assemble_dim(fi_ctx* c)
 	}
 
 	// sort rows by cell
-	DevBuf &row_in = c->scratch[3], &row_sorted = c->scratch[4], &key_sorted = c->scratch[5], &uniq = c->scratch[6],
+	DevBuf &row_sorted = c->scratch[4], &key_sorted = c->scratch[5], &uniq = c->scratch[6],
 	       &counts = c->scratch[7], &starts = c->scratch[8], &nruns = c->scratch[9], &tmp = c->scratch[10];
-	row_in.alloc(sizeof(uint32_t) * total);
 	row_sorted.alloc(sizeof(uint32_t) * total);
 	key_sorted.alloc(sizeof(uint32_t) * total);
 	uniq.alloc(sizeof(uint32_t) * total);
 	counts.alloc(sizeof(uint32_t) * total);
 	starts.alloc(sizeof(uint32_t) * total);
 	nruns.alloc(sizeof(uint32_t) * 4);
-	hipLaunchKernelGGL(k_iota, dim3(blocks_for(total)), dim3(kThreads), 0, st, row_in.as<uint32_t>(), total);
 	int end_bit = 1;
 	while ((1ull << end_bit) <= invalid) { ++end_bit; }
 	size_t tb = 0;
-	FI_HIP_TRY(sort_pairs_u32(nullptr, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
-	                                              row_sorted.as<uint32_t>(), static_cast<int>(total), 0, end_bit, st));
+	FI_HIP_TRY(sort_keys_index_u32(nullptr, tb, key, key_sorted.as<uint32_t>(), row_sorted.as<uint32_t>(), static_cast<unsigned int>(total), 0,
+	                               end_bit, st));
 	tmp.alloc(tb);
-	FI_HIP_TRY(sort_pairs_u32(tmp.p, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(),
-	                                              row_sorted.as<uint32_t>(), static_cast<int>(total), 0, end_bit, st));
+	FI_HIP_TRY(sort_keys_index_u32(tmp.p, tb, key, key_sorted.as<uint32_t>(), row_sorted.as<uint32_t>(), static_cast<unsigned int>(total), 0,
+	                               end_bit, st));
 	// runs of equal keys = occupied cells (+ one run of invalid rows at the end)
 	size_t tb2 = 0;
 	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
@@ -951,8 +1045,8 @@ void assemble_dim(fi_ctx* c)
 	tail3.alloc(sizeof(uint32_t) * 3);
 	hipLaunchKernelGGL(k_rle_tail, dim3(1), dim3(1), 0, st, nruns.as<uint32_t>(), uniq.as<uint32_t>(), counts.as<uint32_t>(),
 	                   tail3.as<uint32_t>());
-	uint32_t h_tail[3] = {0, 0, 0};
-	FI_HIP_TRY(hipMemcpyAsync(h_tail, tail3.p, sizeof(h_tail), hipMemcpyDeviceToHost, st));
+	uint32_t* h_tail = static_cast<uint32_t*>(pinned(c, 0, 3 * sizeof(uint32_t)));
+	FI_HIP_TRY(hipMemcpyAsync(h_tail, tail3.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
 	const uint32_t h_runs = h_tail[0];
 	if (h_runs == 0) {
@@ -999,6 +1093,18 @@ void assemble_dim(fi_ctx* c)
 	DevBuf& heavy = c->scratch[11];
 	heavy.alloc(sizeof(uint32_t) * (static_cast<size_t>(total / kHeavyRows) + 2));
 	FI_HIP_TRY(hipMemsetAsync(heavy.p, 0, sizeof(uint32_t), st));
+	// The packed blocks themselves are what the kernels OUTSIDE the fused marching kernel read (the cell kernel of the
+	// untiled path and of fi_tile_pass, the 2-D tile kernel): a 3-D context the marching kernel will cover keeps only the
+	// factor rows and forms the blocks when somebody asks (ensure_cell_blocks) -- 280 MB of the 530 MB the fp64 level of
+	// config 4 wrote here, at the 3.6 TB/s these stores reach (k_build_blocks3 160 -> 82 us).
+	const bool keep_blocks = !(D == 3 && stencil_will_fuse(c)) || test_switch("FI_BLOCKS_PER_THREAD") || test_switch("FI_KEEP_BLOCKS");
+	c->cells.blk_valid = keep_blocks;
+	if (D == 3 && !test_switch("FI_BLOCKS_PER_THREAD")) {
+		hipLaunchKernelGGL((k_build_blocks3<T>), dim3(blocks_for(ncell * 8)), dim3(kThreads), 0, st, ncell, starts.as<uint32_t>(),
+		                   counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs, c->cells.blk.as<T>(), cell_dr.as<T>(),
+		                   c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(), c->cells.mrow.as<T>(), c->cells.nfac.as<uint32_t>(),
+		                   heavy.as<uint32_t>(), pack_min, keep_blocks ? 1 : 0);
+	} else
 	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
 	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,
 	                   c->cells.blk.as<T>(), cell_dr.as<T>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
@@ -1195,6 +1301,69 @@ int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val)
 
 // 3-D: where every (y, z) row of cells starts in the sorted cell ids: bound[lz * cn1 + ly], one more entry at the end.
 // Formed once per assembly, on the context's stream (the sums over the lattice points and the fused kernel's lists use it).
+namespace {
+// the packed block of a 3-D cell from what the assembly kept of it: its rows (<= 8: the sum of their outer products, the
+// very sums k_build_blocks3 forms), the packed block of a packed cell, or the Cholesky factor rows U of a many-row cell
+// of an fp32 context (U^T U = the block to fp32 rounding)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_blocks_from_factors(long ncell, const uint32_t* __restrict__ nfac, const T* __restrict__ row1,
+                                                                   const T* __restrict__ mrow, T* __restrict__ blk)
+{
+	constexpr int NC = 8, NB = 36;
+	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+	if (c >= ncell) { return; }
+	const uint32_t k = nfac[c];
+	if (k == 0xFFu) {
+		for (int e = 0; e < NB; ++e) { blk[c * NB + e] = mrow[c * NC * NC + e]; }
+		return;
+	}
+	double B[NB];
+	for (int e = 0; e < NB; ++e) { B[e] = 0.0; }
+	for (uint32_t r = 0; r < k; ++r) {
+		const T* f = (k == 1u) ? row1 + c * NC : mrow + (c * NC + r) * NC;
+		double a[NC];
+		for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(f[q]); }
+		int e = 0;
+		for (int i = 0; i < NC; ++i) {
+			for (int j = i; j < NC; ++j) { B[e++] += a[i] * a[j]; }
+		}
+	}
+	for (int e = 0; e < NB; ++e) { blk[c * NB + e] = static_cast<T>(B[e]); }
+}
+}  // namespace
+
+void ensure_cell_blocks(fi_ctx* c)
+{
+	if (c->cells.blk_valid || c->cells.ncell == 0) { return; }
+	FI_REQUIRE(c->g.ndim == 3 && c->cells.mrow.p && c->cells.nfac.p, FI_ERR_STATE, "no cell blocks and nothing to form them from");
+	const long n = static_cast<long>(c->cells.ncell);
+	if (c->dtype == FI_F64) {
+		hipLaunchKernelGGL((k_blocks_from_factors<double>), dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, n, c->cells.nfac.as<uint32_t>(),
+		                   c->cells.row1.as<double>(), c->cells.mrow.as<double>(), c->cells.blk.as<double>());
+	} else {
+		hipLaunchKernelGGL((k_blocks_from_factors<float>), dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, n, c->cells.nfac.as<uint32_t>(),
+		                   c->cells.row1.as<float>(), c->cells.mrow.as<float>(), c->cells.blk.as<float>());
+	}
+	FI_HIP_TRY(hipGetLastError());
+	c->cells.blk_valid = true;
+}
+
+void* pinned(fi_ctx* c, int slot, size_t bytes)
+{
+	if (c->pin_bytes[slot] < bytes) {
+		if (c->pin[slot]) {
+			(void)hipHostFree(c->pin[slot]);
+			c->pin[slot] = nullptr;
+			c->pin_bytes[slot] = 0;
+		}
+		size_t want = 4096;
+		while (want < bytes) { want *= 2; }
+		FI_HIP_TRY(hipHostMalloc(&c->pin[slot], want, hipHostMallocDefault));
+		c->pin_bytes[slot] = want;
+	}
+	return c->pin[slot];
+}
+
 const uint32_t* cell_row_bounds(fi_ctx* c)
 {
 	const Geom& g = c->g;

@@ -158,6 +158,7 @@ struct CellData {
 	int64_t ncell = 0;
 	DevBuf  cell_id;  // uint32[ncell], extended local cell id, ascending
 	DevBuf  blk;      // T[ncell][nb]  upper triangle of the symmetric 2^D x 2^D block, one cell after another
+	bool    blk_valid = false;  // 3-D contexts of the fused kernel: formed from the factor rows on first use (ensure_cell_blocks)
 	DevBuf  nrow;     // uint32[ncell] number of data rows accumulated into the cell
 	DevBuf  row1;     // T[ncell][2^D] the row itself for cells holding exactly one row (block = row row^T)
 	DevBuf  mrow;     // T[ncell][2^D][2^D] (3-D only) up to 2^D factor rows a_k with block = sum a_k a_k^T
@@ -371,6 +372,11 @@ struct fi_ctx {
 	fi::DevBuf partial;       // double[4 * max_blocks]
 	fi::DevBuf scal;          // CgScalars
 	fi::CgScalars* scal_host = nullptr;  // pinned
+	// pinned staging of the assembly's small host copies (slot 0: read-backs of sizes, slot 1: uploads of workgroup lists).
+	// A copy from / to pageable memory is staged by the runtime inside the call, which waits for the stream -- with several
+	// threads assembling levels side by side the others' launches queued up behind it (gaps of 100-150 us in their chains).
+	void*      pin[2] = {nullptr, nullptr};
+	size_t     pin_bytes[2] = {0, 0};
 	int        max_blocks = 0;
 
 	// assembly temporaries, kept between fi_assemble calls (hipMalloc/hipFree are slow and synchronising)
@@ -486,6 +492,9 @@ void generic_error_map(fi_ctx* c, const void* x, void* out);             // out 
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val,
                      float vw, int vk, float gw, int gk, float pos_scale = 1.0f, float nrm_scale = 1.0f);
 void assemble(fi_ctx* c);
+void ensure_cell_blocks(fi_ctx* c);     // CellData::blk of every cell, on the context's stream (no-op when they are there)
+bool stencil_will_fuse(const fi_ctx* c);  // will stencil_prepare() put this context's cells into the marching kernel?
+void* pinned(fi_ctx* c, int slot, size_t bytes);  // the context's pinned staging buffer `slot`, at least `bytes` long (contents not kept when it grows)
 const uint32_t* cell_row_bounds(fi_ctx* c);  // 3-D, after assemble(): first sorted cell of every (y, z) row of cells
 // border prior (src/sdf_field.cpp:218-246): coordinates of the lattice's border points and their distance to the nearest
 // data point added so far, as device buffers; returns their number

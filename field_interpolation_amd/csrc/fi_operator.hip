@@ -464,10 +464,11 @@ void safe_scaling_dim(fi_ctx* c)
 	FI_HIP_TRY(hipGetLastError());
 	c->data_pinned = false;
 	if (weak) {
-		unsigned int h = 1;
-		FI_HIP_TRY(hipMemcpyAsync(&h, weak, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+		unsigned int* h = static_cast<unsigned int*>(pinned(c, 0, sizeof(unsigned int)));
+		*h = 1;
+		FI_HIP_TRY(hipMemcpyAsync(h, weak, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
 		FI_HIP_TRY(hipStreamSynchronize(c->stream));
-		c->data_pinned = h == 0;
+		c->data_pinned = *h == 0;
 	}
 	c->dinv16s_valid = true;
 }
@@ -492,6 +493,7 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 	}
 	if (c->cells.ncell > 0 && (ts > 0 || !cells_fused(c))) {
 		nb_cells = capped_blocks(c->cells.ncell);
+		ensure_cell_blocks(c);
 		const int first = test_switch("FI_CELLS_ATOMIC") ? -1 : 0, last = first < 0 ? -1 : (1 << D) - 1;  // (tests compare the two forms)
 		for (int colour = first; colour <= last; ++colour) {
 			hipLaunchKernelGGL((k_apply_cells<D, T>), dim3(nb_cells), dim3(kThreads), 0, c->stream, g,

@@ -1275,6 +1275,13 @@ void march_launch(fi_ctx* c, const T* x, T* y, double* partial, const ChebEpi<T>
 
 void stencil_prepare_slab_lists(fi_ctx* c);
 
+bool stencil_will_fuse(const fi_ctx* c)
+{
+	if (test_switch("FI_NO_FUSE")) { return false; }
+	MarchParams P{};
+	return c->dtype == FI_F64 ? march_setup<double>(c, &P) : march_setup<float>(c, &P);
+}
+
 void stencil_prepare(fi_ctx* c)
 {
 	MarchState& m = c->march;

@@ -542,7 +542,8 @@ void build_cell_lists(fi_ctx* c)
 	// the per-workgroup flags
 	DevBuf& pack = c->scratch[34];
 	pack.alloc(24 + static_cast<size_t>(nwg));
-	std::vector<uint8_t> h_pack(24 + static_cast<size_t>(nwg));
+	const size_t h_pack_bytes = 24 + static_cast<size_t>(nwg);
+	uint8_t* const h_pack = static_cast<uint8_t*>(pinned(c, 0, h_pack_bytes));
 	if (!test_switch("FI_LISTS_BY_SORT")) {
 		// ---- lists as ranges of the sorted cells (no sort) ----
 		DevBuf &uniq = c->scratch[14], &counts_d = c->scratch[15], &first_d = c->scratch[16], &kinds = c->scratch[17],
@@ -581,7 +582,7 @@ void build_cell_lists(fi_ctx* c)
 		hipLaunchKernelGGL(k_classify_pack, dim3(1), dim3(1024), 0, st, nwg, (P.zc + 1) * 4, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
 		                   m.lay_row.as<uint32_t>() + nbuckets, m.lay_blk.as<uint32_t>() + nbuckets, uniq.as<uint32_t>(),
 		                   m.wg_cells.as<uint32_t>(), m.wg_plain.as<uint32_t>(), pack.as<uint8_t>());
-		FI_HIP_TRY(hipMemcpyAsync(h_pack.data(), pack.p, h_pack.size(), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipMemcpyAsync(h_pack, pack.p, h_pack_bytes, hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
 	} else {
 		// ---- the same lists by a radix sort of (list key, slot) pairs: the form of rounds 1-3, kept for the comparison ----
@@ -636,14 +637,14 @@ void build_cell_lists(fi_ctx* c)
 		hipLaunchKernelGGL(k_classify_pack, dim3(1), dim3(1024), 0, st, nwg, (P.zc + 1) * 4, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
 		                   m.lay_row.as<uint32_t>() + nbuckets, m.lay_blk.as<uint32_t>() + nbuckets, count.as<uint32_t>(),
 		                   m.wg_cells.as<uint32_t>(), m.wg_plain.as<uint32_t>(), pack.as<uint8_t>());
-		FI_HIP_TRY(hipMemcpyAsync(h_pack.data(), pack.p, h_pack.size(), hipMemcpyDeviceToHost, st));
+		FI_HIP_TRY(hipMemcpyAsync(h_pack, pack.p, h_pack_bytes, hipMemcpyDeviceToHost, st));
 		FI_HIP_TRY(hipStreamSynchronize(st));
 	}
 	uint32_t head[6];
-	memcpy(head, h_pack.data(), sizeof(head));
+	memcpy(head, h_pack, sizeof(head));
 	const int counts[2] = {static_cast<int>(head[0]), static_cast<int>(head[1])};
 	const uint32_t totals[2] = {head[2], head[3]}, uniq_cells[2] = {head[4], head[5]};
-	const uint8_t* h_has = h_pack.data() + 24;
+	const uint8_t* h_has = h_pack + 24;
 	m.n_row = totals[0];
 	m.n_blk = totals[1];
 	m.cells_row = uniq_cells[0];
@@ -721,9 +722,14 @@ void build_cell_lists(fi_ctx* c)
 			m.n_wg_plain = static_cast<int>(first.size());
 			m.wg_runs.alloc(sizeof(uint32_t) * (first.size() + 1));
 			if (!first.empty()) {
-				FI_HIP_TRY(hipMemcpyAsync(m.wg_plain.p, first.data(), sizeof(uint32_t) * first.size(), hipMemcpyHostToDevice, st));
-				FI_HIP_TRY(hipMemcpyAsync(m.wg_runs.p, len.data(), sizeof(uint32_t) * len.size(), hipMemcpyHostToDevice, st));
-				FI_HIP_TRY(hipStreamSynchronize(st));  // the host vectors die here
+				// through the context's pinned upload buffer: it is next written by the next call of this function, behind that
+				// call's own round trip -- no wait here
+				const size_t nb = sizeof(uint32_t) * first.size();
+				uint8_t* up = static_cast<uint8_t*>(pinned(c, 1, 2 * nb));
+				memcpy(up, first.data(), nb);
+				memcpy(up + nb, len.data(), nb);
+				FI_HIP_TRY(hipMemcpyAsync(m.wg_plain.p, up, nb, hipMemcpyHostToDevice, st));
+				FI_HIP_TRY(hipMemcpyAsync(m.wg_runs.p, up + nb, nb, hipMemcpyHostToDevice, st));
 			}
 		}
 	}

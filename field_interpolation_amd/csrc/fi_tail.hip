@@ -328,6 +328,7 @@ void tail_build_operator(fi_ctx* c)
 	hipLaunchKernelGGL(k_tail_map, dim3(static_cast<unsigned>((c->cells.ncell + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
 	                   c->cells.ncell, c->cells.cell_id.as<uint32_t>(), c->tail_map.as<uint32_t>());
 	const dim3 grid(static_cast<unsigned>((nn + kThreads - 1) / kThreads));
+	ensure_cell_blocks(c);
 	if (D == 2) {
 		hipLaunchKernelGGL(k_tail_dia<2>, grid, dim3(kThreads), 0, c->stream, g, static_cast<int>(nn), c->tail_map.as<uint32_t>(),
 		                   c->cells.blk.as<float>(), c->tail_dia.as<float>());

@@ -334,6 +334,48 @@ def test_two_row_cells_on_tile_and_chunk_seams(oracle, fi, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["rows", "packed", "factored"])
+def test_blocks_by_eight_lanes_equal_the_one_thread_form(fi, dtype, case, monkeypatch):
+    """3-D cell blocks are summed by eight lanes per cell (a column of the 8 x 8 block each; many-row cells of row-dominated
+    fp32 contexts get their Cholesky factor by the same recurrence spread over the lanes); FI_BLOCKS_PER_THREAD runs the
+    one-thread-per-cell kernel of rounds 1-3.  The same sums in the same order: A^T b, the diagonal and the operator's
+    output agree bit for bit -- single / few-row cells (data rows as factor rows), a context of mostly multi-row cells
+    (packed blocks), and a row-dominated context with clusters of 9-60 rows in some cells (factor rows from the block)."""
+    rng = np.random.default_rng(44)
+    sizes = [50, 21, 37]
+    if case == "rows":
+        pos = np.stack([rng.uniform(-1.2, s + 0.2, 30000) for s in sizes], 1).astype(np.float32)
+        nrm = None
+    elif case == "packed":
+        pos = np.stack([rng.uniform(-1.2, s + 0.2, 30000) for s in sizes], 1).astype(np.float32)
+        nrm = rng.normal(size=(len(pos), 3)).astype(np.float32)          # 4 rows per point: >= 3 rows in most cells
+    else:
+        sparse = np.stack([rng.uniform(0, s - 1, 12000) for s in sizes], 1)
+        centres = np.stack([rng.integers(2, s - 3, 40) for s in sizes], 1)
+        counts = rng.integers(9, 60, 40)
+        clusters = np.concatenate([c + rng.uniform(0.02, 0.98, (n, 3)) for c, n in zip(centres, counts)])
+        pos = np.concatenate([sparse, clusters]).astype(np.float32)
+        nrm = None
+    val = rng.normal(size=len(pos)).astype(np.float32)
+    x = rng.normal(size=int(np.prod(sizes)))
+    w = fi.Weights()
+    got = []
+    for old in (False, True):
+        if old:
+            monkeypatch.setenv("FI_BLOCKS_PER_THREAD", "1")
+        else:
+            monkeypatch.delenv("FI_BLOCKS_PER_THREAD", raising=False)
+        f = fi.LatticeField(sizes, dtype=dtype)
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient if nrm is not None else 0.0, w.gradient_kernel, pos, nrm, None,
+                     values=val)
+        got.append((f.apply_AtA(x).copy(), f.Atb().copy(), f.diag().copy()))
+    monkeypatch.delenv("FI_BLOCKS_PER_THREAD", raising=False)
+    for a, b in zip(got[0], got[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("case", ["dense", "seams", "surface", "tiles of 16 rows"])
 def test_lists_from_cell_ranges_equal_the_sorted_lists(fi, dtype, case, monkeypatch):
     """The fused kernel's per-(workgroup, layer, band) record lists are read off the sorted cells as ranges (no sort,
