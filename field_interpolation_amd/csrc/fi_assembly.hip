@@ -689,10 +689,34 @@ __global__ __launch_bounds__(kThreads) void k_row_bounds(int64_t nrows, uint32_t
 }
 
 constexpr int kTileX = 64, kTileY = 4, kTileZ = 2;
+
+// xt[(row * (ntx + 1) + t) * 2 + which]: first cell of row `row` whose x origin is >= first + 64 t - 1 + which, `first` the
+// extended-local x of the lattice's first owned point.  The cells of the 64 points of tile t in that row -- origins one
+// below the tile's first point up to its last point -- are [xt[.. t ..][0], xt[.. t + 1 ..][1]).
+__global__ __launch_bounds__(kThreads) void k_xtile_bounds(int64_t nrows, int ntx, int first, int row_len, long ncell,
+                                                            const uint32_t* __restrict__ cell_id, uint32_t* __restrict__ xt)
+{
+	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= nrows * (ntx + 1) * 2) { return; }
+	const int     which = static_cast<int>(i & 1);
+	const int64_t e     = i >> 1;
+	const int64_t row   = e / (ntx + 1);
+	const int     t     = static_cast<int>(e % (ntx + 1));
+	int lx = first + kTileX * t - 1 + which;
+	if (lx < 0) { lx = 0; }
+	if (lx > row_len) { lx = row_len; }
+	const uint64_t key = static_cast<uint64_t>(row) * row_len + static_cast<uint64_t>(lx);
+	long lo = 0, hi = ncell;
+	while (lo < hi) {
+		const long mid = (lo + hi) >> 1;
+		if (static_cast<uint64_t>(cell_id[mid]) < key) { lo = mid + 1; } else { hi = mid; }
+	}
+	xt[i] = static_cast<uint32_t>(lo);
+}
 constexpr int kTileCells = (kTileX + 1) * (kTileY + 1) * (kTileZ + 1);  // 975: every cell of the tile's 5 x 3 rows
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_tile_sums3(Geom g, const uint32_t* __restrict__ row_bound,
+__global__ __launch_bounds__(kThreads) void k_tile_sums3(Geom g, const uint32_t* __restrict__ xt, int ntx,
                                                           const uint32_t* __restrict__ cell_id, const T* __restrict__ cell_dr,
                                                           T* __restrict__ atb, T* __restrict__ diag, float* __restrict__ lump)
 {
@@ -732,24 +756,68 @@ __global__ __launch_bounds__(kThreads) void k_tile_sums3(Geom g, const uint32_t*
 		if (ly >= 0 && ly < g.cn[1] && lz >= 0 && lz < g.cn[2]) {
 			const uint32_t row = static_cast<uint32_t>(lz) * static_cast<uint32_t>(g.cn[1]) + static_cast<uint32_t>(ly);
 			key0 = row * static_cast<uint32_t>(g.cn[0]);
-			s = row_bound[row];
-			e = row_bound[row + 1];
+			const int64_t at = (static_cast<int64_t>(row) * (ntx + 1) + static_cast<int64_t>(blockIdx.x)) * 2;
+			s = xt[at];
+			e = xt[at + 3];  // entry (row, tile + 1), second bound
+			if (e < s) { e = s; }
 		}
 		row_first[tid] = s;
 		row_key[tid]   = key0;
-		row_at[tid + 1] = e - s;
-	}
-	__syncthreads();
-	if (tid == 0) {
-		uint32_t a = 0;
-		row_at[0] = 0;
-		for (int r = 0; r < ROWS; ++r) {
-			a += row_at[r + 1];
-			row_at[r + 1] = a;
+		// inclusive scan of the rows' lengths over the first lanes of wave 0 (ROWS <= 64)
+		uint32_t a = e - s;
+#pragma unroll
+		for (int o = 1; o < ROWS; o <<= 1) {
+			const uint32_t up = __shfl_up(a, o, 64);
+			if (tid >= o) { a += up; }
 		}
+		row_at[tid + 1] = a;
+		if (tid == 0) { row_at[0] = 0; }
 	}
 	__syncthreads();
 	const uint32_t in_rows = row_at[ROWS];
+	if (in_rows <= kThreads) {
+		// One cell per thread (the usual case on a sparsely occupied lattice): its record straight into registers, then the
+		// eight colours one after the other -- no list, no counting pass.
+		const bool live = tid < static_cast<int>(in_rows);
+		T     rb[NC], rd[NC];
+		float rl[NC];
+		int   cx = 0, ry = 0, rz = 0, colour = -1;
+		if (live) {
+			int r = 0;
+#pragma unroll
+			for (int jj = 1; jj < ROWS; ++jj) { r += row_at[jj] <= static_cast<uint32_t>(tid) ? 1 : 0; }
+			const long c = row_first[r] + (static_cast<uint32_t>(tid) - row_at[r]);
+			ry = r % (kTileY + 1);
+			rz = r / (kTileY + 1);
+			const int ly = lp0[1] - 1 + ry, lz = lp0[2] - 1 + rz;
+			const int lx = static_cast<int>(cell_id[c] - row_key[r]);
+			cx = lx - (lp0[0] - 1);
+			colour = (lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2);
+#pragma unroll
+			for (int q = 0; q < NC; ++q) {
+				rb[q] = cell_dr[c * kRec * NC + q];
+				rd[q] = cell_dr[c * kRec * NC + NC + q];
+				rl[q] = lump ? static_cast<float>(cell_dr[c * kRec * NC + 2 * NC + q]) : 0.0f;
+			}
+		}
+		for (int col = 0; col < NC; ++col) {
+			if (colour == col) {
+#pragma unroll
+				for (int q = 0; q < NC; ++q) {
+					const int px = cx - 1 + (q & 1), py = ry - 1 + ((q >> 1) & 1), pz = rz - 1 + ((q >> 2) & 1);
+					if (px >= 0 && px < kTileX && py >= 0 && py < kTileY && pz >= 0 && pz < kTileZ) {
+						const int p = (pz * kTileY + py) * kTileX + px;
+						// (no two cells of a colour share a point: the hardware add is the plain sum, without the round
+						// trip of a read-add-write per corner -- 24 dependent LDS round trips per colour)
+						unsafeAtomicAdd(&acc_b[p], rb[q]);
+						unsafeAtomicAdd(&acc_d[p], rd[q]);
+						unsafeAtomicAdd(&acc_l[p], rl[q]);
+					}
+				}
+			}
+			__syncthreads();
+		}
+	} else {
 #pragma unroll 1
 	for (int pass = 0; pass < 2; ++pass) {
 		for (uint32_t k = tid; k < in_rows; k += kThreads) {
@@ -822,6 +890,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_sums3(Geom g, const uint32_t*
 			}
 			__syncthreads();
 		}
+	}
 	}
 	__syncthreads();
 	for (int i = tid; i < NP; i += kThreads) {
@@ -1135,10 +1204,14 @@ void assemble_dim(fi_ctx* c)
 	                   (ext1 + kTileY - 1) / kTileY <= 65535 && (ext2 + kTileZ - 1) / kTileZ <= 65535;
 	if (!(gather || tiles) || g.nown != g.nloc) { zero_operator(); }
 	if (tiles) {
-		DevBuf& rb = c->scratch[24];
-		(void)cell_row_bounds(c);
+		const int     ntx   = (ext0 + kTileX - 1) / kTileX;
+		const int64_t nrows = static_cast<int64_t>(g.cn[1]) * g.cn[2];
+		DevBuf& rb = c->scratch[27];
+		rb.alloc(sizeof(uint32_t) * (nrows * (ntx + 1) * 2 + 4));
+		hipLaunchKernelGGL(k_xtile_bounds, dim3(blocks_for(nrows * (ntx + 1) * 2)), dim3(kThreads), 0, st, nrows, ntx,
+		                   g.own_lo[0] + g.off[0] - g.coff[0], g.cn[0], ncell, c->cells.cell_id.as<uint32_t>(), rb.as<uint32_t>());
 		hipLaunchKernelGGL((k_tile_sums3<T>), dim3((ext0 + kTileX - 1) / kTileX, (ext1 + kTileY - 1) / kTileY, (ext2 + kTileZ - 1) / kTileZ),
-		                   dim3(kThreads), 0, st, g, rb.as<uint32_t>(), c->cells.cell_id.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(),
+		                   dim3(kThreads), 0, st, g, rb.as<uint32_t>(), ntx, c->cells.cell_id.as<uint32_t>(), cell_dr.as<T>(), c->atb.as<T>(),
 		                   c->diag.as<T>(), lump);
 	} else if (gather) {
 		DevBuf& map = c->scratch[24];
