@@ -1026,6 +1026,7 @@ void assemble_dim(fi_ctx* c)
 	const uint32_t invalid = static_cast<uint32_t>(static_cast<int64_t>(g.cn[0]) * g.cn[1] * g.cn[2]);
 
 	// operator arrays over local storage
+	const bool fresh = c->atb.bytes < sizeof(T) * g.nloc || c->diag.bytes < sizeof(T) * g.nloc;
 	c->atb.alloc(sizeof(T) * g.nloc);
 	c->diag.alloc(sizeof(T) * g.nloc);
 	// (zeroed below, once the path of the sums over the lattice points is known: the gather writes every owned point itself)
@@ -1048,7 +1049,9 @@ void assemble_dim(fi_ctx* c)
 	c->stats.num_data_rows = 0;
 	c->stats.num_cells     = 0;
 	if (total == 0) {
-		zero_operator();
+		// (an undivided lumped replica: its diagonal is written whole by operator_prepare, its A^T b is never read and stays
+		// the zeros of its first assembly -- two fills of 67 MB per assemble at 256^3)
+		if (!(c->lumped && g.nown == g.nloc && c->nranks == 1 && !fresh)) { zero_operator(); }
 		return;
 	}
 	FI_REQUIRE(total < (1L << 31), FI_ERR_UNSUPPORTED, "more than 2^31 data rows in one context");

@@ -426,7 +426,9 @@ namespace fi {
 size_t elem_size(const fi_ctx* c);
 
 // fi_operator.hip
-void operator_prepare(fi_ctx* c);                                   // model diag etc. after assemble
+// model diag etc. after assemble; with_scaling: the polynomial smoother's scaling too (prepare_safe_scaling, fused into the
+// same pass on undivided 3-D levels); lump_in: a lumped replica takes its data diagonal from these row sums
+void operator_prepare(fi_ctx* c, bool with_scaling = false, const float* lump_in = nullptr);
 void apply_AtA(fi_ctx* c, const void* x, void* y, double* pq_partial);  // y = AtA x (+ fused x.y partials)
 int  apply_num_partials(const fi_ctx* c);
 double apply_algorithmic_bytes(const fi_ctx* c);

@@ -199,13 +199,10 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		assemble(co);
 		generic_assemble(co);
 		stencil_prepare(co);
-		operator_prepare(co);
 		// the polynomial smoother's scaling (and whether the data pin a small level) with the level's assembly, on its chain's
 		// stream, instead of at the head of the first solve (undivided levels: over slabs the ghost planes' diagonal comes later)
-		if (co->dtype == FI_F32 && co->g.ndim == 3 && co->mg_smoother == 1 && co->value_rows_only && !co->any_trip &&
-		    co->march.valid && co->nranks == 1 && !test_switch("FI_MG_FULL_SMOOTHER")) {
-			prepare_safe_scaling(co);
-		}
+		operator_prepare(co, co->dtype == FI_F32 && co->g.ndim == 3 && co->mg_smoother == 1 && co->value_rows_only && !co->any_trip &&
+		                         co->march.valid && co->nranks == 1 && !test_switch("FI_MG_FULL_SMOOTHER"));
 		co->tail_prog_valid = false;
 		if (tail_level_supported(co)) { tail_build_operator(co); }  // the small-level engine's view of the data rows
 		co->assembled = true;
@@ -331,15 +328,20 @@ void twin_assemble_lumped(fi_ctx* c)
 	assemble(t);  // no rows: atb and diag zeroed, no cells
 	const Geom& g = c->g;
 	FI_REQUIRE(c->want_lump && c->lump.p, FI_ERR_STATE, "the lumped replica needs the row sums of the fp64 level's assembly");
+	generic_assemble(t);
+	stencil_prepare(t);
+	if (g.nown == g.nloc && t->nranks == 1 && g.nloc > (1 << 16)) {
+		// undivided: dlump, the diagonal, both Jacobi scalings and the smoother's scaling in ONE pass over the row sums (until
+		// round 4's last build: two fills, the clamp, the model diagonal and the scaling -- five launches, 275 us at 256^3)
+		operator_prepare(t, true, c->lump.as<float>());
+		return;
+	}
 	t->dlump.alloc(sizeof(float) * g.nloc);
 	if (g.nown != g.nloc) { FI_HIP_TRY(hipMemsetAsync(t->dlump.p, 0, sizeof(float) * g.nloc, c->stream)); }
 	hipLaunchKernelGGL(k_lumped_diag, dim3(stream_blocks(g.nown)), dim3(kThreads), 0, c->stream, g.nown,
 	                   c->lump.as<float>() + g.own_first, t->dlump.as<float>() + g.own_first, t->diag.as<float>() + g.own_first);
 	FI_HIP_TRY(hipGetLastError());
-	generic_assemble(t);
-	stencil_prepare(t);
-	operator_prepare(t);
-	if (t->nranks == 1) { prepare_safe_scaling(t); }  // (the smoother's scaling with the assembly; slabs: after the ghost planes' exchange)
+	operator_prepare(t, t->nranks == 1);  // (the smoother's scaling with the assembly; slabs: after the ghost planes' exchange)
 }
 
 fi_ctx* twin_prepare(fi_ctx* c)

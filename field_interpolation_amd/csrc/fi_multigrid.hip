@@ -9,8 +9,9 @@ namespace fi {
 // solved from the interpolated solution of the level below it, to a loose tolerance; x of `c` receives the
 // interpolated guess.  All on the device.
 template <typename T>
-void cascade_guess(RankSet& R)
+bool cascade_guess(RankSet& R, RankSet* wide)
 {
+	bool wrote_wide = false;
 	// chains[l] = the level-l contexts of all members
 	std::vector<RankSet> chains;
 	{
@@ -90,14 +91,19 @@ void cascade_guess(RankSet& R)
 			// outer iterations; at 512^3 the kernel would cost more than the start it improves
 			const bool cubic = L.ndim == 3 && (lf[i]->nranks == 1 || lc[i]->reach >= 2) && !test_switch("FI_LINEAR_START") &&
 			                   sizeof(T) * static_cast<size_t>(lc[i]->g.nloc) <= (32u << 20);
-			if (cubic) {
-				launch_prolong_cubic<T>(L, lc[i]->x.as<T>(), lf[i]->x.as<T>(), lf[i]->stream);
+			if (cubic && k == 1 && wide && sizeof(T) == 4) {
+				// (same lattice, same slab, same local geometry: the replica's index is the fp64 context's)
+				launch_prolong_cubic<T, double>(L, lc[i]->x.as<T>(), (*wide)[i]->x.as<double>(), lf[i]->stream);
+				wrote_wide = true;
+			} else if (cubic) {
+				launch_prolong_cubic<T, T>(L, lc[i]->x.as<T>(), lf[i]->x.as<T>(), lf[i]->stream);
 			} else {
 				launch_prolong<T>(L, lc[i]->x.as<T>(), lf[i]->x.as<T>(), 0, lf[i]->stream);
 			}
 		}
 		FI_HIP_TRY(hipGetLastError());
 	}
+	return wrote_wide;
 }
 
 // r = b - q (q may be null: r = b);  d = alpha * Dinv r;  x = zero_x ? d : x + d
@@ -993,12 +999,16 @@ void twin_cascade_guess(RankSet& R)
 		c->twin->stats.coarse_iterations = 0;
 		Tw.push_back(c->twin);
 	}
-	cascade_guess<float>(Tw);
+	for (fi_ctx* c : R) {  // (ghost planes outside the lattice; an undivided lattice is written whole below)
+		if (c->g.nown != c->g.nloc) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->g.nloc, c->stream)); }
+	}
+	const bool widened = cascade_guess<float>(Tw, &R);
 	for (fi_ctx* c : R) {
 		fi_ctx* t = c->twin;
-		FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(double) * c->g.nloc, c->stream));
-		hipLaunchKernelGGL(k_widen, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
-		                   t->x.as<float>() + t->g.own_first, c->x.as<double>() + c->g.own_first);
+		if (!widened) {
+			hipLaunchKernelGGL(k_widen, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			                   t->x.as<float>() + t->g.own_first, c->x.as<double>() + c->g.own_first);
+		}
 		c->stats.coarse_iterations = t->stats.coarse_iterations;
 	}
 	FI_HIP_TRY(hipGetLastError());
@@ -1264,8 +1274,8 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 
 
 // ---- explicit instantiations (declared in fi_solver_internal.h) ----
-template void cascade_guess<float>(RankSet&);
-template void cascade_guess<double>(RankSet&);
+template bool cascade_guess<float>(RankSet&, RankSet*);
+template bool cascade_guess<double>(RankSet&, RankSet*);
 template void cg_run_mg<float>(RankSet&, int, float);
 template void cg_run_mg<double>(RankSet&, int, float);
 template void mg_alloc<float>(fi_ctx*);

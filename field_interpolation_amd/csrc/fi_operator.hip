@@ -359,7 +359,8 @@ ModelCoef<T> make_coef(const fi_weights& w)
 constexpr int kDiagRows = 4;  // rows of x per workgroup (256^3: 65 536 workgroups of one row each were bound by their dispatch)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_model_diag3(Geom g, ModelCoef<T> mc, T* __restrict__ diag, T* __restrict__ dinv,
-                                                          unsigned short* __restrict__ d16)
+                                                          unsigned short* __restrict__ d16, unsigned short* __restrict__ d16s, T factor,
+                                                          const float* __restrict__ lump_in, float* __restrict__ dlump_out)
 {
 	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1];
 	const int x = static_cast<int>(blockIdx.x) * kThreads + threadIdx.x;
@@ -370,7 +371,13 @@ __global__ __launch_bounds__(kThreads) void k_model_diag3(Geom g, ModelCoef<T> m
 #pragma unroll
 	for (int j = 0; j < kDiagRows; ++j) {
 		const int64_t idx = lx * g.stride[0] + (g.own_lo[1] + y0 + j) * g.stride[1] + lz * g.stride[2];
-		in[j] = y0 + j < ext1 ? diag[idx] : T(0);
+		if (lump_in) {  // a lumped replica (fi_levels.hip): its data diagonal IS the clamped row sums the fp64 level's assembly formed
+			const float v = y0 + j < ext1 ? lump_in[idx] : 0.0f;
+			in[j] = static_cast<T>(v > 0.0f ? v : 0.0f);
+			if (y0 + j < ext1) { dlump_out[idx] = static_cast<float>(in[j]); }
+		} else {
+			in[j] = y0 + j < ext1 ? diag[idx] : T(0);
+		}
 	}
 #pragma unroll
 	for (int j = 0; j < kDiagRows; ++j) {
@@ -399,11 +406,17 @@ __global__ __launch_bounds__(kThreads) void k_model_diag3(Geom g, ModelCoef<T> m
 			dinv[idx] = v;
 			d16[idx]  = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
 		}
+		if (d16s) {  // the polynomial smoother's scaling in the same pass (k_safe_scaling: the same m, the same sums)
+			const T dd = d > acc ? d - acc : T(0);
+			const T sc = acc + factor * dd;
+			const T v  = (sc > T(0)) ? T(1) / sc : T(1);
+			d16s[idx] = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
+		}
 	}
 }
 
 template <int D, typename T>
-void prepare_dim(fi_ctx* c)
+void prepare_dim(fi_ctx* c, bool with_scaling, const float* lump_in)
 {
 	const Geom& g = c->g;
 	const ModelCoef<T> mc = make_coef<T>(c->w);
@@ -411,10 +424,23 @@ void prepare_dim(fi_ctx* c)
 	c->dinv16.alloc(sizeof(unsigned short) * g.nloc);
 	const bool whole = g.nown == g.nloc;  // no ghost planes: every local point is an owned one
 	const int ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
+	// with_scaling: the polynomial smoother's scaling of an undivided level in the same pass (levels of up to 2^16 points
+	// also want the count of weakly held points: the separate kernel); lump_in: a lumped replica's diagonal from the row sums
+	const bool fuse_scaling = with_scaling && whole && c->nranks == 1 && g.nloc > (1 << 16);
+	FI_REQUIRE(!lump_in || (D == 3 && !mc.on[5] && ext1 <= 65535 && ext2 <= 65535 && whole && sizeof(T) == 4), FI_ERR_STATE,
+	           "lumped replica: unexpected lattice");
 	if (D == 3 && !mc.on[5] && ext1 <= 65535 && ext2 <= 65535) {
+		if (fuse_scaling) { c->dinv16s.alloc(sizeof(unsigned short) * g.nloc); }
+		if (lump_in) { c->dlump.alloc(sizeof(float) * g.nloc); }
 		hipLaunchKernelGGL((k_model_diag3<T>), dim3((g.own_hi[0] - g.own_lo[0] + kThreads - 1) / kThreads, (ext1 + kDiagRows - 1) / kDiagRows, ext2),
 		                   dim3(kThreads), 0, c->stream, g, mc, c->diag.as<T>(), whole ? c->dinv.as<T>() : static_cast<T*>(nullptr),
-		                   whole ? c->dinv16.as<unsigned short>() : static_cast<unsigned short*>(nullptr));
+		                   whole ? c->dinv16.as<unsigned short>() : static_cast<unsigned short*>(nullptr),
+		                   fuse_scaling ? c->dinv16s.as<unsigned short>() : static_cast<unsigned short*>(nullptr),
+		                   static_cast<T>(c->lumped ? 1.0 : c->mg_safe), lump_in, lump_in ? c->dlump.as<float>() : static_cast<float*>(nullptr));
+		if (fuse_scaling) {
+			c->data_pinned   = false;
+			c->dinv16s_valid = true;
+		}
 	} else
 	hipLaunchKernelGGL((k_model_diag<D, T>), dim3(blocks_for(g.nown)), dim3(kThreads), 0, c->stream, g, mc,
 	                   c->diag.as<T>(), whole ? c->dinv.as<T>() : static_cast<T*>(nullptr),
@@ -713,15 +739,16 @@ void prepare_safe_scaling(fi_ctx* c)
 	}
 }
 
-void operator_prepare(fi_ctx* c)
+void operator_prepare(fi_ctx* c, bool with_scaling, const float* lump_in)
 {
 	const bool f64 = c->dtype == FI_F64;
 	c->dinv16s_valid = false;
 	switch (c->g.ndim) {
-	case 1: f64 ? prepare_dim<1, double>(c) : prepare_dim<1, float>(c); break;
-	case 2: f64 ? prepare_dim<2, double>(c) : prepare_dim<2, float>(c); break;
-	default: f64 ? prepare_dim<3, double>(c) : prepare_dim<3, float>(c); break;
+	case 1: f64 ? prepare_dim<1, double>(c, with_scaling, lump_in) : prepare_dim<1, float>(c, with_scaling, lump_in); break;
+	case 2: f64 ? prepare_dim<2, double>(c, with_scaling, lump_in) : prepare_dim<2, float>(c, with_scaling, lump_in); break;
+	default: f64 ? prepare_dim<3, double>(c, with_scaling, lump_in) : prepare_dim<3, float>(c, with_scaling, lump_in); break;
 	}
+	if (with_scaling && !c->dinv16s_valid) { prepare_safe_scaling(c); }
 }
 
 void apply_AtA(fi_ctx* c, const void* x, void* y, double* partial)

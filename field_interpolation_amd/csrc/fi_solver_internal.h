@@ -514,10 +514,12 @@ template <typename T> void cg_run_poly_or_jacobi(RankSet& R, int max_iterations,
 // fi_transfer.hip
 LevelPair level_pair(const fi_ctx* fine, const fi_ctx* coarse);
 template <typename T> void launch_prolong(const LevelPair& L, const T* coarse, T* fine, int mode, hipStream_t st);
-template <typename T> void launch_prolong_cubic(const LevelPair& L, const T* coarse, T* fine, hipStream_t st);
+template <typename T, typename TO> void launch_prolong_cubic(const LevelPair& L, const T* coarse, TO* fine, hipStream_t st);
 template <typename T> void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t st, T* tmp = nullptr, int f_local_planes = 0);
 // fi_multigrid.hip
-template <typename T> void cascade_guess(RankSet& R);
+// coarse-to-fine start into x of R; `wide`: the fp64 contexts whose fp32 replicas R are -- the last interpolation then writes
+// THEIR x where it can (returns true), and the caller has nothing to widen
+template <typename T> bool cascade_guess(RankSet& R, RankSet* wide = nullptr);
 void twin_cascade_guess(RankSet& R);
 template <typename T> void cg_run_mg(RankSet& R, int max_iterations, float tol);
 template <typename T> void mg_alloc(fi_ctx* c);

@@ -248,8 +248,8 @@ __device__ inline void cubic_window(int f, int nc, int cc, int u0, bool live, T*
 // A thread owns a 2 x 2 x 2 block of fine points: the 5 x 5 coarse rows around it are interpolated along x ONCE each (five
 // loads, both x parities) and then spread over the four (y, z) parities -- 125 loads for eight fine points instead of the
 // 64 per point of one thread per pair of points (256^3 from 128^3: 177 -> ... us).
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine)
+template <typename T, typename TO>
+__global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const T* __restrict__ coarse, TO* __restrict__ fine)
 {
 	const int px = (L.nf[0] + 1) / 2, py = (L.nf[1] + 1) / 2;
 	const int jz0 = L.f_z0 >> 1, jz1 = (L.f_z0 + L.f_planes - 1) >> 1;
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(kThreads) void k_prolong3_cubic(LevelPair L, const 
 		for (int pyb = 0; pyb < 2; ++pyb) {
 			if (!live[2][pz] || !live[1][pyb]) { continue; }
 			const int64_t i = (static_cast<int64_t>(2 * jz + pz - L.f_base) * L.nf[1] + (2 * jy + pyb)) * L.nf[0] + 2 * jx;
-			fine[i] = acc[pz][pyb][0];
-			if (live[0][1]) { fine[i + 1] = acc[pz][pyb][1]; }
+			fine[i] = static_cast<TO>(acc[pz][pyb][0]);
+			if (live[0][1]) { fine[i + 1] = static_cast<TO>(acc[pz][pyb][1]); }
 		}
 	}
 }
@@ -575,13 +575,13 @@ void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t s
 
 
 // cubic interpolation of the coarse-to-fine start (k_prolong3_cubic): a thread per 2 x 2 x 2 fine points
-template <typename T>
-void launch_prolong_cubic(const LevelPair& L, const T* coarse, T* fine, hipStream_t st)
+template <typename T, typename TO>
+void launch_prolong_cubic(const LevelPair& L, const T* coarse, TO* fine, hipStream_t st)
 {
 	const int64_t blocks8 = static_cast<int64_t>((L.nf[0] + 1) / 2) * ((L.nf[1] + 1) / 2) *
 	                        (((L.f_z0 + L.f_planes - 1) >> 1) - (L.f_z0 >> 1) + 1);
 	if (L.f_planes > 0) {
-		hipLaunchKernelGGL((k_prolong3_cubic<T>), dim3(static_cast<unsigned>((blocks8 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
+		hipLaunchKernelGGL((k_prolong3_cubic<T, TO>), dim3(static_cast<unsigned>((blocks8 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
 		                   coarse, fine);
 	}
 }
@@ -589,8 +589,9 @@ void launch_prolong_cubic(const LevelPair& L, const T* coarse, T* fine, hipStrea
 // ---- explicit instantiations (declared in fi_solver_internal.h) ----
 template void launch_prolong<float>(const LevelPair&, const float*, float*, int, hipStream_t);
 template void launch_prolong<double>(const LevelPair&, const double*, double*, int, hipStream_t);
-template void launch_prolong_cubic<float>(const LevelPair&, const float*, float*, hipStream_t);
-template void launch_prolong_cubic<double>(const LevelPair&, const double*, double*, hipStream_t);
+template void launch_prolong_cubic<float, float>(const LevelPair&, const float*, float*, hipStream_t);
+template void launch_prolong_cubic<double, double>(const LevelPair&, const double*, double*, hipStream_t);
+template void launch_prolong_cubic<float, double>(const LevelPair&, const float*, double*, hipStream_t);  // the replica's start, widened on the way
 template void launch_restrict<float>(const LevelPair&, const float*, float*, hipStream_t, float*, int);
 template void launch_restrict<double>(const LevelPair&, const double*, double*, hipStream_t, double*, int);
 
