@@ -192,9 +192,10 @@ int fi_ctx_destroy(fi_ctx* c)
 	}
 	if (c->comm && c->owns_comm) { fi::comm_destroy(c->comm); }
 	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
-	for (int s = 0; s < 2; ++s) {
+	for (int s = 0; s < 3; ++s) {
 		if (c->pin[s]) { (void)hipHostFree(c->pin[s]); }
 	}
+	if (c->ev_unwatched) { (void)hipEventDestroy(c->ev_unwatched); }
 	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }
 	delete c;
 	return FI_OK;

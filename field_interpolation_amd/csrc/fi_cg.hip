@@ -531,9 +531,26 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	}
 	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
 
+	// A level of a coarse-to-fine start that has just been solved WITHOUT a look at its stop flag (below): what the flag
+	// said comes in now -- the copy went to pinned memory behind that solve's last kernel, long since done.
+	if (c0->unwatched_pending) {
+		c0->unwatched_pending = false;
+		FI_HIP_TRY(hipEventSynchronize(c0->ev_unwatched));
+		const CgScalars* was = static_cast<const CgScalars*>(pinned(c0, 2, sizeof(CgScalars)));
+		const bool as_expected = (was->done == 1 || was->done == 5) && was->iter > 0 && was->iter <= c0->unwatched_expected;
+		c0->last_cg_iterations = as_expected ? was->iter : 0;  // (0: this solve watches its flag again and learns the new count)
+	}
+	// Such a solve: a coarser level of an undivided lattice whose previous solve ended after n iterations with the same
+	// tolerance gets n iterations and no look at all -- the level below it is waiting for its result, and a look is a host
+	// round trip of ~40 us per level.  Should n not have been enough this time, the start guess is that much worse and the
+	// next solve of this level watches again.
+	const bool unwatched = c0->level > 0 && R.size() == 1 && c0->nranks == 1 && !c0->verify_residual && c0->last_cg_iterations > 0 &&
+	                       c0->last_cg_iterations <= max_iterations && c0->last_cg_iterations <= 64 && c0->last_cg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS");
+	c0->last_cg_tol = tolerance;
+
 	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
 	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
-	FI_HIP_TRY(hipEventRecord(e0, st));
+	if (!unwatched) { FI_HIP_TRY(hipEventRecord(e0, st)); }
 
 	CgScalars init{};
 	init.tol2     = tolerance * tolerance;
@@ -584,6 +601,22 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 	int looks = 0;
 	for (;;) {
 		const bool skip_look = looks == 0 && c0->level > 0 && c0->last_cg_iterations > 0;
+		if (unwatched && looks == 1) {  // the predicted iterations are on the stream: the flag travels to pinned memory, nobody waits
+			if (!c0->ev_unwatched) { FI_HIP_TRY(hipEventCreateWithFlags(&c0->ev_unwatched, hipEventDisableTiming)); }
+			FI_HIP_TRY(hipMemcpyAsync(pinned(c0, 2, sizeof(CgScalars)), sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+			FI_HIP_TRY(hipEventRecord(c0->ev_unwatched, st));
+			c0->unwatched_pending  = true;
+			c0->unwatched_expected = c0->last_cg_iterations;
+			for (fi_ctx* c : R) {  // (what the previous solve reported: the caller reads the iteration count and `converged`)
+				c->stats.iterations = c0->last_cg_iterations;
+				c->stats.converged  = 1;
+				c->stats.operator_applies = c0->last_cg_iterations + 1;
+				c->stats.restarts   = 0;
+				c->stats.solve_ms   = 0.0;
+				c->stats.spmv_samples = 0;
+			}
+			return;
+		}
 		++looks;
 		if (!skip_look) {
 			FI_HIP_TRY(hipMemcpyAsync(c0->scal_host, sc0, sizeof(CgScalars), hipMemcpyDeviceToHost, st));

@@ -366,6 +366,10 @@ struct fi_ctx {
 	int        last_mg_iterations = 0;     // of the previous V-cycle PCG solve of this context, its tolerance, and whether the
 	double     last_mg_tol = 0;            // solve about to run starts the way that one did (no caller's guess): cg_run_mg
 	bool       predictable_start = false;
+	double     last_cg_tol = 0;            // ... and its tolerance
+	bool       unwatched_pending = false;  // a coarse-to-fine level solved without a look at its flag: the flag's copy is in pin[2]
+	int        unwatched_expected = 0;
+	hipEvent_t ev_unwatched = nullptr;
 	int        last_cg_iterations = 0;     // of the previous Jacobi-PCG solve of this context (coarser levels: first look at the stop flag)
 	int        last_outer_iterations = 0;  // of the previous polynomial-PCG solve of this context (first look at the stop flag)
 	int        mg_mode = 0;       // 0: Jacobi-PCG (+ cascade start when levels exist); 1: V-cycle preconditioned CG
@@ -375,8 +379,8 @@ struct fi_ctx {
 	// pinned staging of the assembly's small host copies (slot 0: read-backs of sizes, slot 1: uploads of workgroup lists).
 	// A copy from / to pageable memory is staged by the runtime inside the call, which waits for the stream -- with several
 	// threads assembling levels side by side the others' launches queued up behind it (gaps of 100-150 us in their chains).
-	void*      pin[2] = {nullptr, nullptr};
-	size_t     pin_bytes[2] = {0, 0};
+	void*      pin[3] = {nullptr, nullptr, nullptr};  // (slot 2: the stop flag of an unwatched coarse-level solve, cg_run)
+	size_t     pin_bytes[3] = {0, 0, 0};
 	int        max_blocks = 0;
 
 	// assembly temporaries, kept between fi_assemble calls (hipMalloc/hipFree are slow and synchronising)
