@@ -154,7 +154,7 @@ def workload(args, world):
             raise SystemExit("config 5 is a fixed lattice: use --scaling strong")
         sizes, w, pos, nrm = synth.config5(side=side, num_points=npts, seed=4)
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or 1e-6, dtype=args.dtype or "f64",
-                    levels=6 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-4,
+                    levels=6 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-2,
                     multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, field_tol=None,
                     text="config5: 3D %d^3 SDF from %d oriented points (sdf_from_points, default Weights)" % (side, npts))
     if cfg == 3:
@@ -164,7 +164,9 @@ def workload(args, world):
             raise SystemExit("config 3 is a fixed lattice: use --scaling strong")
         sizes, w, pos, nrm = synth.config3(side=side, points_per_shape=pps, seed=2)
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or 1e-5, dtype=args.dtype or "f64",
-                    levels=7 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-4,
+                    # (hierarchy depth and the levels' tolerance: tools/r4_sweep_c23.sh -- the levels of a coarse-to-fine start are
+                    # worth a loose solve only: 7 levels to 1e-4 62.9 ms per step, 8 levels to 1e-1 30.3)
+                    levels=8 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-1,
                     multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, field_tol=None,
                     text="config3: 2D %dx%d SDF from %d oriented points (triangle + inverted circle)" % (side, side, 2 * pps))
     if cfg == 2:
@@ -174,7 +176,7 @@ def workload(args, world):
             raise SystemExit("config 2 is a fixed lattice: use --scaling strong")
         sizes, w, pos, val = synth.config2(side=side, num_points=npts, seed=1)
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or 1e-5, dtype=args.dtype or "f64",
-                    levels=7 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-4,
+                    levels=4 if args.levels is None else args.levels, coarse_tol=args.coarse_tol or 1e-1,  # (7 levels to 1e-4: 9.8 ms; 5.4)
                     multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, field_tol=None,
                     text="config2: 2D %dx%d lattice, %d noisy value constraints, model_2=10" % (side, side, npts))
     raise SystemExit("--config must be 2, 3, 4 or 5 (config 1 is the CPU-runnable 1-D case: tests/)")
