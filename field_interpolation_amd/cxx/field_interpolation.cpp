@@ -240,7 +240,12 @@ std::vector<float> generate_error_map(const std::vector<Triplet>& triplets, cons
 			fatal("generate_error_map: triplet index out of range");
 		}
 	}
-	return detail::error_map_on_gpu(triplets, solution, rhs);
+	std::vector<float> blame = detail::error_map_on_gpu(triplets, solution, rhs);
+	// The reference's loop cannot fail and its callers index the result without a check: a device failure here ends the
+	// program with the library's message (like the index check above) instead of handing back an empty vector.  There is no
+	// host fallback in this library by design.
+	if (blame.size() != solution.size()) { fatal("generate_error_map: the device path failed (see the message above)"); }
+	return blame;
 }
 
 std::vector<float> upscale_field(const float* field, const std::vector<int>& small_sizes,
