@@ -460,7 +460,8 @@ int  stencil_cheb_partials(const fi_ctx* c);
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
                        double* partial, int part = 0, double zprev_scale = 0.0, double pro_scale = 0.0,
                        const unsigned short* scaling = nullptr,   // scaling: bfloat16 array (default: the context's dinv16)
-                       int extend = 0);  // slabs, deep exchange: the step also covers `extend` ghost planes on either side
+                       int extend = 0,    // slabs, deep exchange: the step also covers `extend` ghost planes on either side
+                       int fmt = 0);      // bfloat16 storage of z (bit 0), z_prev (bit 1), z_new (bit 2): fp32 3-D levels, ChebEpi::fmt
 int  stencil_cheb_partials_max(const fi_ctx* c);  // room for the partials of a step extended over the whole ghost zone
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 // z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the

@@ -577,6 +577,48 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 		}
 	}
 	if (chain_launches) { *chain_launches = terms - 1; }
+	// The iterates between the first and the last step live as bfloat16 on an undivided fp32 level of some size (no ghost
+	// planes to exchange, whole 16-byte groups per row): they are the operands of a PRECONDITIONER, and a step then moves
+	// 8 / 10 / 12 / 14 bytes per point instead of 10 / 14 / 18 / 18 (FI_NO_Z16: fp32 iterates, tests).
+	const bool z16 = single && pro && sizeof(T) == 4 && c0->g.ndim == 3 && c0->g.gn[0] % 4 == 0 && c0->g.nloc >= (1 << 21) &&
+	                 !test_switch("FI_NO_Z16");
+	if (chain_bytes && z16) {
+		*chain_bytes = 0;
+		for (int j = 1; j < terms; ++j) {
+			const bool last = j == terms - 1;
+			const double in = j == 1 ? 4.0 : 2.0, prev = j <= 2 ? 0.0 : 2.0, rr = j == 1 ? 0.0 : 4.0, out = last ? 4.0 : 2.0;
+			*chain_bytes += (in + prev + rr + out + 2.0) * static_cast<double>(c0->g.nown);
+		}
+	}
+	if (z16) {
+		// Where the iterates live: z_j (j = 1 .. n - 1, bfloat16) in one of the four half-buffers of za / zb, chosen so that
+		// a step never writes where its own operands are -- a step that reads bfloat16 and writes fp32 (the last one) or the
+		// other way round is NOT in place -- and the last step finds zb free: z_(n-1), z_(n-2) in the halves of za, z_(n-3),
+		// z_(n-4) in those of zb, and so on (a half is reused four steps later, two after its last reader).
+		fi_ctx* c = c0;
+		const int n = terms - 1;
+		auto where = [&](int j) -> void* {
+			const int d = n - 1 - j;
+			char* base = static_cast<char*>((d & 2) ? (c->*zb).p : (c->*za).p);
+			return base + ((d & 1) ? 2 * static_cast<size_t>(c->g.nloc) : 0);
+		};
+		const unsigned short* sc = c->dinv16s.as<unsigned short>();
+		double rho = 1.0 / sigma;
+		for (int k = 1; k <= n; ++k) {
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+			void* out = k == n ? (c->*zb).p : where(k);
+			const int fmt = (k > 1 ? 1 : 0) | (k > 2 ? 2 : 0) | (k < n ? 4 : 0);
+			if (k == 1) {
+				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, out, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc, 0, fmt);
+			} else {
+				stencil_cheb_step(c, where(k - 1), k == 2 ? (c->*r).p : where(k - 2), (c->*r).p, out, c1, c2, region2(c), 0,
+				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc, 0, fmt);
+			}
+			rho = rho_new;
+		}
+		return zb;
+	}
 	Vec zin = za, zout = zb;
 	double rho = 1.0 / sigma;
 	for (int k = 1; k < terms; ++k) {

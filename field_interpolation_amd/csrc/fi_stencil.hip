@@ -52,6 +52,7 @@
 //   * blockIdx -> tile map is XCD-aware: blocks b, b+8, b+16.. (same XCD, same L2) get adjacent tiles; the
 //     chunk length ZC is chosen so that the grid covers the CUs in whole rounds (pick_chunk).
 
+#include <hip/hip_bf16.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -140,6 +141,12 @@ struct ChebEpi {
 	                     // stencil is formed on load, z_0 = pro_scale * Dinv * r -- z_0 is never stored (z_prev = 0 there)
 	T        zp_scale;  // mode 0, non-zero: z_prev = zp_scale * Dinv * (the vector passed as zprev) -- the polynomial's second
 	                    // step passes r here: its z_prev is z_0 = Dinv r / theta, which then needs no lattice pass of its own
+	int      fmt;       // bfloat16 STORAGE of the polynomial's iterates (plain fp32 variant with the epilogue, mode 0): bit 0 the
+	                    // kernel's input vector, bit 1 z_prev, bit 2 z_new -- the pointers then address unsigned shorts.  The
+	                    // iterates of a preconditioner need no more (section 9 of profiles/r4_ablation.md: the same iteration
+	                    // counts to 1e-9), and a step moves 8-14 bytes per point instead of 10-18.
+	int      round16;   // timing builds (FI_Z16): the step's result rounded to bfloat16 (1) / half (2) precision -- what 16-bit
+	                    // storage of the polynomial's iterates would do to the preconditioner (profiles/r4_ablation.md section 9)
 };
 
 struct CellLists {
@@ -352,7 +359,30 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	const int gyc = gy < P.ny ? gy : P.ny - 1;
 	const uint32_t xoff = static_cast<uint32_t>(gyc) * static_cast<uint32_t>(P.nx) + static_cast<uint32_t>(gxc);
 	auto clamp_plane = [&](int lz) { return lz < lz_lo ? lz_lo : (lz > lz_hi ? lz_hi : lz); };
+	constexpr bool Z16 = EPI && !CELLS && sizeof(T) == 4;  // the variant whose vectors may be stored as bfloat16 (ChebEpi::fmt)
+	auto from16 = [](const DV16& d) -> V {
+		V v;
+		T* p = reinterpret_cast<T*>(&v);
+#pragma unroll
+		for (int j = 0; j < VX; ++j) { p[j] = static_cast<T>(__uint_as_float(static_cast<unsigned int>(d[j]) << 16)); }
+		return v;
+	};
+	auto to16 = [](const V& v) -> DV16 {  // round to nearest even: one v_cvt_pk_bf16_f32 per pair on gfx950
+		DV16 d;
+		const T* p = reinterpret_cast<const T*>(&v);
+#pragma unroll
+		for (int j = 0; j + 1 < VX; j += 2) {
+			const __hip_bfloat162 b = __float22bfloat162_rn(float2{static_cast<float>(p[j]), static_cast<float>(p[j + 1])});
+			d[j]     = __bfloat16_as_ushort(b.x);
+			d[j + 1] = __bfloat16_as_ushort(b.y);
+		}
+		return d;
+	};
 	auto load_own = [&](int lz) -> V {
+		if (Z16 && (E.fmt & 1)) {
+			const unsigned short* xp = reinterpret_cast<const unsigned short*>(x) + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
+			return from16(*reinterpret_cast<const DV16*>(xp + xoff));
+		}
 		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
 		return *reinterpret_cast<const V*>(xp + xoff);
 	};
@@ -361,8 +391,15 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 #ifdef FI_TIMING_BUILD  // timing builds only (tools/build_variant.sh -DFI_TIMING_BUILD): results wrong by construction
 		if (P.dbg & 1) { return; }
 #endif
-		h.vec = *reinterpret_cast<const NV*>(xp + hvg);
-		h.sc  = xp[hsg];
+		if (Z16 && (E.fmt & 1)) {
+			const unsigned short* xq = reinterpret_cast<const unsigned short*>(x) + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
+			const V hv = from16(*reinterpret_cast<const DV16*>(xq + hvg));
+			h.vec = *reinterpret_cast<const NV*>(&hv);
+			h.sc  = static_cast<T>(__uint_as_float(static_cast<unsigned int>(xq[hsg]) << 16));
+		} else {
+			h.vec = *reinterpret_cast<const NV*>(xp + hvg);
+			h.sc  = xp[hsg];
+		}
 		if (PRO) {
 #ifdef FI_TIMING_BUILD
 			if (P.dbg & 64) { return; }  // no halo loads of the scaling
@@ -589,7 +626,11 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	// consumed the previous set, used one step later
 	auto load_epi = [&](int lz, EpiRegs& e) {
 		const int64_t o = static_cast<int64_t>(clamp_plane(lz)) * P.plane + xoff;
-		e.zp = *reinterpret_cast<const V*>(E.zprev + o);  // never null: the host passes z itself with c1 = 0 on the first step
+		if (Z16 && (E.fmt & 2)) {
+			e.zp = from16(*reinterpret_cast<const DV16*>(reinterpret_cast<const unsigned short*>(E.zprev) + o));
+		} else {
+			e.zp = *reinterpret_cast<const V*>(E.zprev + o);  // never null: the host passes z itself with c1 = 0 on the first step
+		}
 		e.rv = *reinterpret_cast<const V*>(E.r + o);
 		e.dv = *reinterpret_cast<const DV16*>(E.dinv + o);
 	};
@@ -961,8 +1002,26 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 					rz += rv[j] * pz[j];
 				}
 			}
+#ifdef FI_TIMING_BUILD
+			if (E.round16 && E.mode == 0 && sizeof(T) == 4) {
+#pragma unroll
+				for (int j = 0; j < VX; ++j) {
+					if (E.round16 == 1) {
+						uint32_t u = __float_as_uint(static_cast<float>(pz[j]));
+						u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+						pz[j] = static_cast<T>(__uint_as_float(u));
+					} else {
+						pz[j] = static_cast<T>(__half2float(__float2half(static_cast<float>(pz[j]))));
+					}
+				}
+			}
+#endif
 			if (active) {
-				*reinterpret_cast<V*>((E.znew + static_cast<int64_t>(z) * P.plane) + col) = zn;
+				if (Z16 && (E.fmt & 4)) {
+					*reinterpret_cast<DV16*>((reinterpret_cast<unsigned short*>(E.znew) + static_cast<int64_t>(z) * P.plane) + col) = to16(zn);
+				} else {
+					*reinterpret_cast<V*>((E.znew + static_cast<int64_t>(z) * P.plane) + col) = zn;
+				}
 				dot_acc += static_cast<double>(rz);
 			} else if (tail) {
 				store_tail(E.znew + static_cast<int64_t>(z) * P.plane, (PRO || E.mode == 1) ? pz : rv, pz);
@@ -1362,8 +1421,10 @@ int  stencil_cheb_partials_max(const fi_ctx* c)
 	return extended_params(c->march.Pplain, c->nranks > 1 ? c->halo : 0).nwg;
 }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling, int extend)
+                       double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling, int extend, int fmt)
 {
+	FI_REQUIRE(fmt == 0 || (!c->tile2.valid && c->dtype == FI_F32 && c->g.gn[0] % 4 == 0), FI_ERR_STATE,
+	           "bfloat16 iterates: fp32 3-D levels with rows of whole 16-byte groups");
 	// pro_scale != 0 (the first step, z_prev = 0): `z` is r and the kernel forms z_0 = pro_scale * Dinv * r on load
 	// zprev == nullptr: the step from z_prev = 0 (z itself stands in under a zero coefficient);
 	// zprev_scale != 0: z_prev = zprev_scale * Dinv r, read through r's own cache lines
@@ -1382,7 +1443,8 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	} else {
 		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
 		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
-		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale)};
+		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), fmt, 0};
+		if (const char* e = tuning_switch("FI_Z16")) { E.round16 = c->level == 0 ? atoi(e) : 0; }
 		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part, pro_scale != 0.0, extend);
 	}
 }

@@ -402,3 +402,36 @@ def test_lumped_replica_of_value_row_data(oracle, fi, monkeypatch, sizes, n):
             assert f.stats()["converged"] == 1 and f.true_residual() <= 1.01e-9 and it2 <= 2 * it + 4
     monkeypatch.delenv("FI_NO_LUMPED_TWIN", raising=False)
     assert its[True] <= its[False] + max(3, its[False] // 3), its
+
+
+def test_bfloat16_iterates_of_the_smoother(fi, monkeypatch):
+    """On undivided fp32 levels of 2^21 points and more the polynomial smoother keeps its iterates between the first and the
+    last step as bfloat16 (fi_multigrid.hip poly_chain; a step moves 8-14 bytes per point instead of 10-18).  They are operands
+    of a preconditioner: the fp64 CG around it must reach the same true residual in the same number of iterations (+-1) as with
+    fp32 iterates (FI_NO_Z16), and the two fields must agree to the stop tolerance's accuracy.  128^3 = 2^21 points, value rows
+    (the lumped replica), 4 and 5 terms."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, val = synth.config4(side=128, num_points=125000, seed=5)
+    for terms in (5, 4):
+        out = {}
+        for z16 in (True, False):
+            if z16:
+                monkeypatch.delenv("FI_NO_Z16", raising=False)
+            else:
+                monkeypatch.setenv("FI_NO_Z16", "1")
+            f = fi.LatticeField(sizes, dtype="f64")
+            f.add_field_constraints(w)
+            f.set_levels(2, 3e-4)
+            f.set_multigrid(True)
+            f.set_mixed_precision(True)
+            f.set_mg_smoother(True, 4.0, terms, 30.0)
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+            f.assemble()
+            x, it, rel = f.solve_cg(None, 0, 1e-8)
+            assert f.stats()["converged"] == 1 and f.true_residual() <= 1.01e-8
+            out[z16] = (it, f.solution_f64().copy())
+        monkeypatch.delenv("FI_NO_Z16", raising=False)
+        assert abs(out[True][0] - out[False][0]) <= 1, (terms, out[True][0], out[False][0])
+        scale = np.abs(out[False][1]).max()
+        assert np.abs(out[True][1] - out[False][1]).max() <= 2e-6 * scale
+
