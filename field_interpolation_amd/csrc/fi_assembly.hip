@@ -220,6 +220,9 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 
 constexpr int kRec = 3;  // the cell's record for the sums over the lattice points: [A^T b | diagonal | row sums] x 2^D corners
 constexpr uint32_t kHeavyRows = 192;  // cells with more rows are summed by a whole workgroup (k_build_heavy)
+// 3-D (eight lanes per cell, all cells side by side): a workgroup per cell only pays for the few cells of the coarsest levels.
+// Config 5's 32^3 level (35 k cells of ~570 rows each) through k_build_heavy: 2.8 ms; through the lanes: see r4_ablation 12.
+constexpr uint32_t kHeavyRows3 = 4096;
 
 // everything after the sums of a cell: block, first row, rhs, factor rows
 // DIRECT: block, first row and the (rhs, diagonal) record go straight to memory (k_build_heavy: one thread per
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks3(long ncell, const ui
 	if (c >= ncell) { return; }  // (whole groups of 8 lanes: the shuffles below stay inside a live group)
 	const uint32_t s = start[c], m = count[c];
 	bool mine = true;
-	if (m > kHeavyRows) {  // coarse levels put 10^4..10^6 rows into one cell: a workgroup's job (k_build_heavy fills the slots)
+	if (m > kHeavyRows3) {  // coarse levels put 10^4..10^6 rows into one cell: a workgroup's job (k_build_heavy fills the slots)
 		if (j == 0) { heavy[1 + atomicAdd(&heavy[0], 1u)] = static_cast<uint32_t>(c); }
 		mine = false;
 	}
@@ -541,13 +544,15 @@ __global__ __launch_bounds__(kThreads) void k_build_heavy(long ncell, const uint
 			}
 		}
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-		for (int e = 0; e < NB + NC; ++e) {
+#pragma unroll
+		for (int e = 0; e < NB + NC; ++e) {  // (unrolled: a run-time index would move the sums to scratch memory)
 			double v = e < NB ? B[e] : gvec[e - NB];
 			for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); }
 			if (lane == 0) { part[wave][e] = v; }
 		}
 		__syncthreads();
 		if (threadIdx.x == 0) {
+#pragma unroll
 			for (int e = 0; e < NB + NC; ++e) {
 				double v = 0;
 				for (int w = 0; w < kThreads / 64; ++w) { v += part[w][e]; }
