@@ -196,6 +196,10 @@ int fi_ctx_destroy(fi_ctx* c)
 		if (c->pin[s]) { (void)hipHostFree(c->pin[s]); }
 	}
 	if (c->ev_unwatched) { (void)hipEventDestroy(c->ev_unwatched); }
+	if (c->ev_asm0) {
+		(void)hipEventDestroy(c->ev_asm0);
+		(void)hipEventDestroy(c->ev_asm1);
+	}
 	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }
 	delete c;
 	return FI_OK;
@@ -417,13 +421,32 @@ int fi_clear_points(fi_ctx* c)
 	FI_API_END
 }
 
+namespace fi {
+// the time of the last fi_assemble, once its second event has passed (waits for it: the events are on the context's stream)
+void finish_assemble_timing(fi_ctx* c)
+{
+	if (!c->asm_time_pending) { return; }
+	c->asm_time_pending = false;
+	if (hipEventSynchronize(c->ev_asm1) != hipSuccess) { return; }
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, c->ev_asm0, c->ev_asm1) == hipSuccess) { c->stats.assemble_ms = ms; }
+}
+}  // namespace fi
+
 int fi_assemble(fi_ctx* c)
 {
 	FI_API_BEGIN
 	fi::check_ctx(c);
 	fi::bind_device(c);
-	fi::EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
-	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
+	// The assembly is timed between two events of the context and nobody waits for the second one here: the caller's next
+	// call -- normally the solve -- queues behind the assembly's last kernels instead of finding an idle GPU after a host
+	// round trip (~0.1 ms of a config-4 step).  fi_get_stats (and the next fi_assemble) read the time.
+	fi::finish_assemble_timing(c);
+	if (!c->ev_asm0) {
+		FI_HIP_TRY(hipEventCreate(&c->ev_asm0));
+		FI_HIP_TRY(hipEventCreate(&c->ev_asm1));
+	}
+	const hipEvent_t e0 = c->ev_asm0, e1 = c->ev_asm1;
 	FI_HIP_TRY(hipEventRecord(e0, c->stream));
 	// Ghost planes along the decomposed axis.  reach: the widest model stencil, at least the cell reach (1) -- the width of
 	// an exchange.  halo (planes stored): the reach, or the polynomial preconditioner's DEEP exchange: 2 (d - 1) planes of
@@ -625,10 +648,8 @@ int fi_assemble(fi_ctx* c)
 		fi::build_twin(c);
 	}
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));
-	FI_HIP_TRY(hipEventSynchronize(e1));
-	float ms = 0;
-	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	c->stats.assemble_ms  = ms;
+	c->asm_time_pending   = true;
+	c->stats.assemble_ms  = 0.0;
 	c->stats.num_levels   = 1;
 	for (fi_ctx* l = c->coarse; l; l = l->coarse) { c->stats.num_levels += 1; }
 	if (c->twin) { c->stats.num_levels = c->twin->stats.num_levels; }
@@ -811,6 +832,7 @@ int fi_get_stats(const fi_ctx* c, fi_stats* out)
 	FI_API_BEGIN
 	fi::check_ctx(c);
 	FI_REQUIRE(out != nullptr, FI_ERR_INVALID, "null output");
+	fi::finish_assemble_timing(const_cast<fi_ctx*>(c));
 	*out = c->stats;
 	FI_API_END
 }

@@ -331,6 +331,8 @@ struct fi_ctx {
 	fi::DevBuf dlump;   // float[nloc]
 	// on the fp64 context of such a pair: the row sums of ITS data term, formed by the assembly beside A^T b and the
 	// diagonal (fi_assembly.hip: a third entry of every cell's record) when fi_assemble sets want_lump
+	hipEvent_t ev_asm0 = nullptr, ev_asm1 = nullptr;  // around the last fi_assemble; read by finish_assemble_timing
+	bool       asm_time_pending = false;
 	bool       row_bounds_valid = false;  // scratch[24] holds cell_row_bounds() of the current cells
 	bool       want_lump = false;
 	fi::DevBuf lump;    // float[nloc]
