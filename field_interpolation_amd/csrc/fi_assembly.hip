@@ -218,6 +218,12 @@ __global__ __launch_bounds__(kThreads) void k_emit_rows(EmitArgs a, long n, cons
 	}
 }
 
+__global__ void k_iota(uint32_t* v, long n)
+{
+	const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n) { v[i] = static_cast<uint32_t>(i); }
+}
+
 constexpr int kRec = 3;  // the cell's record for the sums over the lattice points: [A^T b | diagonal | row sums] x 2^D corners
 constexpr uint32_t kHeavyRows = 192;  // cells with more rows are summed by a whole workgroup (k_build_heavy)
 // 3-D (eight lanes per cell, all cells side by side): a workgroup per cell only pays for the few cells of the coarsest levels.
@@ -1091,22 +1097,26 @@ void assemble_dim(fi_ctx* c)
 	}
 
 	// sort rows by cell
-	DevBuf &row_sorted = c->scratch[4], &key_sorted = c->scratch[5], &uniq = c->scratch[6],
+	DevBuf &row_in = c->scratch[3], &row_sorted = c->scratch[4], &key_sorted = c->scratch[5], &uniq = c->scratch[6],
 	       &counts = c->scratch[7], &starts = c->scratch[8], &nruns = c->scratch[9], &tmp = c->scratch[10];
+	row_in.alloc(sizeof(uint32_t) * total);
 	row_sorted.alloc(sizeof(uint32_t) * total);
 	key_sorted.alloc(sizeof(uint32_t) * total);
 	uniq.alloc(sizeof(uint32_t) * total);
 	counts.alloc(sizeof(uint32_t) * total);
 	starts.alloc(sizeof(uint32_t) * total);
 	nruns.alloc(sizeof(uint32_t) * 4);
+	// (an index array and a pair sort: with a counting iterator as the values rocPRIM first copies keys and values into its
+	// own buffers -- two transform launches instead of this one)
+	hipLaunchKernelGGL(k_iota, dim3(blocks_for(total)), dim3(kThreads), 0, st, row_in.as<uint32_t>(), total);
 	int end_bit = 1;
 	while ((1ull << end_bit) <= invalid) { ++end_bit; }
 	size_t tb = 0;
-	FI_HIP_TRY(sort_keys_index_u32(nullptr, tb, key, key_sorted.as<uint32_t>(), row_sorted.as<uint32_t>(), static_cast<unsigned int>(total), 0,
-	                               end_bit, st));
+	FI_HIP_TRY(sort_pairs_u32(nullptr, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(), row_sorted.as<uint32_t>(),
+	                          static_cast<unsigned int>(total), 0, end_bit, st));
 	tmp.alloc(tb);
-	FI_HIP_TRY(sort_keys_index_u32(tmp.p, tb, key, key_sorted.as<uint32_t>(), row_sorted.as<uint32_t>(), static_cast<unsigned int>(total), 0,
-	                               end_bit, st));
+	FI_HIP_TRY(sort_pairs_u32(tmp.p, tb, key, key_sorted.as<uint32_t>(), row_in.as<uint32_t>(), row_sorted.as<uint32_t>(),
+	                          static_cast<unsigned int>(total), 0, end_bit, st));
 	// runs of equal keys = occupied cells (+ one run of invalid rows at the end)
 	size_t tb2 = 0;
 	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),

@@ -33,16 +33,4 @@ inline hipError_t sort_pairs_u32(void* tmp, size_t& bytes, const uint32_t* keys_
 	return rocprim::radix_sort_pairs<sort_detail::onesweep<9>>(tmp, bytes, keys_in, keys_out, values_in, values_out, n, b0, b1, stream);
 }
 
-// the same with the values 0, 1, 2 .. n - 1 (the permutation that sorts the keys): no index array to fill first
-inline hipError_t sort_keys_index_u32(void* tmp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* index_out,
-                                      unsigned int n, int begin_bit, int end_bit, hipStream_t stream)
-{
-	const unsigned int b0 = static_cast<unsigned int>(begin_bit), b1 = static_cast<unsigned int>(end_bit);
-	rocprim::counting_iterator<uint32_t> iota(0u);
-	if (sort_detail::ten_bit_digits(end_bit - begin_bit)) {
-		return rocprim::radix_sort_pairs<sort_detail::onesweep<10>>(tmp, bytes, keys_in, keys_out, iota, index_out, n, b0, b1, stream);
-	}
-	return rocprim::radix_sort_pairs<sort_detail::onesweep<9>>(tmp, bytes, keys_in, keys_out, iota, index_out, n, b0, b1, stream);
-}
-
 }  // namespace fi
