@@ -390,8 +390,11 @@ def main():
     if acc["prec_n"] > 0 and (mg_run or wl["poly"] > 2):
         roof_main = roof("k_apply_march3d<float, EPI>: Chebyshev steps of the polynomial (%s) = model-operator apply + three-term "
                          "recurrence in the epilogue; ALL steps of the sampled polynomials, timed between one pair of HIP events "
-                         "per polynomial (first: r, bf16 scaling in, z out = 2.5 lattice passes; second 3.5; the others 4.5): "
-                         "bytes of all sampled launches over their time, launch_ms = the mean per launch, finest level"
+                         "per polynomial; bytes as the library counts what it launched -- with the iterates of the V-cycle's "
+                         "polynomial stored as bfloat16 (undivided fp32 levels of >= 2^21 points) 8 / 10 / 12 / 14 bytes per point "
+                         "for the four steps of 5 terms (r, the bf16 scaling, z, z_prev in, z_new out), 10 / 14 / 18 / 18 with fp32 "
+                         "iterates (FI_NO_Z16, the polynomial PCG): bytes of all sampled launches over their time, launch_ms = "
+                         "the mean per launch, finest level"
                          % ("the V-cycle's pre-smoother" if mg_run else "the preconditioner of the polynomial PCG"),
                          st["prec_bytes"], prec_avg_ms, acc["prec_n"], tr("cheb"))
     else:
