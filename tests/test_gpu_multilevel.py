@@ -435,3 +435,48 @@ def test_bfloat16_iterates_of_the_smoother(fi, monkeypatch):
         scale = np.abs(out[False][1]).max()
         assert np.abs(out[True][1] - out[False][1]).max() <= 2e-6 * scale
 
+
+def test_solves_without_looks_at_the_stop_flag(fi, monkeypatch):
+    """From the second solve of a context on, V-cycle PCG looks at its stop flag only from the previous solve's iteration count
+    on, and the Jacobi-PCG levels of the coarse-to-fine start get that many iterations and no look at all (the flag's copy is
+    read at the level's next solve).  The device runs the same kernels either way: three solves in a row must give the
+    iteration counts and the very bits of FI_LOOK_ALWAYS -- also after the data have changed under the predictions (other
+    points, then fewer points: the levels need other iteration counts than predicted and must fall back to watching)."""
+    from field_interpolation_amd import synth
+    sizes, w, pos, val = synth.config4(side=64, num_points=20000, seed=8)
+    rng = np.random.default_rng(8)
+    pos2 = (pos[:5000] * np.float32(0.5) + np.float32(7.0)).astype(np.float32)
+    val2 = rng.normal(size=len(pos2)).astype(np.float32)
+    runs = {}
+    for always in (False, True):
+        if always:
+            monkeypatch.setenv("FI_LOOK_ALWAYS", "1")
+        else:
+            monkeypatch.delenv("FI_LOOK_ALWAYS", raising=False)
+        f = fi.LatticeField(sizes, dtype="f64")
+        f.add_field_constraints(w)
+        f.set_levels(2, 3e-4)
+        f.set_multigrid(True)
+        f.set_mixed_precision(True)
+        out = []
+        for p_, v_ in ((pos, val), (pos, val), (pos, val), (pos2, val2), (pos2, val2), (pos, val)):
+            f.clear_points()
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, p_, None, None, values=v_)
+            f.assemble()
+            x, it, rel = f.solve_cg(None, 0, 1e-8)
+            assert f.stats()["converged"] == 1 and f.true_residual() <= 1.01e-8
+            out.append((it, f.stats()["coarse_iterations"], f.solution_f64().copy()))
+        runs[always] = out
+    monkeypatch.delenv("FI_LOOK_ALWAYS", raising=False)
+    # the watched and the unwatched runs agree bit for bit wherever the levels took the predicted counts (solves 2, 3 and 5)
+    for k in (0, 1, 2, 4):
+        assert runs[False][k][0] == runs[True][k][0]
+        np.testing.assert_array_equal(runs[False][k][2], runs[True][k][2])
+    # Right behind a change of the data a level gets the iterations its PREVIOUS data needed (solve 4: too few, a poorer
+    # start guess; solve 6: more than needed, harmless) -- the fine solve still meets its tolerance, within a quarter of the
+    # watched run's iterations, and the level watches its flag again from the next solve on (solve 5: the same bits).
+    for k in (3, 5):
+        assert abs(runs[False][k][0] - runs[True][k][0]) <= max(2, runs[True][k][0] // 4), (k, runs[False][k][0], runs[True][k][0])
+        scale = np.abs(runs[True][k][2]).max()
+        assert np.abs(runs[False][k][2] - runs[True][k][2]).max() <= 1e-6 * scale
+
