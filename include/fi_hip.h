@@ -190,7 +190,10 @@ int fi_add_rows_coo(fi_ctx* ctx, long nrows, long ntriplets, const fi_triplet* t
                     int memory);
 
 /* Replaces as_sparse_matrix_float + make_square + A^T*b (sparse_linear.cpp:59-70,105-113,120): bins the
- * data rows by lattice cell, accumulates the per-cell A^T A blocks, A^T b and diag(A^T A) on the GPU. */
+ * data rows by lattice cell, accumulates the per-cell A^T A blocks, A^T b and diag(A^T A) on the GPU.
+ * Returns when everything is ENQUEUED on the context's stream (sizes the host needs have been read back on the way): the
+ * next call on the context -- normally fi_solve_cg -- queues behind it.  fi_stats.assemble_ms is the time between two events
+ * around the call's device work; fi_get_stats waits for the second one. */
 int fi_assemble(fi_ctx* ctx);
 
 /* Drops all data rows (model weights are kept). */
