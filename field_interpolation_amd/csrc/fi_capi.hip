@@ -1,6 +1,7 @@
 // fi_capi.hip -- the C ABI of include/fi_hip.h (every entry point cites the reference interface it replaces there): contexts,
 // model, points, assemble, the solver entry points and their options, statistics.  Nothing throws or aborts across it.
 #include "fi_solver_internal.h"
+#include "fi_workers.h"
 
 namespace fi {
 
@@ -557,10 +558,17 @@ int fi_assemble(fi_ctx* c)
 		auto build2 = [&]() {
 			guarded([&]() { fi::build_levels(c->twin, c, c->level_stream2); }, &helper2_code, &helper2_msg);
 		};
-		std::thread helper, helper2;
+		// (persistent threads: fi_workers.h)
+		fi::Worker *helper = nullptr, *helper2 = nullptr;
 		try {
-			if (!lumped) { helper = std::thread(build); }
-			if (mixed64) { helper2 = std::thread(build2); }
+			if (!lumped) {
+				helper = fi::worker_pool().acquire();
+				helper->run(build);
+			}
+			if (mixed64) {
+				helper2 = fi::worker_pool().acquire();
+				helper2->run(build2);
+			}
 		} catch (...) {  // no thread to be had: the levels are built below, after the finest level, on their stream
 		}
 		int main_code = FI_OK;
@@ -590,9 +598,19 @@ int fi_assemble(fi_ctx* c)
 				fi::set_error("unexpected exception while building the lumped replica");
 			}
 		}
-		if (helper.joinable()) { helper.join(); } else if (main_code == FI_OK && !lumped) { build(); }
+		if (helper) {
+			helper->wait();
+			fi::worker_pool().release(helper);
+		} else if (main_code == FI_OK && !lumped) {
+			build();
+		}
 		if (mixed64) {
-			if (helper2.joinable()) { helper2.join(); } else if (main_code == FI_OK) { build2(); }
+			if (helper2) {
+				helper2->wait();
+				fi::worker_pool().release(helper2);
+			} else if (main_code == FI_OK) {
+				build2();
+			}
 			if (helper_code == FI_OK && helper2_code != FI_OK) {
 				helper_code = helper2_code;
 				helper_msg  = helper2_msg;

@@ -2,6 +2,7 @@
 // (its own cells, or the lumped operator).  Reference role: the coarse lattice of src/sdf_field.cpp:272-288 and the weight
 // rescaling rules of field_interpolation.hpp:67-73.
 #include "fi_solver_internal.h"
+#include "fi_workers.h"
 
 namespace fi {
 
@@ -220,7 +221,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		FI_HIP_TRY(hipEventCreateWithFlags(&go_holder.e, hipEventDisableTiming));
 		const hipEvent_t go = go_holder.e;
 		FI_HIP_TRY(hipEventRecord(go, build_stream));  // (behind the caller's wait for the point batches)
-		std::vector<std::thread> workers;
+		std::vector<Worker*> workers;  // (persistent threads: fi_workers.h)
 		std::vector<int>         codes(built.size(), FI_OK);
 		std::vector<std::string> msgs(built.size());
 		for (size_t i = 1; i < built.size(); ++i) {
@@ -245,16 +246,24 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 			}
 		};
 		for (size_t i = 1; i < built.size(); ++i) {
+			Worker* w = nullptr;
 			try {
-				workers.emplace_back(guarded, i);
+				w = worker_pool().acquire();
+				w->run([&guarded, i]() { guarded(i); });
 			} catch (...) {  // no thread to be had: this one on the caller's thread, behind the first level
-				workers.emplace_back();
+				w = nullptr;
 			}
+			workers.push_back(w);
 		}
 		guarded(0);
 		for (size_t i = 1; i < built.size(); ++i) {
-			std::thread& t = workers[i - 1];
-			if (t.joinable()) { t.join(); } else { guarded(i); }
+			Worker* w = workers[i - 1];
+			if (w) {
+				w->wait();
+				worker_pool().release(w);
+			} else {
+				guarded(i);
+			}
 		}
 		// the caller orders `build_stream` against the solver stream: the other chains end in it
 		for (size_t i = 1; i < built.size(); ++i) {
