@@ -330,7 +330,8 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
                                                             T* __restrict__ cell_dr, uint32_t* __restrict__ nrow,
                                                             T* __restrict__ row1, T* __restrict__ mrow,
                                                             uint32_t* __restrict__ nfac, uint32_t* __restrict__ heavy,
-                                                            uint32_t pack_min)
+                                                            uint32_t pack_min, const uint32_t* __restrict__ uniq,
+                                                            uint32_t* __restrict__ cell_id)
 {
 	constexpr int NC = 1 << D;
 	constexpr int NB = NC * (NC + 1) / 2;
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks(long ncell, const uin
 	uint32_t s = 0, m = 0;
 	bool     mine = false;
 	if (c < ncell) {
+		cell_id[c] = uniq[c];
 		s = start[c];
 		m = count[c];
 		if (m > kHeavyRows) {  // coarse levels put 10^4..10^6 rows into one cell: not a job for one thread
@@ -425,7 +427,8 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks3(long ncell, const ui
                                                              T* __restrict__ blk, T* __restrict__ cell_dr,
                                                              uint32_t* __restrict__ nrow, T* __restrict__ row1,
                                                              T* __restrict__ mrow, uint32_t* __restrict__ nfac,
-                                                             uint32_t* __restrict__ heavy, uint32_t pack_min, int write_blk)
+                                                             uint32_t* __restrict__ heavy, uint32_t pack_min, int write_blk,
+                                                             const uint32_t* __restrict__ uniq, uint32_t* __restrict__ cell_id)
 {
 	constexpr int NC = 8, NB = 36;
 	const long t = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
@@ -469,7 +472,10 @@ __global__ __launch_bounds__(kThreads) void k_build_blocks3(long ncell, const ui
 	cell_dr[c * kRec * NC + NC + j]     = static_cast<T>(dj);
 	cell_dr[c * kRec * NC + 2 * NC + j] = static_cast<T>(sum);
 	row1[c * NC + j] = first;
-	if (j == 0) { nrow[c] = m; }
+	if (j == 0) {
+		nrow[c]    = m;
+		cell_id[c] = uniq[c];
+	}
 	if (!mine) { return; }
 	// factor rows for the fused kernel (finish_cell)
 	uint32_t k = 0;
@@ -680,25 +686,11 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, 
 
 // ---- the same sums for 3-D lattices, by TILES of lattice points in LDS ------------------------------------------------
 // One workgroup owns 64 x 4 x 2 owned points: it collects the cells that touch them (the cells are sorted by extended id,
-// x fastest: k_row_bounds gives the range of every (y, z) row of cells, a tile looks at 5 x 3 rows), orders them by the
+// x fastest: k_xtile_bounds gives the range of the tile's x in every (y, z) row of cells, a tile looks at 5 x 3 rows), orders them by the
 // parity colour of their origin, adds their records to the tile's accumulators colour after colour -- within a colour no
 // two cells share a corner -- and stores the tile with full lines.  The same sums in the same order as the 2^D colour
 // launches and the gather launch: the same bits.  No cell map, no zeroing of the arrays, and the time follows the occupied
 // cells, not the look-ups (256^3 fp64, 6 % of the cells occupied: gather 310 us + map 45 us + zeroing 42 us -> ... us).
-__global__ __launch_bounds__(kThreads) void k_row_bounds(int64_t nrows, uint32_t row_len, long ncell,
-                                                          const uint32_t* __restrict__ cell_id, uint32_t* __restrict__ bound)
-{
-	const int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-	if (r > nrows) { return; }
-	const uint64_t key = static_cast<uint64_t>(r) * row_len;  // first index with cell_id >= key
-	long lo = 0, hi = ncell;
-	while (lo < hi) {
-		const long mid = (lo + hi) >> 1;
-		if (static_cast<uint64_t>(cell_id[mid]) < key) { lo = mid + 1; } else { hi = mid; }
-	}
-	bound[r] = static_cast<uint32_t>(lo);
-}
-
 constexpr int kTileX = 64, kTileY = 4, kTileZ = 2;
 
 // xt[(row * (ntx + 1) + t) * 2 + which]: first cell of row `row` whose x origin is >= first + 64 t - 1 + which, `first` the
@@ -978,8 +970,9 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells(Geom g, long ncell, c
 
 // {number of runs, key of the last run, length of the last run}
 __global__ void k_rle_tail(const uint32_t* __restrict__ nruns, const uint32_t* __restrict__ uniq,
-                           const uint32_t* __restrict__ counts, uint32_t* __restrict__ out)
+                           const uint32_t* __restrict__ counts, uint32_t* __restrict__ out, uint32_t* __restrict__ heavy_count)
 {
+	*heavy_count = 0u;  // (the list of many-row cells k_build_blocks* fill: one fill less per level)
 	const uint32_t n = nruns[0];
 	out[0] = n;
 	out[1] = n ? uniq[n - 1] : 0u;
@@ -1130,8 +1123,10 @@ void assemble_dim(fi_ctx* c)
 	// the run count and the last run (the invalid rows, if any) in ONE host round trip
 	DevBuf& tail3 = c->scratch[26];
 	tail3.alloc(sizeof(uint32_t) * 3);
+	DevBuf& heavy = c->scratch[28];  // cells with very many rows (coarse levels): listed by k_build_blocks*, summed by k_build_heavy
+	heavy.alloc(sizeof(uint32_t) * (static_cast<size_t>(total / kHeavyRows) + 2));
 	hipLaunchKernelGGL(k_rle_tail, dim3(1), dim3(1), 0, st, nruns.as<uint32_t>(), uniq.as<uint32_t>(), counts.as<uint32_t>(),
-	                   tail3.as<uint32_t>());
+	                   tail3.as<uint32_t>(), heavy.as<uint32_t>());
 	uint32_t* h_tail = static_cast<uint32_t*>(pinned(c, 0, 3 * sizeof(uint32_t)));
 	FI_HIP_TRY(hipMemcpyAsync(h_tail, tail3.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
@@ -1173,13 +1168,9 @@ void assemble_dim(fi_ctx* c)
 		c->cells.mrow.alloc(sizeof(T) * NC * NC * ncell);
 		c->cells.nfac.alloc(sizeof(uint32_t) * ncell);
 	}
-	FI_HIP_TRY(hipMemcpyAsync(c->cells.cell_id.p, uniq.p, sizeof(uint32_t) * ncell, hipMemcpyDeviceToDevice, st));
 	DevBuf& cell_dr = c->scratch[13];
 	cell_dr.alloc(sizeof(T) * kRec * NC * ncell);
-	// cells with very many rows (coarse levels) are listed by the first kernel and summed by workgroups in the second
-	DevBuf& heavy = c->scratch[11];
-	heavy.alloc(sizeof(uint32_t) * (static_cast<size_t>(total / kHeavyRows) + 2));
-	FI_HIP_TRY(hipMemsetAsync(heavy.p, 0, sizeof(uint32_t), st));
+	// (the cells' ids travel from the run-length encoding to CellData::cell_id inside k_build_blocks*: no copy of its own)
 	// The packed blocks themselves are what the kernels OUTSIDE the fused marching kernel read (the cell kernel of the
 	// untiled path and of fi_tile_pass, the 2-D tile kernel): a 3-D context the marching kernel will cover keeps only the
 	// factor rows and forms the blocks when somebody asks (ensure_cell_blocks) -- 280 MB of the 530 MB the fp64 level of
@@ -1190,13 +1181,14 @@ void assemble_dim(fi_ctx* c)
 		hipLaunchKernelGGL((k_build_blocks3<T>), dim3(blocks_for(ncell * 8)), dim3(kThreads), 0, st, ncell, starts.as<uint32_t>(),
 		                   counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs, c->cells.blk.as<T>(), cell_dr.as<T>(),
 		                   c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(), c->cells.mrow.as<T>(), c->cells.nfac.as<uint32_t>(),
-		                   heavy.as<uint32_t>(), pack_min, keep_blocks ? 1 : 0);
+		                   heavy.as<uint32_t>(), pack_min, keep_blocks ? 1 : 0, uniq.as<uint32_t>(), c->cells.cell_id.as<uint32_t>());
 	} else
 	hipLaunchKernelGGL((k_build_blocks<D, T>), dim3(blocks_for(ncell)), dim3(kThreads), 0, st, ncell,
 	                   starts.as<uint32_t>(), counts.as<uint32_t>(), row_sorted.as<uint32_t>(), coef, rhs,
 	                   c->cells.blk.as<T>(), cell_dr.as<T>(), c->cells.nrow.as<uint32_t>(), c->cells.row1.as<T>(),
 	                   D == 3 ? c->cells.mrow.as<T>() : static_cast<T*>(nullptr),
-	                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr), heavy.as<uint32_t>(), pack_min);
+	                   D == 3 ? c->cells.nfac.as<uint32_t>() : static_cast<uint32_t*>(nullptr), heavy.as<uint32_t>(), pack_min,
+	                   uniq.as<uint32_t>(), c->cells.cell_id.as<uint32_t>());
 	{
 		const long max_heavy = total / kHeavyRows + 1;
 		const int  grid = static_cast<int>(max_heavy < 2048 ? max_heavy : 2048);
@@ -1390,8 +1382,6 @@ int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val)
 	return nb;
 }
 
-// 3-D: where every (y, z) row of cells starts in the sorted cell ids: bound[lz * cn1 + ly], one more entry at the end.
-// Formed once per assembly, on the context's stream (the sums over the lattice points and the fused kernel's lists use it).
 namespace {
 // the packed block of a 3-D cell from what the assembly kept of it: its rows (<= 8: the sum of their outer products, the
 // very sums k_build_blocks3 forms), the packed block of a packed cell, or the Cholesky factor rows U of a many-row cell
@@ -1455,21 +1445,6 @@ void* pinned(fi_ctx* c, int slot, size_t bytes)
 	return c->pin[slot];
 }
 
-const uint32_t* cell_row_bounds(fi_ctx* c)
-{
-	const Geom& g = c->g;
-	DevBuf& rb = c->scratch[24];
-	if (!c->row_bounds_valid) {
-		const int64_t nrows = static_cast<int64_t>(g.cn[1]) * g.cn[2];
-		rb.alloc(sizeof(uint32_t) * (nrows + 1));
-		hipLaunchKernelGGL(k_row_bounds, dim3(blocks_for(nrows + 1)), dim3(kThreads), 0, c->stream, nrows, static_cast<uint32_t>(g.cn[0]),
-		                   static_cast<long>(c->cells.ncell), c->cells.cell_id.as<uint32_t>(), rb.as<uint32_t>());
-		FI_HIP_TRY(hipGetLastError());
-		c->row_bounds_valid = true;
-	}
-	return rb.as<uint32_t>();
-}
-
 void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, const float* pw, const float* val, float vw,
                      int vk, float gw, int gk, float pos_scale, float nrm_scale)
 {
@@ -1482,7 +1457,6 @@ void emit_point_rows(fi_ctx* c, long n, const float* pos, const float* nrm, cons
 
 void assemble(fi_ctx* c)
 {
-	c->row_bounds_valid = false;
 	const bool f64 = c->dtype == FI_F64;
 	switch (c->g.ndim) {
 	case 1: f64 ? assemble_dim<1, double>(c) : assemble_dim<1, float>(c); break;

@@ -333,7 +333,6 @@ struct fi_ctx {
 	// diagonal (fi_assembly.hip: a third entry of every cell's record) when fi_assemble sets want_lump
 	hipEvent_t ev_asm0 = nullptr, ev_asm1 = nullptr;  // around the last fi_assemble; read by finish_assemble_timing
 	bool       asm_time_pending = false;
-	bool       row_bounds_valid = false;  // scratch[24] holds cell_row_bounds() of the current cells
 	bool       want_lump = false;
 	fi::DevBuf lump;    // float[nloc]
 	bool       data_pinned = false;  // (levels of <= 2^16 points, set with dinv16s) every point's data diagonal reaches its model
@@ -504,7 +503,6 @@ void assemble(fi_ctx* c);
 void ensure_cell_blocks(fi_ctx* c);     // CellData::blk of every cell, on the context's stream (no-op when they are there)
 bool stencil_will_fuse(const fi_ctx* c);  // will stencil_prepare() put this context's cells into the marching kernel?
 void* pinned(fi_ctx* c, int slot, size_t bytes);  // the context's pinned staging buffer `slot`, at least `bytes` long (contents not kept when it grows)
-const uint32_t* cell_row_bounds(fi_ctx* c);  // 3-D, after assemble(): first sorted cell of every (y, z) row of cells
 // border prior (src/sdf_field.cpp:218-246): coordinates of the lattice's border points and their distance to the nearest
 // data point added so far, as device buffers; returns their number
 int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void k_cell_kinds(MarchParams P, Geom g, 
 
 // seg[(row * (tiles_x + 1) + t) * 2 + {0, 1}]: first cell of row `row` with x origin >= t * tx - 1 / >= t * tx (extended-local
 // rows: row = lz * cn1 + ly).  Tile t's cells in the row: [seg[.. t ..][0], seg[.. t + 1 ..][1]).
-__global__ __launch_bounds__(kThreads) void k_seg_bounds(MarchParams P, Geom g, int64_t nrows, const uint32_t* __restrict__ row_bound,
+__global__ __launch_bounds__(kThreads) void k_seg_bounds(MarchParams P, Geom g, int64_t nrows, int64_t ncell,
                                                           const uint32_t* __restrict__ cell_id, uint32_t* __restrict__ seg)
 {
 	const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
@@ -193,22 +193,19 @@ __global__ __launch_bounds__(kThreads) void k_seg_bounds(MarchParams P, Geom g, 
 	if (i >= nrows * per) { return; }
 	const int64_t row = i / per;
 	const int     t   = static_cast<int>(i % per);
-	const uint32_t key0 = static_cast<uint32_t>(row) * static_cast<uint32_t>(g.cn[0]);
-	const uint32_t a = row_bound[row], b = row_bound[row + 1];
+	// (binary searches over ALL the sorted cells, ~20 steps: a table of the rows' bounds first would be a launch more)
 #pragma unroll
 	for (int which = 0; which < 2; ++which) {
 		int lx = t * P.tx - 1 + which - g.coff[0];  // first extended-local x of interest
 		if (lx < 0) { lx = 0; }
-		uint32_t lo = a, hi = b;
-		if (lx >= g.cn[0]) {
-			lo = b;
-		} else {
-			while (lo < hi) {
-				const uint32_t mid = (lo + hi) >> 1;
-				if (cell_id[mid] < key0 + static_cast<uint32_t>(lx)) { lo = mid + 1; } else { hi = mid; }
-			}
+		if (lx > g.cn[0]) { lx = g.cn[0]; }    // (= the first cell of the next row)
+		const uint64_t key = static_cast<uint64_t>(row) * static_cast<uint64_t>(g.cn[0]) + static_cast<uint64_t>(lx);
+		int64_t lo = 0, hi = ncell;
+		while (lo < hi) {
+			const int64_t mid = (lo + hi) >> 1;
+			if (static_cast<uint64_t>(cell_id[mid]) < key) { lo = mid + 1; } else { hi = mid; }
 		}
-		seg[i * 2 + which] = lo;
+		seg[i * 2 + which] = static_cast<uint32_t>(lo);
 	}
 }
 
@@ -548,7 +545,6 @@ void build_cell_lists(fi_ctx* c)
 		// ---- lists as ranges of the sorted cells (no sort) ----
 		DevBuf &uniq = c->scratch[14], &counts_d = c->scratch[15], &first_d = c->scratch[16], &kinds = c->scratch[17],
 		       &pre = c->scratch[18], &seg = c->scratch[19], &tmp = c->scratch[20];
-		const uint32_t* row_bound = cell_row_bounds(c);
 		const int64_t nrows = static_cast<int64_t>(c->g.cn[1]) * c->g.cn[2];
 		const int64_t nseg  = nrows * (P.tiles_x + 1);
 		uniq.alloc(sizeof(uint32_t) * kCountWords);
@@ -567,7 +563,7 @@ void build_cell_lists(fi_ctx* c)
 		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb0, kinds.as<unsigned long long>(), pre.as<unsigned long long>(),
 		                                            static_cast<int>(ncell + 1), st));
 		hipLaunchKernelGGL(k_seg_bounds, dim3(static_cast<int>((nseg + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, c->g, nrows,
-		                   row_bound, c->cells.cell_id.as<uint32_t>(), seg.as<uint32_t>());
+		                   ncell, c->cells.cell_id.as<uint32_t>(), seg.as<uint32_t>());
 		const int nbb = static_cast<int>((nbuckets + 1 + kThreads - 1) / kThreads);
 		hipLaunchKernelGGL(k_list_count, dim3(nbb), dim3(kThreads), 0, st, P, c->g, nbuckets, seg.as<uint32_t>(),
 		                   pre.as<unsigned long long>(), counts_d.as<uint32_t>());
