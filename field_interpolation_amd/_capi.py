@@ -48,7 +48,8 @@ class FiStats(C.Structure):
                 ("restarts", C.c_int), ("verified_residual", C.c_double),
                 ("num_levels", C.c_int), ("coarse_iterations", C.c_int),
                 ("prec_ms_avg", C.c_double), ("prec_samples", C.c_int), ("prec_bytes", C.c_double),
-                ("operator_applies", C.c_int), ("halo_exchanges", C.c_int), ("reductions", C.c_int)]
+                ("operator_applies", C.c_int), ("halo_exchanges", C.c_int), ("reductions", C.c_int),
+                ("coarse_unconverged", C.c_int)]
 
 
 class FiError(RuntimeError):

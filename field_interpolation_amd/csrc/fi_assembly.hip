@@ -1387,8 +1387,8 @@ namespace {
 // very sums k_build_blocks3 forms), the packed block of a packed cell, or the Cholesky factor rows U of a many-row cell
 // of an fp32 context (U^T U = the block to fp32 rounding)
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_blocks_from_factors(long ncell, const uint32_t* __restrict__ nfac, const T* __restrict__ row1,
-                                                                   const T* __restrict__ mrow, T* __restrict__ blk)
+__global__ __launch_bounds__(kThreads) void k_blocks_from_factors(long ncell, const uint32_t* __restrict__ nfac, const uint32_t* __restrict__ nrow,
+                                                                   const T* __restrict__ row1, const T* __restrict__ mrow, T* __restrict__ blk)
 {
 	constexpr int NC = 8, NB = 36;
 	const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
@@ -1398,10 +1398,14 @@ __global__ __launch_bounds__(kThreads) void k_blocks_from_factors(long ncell, co
 		for (int e = 0; e < NB; ++e) { blk[c * NB + e] = mrow[c * NC * NC + e]; }
 		return;
 	}
+	// A cell of exactly ONE data row keeps no factor row of its own: the row itself is row1.  (nfac == 1 does not say that: the
+	// Cholesky factor of a many-row cell whose block has rank one -- more than 8 nearest-neighbour rows on one corner,
+	// duplicated points -- is ONE row of mrow, and row1 is then only the first of the data rows.)
+	const bool single = nrow[c] == 1u;
 	double B[NB];
 	for (int e = 0; e < NB; ++e) { B[e] = 0.0; }
 	for (uint32_t r = 0; r < k; ++r) {
-		const T* f = (k == 1u) ? row1 + c * NC : mrow + (c * NC + r) * NC;
+		const T* f = single ? row1 + c * NC : mrow + (c * NC + r) * NC;
 		double a[NC];
 		for (int q = 0; q < NC; ++q) { a[q] = static_cast<double>(f[q]); }
 		int e = 0;
@@ -1420,10 +1424,10 @@ void ensure_cell_blocks(fi_ctx* c)
 	const long n = static_cast<long>(c->cells.ncell);
 	if (c->dtype == FI_F64) {
 		hipLaunchKernelGGL((k_blocks_from_factors<double>), dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, n, c->cells.nfac.as<uint32_t>(),
-		                   c->cells.row1.as<double>(), c->cells.mrow.as<double>(), c->cells.blk.as<double>());
+		                   c->cells.nrow.as<uint32_t>(), c->cells.row1.as<double>(), c->cells.mrow.as<double>(), c->cells.blk.as<double>());
 	} else {
 		hipLaunchKernelGGL((k_blocks_from_factors<float>), dim3(blocks_for(n)), dim3(kThreads), 0, c->stream, n, c->cells.nfac.as<uint32_t>(),
-		                   c->cells.row1.as<float>(), c->cells.mrow.as<float>(), c->cells.blk.as<float>());
+		                   c->cells.nrow.as<uint32_t>(), c->cells.row1.as<float>(), c->cells.mrow.as<float>(), c->cells.blk.as<float>());
 	}
 	FI_HIP_TRY(hipGetLastError());
 	c->cells.blk_valid = true;

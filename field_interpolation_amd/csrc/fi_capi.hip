@@ -471,6 +471,7 @@ int fi_assemble(fi_ctx* c)
 		}
 		c->any_trip        = trip;
 		c->value_rows_only = !grad && !trip;
+		c->facts_forced    = false;  // (the group's verdict is for THIS assemble: a later fi_assemble of a member looks again)
 	}
 	const int reach = fi::model_reach(c->w);
 	const int want_reach = reach > 1 ? reach : 1;
@@ -852,6 +853,20 @@ int fi_get_stats(const fi_ctx* c, fi_stats* out)
 	FI_REQUIRE(out != nullptr, FI_ERR_INVALID, "null output");
 	fi::finish_assemble_timing(const_cast<fi_ctx*>(c));
 	*out = c->stats;
+	// Levels of the coarse-to-fine start that were solved without a look at their stop flag (cg_run, `unwatched`) reported
+	// the PREDICTED iteration count; the flag's copy has reached pinned memory since (the finest level's solve ended with a
+	// synchronisation behind it): the caller gets what the levels really did, and `coarse_unconverged` says how many of
+	// them had not met their tolerance after the predicted steps (their start guess was that much poorer, nothing else).
+	out->coarse_unconverged = 0;
+	const fi_ctx* top = c->twin && c->twin->coarse ? c->twin : c;
+	for (const fi_ctx* l = top->coarse; l; l = l->coarse) {
+		if (!l->unwatched_pending || !l->ev_unwatched || !l->pin[2]) { continue; }
+		if (hipEventSynchronize(l->ev_unwatched) != hipSuccess) { continue; }
+		const fi::CgScalars* was = static_cast<const fi::CgScalars*>(l->pin[2]);
+		const bool met = was->done == 1 || was->done == 5 || was->done == 4;
+		if (!met) { out->coarse_unconverged += 1; }
+		out->coarse_iterations += (met ? was->iter : l->unwatched_expected) - l->unwatched_expected;
+	}
 	FI_API_END
 }
 

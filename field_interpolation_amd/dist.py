@@ -40,10 +40,12 @@ def point_range(lo, hi, levels=0):
 
 
 def has_replicated_tail(sizes, nranks, levels, reach=2):
-    """plan_levels of the library (fi_solver.hip): does a hierarchy of `levels` coarser levels over `nranks` slabs end in
+    """plan_levels of the library (fi_levels.hip): does a hierarchy of `levels` coarser levels over `nranks` slabs end in
     REPLICATED levels (whole lattices on every rank, once a level's slabs would be thinner than max(reach, 4) planes)?
-    Such levels are assembled from ALL the points: fi_slab_point_range then returns everything."""
-    if nranks <= 1 or levels <= 0:
+    Such levels are assembled from ALL the points: fi_slab_point_range then returns everything.  (The library's test switch
+    FI_NO_REPLICATED_TAIL cuts the hierarchy instead: honoured here too.)"""
+    import os
+    if nranks <= 1 or levels <= 0 or os.environ.get("FI_NO_REPLICATED_TAIL"):
         return False
     n = [int(s) for s in sizes]
     planes = n[-1]

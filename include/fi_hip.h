@@ -94,13 +94,18 @@ typedef struct fi_stats {
 	int    restarts;           /* residual replacements: b - A x was evaluated this many times at convergence */
 	double verified_residual;  /* ||b - A x||/||b|| at the last such evaluation (-1: none) */
 	int    num_levels;         /* 1 + coarser levels built by the last fi_assemble */
-	int    coarse_iterations;  /* CG iterations spent on coarser levels by the last solve (cascade start) */
+	int    coarse_iterations;  /* CG iterations spent on coarser levels by the last solve (cascade start); a level solved without
+	                              a look at its stop flag (same problem shape and tolerance as the solve before) counts what its
+	                              flag said afterwards */
 	double prec_ms_avg;        /* mean duration of the sampled Chebyshev-step launches of the polynomial preconditioner */
 	int    prec_samples;
 	double prec_bytes;         /* mean algorithmic bytes of the sampled launches (every step of the sampled polynomials: 2.5 / 3.5 / 4.5 lattice passes) */
 	int    operator_applies;   /* full operator applications + preconditioner steps of the last solve (finest level) */
 	int    halo_exchanges;     /* slabs: halo exchanges of the finest level during the last solve (polynomial PCG) */
 	int    reductions;         /* slabs: dot-product reductions across the ranks during the last solve (polynomial PCG) */
+	int    coarse_unconverged; /* levels of the coarse-to-fine start that had NOT met their tolerance after the iterations their
+	                              previous solve had needed (no look at the flag in between): the finest level then started from a
+	                              poorer guess and still converged to ITS tolerance; those levels watch their flag again next time */
 } fi_stats;
 
 const char* fi_last_error(void);

@@ -48,16 +48,17 @@ def main():
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--side4", type=int, default=256)
+    ap.add_argument("--seeds4", default="3", help="synth.config4 seeds (3: bench.py's; others are stored as config4_<side>_seed<S>_oracle_f64.npz)")
     ap.add_argument("--side5", type=int, default=128)
     ap.add_argument("--stride", type=int, default=8)
     ap.add_argument("--max-it", type=int, default=200000)
     args = ap.parse_args()
     which = [int(w) for w in args.which.split(",")]
 
-    if 4 in which:
+    for seed4 in ([int(s) for s in args.seeds4.split(",")] if 4 in which else []):
         side = args.side4
         npts = int(round(1_000_000 * (side / 256.0) ** 3))
-        sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=3)
+        sizes, w, pos, val = synth.config4(side=side, num_points=npts, seed=seed4)
         t0 = time.perf_counter()
         f = fo.LatticeField(sizes)
         f.add_field_constraints(fo.Weights(model_2=w.model_2))
@@ -70,9 +71,10 @@ def main():
         tr = float(np.linalg.norm(atb - f.apply_normal(x)) / np.linalg.norm(atb))
         print("  true residual through A^T(A x): %.3e" % tr, flush=True)
         assert tr <= 2 * args.tol
-        store("config4_%d_oracle_f64.npz" % side, sizes, x, args.stride,
-              dict(iterations=np.int32(it), true_rel_residual=np.float64(tr), num_points=np.int32(npts), seed=np.int32(3),
-                   what="config 4 (synth.config4 seed 3), oracle fp64 Jacobi-PCG on the explicit AtA of the reference's rows"))
+        store(("config4_%d_oracle_f64.npz" % side) if seed4 == 3 else ("config4_%d_seed%d_oracle_f64.npz" % (side, seed4)), sizes, x,
+              args.stride,
+              dict(iterations=np.int32(it), true_rel_residual=np.float64(tr), num_points=np.int32(npts), seed=np.int32(seed4),
+                   what="config 4 (synth.config4 seed %d), oracle fp64 Jacobi-PCG on the explicit AtA of the reference's rows" % seed4))
         del f, x
     if 5 in which:
         side = args.side5

@@ -245,6 +245,31 @@ def test_tile_pass_equals_tile_solver(oracle, fi, dtype, sizes, ts, kw):
         fg.tile_pass(g, 1)                                     # CHECK_GE_F(tile_size, 2), sparse_linear.cpp:254
 
 
+def test_tile_pass_with_a_rank_one_cell_of_many_rows(oracle, fi, monkeypatch):
+    """a 3-D fp32 cell that holds MORE than 8 data rows whose block has rank one (20 nearest-neighbour value rows
+    on one corner) keeps ONE Cholesky factor row; the packed block the tile pre-solver asks for (ensure_cell_blocks on a
+    context whose marching kernel owns the cells) must be that row's outer product -- the sum over all 20 rows -- and not
+    the outer product of the first data row.  Sparse single-row cells around it keep the context on factor rows (no
+    packed blocks).  Compared with the blocks the assembly stores itself (FI_KEEP_BLOCKS) and with the oracle's tile solver."""
+    sizes = [24, 20, 16]
+    rng = np.random.default_rng(77)
+    octant = (np.array([7.0, 9.0, 5.0]) + rng.uniform(0.02, 0.45, size=(20, 3))).astype(np.float32)   # all round to (7, 9, 5)
+    singles = np.stack([rng.uniform(0.5, s - 1.5, 300) for s in sizes], 1).astype(np.float32)
+    pos = np.concatenate([octant, singles])
+    nrm = rng.normal(size=pos.shape).astype(np.float32)
+    val = rng.normal(size=len(pos)).astype(np.float32)
+    w = fi.Weights(value_kernel=fi.ValueKernel(0), data_gradient=0.0)
+    g = rng.normal(size=int(np.prod(sizes))).astype(np.float32)
+    fo, fg = build_pair(oracle, fi, sizes, w, pos, nrm, None, val, dtype="f32")
+    x = fg.tile_pass(g, 8)
+    monkeypatch.setenv("FI_KEEP_BLOCKS", "1")
+    _, fk = build_pair(oracle, fi, sizes, w, pos, nrm, None, val, dtype="f32")
+    xk = fk.tile_pass(g, 8)
+    assert np.abs(x - xk).max() <= 2e-5 * np.abs(xk).max()
+    xo, _, _ = fo.solve_tiled_with_guess(g, sizes, oracle.SolveOptions(tile=1, tile_size=8, cg=0))
+    assert np.abs(x - xo).max() <= 5e-3 * np.abs(xo).max()
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("sizes,kw,gk", [([40], dict(), 1), ([17, 12], dict(model_1=0.3), 1),
                                         ([9, 8, 7], dict(model_0=0.2, model_3=0.4, gradient_smoothness=0.3), 0),
