@@ -644,24 +644,28 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 
 // ---- the V-cycle of the hierarchy's tail as a program of the small-level engine (fi_tail.h) ----------------------------
 // The same cycle as vcycle() below -- the same smoothers with the same constants, the same transfers -- written out as the
-// stages of ONE cooperative launch.  Vectors: rhs b and result x as the caller names them on the top level, mg_b / mg_x
-// below; work vectors mg_r (residual), mg_d and q (the polynomials' iterates: x itself is only ever the final target of a
-// stage, never an intermediate, so the program's pointers stay valid from cycle to cycle).
+// stages of ONE launch of one workgroup.  Every tail level has five vectors in LDS (fi_tail.h): B (right-hand side), X
+// (result), R (residual), W0, W1 (the polynomials' iterates); the top level's B is filled from the caller's vector when the
+// kernel starts, its X goes back to the caller's when it ends -- the program holds no pointer to a vector, so it stays valid
+// from cycle to cycle and from solve to solve (until the levels are re-assembled or a smoother's interval is widened).
 template <typename T>
 bool poly_smoother_ok(const RankSet& R);
 
 struct TailProgram {
+	enum { B = 0, X = 1, Rr = 2, W0 = 3, W1 = 4 };
 	std::vector<TailOp> ops;
 	std::vector<fi_ctx*> chain;
+	std::vector<int> base, nn;
 	bool ok = true;
 
-	void op(int kind, int level, const float* a, const float* b, const float* c, float* out, float* acc, const unsigned short* scale,
-	        double s0 = 0, double s1 = 0, double s2 = 0)
+	int vec(int l, int v) const { return base[l] + v * nn[l]; }
+	void op(int kind, int level, int a, int b, int c, int out, int acc, const unsigned short* scale, double s0 = 0, double s1 = 0, double s2 = 0)
 	{
-		ops.push_back(TailOp{kind, level, a, b, c, out, acc, scale, static_cast<float>(s0), static_cast<float>(s1), static_cast<float>(s2), 0});
+		ops.push_back(TailOp{kind, level, a, b, c, out, acc, 0, scale, static_cast<float>(s0), static_cast<float>(s1), static_cast<float>(s2), 0});
 	}
-	// target (+)= M r: the polynomial in A_model + f diag(A_data) (poly_chain); out: target of the last step, acc: accumulate
-	void poly_ops(int l, const float* r, float* out, float* acc)
+	// target (+)= M r: the polynomial in A_model + f diag(A_data) (poly_chain); r: vector id of the level; out: target of the last
+	// step (-1: none), acc: accumulate into (-1: none)
+	void poly_ops(int l, int r, int out, int acc)
 	{
 		fi_ctx* c = chain[l];
 		const int    terms = mg_poly_terms(c);
@@ -669,38 +673,39 @@ struct TailProgram {
 		const double hi = 1.1 * lam, lo = hi / mg_poly_ratio(c);
 		const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
 		const unsigned short* sc = c->dinv16s.as<unsigned short>();
-		float* W[2] = {c->mg_d.as<float>(), c->q.as<float>()};
-		if (terms < 2) { ok = false; return; }
-		op(kTailScale, l, r, nullptr, nullptr, W[0], nullptr, sc, 1.0 / theta);
+		const int W[2] = {vec(l, W0), vec(l, W1)};
+		if (terms < 2 || !c->dinv16s_valid) { ok = false; return; }
+		op(kTailScale, l, vec(l, r), -1, -1, W[0], -1, sc, 1.0 / theta);
 		int cur = 0;
 		double rho = 1.0 / sigma;
 		for (int k = 1; k < terms; ++k) {
 			const double rho_new = 1.0 / (2.0 * sigma - rho);
 			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
 			const bool   last = k == terms - 1;
-			op(kTailPolyStep, l, W[cur], k == 1 ? nullptr : W[1 - cur], r, last ? out : W[1 - cur], last ? acc : nullptr, sc, 1.0 + c1,
-			   k == 1 ? 0.0 : c1, c2);
+			op(kTailPolyStep, l, W[cur], k == 1 ? -1 : W[1 - cur], vec(l, r), last ? (out >= 0 ? vec(l, out) : -1) : W[1 - cur],
+			   last && acc >= 0 ? vec(l, acc) : -1, sc, 1.0 + c1, k == 1 ? 0.0 : c1, c2);
 			cur = 1 - cur;
 			rho = rho_new;
 		}
 	}
-	// degree-k Chebyshev smoothing in the full operator (cheb_smooth_fused): x starts at zero / at its present value
-	void cheb_ops(int l, const float* b, float* x, int degree, double ratio, bool from_zero)
+	// degree-k Chebyshev smoothing in the full operator (cheb_smooth_fused): X starts at zero / at its present value
+	void cheb_ops(int l, int degree, double ratio, bool from_zero)
 	{
 		fi_ctx* c = chain[l];
 		const double hi = 1.1 * c->lambda_max, lo = hi / ratio;
 		const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
 		const unsigned short* sc = c->dinv16.as<unsigned short>();
-		float* W[2] = {c->mg_d.as<float>(), c->mg_r.as<float>()};
+		const int b = vec(l, B), x = vec(l, X);
+		const int W[3] = {vec(l, W0), vec(l, W1), vec(l, Rr)};   // (the residual vector is free while a smoother runs)
 		if (degree < 2 || !(c->lambda_max > 0)) { ok = false; return; }
-		const float* zk = nullptr;    // x_k
-		const float* zp = nullptr;    // x_{k-1} (null: zero, or no such term)
-		int steps = degree - 1;       // recurrence steps after the first term
+		int zk = -1;    // x_k
+		int zp = -1;    // x_{k-1} (-1: zero, or no such term)
+		const int steps = degree - 1;  // recurrence steps after the first term
 		if (from_zero) {
-			op(kTailScale, l, b, nullptr, nullptr, W[0], nullptr, sc, 1.0 / theta);   // x_1 = Dinv b / theta
+			op(kTailScale, l, b, -1, -1, W[0], -1, sc, 1.0 / theta);   // x_1 = Dinv b / theta
 			zk = W[0];
 		} else {
-			op(kTailChebStep, l, x, nullptr, b, W[0], nullptr, sc, 1.0, 0.0, 1.0 / theta);  // x_1 = x_0 + Dinv (b - A x_0) / theta
+			op(kTailChebStep, l, x, -1, b, W[0], -1, sc, 1.0, 0.0, 1.0 / theta);  // x_1 = x_0 + Dinv (b - A x_0) / theta
 			zk = W[0];
 			zp = x;
 		}
@@ -709,16 +714,24 @@ struct TailProgram {
 			const double rho_new = 1.0 / (2.0 * sigma - rho);
 			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
 			const bool   last = k == steps;
-			float* out = last ? x : (zk == W[0] ? W[1] : W[0]);   // (x_{k-1}'s buffer may be overwritten: it is read at the point itself only)
-			op(kTailChebStep, l, zk, zp, b, out, nullptr, sc, 1.0 + c1, zp ? c1 : 0.0, c2);
+			// a stage reads its input's NEIGHBOURS: the output is a vector that is neither x_k nor (read at the point only, but
+			// by other threads' stages not at all) x_{k-1}'s: three work vectors rotate, the last step lands in X
+			int out = x;
+			if (!last || zk == x) {
+				for (int w = 0; w < 3; ++w) {
+					if (W[w] != zk && W[w] != zp) { out = W[w]; break; }
+				}
+			}
+			op(kTailChebStep, l, zk, zp, b, out, -1, sc, 1.0 + c1, zp >= 0 ? c1 : 0.0, c2);
 			zp = zk;
 			zk = out;
 			rho = rho_new;
 		}
+		if (zk != x) { ok = false; }  // (cannot happen: the last step writes X unless X is its own input, and it never is)
 	}
-	void residual(int l, const float* x, const float* b, float* out) { op(kTailResidual, l, x, nullptr, b, out, nullptr, nullptr); }
+	void residual(int l) { op(kTailResidual, l, vec(l, X), -1, vec(l, B), vec(l, Rr), -1, nullptr); }
 
-	void cycle(int l, const float* b, float* x)
+	void cycle(int l)
 	{
 		fi_ctx* c = chain[l];
 		RankSet one{c};
@@ -726,33 +739,31 @@ struct TailProgram {
 		const bool poly = poly_smoother_ok<float>(one);
 		const int    deg = mg_degree();
 		const double ratio = mg_ratio();
-		float* r = c->mg_r.as<float>();
 		if (c->lumped) { ok = false; return; }
 		if (last) {
 			if (poly && c->dinv16s_valid && c->data_pinned && !test_switch("FI_MG_COARSEST_CHEB")) {
-				poly_ops(l, b, x, nullptr);
-				residual(l, x, b, r);
-				poly_ops(l, r, nullptr, x);
+				poly_ops(l, B, X, -1);
+				residual(l);
+				poly_ops(l, Rr, -1, X);
 			} else {
-				cheb_ops(l, b, x, 4 * deg + 4, 10.0 * ratio, true);
+				cheb_ops(l, 4 * deg + 4, 10.0 * ratio, true);
 			}
 			return;
 		}
-		fi_ctx* co = chain[l + 1];
 		if (poly) {
-			poly_ops(l, b, x, nullptr);
+			poly_ops(l, B, X, -1);
 		} else {
-			cheb_ops(l, b, x, deg, ratio, true);
+			cheb_ops(l, deg, ratio, true);
 		}
-		residual(l, x, b, r);
-		op(kTailRestrict, l, r, nullptr, nullptr, co->mg_b.as<float>(), nullptr, nullptr);
-		cycle(l + 1, co->mg_b.as<float>(), co->mg_x.as<float>());
-		op(kTailProlongAdd, l, co->mg_x.as<float>(), nullptr, nullptr, x, nullptr, nullptr);
+		residual(l);
+		op(kTailRestrict, l, vec(l, Rr), -1, -1, vec(l + 1, B), -1, nullptr);
+		cycle(l + 1);
+		op(kTailProlongAdd, l, vec(l + 1, X), -1, -1, vec(l, X), -1, nullptr);
 		if (poly) {
-			residual(l, x, b, r);
-			poly_ops(l, r, nullptr, x);
+			residual(l);
+			poly_ops(l, Rr, -1, X);
 		} else {
-			cheb_ops(l, b, x, deg, ratio, false);
+			cheb_ops(l, deg, ratio, false);
 		}
 	}
 };
@@ -764,23 +775,26 @@ bool tail_vcycle(RankSet& R, Vec b, Vec x)
 	if (sizeof(T) != 4 || R.size() != 1) { return false; }
 	fi_ctx* c = R[0];
 	if (c->level == 0 || !c->tail_ok || c->nranks != 1) { return false; }
-	const void* bp = (c->*b).p;
-	const void* xp = (c->*x).p;
-	if (!c->tail_prog_valid || c->tail_prog_b != bp || c->tail_prog_x != xp) {
+	if (!c->tail_prog_valid) {
 		TailProgram P;
-		for (fi_ctx* l = c; l; l = l->coarse) { P.chain.push_back(l); }
-		P.cycle(0, static_cast<const float*>(bp), static_cast<float*>(const_cast<void*>(xp)));
-		if (!P.ok || P.ops.empty()) {
+		int floats = 0;
+		for (fi_ctx* l = c; l; l = l->coarse) {
+			P.chain.push_back(l);
+			P.base.push_back(floats);
+			P.nn.push_back(static_cast<int>(l->g.nloc));
+			floats += kTailSlots * static_cast<int>(l->g.nloc);
+		}
+		P.cycle(0);
+		if (!P.ok || P.ops.empty() || static_cast<int>(P.chain.size()) > kTailMaxLevels || floats * sizeof(float) > 160u * 1024u) {
 			c->tail_ok = false;  // (a setting the engine does not cover: the tiled kernels run this hierarchy)
 			return false;
 		}
 		std::vector<unsigned char> blob(sizeof(TailLevel) * kTailMaxLevels + sizeof(TailOp) * P.ops.size());
 		TailLevel* lv = reinterpret_cast<TailLevel*>(blob.data());
-		int64_t widest = 0;
 		for (size_t k = 0; k < P.chain.size(); ++k) {
 			lv[k] = tail_level_of(P.chain[k]);
+			lv[k].base = P.base[k];
 			if (k + 1 < P.chain.size()) { lv[k].to_coarse = level_pair(P.chain[k], P.chain[k + 1]); }
-			widest = lv[k].nn > widest ? lv[k].nn : widest;
 		}
 		std::memcpy(blob.data() + sizeof(TailLevel) * kTailMaxLevels, P.ops.data(), sizeof(TailOp) * P.ops.size());
 		c->tail_prog.alloc(blob.size());
@@ -788,12 +802,10 @@ bool tail_vcycle(RankSet& R, Vec b, Vec x)
 		FI_HIP_TRY(hipStreamSynchronize(c->stream));  // (the host buffer dies here)
 		c->tail_nlev       = static_cast<int>(P.chain.size());
 		c->tail_nops       = static_cast<int>(P.ops.size());
-		c->tail_widest     = widest;
-		c->tail_prog_b     = bp;
-		c->tail_prog_x     = xp;
+		c->tail_widest     = floats;
 		c->tail_prog_valid = true;
 	}
-	tail_run(c, c->tail_prog.p, c->tail_nlev, c->tail_nops, c->tail_widest);
+	tail_run(c, c->tail_prog.p, c->tail_nlev, c->tail_nops, static_cast<int>(c->tail_widest), (c->*b).as<float>(), (c->*x).as<float>());
 	return true;
 }
 

@@ -1,20 +1,16 @@
-// fi_tail.hip -- the small-level engine (fi_tail.h): the coarse tail of a level hierarchy in one cooperative launch.
+// fi_tail.hip -- the small-level engine (fi_tail.h): the coarse tail of a level hierarchy in ONE launch of ONE workgroup.
 //
-// Why: a V-cycle visits every level of <= 64^3 / 512^2 unknowns with 15-25 launches that each finish in 4-7 us -- less than
-// the launch itself costs -- and config 3 (2-D 4096^2, seven coarser levels) spent 58 % of its GPU time in 18 820 such
-// launches per four steps (profiles/r3_kernel_stats_c3.md).  Here the stages of the cycle (smoother steps, residuals,
-// restriction, interpolation) of ALL tail levels run inside one kernel, separated by grid barriers (hipLaunchCooperative-
-// Kernel: every workgroup is resident, so the barrier cannot starve).
+// Why: a V-cycle visits every level of a few thousand unknowns with 15-25 launches that each finish in 4-7 us -- the kernel
+// boundary, not the work -- and configs 2 / 3 spend a fifth of their step in such launches (profiles/r4_by_grid_c{2,3}.md: 171
+// and 773 launches per step on the coarsest level alone).  Here the stages of the cycle (smoother steps, residuals,
+// restriction, interpolation) of ALL tail levels run inside one kernel of 1024 threads: five vectors per level in LDS, a
+// workgroup barrier behind every stage, the restricted residual read from and the correction written to global memory once.
 //
 // Operator of a level: the model rows (model_0 / model_1 / model_2, field_interpolation.cpp:257-280) matrix-free from the
 // global coordinates -- the same boundary rows as the tiled kernels -- and the data rows (cell blocks of fi_assembly.hip) as
-// 3^D diagonals (`dia`): out-of-lattice corners of a cell carry zero coefficients, so the diagonals need no masks.
-// Reference role: the small exact solves of tile_solver_square (sparse_linear.cpp:246-390).
-#include <hip/hip_cooperative_groups.h>
-
+// 3^D diagonals (`dia`, global memory): out-of-lattice corners of a cell carry zero coefficients, so the diagonals need no
+// masks.  Reference role: the small exact solves of tile_solver_square (sparse_linear.cpp:246-390).
 #include "fi_tail.h"
-
-namespace cg = cooperative_groups;
 
 namespace fi {
 
@@ -47,135 +43,199 @@ __device__ inline void axis_coefs(int c, int n, float w0sq, float w1sq, float w2
 	k[4] = e2;
 }
 
+__device__ inline int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// coordinates of a point, packed by the kernel's prologue into the level's sixth LDS vector: x | y << 12 | z << 24
+// (extents: 2-D <= 512, 3-D <= 64 -- a level has at most 4096 points and no extent below 8)
 template <int D>
-__device__ inline void coords_of(const TailLevel& L, int i, int* c)
+__device__ inline void unpack_coords(int pc, int* c)
 {
-	c[0] = i % L.n[0];
-	int t = i / L.n[0];
-	if (D > 1) {
-		c[1] = t % L.n[1];
-		t /= L.n[1];
-	}
-	if (D > 2) { c[2] = t; }
+	c[0] = pc & 0xFFF;
+	if (D > 1) { c[1] = (pc >> 12) & 0xFFF; }
+	if (D > 2) { c[2] = (pc >> 24) & 0xFF; }
 }
 
-__device__ inline int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+// The values of `v` (a vector of the level, LDS offset `off`) the operator reads around point i: the 3^D box (data rows;
+// its axis neighbours serve the model rows too) and the four-D points two steps away along the axes.  Indices are clamped
+// into the vector: a clamped value only ever meets a zero coefficient.
+template <int D>
+struct Around {
+	float box[D == 2 ? 9 : 27];
+	float far[2 * D];
+};
+// every vector of the tail: ONE dynamic LDS array, named at file scope so that every access below is an LDS access by type
+// (through a `float*` parameter the address space is only inferred, and was not everywhere: flat loads, scratch)
+extern __shared__ float fi_tail_lds[];
+#define FI_TAIL_LDS(off, idx) fi_tail_lds[(off) + (idx)]
+
+template <int D, bool BOX>
+__device__ inline void load_around(const TailLevel& L, int off, int i, Around<D>& A)
+{
+	const int n0 = L.n[0], n01 = L.n[0] * L.n[1], hi = L.nn - 1;
+	if (BOX) {
+#pragma unroll
+		for (int s = 0; s < (D == 2 ? 9 : 27); ++s) {
+			const int dx = s % 3 - 1, dy = (s / 3) % 3 - 1, dz = D > 2 ? s / 9 - 1 : 0;
+			A.box[s] = FI_TAIL_LDS(off, clampi(i + dx + dy * n0 + dz * n01, hi));
+		}
+	} else {  // the axis neighbours and the centre only
+		constexpr int ctr = D == 2 ? 4 : 13;
+		A.box[ctr]     = FI_TAIL_LDS(off, i);
+		A.box[ctr - 1] = FI_TAIL_LDS(off, clampi(i - 1, hi));
+		A.box[ctr + 1] = FI_TAIL_LDS(off, clampi(i + 1, hi));
+		A.box[ctr - 3] = FI_TAIL_LDS(off, clampi(i - n0, hi));
+		A.box[ctr + 3] = FI_TAIL_LDS(off, clampi(i + n0, hi));
+		if (D > 2) {
+			A.box[ctr - 9] = FI_TAIL_LDS(off, clampi(i - n01, hi));
+			A.box[ctr + 9] = FI_TAIL_LDS(off, clampi(i + n01, hi));
+		}
+	}
+	A.far[0] = FI_TAIL_LDS(off, clampi(i - 2, hi));
+	A.far[1] = FI_TAIL_LDS(off, clampi(i + 2, hi));
+	A.far[2] = FI_TAIL_LDS(off, clampi(i - 2 * n0, hi));
+	A.far[3] = FI_TAIL_LDS(off, clampi(i + 2 * n0, hi));
+	if (D > 2) {
+		A.far[4] = FI_TAIL_LDS(off, clampi(i - 2 * n01, hi));
+		A.far[5] = FI_TAIL_LDS(off, clampi(i + 2 * n01, hi));
+	}
+}
 
 // (A_model v)_i and the model diagonal of point i
 template <int D>
-__device__ inline float model_row(const TailLevel& L, int i, const int* c, const float* __restrict__ v, float* diag)
+__device__ inline float model_row(const TailLevel& L, const int* c, const Around<D>& A, float* diag)
 {
+	constexpr int ctr = D == 2 ? 4 : 13;
 	float acc = 0.0f, m = 0.0f;
-	int stride = 1;
 #pragma unroll
 	for (int d = 0; d < D; ++d) {
 		float k[5];
 		axis_coefs(c[d], L.n[d], L.w0sq, L.w1sq, L.w2sq, k);
+		const int st = d == 0 ? 1 : (d == 1 ? 3 : 9);  // the axis neighbour's place in the box
 		m += k[2];
-#pragma unroll
-		for (int t = 0; t < 5; ++t) {
-			// (a coefficient is non-zero only where the neighbour exists; the clamp keeps the other loads inside the array)
-			acc += k[t] * v[clampi(i + (t - 2) * stride, L.nn - 1)];
-		}
-		stride *= L.n[d];
+		acc += k[0] * A.far[2 * d] + k[1] * A.box[ctr - st] + k[2] * A.box[ctr] + k[3] * A.box[ctr + st] + k[4] * A.far[2 * d + 1];
 	}
 	*diag = m;
 	return acc;
 }
 
-// (A_data v)_i: the 3^D diagonals
+// (A_data v)_i: the 3^D diagonals (global memory, consecutive points in consecutive lanes)
 template <int D>
-__device__ inline float data_row(const TailLevel& L, int i, const float* __restrict__ v)
+__device__ inline float data_row(const TailLevel& L, int i, const Around<D>& A)
 {
-	if (!L.dia) { return 0.0f; }
 	float acc = 0.0f;
-	const int n0 = L.n[0], n01 = L.n[0] * (D > 1 ? L.n[1] : 1);
 #pragma unroll
-	for (int s = 0; s < ipow3(D); ++s) {
-		const int dx = s % 3 - 1, dy = D > 1 ? (s / 3) % 3 - 1 : 0, dz = D > 2 ? s / 9 - 1 : 0;
-		const int off = dx + dy * n0 + dz * n01;
-		acc += L.dia[static_cast<int64_t>(s) * L.nn + i] * v[clampi(i + off, L.nn - 1)];
-	}
+	for (int s = 0; s < (D == 2 ? 9 : 27); ++s) { acc += L.dia[s * L.nn + i] * A.box[s]; }
 	return acc;
 }
 
 template <int D>
-__device__ inline void stage(const TailLevel* __restrict__ levels, const TailOp& op, int tid, int nthreads)
+__device__ inline void stage(const TailLevel* __restrict__ levels, const TailOp& op, int tid)
 {
+	constexpr int nthreads = kTailThreads;
 	const TailLevel& L = levels[op.level];
+	const int ctab = L.base + kTailVectors * L.nn;
+	const bool data = L.dia != nullptr;
 	switch (op.kind) {
 	case kTailScale:
-		for (int i = tid; i < L.nn; i += nthreads) { op.out[i] = op.s0 * bf16(op.scale[i]) * op.a[i]; }
+		for (int i = tid; i < L.nn; i += nthreads) { FI_TAIL_LDS(op.out, i) = op.s0 * bf16(op.scale[i]) * FI_TAIL_LDS(op.a, i); }
 		break;
 	case kTailPolyStep:
 		for (int i = tid; i < L.nn; i += nthreads) {
 			int c[3];
-			coords_of<D>(L, i, c);
+			unpack_coords<D>(__float_as_int(FI_TAIL_LDS(ctab, i)), c);
+			Around<D> A;
+			load_around<D, false>(L, op.a, i, A);
 			float m;
-			const float q  = model_row<D>(L, i, c, op.a, &m);
-			const float z  = op.a[i], dv = bf16(op.scale[i]);
+			const float q  = model_row<D>(L, c, A, &m);
+			const float z  = A.box[D == 2 ? 4 : 13], dv = bf16(op.scale[i]);
 			const float sv = dv * (q - m * z) + z;
-			const float zp = op.b ? op.b[i] : 0.0f;
-			const float zn = op.s0 * z - op.s1 * zp + op.s2 * (dv * op.c[i] - sv);
-			if (op.out) { op.out[i] = zn; }
-			if (op.acc) { op.acc[i] += zn; }
+			const float zp = op.b >= 0 ? FI_TAIL_LDS(op.b, i) : 0.0f;
+			const float zn = op.s0 * z - op.s1 * zp + op.s2 * (dv * FI_TAIL_LDS(op.c, i) - sv);
+			if (op.out >= 0) { FI_TAIL_LDS(op.out, i) = zn; }
+			if (op.acc >= 0) { FI_TAIL_LDS(op.acc, i) += zn; }
 		}
 		break;
 	case kTailChebStep:
-		for (int i = tid; i < L.nn; i += nthreads) {
+	case kTailResidual: {
+		// A thread's points (at most kTailMaxPoints / kTailThreads = 4): the diagonals of ALL of them are requested from global
+		// memory before the first is used -- one point after the other the stage was a chain of cache round trips (5 us for 4096
+		// points: four trips of ~1 us per wave), not work
+		constexpr int PER = static_cast<int>(kTailMaxPoints) / kTailThreads;
+		constexpr int NS  = D == 2 ? 9 : 27;
+		float dia[PER][D == 2 ? 9 : 1];
+		float scl[PER];
+		if (D == 2 && data) {
+#pragma unroll
+			for (int k = 0; k < PER; ++k) {
+				const int i = tid + k * nthreads;
+				const int ii = i < L.nn ? i : L.nn - 1;
+#pragma unroll
+				for (int s2 = 0; s2 < NS; ++s2) { dia[k][s2 % (D == 2 ? 9 : 1)] = L.dia[s2 * L.nn + ii]; }
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const int i = tid + k * nthreads;
+			scl[k] = (op.kind == kTailChebStep && i < L.nn) ? bf16(op.scale[i]) : 0.0f;
+		}
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const int i = tid + k * nthreads;
+			if (i >= L.nn) { break; }
 			int c[3];
-			coords_of<D>(L, i, c);
-			float m;
-			const float q  = model_row<D>(L, i, c, op.a, &m) + data_row<D>(L, i, op.a);
-			const float xp = op.b ? op.b[i] : 0.0f;
-			op.out[i] = op.s0 * op.a[i] - op.s1 * xp + op.s2 * (bf16(op.scale[i]) * (op.c[i] - q));
+			unpack_coords<D>(__float_as_int(FI_TAIL_LDS(ctab, i)), c);
+			Around<D> A;
+			float m, q;
+			if (data) {
+				load_around<D, true>(L, op.a, i, A);
+				q = model_row<D>(L, c, A, &m);
+				if (D == 2) {
+#pragma unroll
+					for (int s2 = 0; s2 < 9; ++s2) { q += dia[k][s2 % (D == 2 ? 9 : 1)] * A.box[s2]; }
+				} else {
+					q += data_row<D>(L, i, A);
+				}
+			} else {
+				load_around<D, false>(L, op.a, i, A);
+				q = model_row<D>(L, c, A, &m);
+			}
+			const float rhs = FI_TAIL_LDS(op.c, i);
+			if (op.kind == kTailResidual) {
+				FI_TAIL_LDS(op.out, i) = rhs - q;
+			} else {
+				const float xp = op.b >= 0 ? FI_TAIL_LDS(op.b, i) : 0.0f;
+				FI_TAIL_LDS(op.out, i) = op.s0 * A.box[D == 2 ? 4 : 13] - op.s1 * xp + op.s2 * (scl[k] * (rhs - q));
+			}
 		}
 		break;
-	case kTailResidual:
-		for (int i = tid; i < L.nn; i += nthreads) {
-			int c[3];
-			coords_of<D>(L, i, c);
-			float m;
-			op.out[i] = op.c[i] - (model_row<D>(L, i, c, op.a, &m) + data_row<D>(L, i, op.a));
-		}
-		break;
+	}
 	case kTailRestrict: {
 		const LevelPair& P = L.to_coarse;
 		const TailLevel& C = levels[op.level + 1];
+		const int ctab_c = C.base + kTailVectors * C.nn;
 		for (int j = tid; j < C.nn; j += nthreads) {
 			int c[3];
-			coords_of<D>(C, j, c);
-			int   f[3][kRTaps];
-			float w[3][kRTaps];
-#pragma unroll
-			for (int d = 0; d < D; ++d) { restrict_taps<float>(c[d], P.nf[d], P.nc[d], P.cc[d], 0, f[d], w[d]); }
+			unpack_coords<D>(__float_as_int(FI_TAIL_LDS(ctab_c, j)), c);
+			int   f0[kRTaps], f1[kRTaps], f2[kRTaps];
+			float w0[kRTaps], w1[kRTaps], w2[kRTaps];
+			restrict_taps<float>(c[0], P.nf[0], P.nc[0], P.cc[0], 0, f0, w0);
+			restrict_taps<float>(c[1], P.nf[1], P.nc[1], P.cc[1], 0, f1, w1);
+			if (D > 2) { restrict_taps<float>(c[2], P.nf[2], P.nc[2], P.cc[2], 0, f2, w2); }
 			float acc = 0.0f;
-			if (D == 2) {
+#pragma unroll
+			for (int k2 = 0; k2 < (D > 2 ? kRTaps : 1); ++k2) {
+				float r2 = 0.0f;
 #pragma unroll
 				for (int k1 = 0; k1 < kRTaps; ++k1) {
+					const int base = ((D > 2 ? f2[k2] * P.nf[1] : 0) + f1[k1]) * P.nf[0];
 					float r = 0.0f;
 #pragma unroll
-					for (int k0 = 0; k0 < kRTaps; ++k0) { r += w[0][k0] * op.a[f[1][k1] * P.nf[0] + f[0][k0]]; }
-					acc += w[1][k1] * r;
+					for (int k0 = 0; k0 < kRTaps; ++k0) { r += w0[k0] * FI_TAIL_LDS(op.a, base + f0[k0]); }
+					r2 += w1[k1] * r;
 				}
-			} else {
-#pragma unroll
-				for (int k2 = 0; k2 < kRTaps; ++k2) {
-					if (w[2][k2] == 0.0f) { continue; }
-					float r2 = 0.0f;
-#pragma unroll
-					for (int k1 = 0; k1 < kRTaps; ++k1) {
-						if (w[1][k1] == 0.0f) { continue; }
-						const int base = (f[2][k2] * P.nf[1] + f[1][k1]) * P.nf[0];
-						float r = 0.0f;
-#pragma unroll
-						for (int k0 = 0; k0 < kRTaps; ++k0) { r += w[0][k0] * op.a[base + f[0][k0]]; }
-						r2 += w[1][k1] * r;
-					}
-					acc += w[2][k2] * r2;
-				}
+				acc += (D > 2 ? w2[k2] : 1.0f) * r2;
 			}
-			op.out[j] = acc;
+			FI_TAIL_LDS(op.out, j) = acc;
 		}
 		break;
 	}
@@ -183,27 +243,20 @@ __device__ inline void stage(const TailLevel* __restrict__ levels, const TailOp&
 		const LevelPair& P = L.to_coarse;
 		for (int i = tid; i < L.nn; i += nthreads) {
 			int c[3];
-			coords_of<D>(L, i, c);
-			int   c0[3], c1[3];
-			float w0[3], w1[3];
-#pragma unroll
-			for (int d = 0; d < D; ++d) { prolong_taps<float>(c[d], P.nc[d], P.cc[d], &c0[d], &c1[d], &w0[d], &w1[d]); }
+			unpack_coords<D>(__float_as_int(FI_TAIL_LDS(ctab, i)), c);
+			int   a0, a1, b0, b1, e0 = 0, e1 = 0;
+			float u0, u1, v0, v1, t0 = 1.0f, t1 = 0.0f;
+			prolong_taps<float>(c[0], P.nc[0], P.cc[0], &a0, &a1, &u0, &u1);
+			prolong_taps<float>(c[1], P.nc[1], P.cc[1], &b0, &b1, &v0, &v1);
+			if (D > 2) { prolong_taps<float>(c[2], P.nc[2], P.cc[2], &e0, &e1, &t0, &t1); }
 			float acc = 0.0f;
 #pragma unroll
 			for (int q = 0; q < (1 << D); ++q) {
-				float w   = (q & 1) ? w1[0] : w0[0];
-				int   idx = (q & 1) ? c1[0] : c0[0];
-				if (D > 1) {
-					w *= (q & 2) ? w1[1] : w0[1];
-					idx += P.nc[0] * ((q & 2) ? c1[1] : c0[1]);
-				}
-				if (D > 2) {
-					w *= (q & 4) ? w1[2] : w0[2];
-					idx += P.nc[0] * P.nc[1] * ((q & 4) ? c1[2] : c0[2]);
-				}
-				if (w != 0.0f) { acc += w * op.a[idx]; }
+				const float w = ((q & 1) ? u1 : u0) * ((q & 2) ? v1 : v0) * (D > 2 ? ((q & 4) ? t1 : t0) : 1.0f);
+				const int idx = ((q & 1) ? a1 : a0) + P.nc[0] * (((q & 2) ? b1 : b0) + (D > 2 ? P.nc[1] * ((q & 4) ? e1 : e0) : 0));
+				acc += w * FI_TAIL_LDS(op.a, idx);
 			}
-			op.out[i] += acc;
+			FI_TAIL_LDS(op.out, i) += acc;
 		}
 		break;
 	}
@@ -211,32 +264,35 @@ __device__ inline void stage(const TailLevel* __restrict__ levels, const TailOp&
 	}
 }
 
-// One barrier per stage.  A monotone arrival counter (zeroed by the host before the launch): the stage with index s is
-// complete when the counter has reached (s + 1) * gridDim.x.  Every workgroup is resident (cooperative launch), and every
-// wave reaches every barrier (the stage loops have no early exit), so the wait always ends.
-__device__ inline void grid_barrier(unsigned int* counter, unsigned int target)
+// ONE workgroup.  The right-hand side of the tail's top level comes in from global memory, its result goes out; everything
+// in between -- every vector of every tail level -- lives in LDS, a stage ends in a workgroup barrier.  The stage loops have
+// no early exit: every wave reaches every barrier.
+template <int D>
+__global__ __launch_bounds__(kTailThreads) void k_tail(const TailLevel* __restrict__ levels, const TailOp* __restrict__ ops, int nlev, int nops,
+                                                        const float* __restrict__ b, float* __restrict__ x)
 {
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		__threadfence();
-		atomicAdd(counter, 1u);
-		while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) { __builtin_amdgcn_s_sleep(1); }
-		__threadfence();
+	float* const lds = fi_tail_lds;
+	const int tid = threadIdx.x;
+	const int nn0 = levels[0].nn, base0 = levels[0].base;
+	for (int i = tid; i < nn0; i += kTailThreads) { lds[base0 + i] = b[i]; }
+	for (int l = 0; l < nlev; ++l) {  // the points' coordinates, once
+		const TailLevel& L = levels[l];
+		const int ctab = L.base + kTailVectors * L.nn;
+		for (int i = tid; i < L.nn; i += kTailThreads) {
+			const int cx = i % L.n[0], t = i / L.n[0];
+			const int cy = D > 2 ? t % L.n[1] : t, cz = D > 2 ? t / L.n[1] : 0;
+			lds[ctab + i] = __int_as_float(cx | (cy << 12) | (cz << 24));
+		}
 	}
 	__syncthreads();
-}
-
-template <int D>
-__global__ __launch_bounds__(kThreads) void k_tail(const TailLevel* __restrict__ levels, const TailOp* __restrict__ ops, int nops,
-                                                    unsigned int* counter)
-{
-	const int tid = blockIdx.x * kThreads + threadIdx.x, nthreads = gridDim.x * kThreads;
 	for (int o = 0; o < nops; ++o) {
 		const TailOp op = ops[o];
-		stage<D>(levels, op, tid, nthreads);
-		if (o + 1 < nops) { grid_barrier(counter, static_cast<unsigned int>(o + 1) * gridDim.x); }
+		stage<D>(levels, op, tid);
+		__syncthreads();
 	}
+	for (int i = tid; i < nn0; i += kTailThreads) { x[i] = lds[base0 + nn0 + i]; }
 }
+#undef FI_TAIL_LDS
 
 __global__ __launch_bounds__(kThreads) void k_tail_map(int64_t ncell, const uint32_t* __restrict__ cell_id, uint32_t* __restrict__ map)
 {
@@ -297,11 +353,7 @@ __global__ __launch_bounds__(kThreads) void k_tail_dia(Geom g, int nn, const uin
 bool tail_level_supported(const fi_ctx* c)
 {
 	const fi_weights& w = c->w;
-	// MEASURED AND NOT SHIPPED (profiles/r4_ablation.md section 5): a grid barrier across the 8 XCDs of an MI355X costs as much as
-	// the kernel boundary it replaces (3-25 us with 64-512 workgroups arriving on one counter, cache write-back and
-	// invalidate included), so 45 stages in one launch take 0.29-1.45 ms where 45 launches take 0.2 ms.  The engine runs in
-	// timing builds only (-DFI_TIMING_BUILD, FI_TAIL_ENGINE=1).
-	if (!tuning_switch("FI_TAIL_ENGINE")) { return false; }
+	if (test_switch("FI_NO_TAIL")) { return false; }  // tests: the tiled kernels run every level
 	if (c->dtype != FI_F32 || c->nranks != 1 || (c->g.ndim != 2 && c->g.ndim != 3)) { return false; }
 	if (w.model_3 > 0 || w.model_4 > 0 || w.gradient_smoothness > 0 || !(w.model_1 > 0 || w.model_2 > 0)) { return false; }
 	if (c->generic.ntrip != 0 || c->any_trip) { return false; }
@@ -354,46 +406,28 @@ TailLevel tail_level_of(const fi_ctx* c)
 	return L;
 }
 
-void tail_run(fi_ctx* top, const void* prog, int nlev, int nops, int64_t widest)
+void tail_run(fi_ctx* top, const void* prog, int nlev, int nops, int lds_floats, const float* b, float* x)
 {
-	(void)nlev;
-	static int max_blocks[2] = {0, 0};  // resident workgroups of k_tail<2> / k_tail<3> on this device
+	static bool lds_allowed[2] = {false, false};  // the dynamic LDS limit of k_tail<2> / k_tail<3> has been raised
 	const int D = top->g.ndim;
-	int& limit = max_blocks[D - 2];
-	if (limit == 0) {
-		int per_cu = 0, cus = 0;
+	const size_t lds_bytes = sizeof(float) * static_cast<size_t>(lds_floats);
+	FI_REQUIRE(lds_bytes <= 160u * 1024u, FI_ERR_STATE, "the small-level engine's vectors (%zu bytes) do not fit the LDS", lds_bytes);
+	if (!lds_allowed[D - 2]) {
 		if (D == 2) {
-			FI_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail<2>, kThreads, 0));
+			FI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		} else {
-			FI_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail<3>, kThreads, 0));
+			FI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		}
-		FI_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, top->device));
-		limit = per_cu * cus;
-		FI_REQUIRE(limit > 0, FI_ERR_HIP, "the small-level engine does not fit the device");
+		lds_allowed[D - 2] = true;
 	}
-	// two workgroups per CU at most: the barrier's cost grows with the number of arrivals, the stages' work does not need more
-	int cus = 256;
-	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, top->device);
-	int64_t want = (widest + kThreads - 1) / kThreads;
-	if (want > 2 * cus) { want = 2 * cus; }
-	if (want > limit) { want = limit; }
-	if (const char* e = tuning_switch("FI_TAIL_BLOCKS")) {
-		if (atoi(e) > 0 && atoi(e) <= limit) { want = atoi(e); }
-	}
-	if (want < 1) { want = 1; }
-	top->tail_bar.alloc(sizeof(unsigned int) * 16);
-	FI_HIP_TRY(hipMemsetAsync(top->tail_bar.p, 0, sizeof(unsigned int), top->stream));
 	const TailLevel* levels = static_cast<const TailLevel*>(prog);
 	const TailOp*    ops    = reinterpret_cast<const TailOp*>(levels + kTailMaxLevels);
-	unsigned int*    bar    = top->tail_bar.as<unsigned int>();
-	void* args[] = {&levels, &ops, &nops, &bar};
 	if (D == 2) {
-		FI_HIP_TRY(hipLaunchCooperativeKernel(reinterpret_cast<void*>(k_tail<2>), dim3(static_cast<unsigned>(want)), dim3(kThreads), args, 0,
-		                                      top->stream));
+		hipLaunchKernelGGL(k_tail<2>, dim3(1), dim3(kTailThreads), lds_bytes, top->stream, levels, ops, nlev, nops, b, x);
 	} else {
-		FI_HIP_TRY(hipLaunchCooperativeKernel(reinterpret_cast<void*>(k_tail<3>), dim3(static_cast<unsigned>(want)), dim3(kThreads), args, 0,
-		                                      top->stream));
+		hipLaunchKernelGGL(k_tail<3>, dim3(1), dim3(kTailThreads), lds_bytes, top->stream, levels, ops, nlev, nops, b, x);
 	}
+	FI_HIP_TRY(hipGetLastError());
 }
 
 }  // namespace fi

@@ -32,10 +32,8 @@ def test_config2_1024x1024_noisy_values(fi):
     """2D 1024x1024, 10k random noisy value constraints + smoothness prior (model_2 = 10)."""
     from field_interpolation_amd import synth
     sizes, w, pos, val = synth.config2()
-    f = fi.LatticeField(sizes, dtype="f64")
-    f.add_field_constraints(w)
-    f.set_levels(6, 1e-4)
-    f.set_multigrid(True)
+    from field_interpolation_amd import bench_settings as bs
+    f = bs.headline_field(fi, 2, sizes, w)           # bench.py --config 2's settings
     f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
     f.assemble()
     assert f.stats()["num_data_rows"] == 10000
@@ -55,9 +53,9 @@ def test_config3_4096x4096_sdf_from_oriented_points(fi):
     """2D 4096x4096 SDF from 200k oriented point-cloud samples (value + gradient rows)."""
     from field_interpolation_amd import synth
     sizes, w, pos, nrm = synth.config3()
+    from field_interpolation_amd import bench_settings as bs
     f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
-    f.set_levels(7, 1e-4)
-    f.set_multigrid(True)
+    bs.configure(f, bs.SETTINGS[3]["levels"], bs.SETTINGS[3]["coarse_tol"])   # bench.py --config 3's settings
     f.assemble()
     assert f.stats()["num_data_rows"] == 3 * 200000
     x, it, rel = f.solve_cg(None, 3000, 1e-5)
@@ -97,16 +95,14 @@ def test_config4_256cubed_bench_workload(fi):
     st = f.stats()
     assert st["converged"] == 1 and st["verified_residual"] <= 1e-5
     assert abs(it - 15) <= 2, it                      # bench.py: 15 outer iterations (17 on the coarser level)
-    a = fi.LatticeField(sizes, dtype="f64")
-    a.add_field_constraints(w)
-    a.set_levels(3, 1e-5)
-    a.set_multigrid(True)
-    a.set_mixed_precision(True)
+    from field_interpolation_amd import bench_settings as bs
+    a = bs.headline_field(fi, 4, sizes, w)            # bench.py's headline solver, its settings
     a.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
     a.assemble()
-    xa, ita, rela = a.solve_cg(None, 0, 1e-7)
-    assert a.stats()["converged"] == 1 and a.true_residual() <= 1.01e-7
-    assert abs(ita - 7) <= 2, ita                     # bench.py's accurate leg: 7 iterations
+    tol = bs.config4_tolerance(sizes, len(pos))
+    xa, ita, rela = a.solve_cg(None, 0, tol)
+    assert a.stats()["converged"] == 1 and a.true_residual() <= 1.01 * tol
+    assert abs(ita - 5) <= 1, ita                     # bench.py: 5 iterations
     assert np.abs(x - xa).max() <= 5e-3 * np.abs(xa).max()   # the fp32 field at a 1e-5 residual: 2e-3 (bench: solution_rel_err)
     del a
     # the field is the (noisy) signed distance to the sphere, smoothed: check it on the lattice
@@ -141,17 +137,16 @@ def test_config5_512cubed_sdf_tol_1e6(fi):
     near the sphere."""
     from field_interpolation_amd import synth
     sizes, w, pos, nrm = synth.config5()
+    from field_interpolation_amd import bench_settings as bs
     f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
-    f.set_levels(6, 1e-4)
-    f.set_multigrid(True)
-    f.set_mixed_precision(True)                      # bench.py --config 5: fp64 CG, fp32 V-cycle
+    bs.configure(f, bs.SETTINGS[5]["levels"], bs.SETTINGS[5]["coarse_tol"])   # bench.py --config 5: fp64 CG, fp32 V-cycle, 6 levels to 1e-2
     f.assemble()
     st = f.stats()
     assert st["num_data_rows"] == 4 * 5000000 and st["num_levels"] == 7
     x, it, rel = f.solve_cg(None, 1000, 1e-6)
     st = f.stats()
     assert st["converged"] == 1 and st["verified_residual"] <= 1e-6
-    assert abs(it - 25) <= 3, it                     # bench.py --config 5: 25 iterations
+    assert abs(it - 24) <= 3, it                     # bench.py --config 5: 24 iterations
     field = x.reshape(512, 512, 512)
     c, R = 255.5, 0.3 * 511
     # "only accurate near field = 0" (field_interpolation.hpp:165): a signed distance close to the surface,

@@ -36,33 +36,41 @@ def _against_sample(x, g):
     return float(np.abs(got - g["sample"]).max() / float(g["field_maxabs"]))
 
 
-def test_config4_at_256_cubed_against_the_oracle(fi, capsys):
+@pytest.mark.parametrize("seed", [3, 11, 12])
+def test_config4_at_256_cubed_against_the_oracle(fi, capsys, seed):
+    """bench.py's headline solver with bench.py's EXACT settings (field_interpolation_amd/bench_settings.py: levels, the
+    start's tolerance, the stop residual 3e-7) on three seeds of the metric's workload, each against the oracle's fp64
+    solution of that seed: the field stays within the north-star's 1e-5 on every one (the stop residual had been
+    checked on the one seed it was tuned on)."""
+    from field_interpolation_amd import bench_settings as bs
     from field_interpolation_amd import synth
-    g = np.load(os.path.join(GOLDEN, "config4_256_oracle_f64.npz"))
-    assert float(g["true_rel_residual"]) <= 2e-10
-    sizes, w, pos, val = synth.config4()
+    name = "config4_256_oracle_f64.npz" if seed == 3 else "config4_256_seed%d_oracle_f64.npz" % seed
+    g = np.load(os.path.join(GOLDEN, name))
+    assert float(g["true_rel_residual"]) <= 2e-10 and int(g["seed"]) == seed
+    sizes, w, pos, val = synth.config4(seed=seed)
     assert sizes == [int(s) for s in g["sizes"]] and len(pos) == int(g["num_points"])
+    assert seed in bs.CONFIG4_SEEDS
 
-    # bench.py's headline solver: fp64 CG preconditioned by the fp32 V-cycle, to the residual the bench uses
-    a = fi.LatticeField(sizes, dtype="f64")
-    a.add_field_constraints(w)
-    a.set_levels(3, 1e-5)
-    a.set_multigrid(True)
-    a.set_mixed_precision(True)
+    a = bs.headline_field(fi, 4, sizes, w)
     a.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
     a.assemble()
-    xa, ita, rela = a.solve_cg(None, 0, 1e-7)
-    assert a.stats()["converged"] == 1 and a.true_residual() <= 1.01e-7
+    tol = bs.config4_tolerance(sizes, len(pos))
+    assert tol == 3e-7 and bs.SETTINGS[4]["levels"] == 3
+    xa, ita, rela = a.solve_cg(None, 0, tol)
+    assert a.stats()["converged"] == 1 and a.true_residual() <= 1.01 * tol
     x64 = a.solution_f64()
     err = _against_sample(x64, g)
     # whole-field checksums of the oracle's solution (what the strided sample cannot see)
     sum_err = abs(x64.sum() - float(g["field_sum"])) / (float(g["field_maxabs"]) * x64.size)
     sq_err = abs((x64 * x64).sum() / float(g["field_sumsq"]) - 1.0)
     with capsys.disabled():
-        print("\n[P4 config 4 at 256^3 against the oracle] fp64 CG + fp32 V-cycle to 1e-7: %d iterations, field error %.2e "
-              "(sample of %d values), mean error %.1e, energy error %.1e" % (ita, err, g["sample"].size, sum_err, sq_err))
+        print("\n[P4 config 4 at 256^3, seed %d, against the oracle] bench settings (fp64 CG + fp32 V-cycle, %d levels to %g, stop %g): "
+              "%d iterations, field error %.2e (sample of %d values), mean error %.1e, energy error %.1e"
+              % (seed, bs.SETTINGS[4]["levels"], bs.SETTINGS[4]["coarse_tol"], tol, ita, err, g["sample"].size, sum_err, sq_err))
     assert err <= FIELD_TOL
     assert sum_err <= FIELD_TOL and sq_err <= 10 * FIELD_TOL
+    if seed != 3:
+        return
     # ... and driven to the oracle's own tolerance: what fp64 delivers
     xb, itb, relb = a.solve_cg(None, 0, 1e-10)
     assert a.true_residual() <= 1.01e-10
@@ -110,3 +118,56 @@ def test_config5_shape_against_the_oracle(fi, capsys):
             print("\n[P4 config-5 shape at %d^3 against the oracle (%d PCG iterations there)] mixed V-cycle PCG %d iterations, "
                   "field error %.2e" % (side, int(g["iterations"]), it, err))
         assert err <= FIELD_TOL
+
+
+def test_config2_full_size_against_the_oracles_exact_solve(fi, capsys):
+    """BASELINE config 2 at its FULL size (1024^2, 10 k noisy value constraints, model_2 = 10) against the reference's exact
+    route -- the oracle's explicit fp64 AtA, banded Cholesky, one refinement step through the rows
+    (tests/golden/make_golden_2d.py) -- with bench.py --config 2's settings.  At the configuration's residual (1e-5) the field
+    is what kappa allows (reported); driven to the residual that buys it the field is within 1e-5."""
+    from field_interpolation_amd import bench_settings as bs
+    from field_interpolation_amd import synth
+    g = np.load(os.path.join(GOLDEN, "config2_1024_oracle_f64.npz"))
+    assert float(g["true_rel_residual"]) <= 1e-10
+    sizes, w, pos, val = synth.config2()
+    assert sizes == [int(s) for s in g["sizes"]] and len(pos) == int(g["num_points"])
+    f = bs.headline_field(fi, 2, sizes, w)
+    f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    f.assemble()
+    rows = []
+    for tol in (bs.SETTINGS[2]["tol"], 1e-7, 1e-9, 1e-11):
+        x, it, rel = f.solve_cg(None, 0, tol)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.01 * tol
+        rows.append((tol, it, _against_sample(f.solution_f64(), g)))
+        if rows[-1][2] <= FIELD_TOL:
+            break
+    with capsys.disabled():
+        print("\n[config 2 at 1024^2 against the oracle's exact solve] " + "; ".join("residual %g: %d iterations, field error %.2e" % r for r in rows))
+    assert rows[0][2] <= 5e-2          # the configuration's own residual: reported, bounded
+    assert rows[-1][2] <= FIELD_TOL    # the solver reaches the reference's solution
+
+
+def test_config3_shape_against_the_oracles_exact_solve(fi, capsys):
+    """BASELINE config 3's shape (SDF from oriented points: triangle + inverted circle, default Weights) at 1024^2 against
+    the reference's exact route (as above), with bench.py --config 3's settings on the same coarsest lattice."""
+    from field_interpolation_amd import bench_settings as bs
+    from field_interpolation_amd import synth
+    g = np.load(os.path.join(GOLDEN, "config3_1024_oracle_f64.npz"))
+    assert float(g["true_rel_residual"]) <= 1e-10
+    sizes, w, pos, nrm = synth.config3(side=1024, points_per_shape=int(g["num_points"]) // 2, seed=2)
+    assert sizes == [int(s) for s in g["sizes"]]
+    f = fi.LatticeField(sizes, dtype="f64")
+    f.add_field_constraints(w)
+    bs.configure(f, bs.SETTINGS[3]["levels"] - 2, bs.SETTINGS[3]["coarse_tol"])     # 4096 -> 1024: two levels less, the same coarsest lattice
+    f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+    f.assemble()
+    rows = []
+    for tol in (bs.SETTINGS[3]["tol"], 1e-7, 1e-9, 1e-11):
+        x, it, rel = f.solve_cg(None, 0, tol)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.01 * tol
+        rows.append((tol, it, _against_sample(f.solution_f64(), g)))
+        if rows[-1][2] <= FIELD_TOL:
+            break
+    with capsys.disabled():
+        print("\n[config 3's shape at 1024^2 against the oracle's exact solve] " + "; ".join("residual %g: %d iterations, field error %.2e" % r for r in rows))
+    assert rows[-1][2] <= FIELD_TOL

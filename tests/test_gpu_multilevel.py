@@ -220,6 +220,50 @@ def test_fused_smoother_equals_the_unfused_one(fi, sizes, kw, monkeypatch):
     assert rel_inf(out[0][0], out[1][0]) <= 2e-4      # two fp32 solves to a 1e-5 residual
 
 
+@pytest.mark.parametrize("sizes,levels,oriented,mixed", [([256, 256], 5, False, True), ([200, 136], 4, True, True), ([64, 64, 64], 3, False, True),
+                                                        ([72, 60, 56], 3, True, True), ([128, 128], 4, True, False), ([40, 36, 44], 2, False, False)])
+def test_small_levels_in_one_workgroup_equal_the_tiled_kernels(fi, monkeypatch, sizes, levels, oriented, mixed):
+    """The small-level engine (fi_tail.hip): every level of <= 4096 unknowns at the bottom of a hierarchy runs its share of a
+    V-cycle in ONE launch of one workgroup, vectors in LDS -- the same smoothers, constants and transfers as the tiled
+    kernels (FI_NO_TAIL), so V-cycle PCG takes the same iterations (rounding may move the count by one) to the same
+    solution.  2-D and 3-D, value rows (polynomial smoother on 3-D levels) and oriented points (Chebyshev in the full
+    operator), fp64 CG around the fp32 cycle and plain fp32."""
+    from field_interpolation_amd import _capi
+    rng = np.random.default_rng(sum(sizes))
+    D = len(sizes)
+    n = 400 if D == 2 else 4000
+    if oriented:
+        pos, nrm = sphere_points(rng, sizes, n)
+        val = None
+    else:
+        pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+        nrm = None
+        val = rng.normal(size=n).astype(np.float32)
+    w = fi.Weights() if oriented else fi.Weights(model_2=0.5)
+    out = []
+    for no_tail in (False, True):
+        if no_tail:
+            monkeypatch.setenv("FI_NO_TAIL", "1")
+        else:
+            monkeypatch.delenv("FI_NO_TAIL", raising=False)
+        f = fi.LatticeField(sizes, dtype="f64" if mixed else "f32")
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, w.data_gradient if oriented else 0.0, w.gradient_kernel, pos, nrm, None, values=val)
+        f.set_levels(levels, 1e-4)
+        f.set_multigrid(True)
+        if mixed:
+            f.set_mixed_precision(True)
+        f.assemble()
+        tol = 1e-8 if mixed else 1e-5
+        x, it, rel = f.solve_cg(None, 0, tol)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.2 * tol
+        out.append((f.solution_f64() if mixed else x.astype(np.float64), it, f.stats()["coarse_iterations"]))
+        del f
+    monkeypatch.delenv("FI_NO_TAIL", raising=False)
+    assert abs(out[0][1] - out[1][1]) <= 1, (out[0][1:], out[1][1:])
+    assert rel_inf(out[0][0], out[1][0]) <= (1e-5 if mixed else 3e-4)
+
+
 def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
     """fi_assemble builds the coarser levels on a helper thread and a second stream while the calling thread assembles
     the finest level; FI_SERIAL_LEVELS builds them afterwards on the solver stream.  Same kernels on the same data: the
