@@ -464,6 +464,9 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
                        int extend = 0,    // slabs, deep exchange: the step also covers `extend` ghost planes on either side
                        int fmt = 0);      // bfloat16 storage of z (bit 0), z_prev (bit 1), z_new (bit 2): fp32 3-D levels, ChebEpi::fmt
 int  stencil_cheb_partials_max(const fi_ctx* c);  // room for the partials of a step extended over the whole ghost zone
+// small undivided fp32 levels: a step whose caller wants no partials (partial == nullptr) runs as one thread per point with
+// direct neighbour loads instead of the z-marching kernel (fi_stencil.hip, k_cheb_direct3)
+bool stencil_cheb_direct(const fi_ctx* c);
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 // z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the
 // marching kernel(s) over the lattice; z with valid ghost planes.  Dinv is the context's bfloat16 copy (dinv16).

@@ -561,7 +561,8 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 	bool ghosts_scaled = true;
 	for (const fi_ctx* c : R) { ghosts_scaled = ghosts_scaled && c->scaling_ghosts; }
 	const bool pro = (single || ghosts_scaled) && terms > 2 && c0->march.valid && !test_switch("FI_NO_Z0_ON_LOAD");
-	auto region2 = [](fi_ctx* c) { return c->partial.as<double>() + 2 * static_cast<size_t>(c->max_blocks); };
+	// (the V-cycle's smoother takes no dot products: a small level then runs its steps as direct launches, fi_stencil.hip)
+	auto region2 = [](fi_ctx* c) { return stencil_cheb_direct(c) ? nullptr : c->partial.as<double>() + 2 * static_cast<size_t>(c->max_blocks); };
 	if (!pro) {
 		for (fi_ctx* c : R) {  // z_0 = Dinv r / theta
 			hipLaunchKernelGGL((k_cheb_first16<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,

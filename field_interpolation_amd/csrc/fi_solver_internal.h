@@ -389,8 +389,19 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
                                                         int phase)
 {
 	if (sc->done && phase != kMgInitRr && phase != kMgInitRz) { return; }
+	// (eight loads in flight per thread: a 4096^2 lattice hands over 16 384 partials, and one load per trip of the loop made
+	// this single workgroup a chain of 64 cache round trips -- 37 us per reduction, profiles/r4_by_grid_c3.md; the order of the
+	// additions is fixed all the same: run to run the same bits)
 	double acc[1] = {0};
-	for (int i = threadIdx.x; i < count; i += kThreads) { acc[0] += partial[i]; }
+	int i = threadIdx.x;
+	for (; i + 7 * kThreads < count; i += 8 * kThreads) {
+		double v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { v[k] = partial[i + k * kThreads]; }
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { acc[0] += v[k]; }
+	}
+	for (; i < count; i += kThreads) { acc[0] += partial[i]; }
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x != 0) { return; }

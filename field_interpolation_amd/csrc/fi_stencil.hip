@@ -1412,6 +1412,98 @@ extern "C" int fi_debug_stamps(unsigned long long* out)
 namespace fi {
 #endif
 
+// ---- the polynomial's step on SMALL levels: one thread per point, neighbours straight from the caches ------------------
+// The marching kernel walks a workgroup through zc + 5 plane steps, a barrier each: on a 64^3 level that is 8-9 us per launch
+// for 3 MB of traffic, on 32^3 7 us -- the latency of the walk, not work (profiles/r4_step_timeline_c4.txt: the coarse levels
+// of a V-cycle cost 405 us of 1.2 ms).  A level of <= 2^19 points runs the same step (ChebEpi mode 0, with or without the
+// operand formed on load) as ONE round of loads per point: 13 neighbours through L1 / L2, the same arithmetic (u = S x
+// masked from the global coordinates, S^T u, the model diagonal from the same masks).  Undivided fp32 levels, whole lattice,
+// fp32 iterates, no dot-product partials (the V-cycle's smoother takes none).
+constexpr int64_t kDirectMaxPoints = int64_t(1) << 19;
+__device__ inline float bf16_of(unsigned short v) { return __uint_as_float(static_cast<unsigned int>(v) << 16); }
+
+template <bool HAS1, bool HAS2, bool PRO>
+__global__ __launch_bounds__(kThreads) void k_cheb_direct3(int nx, int ny, int nz, MarchCoef<float> C, const float* __restrict__ z,
+                                                            ChebEpi<float> E, const int* __restrict__ done)
+{
+	const int n = nx * ny * nz;  // (<= 2^19: 32-bit index arithmetic)
+	const int i = static_cast<int>(blockIdx.x) * kThreads + threadIdx.x;
+	if (i >= n) { return; }
+	const int cx = i % nx;
+	const int t  = i / nx;
+	const int cy = t % ny, cz = t / ny;
+	const int cc[3] = {cx, cy, cz}, nn[3] = {nx, ny, nz};
+	const int st[3] = {1, nx, nx * ny};
+	// every load of the step is issued before anything is waited for (the stop flag included: a finished solve stores nothing)
+	const int stop = done ? *done : 0;
+	float v[3][5];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+#pragma unroll
+		for (int k = -2; k <= 2; ++k) {
+			if (k == 0 && d > 0) {
+				v[d][2] = 0.0f;
+				continue;
+			}
+			if (!HAS2 && (k == -2 || k == 2)) {
+				v[d][k + 2] = 0.0f;
+				continue;
+			}
+			const int g = cc[d] + k;
+			const int j = i + (g < 0 ? -cc[d] : (g >= nn[d] ? nn[d] - 1 - cc[d] : k)) * st[d];  // clamped: met by a zero mask only
+			v[d][k + 2] = PRO ? E.pro_scale * bf16_of(E.dinv[j]) * z[j] : z[j];
+		}
+	}
+	const float dv = bf16_of(E.dinv[i]);
+	const float rv = PRO ? 0.0f : E.r[i];
+	const float zp = PRO ? 0.0f : E.zprev[i];
+	if (stop) { return; }
+	const float pc = v[0][2];
+	float acc2 = 0.0f, acc1 = 0.0f, m2 = 0.0f, m1 = 0.0f;
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const int c = cc[d], nd = nn[d];
+		const float w[5] = {v[d][0], v[d][1], pc, v[d][3], v[d][4]};
+		if (HAS2) {
+			// rows anchored at a = c - 2, c - 1, c exist iff 0 <= a and a + 2 < n (field_interpolation.cpp:273)
+			const float e0 = (c - 2 >= 0 && c < nd) ? 1.0f : 0.0f, e1 = (c - 1 >= 0 && c + 1 < nd) ? 1.0f : 0.0f, e2 = (c + 2 < nd) ? 1.0f : 0.0f;
+			const float u0 = e0 * (w[0] - 2.0f * w[1] + w[2]), u1 = e1 * (w[1] - 2.0f * w[2] + w[3]), u2 = e2 * (w[2] - 2.0f * w[3] + w[4]);
+			acc2 += u0 - 2.0f * u1 + u2;
+			m2 += e0 + 4.0f * e1 + e2;
+		}
+		if (HAS1) {
+			const float f0 = (c - 1 >= 0) ? 1.0f : 0.0f, f1 = (c + 1 < nd) ? 1.0f : 0.0f;   // rows [-1, +1] anchored at c - 1, c (:265)
+			const float d0 = f0 * (w[2] - w[1]), d1 = f1 * (w[3] - w[2]);
+			acc1 += d0 - d1;
+			m1 += f0 + f1;
+		}
+	}
+	float po = C.w0x3 * pc, m = C.w0x3;
+	if (HAS2) {
+		po += C.w2sq * acc2;
+		m += C.w2sq * m2;
+	}
+	if (HAS1) {
+		po += C.w1sq * acc1;
+		m += C.w1sq * m1;
+	}
+	const float sv = dv * (po - m * pc) + pc;
+	float zn;
+	if (PRO) {
+		zn = E.a * pc + E.c2 * (pc * (1.0f / E.pro_scale) - sv);
+	} else {
+		const float zq = E.zp_scale != 0.0f ? E.zp_scale * dv * zp : zp;
+		zn = E.a * pc - E.c1 * zq + E.c2 * (dv * rv - sv);
+	}
+	E.znew[i] = zn;
+}
+
+bool stencil_cheb_direct(const fi_ctx* c)
+{
+	return c->march.valid && c->dtype == FI_F32 && c->nranks == 1 && c->g.nown == c->g.nloc && c->g.nloc <= kDirectMaxPoints &&
+	       !test_switch("FI_NO_DIRECT_STEP");
+}
+
 // Chebyshev step through the marching kernel (see ChebEpi); false when the kernel does not apply to this context.
 bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid || c->tile2.valid; }  // (2-D: the tile kernel)
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.valid ? c->march.Pplain.nwg : tile2d_partials(c); }
@@ -1436,6 +1528,27 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	const unsigned short* d16 = scaling ? scaling : c->dinv16.as<unsigned short>();
 	const void* zp = zprev_scale != 0.0 ? r : (zprev ? zprev : z);
 	const bool  has_prev = zprev_scale != 0.0 || zprev;
+	if (!partial && part == 0 && extend == 0 && fmt == 0 && stencil_cheb_direct(c)) {  // small levels: one round of loads per point
+		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
+		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
+		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), 0, 0};
+		const MarchCoef<float> C = march_coef<float>(c->w);
+		const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
+		const int  nx = c->g.n[0], ny = c->g.n[1], nz = c->g.n[2];
+		const dim3 grid(static_cast<unsigned>((c->g.nloc + kThreads - 1) / kThreads));
+		const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0, pro = pro_scale != 0.0;
+		const float* zin = static_cast<const float*>(z);
+		auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(kThreads), 0, c->stream, nx, ny, nz, C, zin, E, done); };
+		if (h1 && h2) {
+			pro ? launch(k_cheb_direct3<true, true, true>) : launch(k_cheb_direct3<true, true, false>);
+		} else if (h2) {
+			pro ? launch(k_cheb_direct3<false, true, true>) : launch(k_cheb_direct3<false, true, false>);
+		} else {
+			pro ? launch(k_cheb_direct3<true, false, true>) : launch(k_cheb_direct3<true, false, false>);
+		}
+		FI_HIP_TRY(hipGetLastError());
+		return;
+	}
 	if (c->dtype == FI_F64) {
 		ChebEpi<double> E{static_cast<const double*>(zp), static_cast<const double*>(r), d16, static_cast<double*>(znew), 1.0 + c1,
 		                  has_prev ? c1 : 0.0, c2, 0, pro_scale, zprev_scale};

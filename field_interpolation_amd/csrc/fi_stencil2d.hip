@@ -98,7 +98,10 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 	__shared__ T ydump[CELLS ? 64 : 1];
 	__shared__ double red[kThreads / 64];
 
-	if (done && *done) { return; }
+	// The stop flag is REQUESTED here and looked at below, when every load of the prologue is on its way: as the first
+	// statement it was a cache round trip of its own in front of everything else, and the levels of a V-cycle's lower half
+	// are launches of 4-8 us that consist of three or four such trips (profiles/r5_ablation.md).
+	const int stop = done ? *done : 0;
 	const int per  = (P.ntiles + 7) / 8;
 	const int tile = (blockIdx.x % 8) * per + blockIdx.x / 8;  // XCD-aware: neighbouring tiles share an L2
 	if (tile >= P.ntiles) { return; }
@@ -129,6 +132,18 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 		re = L.off[tile + 1];
 	}
 	const bool has_cells = CELLS && re > rs;  // workgroup-uniform
+	// operands of the epilogue (EPI), requested with the tile itself instead of after the stencil (one more round trip)
+	T e_r[EPI ? VX : 1], e_zp[EPI ? VX : 1];
+	unsigned short e_dv[EPI ? VX : 1];
+	if (EPI) {
+#pragma unroll
+		for (int j = 0; j < VX; ++j) {
+			const int64_t i = static_cast<int64_t>(lyr < P.own_y1 ? lyr : P.own_y1 - 1) * P.nx + (gx + j < P.nx ? gx + j : P.nx - 1);
+			e_r[j]  = E.residual != 3 ? E.r[i] : T(0);
+			e_zp[j] = (E.residual == 0 || E.residual == 2) ? E.zprev[i] : T(0);
+			e_dv[j] = (E.residual == 0 || E.residual == 2) ? E.dinv[i] : static_cast<unsigned short>(0);
+		}
+	}
 
 	const V own = *reinterpret_cast<const V*>(x + static_cast<int64_t>(clamp_row(lyr)) * P.nx + clamp_x(gx, VX));
 	*reinterpret_cast<V*>(&xs[ly][lx]) = own;
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 #pragma unroll
 		for (int q = 0; q < 4; ++q) { *reinterpret_cast<V*>(&yb[q][ty][VX * tx]) = zero; }
 	}
+	if (stop) { return; }  // (workgroup-uniform; nothing has been stored to memory yet)
 	__syncthreads();
 
 	// ---- data cells of this tile ---------------------------------------------------------------------
@@ -284,13 +300,12 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 		T part = T(0);
 		for (int j = 0; j < VX; ++j) {  // (point by point: rows need not be 16-byte multiples)
 			if (j < nvalid) {
-				const int64_t i = static_cast<int64_t>(lyr) * P.nx + gx + j;
 				T zn;
 				if (E.residual == 1) {
-					zn = E.r[i] - po[j];
+					zn = e_r[j] - po[j];
 				} else if (E.residual == 0) {
-					const T dv = static_cast<T>(__uint_as_float(static_cast<unsigned int>(E.dinv[i]) << 16));
-					zn = E.a * pc[j] - E.c1 * E.zprev[i] + E.c2 * (dv * (E.r[i] - po[j]));
+					const T dv = static_cast<T>(__uint_as_float(static_cast<unsigned int>(e_dv[j]) << 16));
+					zn = E.a * pc[j] - E.c1 * e_zp[j] + E.c2 * (dv * (e_r[j] - po[j]));
 				} else {
 					const int g = gx + j;
 					T m = my;
@@ -303,10 +318,10 @@ __global__ __launch_bounds__(kThreads) void k_apply_tile2d(Tile2Params P, Coef2<
 						zn = po[j] / m;
 						part += zn * zn;
 					} else {
-						const T dv = static_cast<T>(__uint_as_float(static_cast<unsigned int>(E.dinv[i]) << 16));
-						const T rv = E.r[i];
+						const T dv = static_cast<T>(__uint_as_float(static_cast<unsigned int>(e_dv[j]) << 16));
+						const T rv = e_r[j];
 						const T sv = dv * (po[j] - m * pc[j]) + pc[j];
-						const T zq = E.zp_scale != T(0) ? E.zp_scale * dv * E.zprev[i] : E.zprev[i];
+						const T zq = E.zp_scale != T(0) ? E.zp_scale * dv * e_zp[j] : e_zp[j];
 						zn = E.a * pc[j] - E.c1 * zq + E.c2 * (dv * rv - sv);
 						part += rv * zn;
 					}
