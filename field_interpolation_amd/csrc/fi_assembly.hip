@@ -18,7 +18,7 @@
 // HBM layout: rows: key[], coef[row][2^D], rhs[]; blocks: blk[cell][2^D(2^D+1)/2] (144 B per 3-D cell in
 // fp32: the apply kernels read a block as 9 consecutive 16-byte loads).
 
-#include <hipcub/hipcub.hpp>
+#include "fi_prim.h"
 
 #include "fi_internal.h"
 #include "fi_sort.h"
@@ -1112,14 +1112,12 @@ void assemble_dim(fi_ctx* c)
 	                          static_cast<unsigned int>(total), 0, end_bit, st));
 	// runs of equal keys = occupied cells (+ one run of invalid rows at the end)
 	size_t tb2 = 0;
-	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
-	                                                 counts.as<uint32_t>(), nruns.as<uint32_t>(),
-	                                                 static_cast<int>(total), st));
+	FI_HIP_TRY(prim::run_length_encode(nullptr, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(), counts.as<uint32_t>(),
+	                                    nruns.as<uint32_t>(), static_cast<size_t>(total), st));
 	DevBuf& tmp2 = c->scratch[11];
 	tmp2.alloc(tb2);
-	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp2.p, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(),
-	                                                 counts.as<uint32_t>(), nruns.as<uint32_t>(),
-	                                                 static_cast<int>(total), st));
+	FI_HIP_TRY(prim::run_length_encode(tmp2.p, tb2, key_sorted.as<uint32_t>(), uniq.as<uint32_t>(), counts.as<uint32_t>(),
+	                                    nruns.as<uint32_t>(), static_cast<size_t>(total), st));
 	// the run count and the last run (the invalid rows, if any) in ONE host round trip
 	DevBuf& tail3 = c->scratch[26];
 	tail3.alloc(sizeof(uint32_t) * 3);
@@ -1149,12 +1147,10 @@ void assemble_dim(fi_ctx* c)
 		return;
 	}
 	size_t tb3 = 0;
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(),
-	                                            static_cast<int>(h_runs), st));
+	FI_HIP_TRY(prim::exclusive_sum(nullptr, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(), static_cast<size_t>(h_runs), st));
 	DevBuf& tmp3 = c->scratch[12];
 	tmp3.alloc(tb3);
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(),
-	                                            static_cast<int>(h_runs), st));
+	FI_HIP_TRY(prim::exclusive_sum(tmp3.p, tb3, counts.as<uint32_t>(), starts.as<uint32_t>(), static_cast<size_t>(h_runs), st));
 
 	c->cells.ncell = ncell;
 	// two or more data rows per occupied cell on average: multi-row cells as packed blocks (finish_cell)
@@ -1349,11 +1345,10 @@ int64_t border_prior_points(fi_ctx* c, DevBuf& pos, DevBuf& val)
 	idx.alloc(sizeof(uint32_t) * (nb_expected + 1));
 	count.alloc(sizeof(int));
 	hipStream_t st = c->stream;
-	hipcub::CountingInputIterator<uint32_t> all(0u);
 	size_t tb = 0;
-	FI_HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, all, idx.as<uint32_t>(), count.as<int>(), static_cast<int>(total), pred, st));
+	FI_HIP_TRY(prim::select_indices(nullptr, tb, idx.as<uint32_t>(), count.as<int>(), static_cast<size_t>(total), pred, st));
 	tmp.alloc(tb);
-	FI_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, all, idx.as<uint32_t>(), count.as<int>(), static_cast<int>(total), pred, st));
+	FI_HIP_TRY(prim::select_indices(tmp.p, tb, idx.as<uint32_t>(), count.as<int>(), static_cast<size_t>(total), pred, st));
 	int nb = 0;
 	FI_HIP_TRY(hipMemcpyAsync(&nb, count.p, sizeof(int), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));

@@ -440,7 +440,7 @@ void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec, int width)  // width planes 
 // workgroups -- the caller then exchanges first and applies in one go.
 bool overlap_possible(const fi_ctx* c)
 {
-	return c->nranks > 1 && c->march.valid && c->march.n_inner > 0 && !c->any_trip && c->generic.ntrip == 0 && c->tile_ts == 0 &&
+	return c->nranks > 1 && c->march.valid && !c->march.wide && c->march.n_inner > 0 && !c->any_trip && c->generic.ntrip == 0 && c->tile_ts == 0 &&
 	       (c->cells.ncell == 0 || cells_fused(c)) && !test_switch("FI_NO_OVERLAP");
 }
 void exchange_begin(fi_ctx* c, void* v)

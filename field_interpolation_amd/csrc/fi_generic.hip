@@ -16,7 +16,7 @@
 // Rows are short (<= 16 entries on lattice problems), so thread-per-row is adequate; traffic per apply:
 // 2 * nnz * (4 + sizeof(T)) bytes + gathers.  Single-GPU contexts only (columns are global unknowns).
 
-#include <hipcub/hipcub.hpp>
+#include "fi_prim.h"
 
 #include "fi_internal.h"
 
@@ -366,11 +366,11 @@ static void generic_assemble_t(fi_ctx* c)
 	G.csr_val.alloc(sizeof(T) * n);
 	nruns.alloc(sizeof(int) * 2);
 	size_t tb = 0;
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, G.key.as<uint64_t>(), ksort.as<uint64_t>(), G.val.as<float>(),
-	                                              vsort.as<float>(), n, 0, 64, st));
+	FI_HIP_TRY(prim::sort_pairs_u64(nullptr, tb, G.key.as<uint64_t>(), ksort.as<uint64_t>(), G.val.as<float>(), vsort.as<float>(),
+	                                 static_cast<size_t>(n), 0, 64, st));
 	tmp.alloc(tb);
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, G.key.as<uint64_t>(), ksort.as<uint64_t>(), G.val.as<float>(),
-	                                              vsort.as<float>(), n, 0, 64, st));
+	FI_HIP_TRY(prim::sort_pairs_u64(tmp.p, tb, G.key.as<uint64_t>(), ksort.as<uint64_t>(), G.val.as<float>(), vsort.as<float>(),
+	                                 static_cast<size_t>(n), 0, 64, st));
 	// slabs: global -> local column numbers (the local array starts at global plane g.off[L]: a uniform shift, the order
 	// stays).  Every kept row lies within the ghost planes: it touches an owned plane and reaches 2 planes (reach >= 2).
 	const int64_t col_shift = static_cast<int64_t>(c->g.off[c->g.ndim - 1]) * c->g.stride[c->g.ndim - 1];
@@ -385,12 +385,12 @@ static void generic_assemble_t(fi_ctx* c)
 	hipLaunchKernelGGL((k_widen<T>), dim3(blocks_for(n)), dim3(kThreads), 0, st, static_cast<int64_t>(n), vsort.as<float>(),
 	                   vT.as<T>());
 	size_t tb2 = 0;
-	FI_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, ksort.as<uint64_t>(), ukey.as<uint64_t>(), vT.as<T>(),
-	                                             G.csr_val.as<T>(), nruns.as<int>(), hipcub::Sum(), n, st));
+	FI_HIP_TRY(prim::sum_by_key(nullptr, tb2, ksort.as<uint64_t>(), ukey.as<uint64_t>(), vT.as<T>(), G.csr_val.as<T>(), nruns.as<int>(),
+	                             static_cast<size_t>(n), st));
 	DevBuf tmp2;
 	tmp2.alloc(tb2);
-	FI_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(tmp2.p, tb2, ksort.as<uint64_t>(), ukey.as<uint64_t>(), vT.as<T>(),
-	                                             G.csr_val.as<T>(), nruns.as<int>(), hipcub::Sum(), n, st));
+	FI_HIP_TRY(prim::sum_by_key(tmp2.p, tb2, ksort.as<uint64_t>(), ukey.as<uint64_t>(), vT.as<T>(), G.csr_val.as<T>(), nruns.as<int>(),
+	                             static_cast<size_t>(n), st));
 	int nnz = 0;
 	FI_HIP_TRY(hipMemcpyAsync(&nnz, nruns.p, sizeof(int), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
@@ -404,12 +404,10 @@ static void generic_assemble_t(fi_ctx* c)
 	hipLaunchKernelGGL(k_unpack_csr, dim3(blocks_for(nnz)), dim3(kThreads), 0, st, nnz, ukey.as<uint64_t>(),
 	                   G.csr_col.as<uint32_t>(), rowcount.as<uint32_t>());
 	size_t tb3 = 0;
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, rowcount.as<uint32_t>(), G.csr_ptr.as<uint32_t>(),
-	                                            static_cast<int>(G.nrows + 1), st));
+	FI_HIP_TRY(prim::exclusive_sum(nullptr, tb3, rowcount.as<uint32_t>(), G.csr_ptr.as<uint32_t>(), static_cast<size_t>(G.nrows + 1), st));
 	DevBuf tmp3;
 	tmp3.alloc(tb3);
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb3, rowcount.as<uint32_t>(), G.csr_ptr.as<uint32_t>(),
-	                                            static_cast<int>(G.nrows + 1), st));
+	FI_HIP_TRY(prim::exclusive_sum(tmp3.p, tb3, rowcount.as<uint32_t>(), G.csr_ptr.as<uint32_t>(), static_cast<size_t>(G.nrows + 1), st));
 	// CSC: sort the unique entries by (col, row)
 	tkey.alloc(sizeof(uint64_t) * nnz);
 	tkey_s.alloc(sizeof(uint64_t) * nnz);
@@ -417,12 +415,12 @@ static void generic_assemble_t(fi_ctx* c)
 	hipLaunchKernelGGL(k_transpose_keys, dim3(blocks_for(nnz)), dim3(kThreads), 0, st, nnz, ukey.as<uint64_t>(),
 	                   tkey.as<uint64_t>());
 	size_t tb4 = 0;
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, tkey.as<uint64_t>(), tkey_s.as<uint64_t>(),
-	                                              G.csr_val.as<T>(), G.csc_val.as<T>(), nnz, 0, 64, st));
+	FI_HIP_TRY(prim::sort_pairs_u64(nullptr, tb4, tkey.as<uint64_t>(), tkey_s.as<uint64_t>(), G.csr_val.as<T>(), G.csc_val.as<T>(),
+	                                 static_cast<size_t>(nnz), 0, 64, st));
 	DevBuf tmp4;
 	tmp4.alloc(tb4);
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp4.p, tb4, tkey.as<uint64_t>(), tkey_s.as<uint64_t>(),
-	                                              G.csr_val.as<T>(), G.csc_val.as<T>(), nnz, 0, 64, st));
+	FI_HIP_TRY(prim::sort_pairs_u64(tmp4.p, tb4, tkey.as<uint64_t>(), tkey_s.as<uint64_t>(), G.csr_val.as<T>(), G.csc_val.as<T>(),
+	                                 static_cast<size_t>(nnz), 0, 64, st));
 	G.csc_row.alloc(sizeof(uint32_t) * nnz);
 	colkey.alloc(sizeof(uint32_t) * nnz);
 	hipLaunchKernelGGL(k_unpack_csc, dim3(blocks_for(nnz)), dim3(kThreads), 0, st, nnz, tkey_s.as<uint64_t>(),
@@ -430,12 +428,12 @@ static void generic_assemble_t(fi_ctx* c)
 	G.csc_cols.alloc(sizeof(uint32_t) * nnz);
 	colcount.alloc(sizeof(uint32_t) * (nnz + 1));
 	size_t tb5 = 0;
-	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb5, colkey.as<uint32_t>(), G.csc_cols.as<uint32_t>(),
-	                                                 colcount.as<uint32_t>(), nruns.as<int>(), nnz, st));
+	FI_HIP_TRY(prim::run_length_encode(nullptr, tb5, colkey.as<uint32_t>(), G.csc_cols.as<uint32_t>(), colcount.as<uint32_t>(), nruns.as<int>(),
+	                                    static_cast<size_t>(nnz), st));
 	DevBuf tmp5;
 	tmp5.alloc(tb5);
-	FI_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp5.p, tb5, colkey.as<uint32_t>(), G.csc_cols.as<uint32_t>(),
-	                                                 colcount.as<uint32_t>(), nruns.as<int>(), nnz, st));
+	FI_HIP_TRY(prim::run_length_encode(tmp5.p, tb5, colkey.as<uint32_t>(), G.csc_cols.as<uint32_t>(), colcount.as<uint32_t>(), nruns.as<int>(),
+	                                    static_cast<size_t>(nnz), st));
 	int ncols = 0;
 	FI_HIP_TRY(hipMemcpyAsync(&ncols, nruns.p, sizeof(int), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));
@@ -443,10 +441,10 @@ static void generic_assemble_t(fi_ctx* c)
 	G.csc_ptr.alloc(sizeof(uint32_t) * (ncols + 2));
 	FI_HIP_TRY(hipMemsetAsync(colcount.as<uint32_t>() + ncols, 0, sizeof(uint32_t), st));
 	size_t tb6 = 0;
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb6, colcount.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), ncols + 1, st));
+	FI_HIP_TRY(prim::exclusive_sum(nullptr, tb6, colcount.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), static_cast<size_t>(ncols + 1), st));
 	DevBuf tmp6;
 	tmp6.alloc(tb6);
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp6.p, tb6, colcount.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), ncols + 1, st));
+	FI_HIP_TRY(prim::exclusive_sum(tmp6.p, tb6, colcount.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), static_cast<size_t>(ncols + 1), st));
 	G.t.alloc(elem_size(c) * (G.nrows + 1));
 	hipLaunchKernelGGL((k_generic_rhs_diag<T>), dim3(blocks_for(ncols)), dim3(kThreads), 0, st, ncols,
 	                   G.csc_cols.as<uint32_t>(), G.csc_ptr.as<uint32_t>(), G.csc_row.as<uint32_t>(), G.csc_val.as<T>(),

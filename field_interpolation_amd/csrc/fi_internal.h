@@ -188,6 +188,10 @@ struct MarchParams {
 struct MarchState {
 	bool        valid = false;  // the marching kernel applies to this context
 	bool        fused = false;  // cell blocks are applied inside the marching kernel
+	bool        wide = false;   // the model has rows the marching kernel does not carry (model_3, model_4, gradient_smoothness,
+	                            // field_interpolation.cpp:282-315): it applies model_0/1/2 and the cells, k_add_wide3 (fi_operator.hip)
+	                            // adds the rest onto its result.  Whoever takes the marching kernel for the WHOLE operator -- the
+	                            // epilogue recurrences, the polynomial, the split launches over slabs -- must look at this flag
 	MarchParams P{};
 	MarchParams Pplain{};  // chunking for launches of the plain (model-only) variant over the whole lattice: the
 	                       // polynomial preconditioner's steps (4 workgroups per CU, longer chunks)

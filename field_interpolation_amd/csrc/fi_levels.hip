@@ -203,7 +203,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		// the polynomial smoother's scaling (and whether the data pin a small level) with the level's assembly, on its chain's
 		// stream, instead of at the head of the first solve (undivided levels: over slabs the ghost planes' diagonal comes later)
 		operator_prepare(co, co->dtype == FI_F32 && co->g.ndim == 3 && co->mg_smoother == 1 && co->value_rows_only && !co->any_trip &&
-		                         co->march.valid && co->nranks == 1 && !test_switch("FI_MG_FULL_SMOOTHER"));
+		                         co->march.valid && !co->march.wide && co->nranks == 1 && !test_switch("FI_MG_FULL_SMOOTHER"));
 		co->tail_prog_valid = false;
 		if (tail_level_supported(co)) { tail_build_operator(co); }  // the small-level engine's view of the data rows
 		co->assembled = true;

@@ -150,6 +150,149 @@ __global__ __launch_bounds__(kThreads) void k_apply_generic(Geom g, ModelCoef<T>
 	}
 }
 
+// ---- the wide model rows of a 3-D lattice the marching kernel covers (MarchState::wide) -----------------------------------
+// y += (S3^T S3 + S4^T S4 + the gradient_smoothness rows) x: model_3 [+1,-3,+3,-1], model_4 [+1,-4,+6,-4,+1] along every
+// axis, gradient_smoothness [-1,+1,+1,-1] on every axis pair (field_interpolation.cpp:282-315), rows that exist by the
+// reference's rule in GLOBAL coordinates, coefficients fp32(stencil * weight) as in A.  The marching kernel has stored
+// (A_model_0/1/2 + A_data) x in y; this kernel adds onto it -- every point by its own thread, a plain read-add-write: the
+// same bits on every run.  A workgroup owns 64 x 4 points of one plane and walks over the tiles of its share of the lattice;
+// a point's neighbours (+-4 per axis, the 3 x 3 patches of the axis pairs) come through L1 / L2: the two rows and the
+// eight planes around a tile are another workgroup's tiles.  Rounds 1-4 ran these contexts through k_apply_generic + 2^D
+// colour launches of k_apply_cells: 0.7-1.5 ms per apply at 256^3 (0.03-0.06 of the HBM peak, profiles/r4_wide_stencils.txt).
+constexpr int kWideTX = 64, kWideTY = 4, kWideTZ = 4;
+// the 2R + 1 coefficients of (S3^T S3 + S4^T S4) along an axis where every row exists (R points or more from both ends)
+template <typename T>
+struct WideTaps {
+	T cf[9];  // cf[4 + t], t = -4 .. 4
+};
+template <typename T, bool K3, bool K4, int R>
+__device__ inline T wide_axis(const ModelCoef<T>& mc, const WideTaps<T>& tp, const T* win, int c, int n)  // win[R] = the point itself
+{
+	if (c >= R && c + R < n) {  // interior: one fixed stencil
+		T acc = 0;
+#pragma unroll
+		for (int t = -R; t <= R; ++t) { acc += tp.cf[4 + t] * win[R + t]; }
+		return acc;
+	}
+	T acc = 0;
+	if (K3) {
+#pragma unroll
+		for (int m = 0; m <= 3; ++m) {
+			const int a = c - m;  // anchor of a row that touches this point with coefficient c[3][m]
+			T tsum = 0;
+#pragma unroll
+			for (int j = 0; j <= 3; ++j) { tsum += mc.c[3][j] * win[R - m + j]; }
+			acc += (a >= 0 && a + 3 < n) ? mc.c[3][m] * tsum : T(0);
+		}
+	}
+	if (K4) {
+#pragma unroll
+		for (int m = 0; m <= 4; ++m) {
+			const int a = c - m;
+			T tsum = 0;
+#pragma unroll
+			for (int j = 0; j <= 4; ++j) { tsum += mc.c[4][j] * win[R - m + j]; }
+			acc += (a >= 0 && a + 4 < n) ? mc.c[4][m] * tsum : T(0);
+		}
+	}
+	return acc;
+}
+
+template <typename T, bool K3, bool K4, bool GS>
+__global__ __launch_bounds__(kThreads) void k_add_wide3(Geom g, ModelCoef<T> mc, WideTaps<T> tp, const T* __restrict__ x, T* __restrict__ y,
+                                                         double* __restrict__ partial, const int* __restrict__ done, int tiles_x,
+                                                         int tiles_y, int ntiles)
+{
+	constexpr int R = K4 ? 4 : 3;
+	constexpr bool STAR = K3 || K4;
+	const int stop = done ? *done : 0;
+	if (stop) { return; }
+	const int tx = threadIdx.x % kWideTX, ty = threadIdx.x / kWideTX;
+	const int ext0 = g.own_hi[0] - g.own_lo[0], ext1 = g.own_hi[1] - g.own_lo[1], ext2 = g.own_hi[2] - g.own_lo[2];
+	const int64_t s1 = g.stride[1], s2 = g.stride[2];
+	double contrib = 0.0;
+	for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+		const int tz = t / (tiles_x * tiles_y), r = t - tz * (tiles_x * tiles_y);
+		const int oy = (r / tiles_x) * kWideTY + ty, ox = (r % tiles_x) * kWideTX + tx;
+		if (ox >= ext0 || oy >= ext1) { continue; }
+		const int lx = g.own_lo[0] + ox, ly = g.own_lo[1] + oy, lz0 = g.own_lo[2] + tz * kWideTZ;
+		const int cx = lx + g.off[0], cy = ly + g.off[1];
+		const int64_t col = lx + ly * s1;
+		// the thread's column of kWideTZ points: its z window is loaded once (R planes below, R above)
+		T wz[STAR ? kWideTZ + 2 * R : 1];
+		if (STAR) {
+#pragma unroll
+			for (int j = 0; j < kWideTZ + 2 * R; ++j) {
+				const int lz = lz0 + j - R, gz = lz + g.off[2];
+				wz[j] = (gz >= 0 && gz < g.gn[2] && lz >= 0 && lz < g.n[2]) ? x[col + lz * s2] : T(0);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < kWideTZ; ++k) {
+			if (tz * kWideTZ + k >= ext2) { break; }
+			const int lz = lz0 + k, cz = lz + g.off[2];
+			const int64_t idx = col + lz * s2;
+			const T xi = STAR ? wz[k + R] : x[idx];
+			T acc = 0;
+			if (STAR) {
+				T win[2 * R + 1];
+#pragma unroll
+				for (int m = -R; m <= R; ++m) { win[m + R] = (cx + m >= 0 && cx + m < g.gn[0]) ? x[idx + m] : T(0); }
+				acc += wide_axis<T, K3, K4, R>(mc, tp, win, cx, g.gn[0]);
+#pragma unroll
+				for (int m = -R; m <= R; ++m) { win[m + R] = (cy + m >= 0 && cy + m < g.gn[1]) ? x[idx + m * s1] : T(0); }
+				acc += wide_axis<T, K3, K4, R>(mc, tp, win, cy, g.gn[1]);
+				acc += wide_axis<T, K3, K4, R>(mc, tp, &wz[k], cz, g.gn[2]);
+			}
+			if (GS) {
+				const int li[3] = {lx, ly, lz};
+#pragma unroll
+				for (int d = 0; d < 3; ++d) {
+#pragma unroll
+					for (int e = d + 1; e < 3; ++e) {
+						const int cd = li[d] + g.off[d], ce = li[e] + g.off[e];
+						const int64_t sd = d == 0 ? 1 : (d == 1 ? s1 : s2), se = e == 1 ? s1 : s2;
+#pragma unroll
+						for (int bd = 0; bd < 2; ++bd) {
+#pragma unroll
+							for (int be = 0; be < 2; ++be) {
+								const int ad = cd - bd, ae = ce - be;
+								if (ad >= 0 && ad + 1 < g.gn[d] && ae >= 0 && ae + 1 < g.gn[e]) {
+									const int64_t a = idx - bd * sd - be * se;
+									const T row  = mc.gs * (-x[a] + x[a + sd] + x[a + se] - x[a + sd + se]);
+									const T sign = (bd ^ be) ? T(1) : T(-1);
+									acc += T(2) * (sign * mc.gs) * row;   // (every axis pair is emitted twice: cpp:303-315)
+								}
+							}
+						}
+					}
+				}
+			}
+			y[idx] += acc;
+			contrib += static_cast<double>(xi) * static_cast<double>(acc);
+		}
+	}
+	if (partial) {
+		const double sum = block_sum(contrib);
+		if (threadIdx.x == 0) { partial[blockIdx.x] = sum; }
+	}
+}
+
+struct WideLaunch {
+	int tiles_x, tiles_y, ntiles, blocks;
+};
+inline WideLaunch wide_launch(const fi_ctx* c)
+{
+	const Geom& g = c->g;
+	WideLaunch w;
+	w.tiles_x = (g.own_hi[0] - g.own_lo[0] + kWideTX - 1) / kWideTX;
+	w.tiles_y = (g.own_hi[1] - g.own_lo[1] + kWideTY - 1) / kWideTY;
+	const int64_t nt = static_cast<int64_t>(w.tiles_x) * w.tiles_y * ((g.own_hi[2] - g.own_lo[2] + kWideTZ - 1) / kWideTZ);
+	w.ntiles = static_cast<int>(nt);
+	w.blocks = static_cast<int>(nt < 2048 ? (nt < 1 ? 1 : nt) : 2048);  // (its partials are summed by single-workgroup kernels)
+	return w;
+}
+
 template <typename T>
 __device__ inline void atomic_add(T* p, T v)
 {
@@ -512,6 +655,34 @@ void apply_dim(fi_ctx* c, const T* x, T* y, double* partial)
 	int nb_cells = 0;
 	if (nb_model > 0) {
 		stencil_apply(c, x, y, partial);
+		if (D == 3 && c->march.valid && c->march.wide) {  // the wide model rows on top of what the marching kernel stored
+			const WideLaunch wl = wide_launch(c);
+			double* pw = partial ? partial + nb_model : nullptr;
+			const bool k3 = mc.on[3], k4 = mc.on[4], gs = mc.on[5];
+			WideTaps<T> tp{};
+			for (int t = -4; t <= 4; ++t) {  // (S3^T S3 + S4^T S4)(c, c + t) where every row exists
+				T v = 0;
+				for (int k = 3; k <= 4; ++k) {
+					if (!mc.on[k]) { continue; }
+					for (int m = 0; m <= k; ++m) {
+						const int j = m + t;
+						if (j >= 0 && j <= k) { v += mc.c[k][m] * mc.c[k][j]; }
+					}
+				}
+				tp.cf[4 + t] = v;
+			}
+			auto launch = [&](auto kernel) {
+				hipLaunchKernelGGL(kernel, dim3(wl.blocks), dim3(kThreads), 0, c->stream, g, mc, tp, x, y, pw, done, wl.tiles_x, wl.tiles_y, wl.ntiles);
+			};
+			if (gs) {
+				k4 ? (k3 ? launch(k_add_wide3<T, true, true, true>) : launch(k_add_wide3<T, false, true, true>))
+				   : (k3 ? launch(k_add_wide3<T, true, false, true>) : launch(k_add_wide3<T, false, false, true>));
+			} else {
+				k4 ? (k3 ? launch(k_add_wide3<T, true, true, false>) : launch(k_add_wide3<T, false, true, false>))
+				   : launch(k_add_wide3<T, true, false, false>);
+			}
+			nb_model += wl.blocks;
+		}
 	} else {
 		nb_model = capped_blocks(g.nown);
 		hipLaunchKernelGGL((k_apply_generic<D, T>), dim3(nb_model), dim3(kThreads), 0, c->stream, g, mc, x, y, partial,
@@ -547,6 +718,7 @@ int apply_num_partials(const fi_ctx* c)
 	}
 	int nb_model = stencil_partials(c);
 	if (nb_model <= 0) { nb_model = capped_blocks(c->g.nown); }
+	if (c->march.valid && c->march.wide) { nb_model += wide_launch(c).blocks; }  // k_add_wide3's share of x . A x
 	int n = nb_model + generic_num_partials(c);
 	if (!cells_fused(c) && c->cells.ncell > 0) { n += cells_partials(c); }
 	return n;

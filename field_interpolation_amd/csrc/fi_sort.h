@@ -4,6 +4,9 @@
 // launches it issues (~5 us each, ~560 per step in round 3), so the lists are sorted by Onesweep from 16 k items on.
 #pragma once
 
+#include <cstring>
+#include <iterator>
+
 #include <rocprim/rocprim.hpp>
 
 #include "fi_internal.h"

@@ -53,7 +53,6 @@
 //     chunk length ZC is chosen so that the grid covers the CUs in whole rounds (pick_chunk).
 
 #include <hip/hip_bf16.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -1147,8 +1146,11 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 	if (g.ndim != 3) { return false; }
 	if (g.gn[0] < VX) { return false; }  // rows shorter than one 16-byte group: the plain kernel
 	const fi_weights& w = c->w;
-	if (w.model_3 > 0 || w.model_4 > 0 || w.gradient_smoothness > 0) { return false; }
-	if (!(w.model_1 > 0) && !(w.model_2 > 0)) { return false; }
+	// model_3 / model_4 / gradient_smoothness (field_interpolation.cpp:282-315): this kernel applies the model_0/1/2 rows and
+	// the data cells of such a context, k_add_wide3 (fi_operator.hip) adds the wide rows onto its result (MarchState::wide)
+	const bool wide = w.model_3 > 0 || w.model_4 > 0 || w.gradient_smoothness > 0;
+	if (wide && test_switch("FI_NO_WIDE_MARCH")) { return false; }  // tests: the untiled path (k_apply_generic + colour launches)
+	if (!(w.model_1 > 0) && !(w.model_2 > 0) && !wide) { return false; }
 	P->nx = g.gn[0];
 	P->ny = g.gn[1];
 	P->nzl = g.n[2];
@@ -1346,6 +1348,7 @@ void stencil_prepare(fi_ctx* c)
 	MarchState& m = c->march;
 	m.valid = c->dtype == FI_F64 ? march_setup<double>(c, &m.P) : march_setup<float>(c, &m.P);
 	m.fused = false;
+	m.wide  = m.valid && (c->w.model_3 > 0 || c->w.model_4 > 0 || c->w.gradient_smoothness > 0);
 	m.n_row = m.n_blk = 0;
 	if (m.valid) {  // chunking of whole-lattice launches of the plain variant (polynomial preconditioner)
 		c->dtype == FI_F64 ? march_setup<double>(c, &m.Pplain, 0, true) : march_setup<float>(c, &m.Pplain, 0, true);
@@ -1500,12 +1503,12 @@ __global__ __launch_bounds__(kThreads) void k_cheb_direct3(int nx, int ny, int n
 
 bool stencil_cheb_direct(const fi_ctx* c)
 {
-	return c->march.valid && c->dtype == FI_F32 && c->nranks == 1 && c->g.nown == c->g.nloc && c->g.nloc <= kDirectMaxPoints &&
+	return c->march.valid && !c->march.wide && c->dtype == FI_F32 && c->nranks == 1 && c->g.nown == c->g.nloc && c->g.nloc <= kDirectMaxPoints &&
 	       !test_switch("FI_NO_DIRECT_STEP");
 }
 
 // Chebyshev step through the marching kernel (see ChebEpi); false when the kernel does not apply to this context.
-bool stencil_cheb_available(const fi_ctx* c) { return c->march.valid || c->tile2.valid; }  // (2-D: the tile kernel)
+bool stencil_cheb_available(const fi_ctx* c) { return (c->march.valid && !c->march.wide) || c->tile2.valid; }  // (2-D: the tile kernel)
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.valid ? c->march.Pplain.nwg : tile2d_partials(c); }
 int  stencil_cheb_partials_max(const fi_ctx* c)
 {
@@ -1587,7 +1590,7 @@ bool stencil_full_epi_available(const fi_ctx* c)
 	// the tiled kernels: a recurrence step in THEIR epilogue would smooth with an operator that lacks those rows
 	if (c->generic.ntrip != 0) { return false; }
 	if (c->tile2.valid) { return tile2d_full_epi_available(c); }  // 2-D: the tile kernel, both precisions
-	return c->march.valid && c->dtype == FI_F32 && (c->cells.ncell == 0 || c->march.fused);
+	return c->march.valid && !c->march.wide && c->dtype == FI_F32 && (c->cells.ncell == 0 || c->march.fused);
 }
 void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* r, bool residual, void* znew, double a,
                        double c1, double c2)

@@ -15,7 +15,8 @@
 // owner of a lattice point adds its 4 slots.  x.y partials: fp64 per thread, wave64 shuffle tree, one per
 // workgroup.  Algorithmic traffic: 2*sizeof(T) B per lattice point + (4 + 16*sizeof(T)) B per occupied cell.
 
-#include <hipcub/hipcub.hpp>
+#include "fi_prim.h"
+#include "fi_sort.h"
 
 #include "fi_internal.h"
 
@@ -471,15 +472,14 @@ void build_lists2(fi_ctx* c)
 	hipLaunchKernelGGL(k_iota2, dim3(static_cast<int>((nslots + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
 	                   slot_in.as<uint32_t>(), nslots);
 	size_t tb = 0, tb2 = 0;
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
-	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-	                                              static_cast<int>(nslots), 0, 32, st));
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, count.as<uint32_t>(), m.off.as<uint32_t>(), P.ntiles + 1, st));
+	const int key_bits = 32;  // (slots outside every tile carry the key 0xFFFFFFFF: they sort to the end)
+	FI_HIP_TRY(sort_pairs_u32(nullptr, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(), slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
+	                          static_cast<unsigned int>(nslots), 0, key_bits, st));
+	FI_HIP_TRY(prim::exclusive_sum(nullptr, tb2, count.as<uint32_t>(), m.off.as<uint32_t>(), static_cast<size_t>(P.ntiles + 1), st));
 	tmp.alloc(tb > tb2 ? tb : tb2);
-	FI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(),
-	                                              slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
-	                                              static_cast<int>(nslots), 0, 32, st));
-	FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, count.as<uint32_t>(), m.off.as<uint32_t>(), P.ntiles + 1, st));
+	FI_HIP_TRY(sort_pairs_u32(tmp.p, tb, key.as<uint32_t>(), key_sorted.as<uint32_t>(), slot_in.as<uint32_t>(), slot_sorted.as<uint32_t>(),
+	                          static_cast<unsigned int>(nslots), 0, key_bits, st));
+	FI_HIP_TRY(prim::exclusive_sum(tmp.p, tb2, count.as<uint32_t>(), m.off.as<uint32_t>(), static_cast<size_t>(P.ntiles + 1), st));
 	uint32_t total = 0;
 	FI_HIP_TRY(hipMemcpyAsync(&total, m.off.as<uint32_t>() + P.ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	FI_HIP_TRY(hipStreamSynchronize(st));

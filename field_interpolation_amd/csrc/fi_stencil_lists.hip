@@ -1,7 +1,7 @@
 // fi_stencil_lists.hip -- the per-workgroup, per-layer record lists the fused marching kernel (fi_stencil.hip) applies its
 // data cells from: membership count and write, radix sort by (workgroup, layer, band), list bounds, self-contained records,
 // classification of the workgroups with and without cells.  Part of the assembly (sparse_linear.cpp:59-70, 105-113 replaced).
-#include <hipcub/hipcub.hpp>
+#include "fi_prim.h"
 
 #include <algorithm>
 #include <cmath>
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(1024) void k_classify_pack(int nwg, int per_wg, con
                                                          uint32_t* __restrict__ wg_cells, uint32_t* __restrict__ wg_plain,
                                                          uint8_t* __restrict__ out)
 {
-	using Scan = hipcub::BlockScan<int, 1024>;
-	__shared__ typename Scan::TempStorage tmp;
+	using Scan = rocprim::block_scan<int, 1024>;
+	__shared__ typename Scan::storage_type tmp;
 	__shared__ int base_with, base_without;
 	if (threadIdx.x == 0) {
 		base_with    = 0;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(1024) void k_classify_pack(int nwg, int per_wg, con
 		}
 		const int flag = (wg < nwg && any) ? 1 : 0;
 		int pos = 0, total = 0;
-		Scan(tmp).ExclusiveSum(flag, pos, total);
+		Scan().exclusive_scan(flag, pos, 0, total, tmp, rocprim::plus<int>());
 		const int live = nwg - w0 < 1024 ? nwg - w0 : 1024;  // workgroups of this chunk
 		if (wg < nwg) {
 			if (any) {
@@ -557,22 +557,18 @@ void build_cell_lists(fi_ctx* c)
 		hipLaunchKernelGGL(k_cell_kinds, dim3(static_cast<int>((ncell + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, c->g, ncell,
 		                   c->cells.cell_id.as<uint32_t>(), c->cells.nrow.as<uint32_t>(), kinds.as<unsigned long long>(), uniq.as<uint32_t>());
 		size_t tb0 = 0;
-		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb0, kinds.as<unsigned long long>(), pre.as<unsigned long long>(),
-		                                            static_cast<int>(ncell + 1), st));
+		FI_HIP_TRY(prim::exclusive_sum(nullptr, tb0, kinds.as<unsigned long long>(), pre.as<unsigned long long>(), static_cast<size_t>(ncell + 1), st));
 		tmp.alloc(tb0);
-		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb0, kinds.as<unsigned long long>(), pre.as<unsigned long long>(),
-		                                            static_cast<int>(ncell + 1), st));
+		FI_HIP_TRY(prim::exclusive_sum(tmp.p, tb0, kinds.as<unsigned long long>(), pre.as<unsigned long long>(), static_cast<size_t>(ncell + 1), st));
 		hipLaunchKernelGGL(k_seg_bounds, dim3(static_cast<int>((nseg + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, P, c->g, nrows,
 		                   ncell, c->cells.cell_id.as<uint32_t>(), seg.as<uint32_t>());
 		const int nbb = static_cast<int>((nbuckets + 1 + kThreads - 1) / kThreads);
 		hipLaunchKernelGGL(k_list_count, dim3(nbb), dim3(kThreads), 0, st, P, c->g, nbuckets, seg.as<uint32_t>(),
 		                   pre.as<unsigned long long>(), counts_d.as<uint32_t>());
 		size_t tb1 = 0;
-		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, counts_d.as<uint32_t>(), first_d.as<uint32_t>(),
-		                                            static_cast<int>(2 * nbuckets), st));
+		FI_HIP_TRY(prim::exclusive_sum(nullptr, tb1, counts_d.as<uint32_t>(), first_d.as<uint32_t>(), static_cast<size_t>(2 * nbuckets), st));
 		tmp.alloc(tb1 > tb0 ? tb1 : tb0);
-		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb1, counts_d.as<uint32_t>(), first_d.as<uint32_t>(),
-		                                            static_cast<int>(2 * nbuckets), st));
+		FI_HIP_TRY(prim::exclusive_sum(tmp.p, tb1, counts_d.as<uint32_t>(), first_d.as<uint32_t>(), static_cast<size_t>(2 * nbuckets), st));
 		hipLaunchKernelGGL(k_list_layout, dim3(nbb), dim3(kThreads), 0, st, nbuckets, counts_d.as<uint32_t>(), first_d.as<uint32_t>(),
 		                   m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>());
 		hipLaunchKernelGGL(k_classify_pack, dim3(1), dim3(1024), 0, st, nwg, (P.zc + 1) * 4, m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(),
@@ -595,9 +591,9 @@ void build_cell_lists(fi_ctx* c)
 		                   static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
 		                   static_cast<uint32_t*>(nullptr), count.as<uint32_t>());
 		size_t tb0 = 0;
-		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
+		FI_HIP_TRY(prim::exclusive_sum(nullptr, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<size_t>(ncell), st));
 		tmp.alloc(tb0);
-		FI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<int>(ncell), st));
+		FI_HIP_TRY(prim::exclusive_sum(tmp.p, tb0, nslot.as<uint32_t>(), first.as<uint32_t>(), static_cast<size_t>(ncell), st));
 		hipLaunchKernelGGL(k_slot_total, dim3(1), dim3(1), 0, st, ncell, first.as<uint32_t>(), nslot.as<uint32_t>(),
 		                   first.as<uint32_t>() + ncell);
 		uint32_t h_slots = 0;
