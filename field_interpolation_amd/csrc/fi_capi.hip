@@ -482,6 +482,15 @@ int fi_assemble(fi_ctx* c)
 		const int thinnest = c->g.gn[2] / c->nranks;  // (the equal split: floor(G / n) is the thinnest slab)
 		if (deep > want_halo && thinnest >= deep) { want_halo = deep; }
 	}
+	// ... and the V-cycle's polynomial smoother (fp32 levels of value rows, 3 to 5 terms: poly_chain, fi_multigrid.hip)
+	if (c->nranks > 1 && c->g.ndim == 3 && c->mg_mode == 1 && c->mg_smoother == 1 && c->levels_wanted > 0 && c->value_rows_only &&
+	    !c->any_trip && (c->dtype == FI_F32 || c->mixed) && c->mg_terms >= 3 && c->mg_terms <= 5 &&
+	    !(c->w.model_3 > 0 || c->w.model_4 > 0 || c->w.gradient_smoothness > 0) && !fi::test_switch("FI_NO_DEEP_HALO") &&
+	    !fi::test_switch("FI_MG_FULL_SMOOTHER")) {
+		const int deep = 2 * (c->mg_terms - 1);
+		const int thinnest = c->g.gn[2] / c->nranks;
+		if (deep > want_halo && thinnest >= deep) { want_halo = deep; }
+	}
 	c->min_slab = c->nranks > 1 ? c->g.gn[c->g.ndim - 1] / c->nranks : c->g.gn[c->g.ndim - 1];
 	if (c->nranks > 1 && (want_halo != c->halo || want_reach != c->reach)) {
 		c->halo  = want_halo;

@@ -408,6 +408,7 @@ void store_owned(fi_ctx* c, const DevBuf& v, float* dst, int memory)
 void halo_exchange(RankSet& R, DevBuf fi_ctx::*vec, int width)  // width planes next to the slabs (0: the stencil's reach)
 {
 	if (R[0]->nranks == 1) { return; }  // whole lattices (a loop-back group's copies of the replicated tail included)
+	++R[0]->n_halo_exchanges;
 	if (R.size() == 1) {
 		exchange_halo(R[0], (R[0]->*vec).p, width);
 		return;

@@ -278,6 +278,7 @@ struct fi_ctx {
 	int        dtype = FI_F32;
 	int        device = 0;
 	int        rank = 0, nranks = 1;
+	int        n_halo_exchanges = 0;  // halo exchanges of this level since the solve reset it (cg_run_mg: fi_stats.halo_exchanges)
 	int        halo = 0;    // ghost planes STORED on each side of the slab along the slowest axis (>= reach)
 	int        min_slab = 0;  // the thinnest slab of this level over all ranks (a deep exchange needs that many planes to send)
 	int        reach = 1;   // planes a stencil / transfer reads beyond the slab = the default width of an exchange.  halo > reach:

@@ -620,21 +620,33 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 		}
 		return zb;
 	}
+	// Deep exchange over slabs (the polynomial PCG's, fi_poly.hip, for the V-cycle's smoother): fi_assemble has given the
+	// vectors 2 (d - 1) ghost planes; r's travel ONCE per polynomial, step k then also computes its 2 (d - 1 - k) nearest ghost
+	// planes -- what the neighbour computes for its own planes, bit for bit -- and no step waits for an exchange: one
+	// exchange per polynomial instead of d - 1 (a level's cycle: 6 instead of 12).  Levels whose slabs are thinner than the
+	// deep width keep one exchange per step; FI_NO_DEEP_HALO: every level does (tests: the same bits).
+	const int  deep_width = 2 * (terms - 1);
+	const bool deep = pro && c0->nranks > 1 && c0->halo >= deep_width && c0->min_slab >= deep_width && !test_switch("FI_NO_DEEP_HALO");
 	Vec zin = za, zout = zb;
 	double rho = 1.0 / sigma;
 	for (int k = 1; k < terms; ++k) {
 		const double rho_new = 1.0 / (2.0 * sigma - rho);
 		const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
 		const bool   first_on_load = pro && k == 1;
-		halo_exchange(R, first_on_load ? r : zin);
+		const int    ext = deep ? 2 * (terms - 1 - k) : 0;  // ghost planes this step computes for the next one
+		if (deep) {
+			if (k == 1) { halo_exchange(R, r, deep_width); }
+		} else {
+			halo_exchange(R, first_on_load ? r : zin);
+		}
 		for (fi_ctx* c : R) {
 			const unsigned short* sc = c->dinv16s.as<unsigned short>();
 			if (first_on_load) {
-				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc);
+				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc, ext);
 			} else {
 				// the second step's z_prev is z_0 = Dinv r / theta, recomputed from r and the scaling
 				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0,
-				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc);
+				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc, ext);
 			}
 		}
 		std::swap(zin, zout);
@@ -1165,6 +1177,11 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	// trip of 25-40 us in front of every V-cycle.  Should the solve be over earlier, the fp64 kernels exit on the flag and
 	// the cycles in between are wasted, nothing else; from the predicted count on every iteration looks again.
 	const int predicted = (c0->predictable_start && c0->last_mg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS")) ? c0->last_mg_iterations : 0;
+	{  // (slabs: the exchanges of every level of the solve, counted by halo_exchange)
+		RankSet& top = mixed ? Tw : R;
+		for (fi_ctx* l = top[0]; l; l = l->coarse) { l->n_halo_exchanges = 0; }
+		c0->n_halo_exchanges = 0;
+	}
 	int  steps = 0;
 	bool first_restart = true;
 	auto restart = [&]() -> int {
@@ -1314,6 +1331,11 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		c->stats.prec_ms_avg  = pused && plaunch ? psum / (pused * plaunch) : 0.0;
 		c->stats.prec_bytes   = pused && plaunch ? prec_ctx->prec_chain_bytes / plaunch : 0.0;
 		c->stats.operator_applies = h.iter + 1 + h.restarts;
+		{
+			int ex = c0->n_halo_exchanges;
+			for (fi_ctx* l = (mixed ? Tw[0] : c0->coarse); l; l = l->coarse) { ex += l->n_halo_exchanges; }
+			c->stats.halo_exchanges = ex;
+		}
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
 		c->last_mg_iterations = timed_out || h.done == 2 ? 0 : h.iter;  // (the same on every rank: the scalars are sums over all)

@@ -250,3 +250,53 @@ def test_python_point_filter_follows_the_library_rule(fi, sizes, nranks):
             plo, phi = fdist.point_range(sl[0], sl[1], levels)
             assert plo <= lo + 1e-3 and phi >= hi - 1e-3      # the Python margin covers the library's
         del grp
+
+
+@pytest.mark.parametrize("dtype,mixed,nranks,sizes,levels", [("f64", True, 4, [40, 36, 64], 2), ("f32", False, 2, [36, 40, 48], 2),
+                                                            ("f64", True, 3, [32, 32, 72], 1)])
+def test_vcycle_polynomial_deep_exchange_equals_one_exchange_per_step(fi, monkeypatch, dtype, mixed, nranks, sizes, levels):
+    """over slabs the V-cycle's polynomial smoother (value rows, fp32 levels) exchanges the ghost planes of
+    its right-hand side ONCE per polynomial -- 2 (d - 1) = 8 planes, which fi_assemble gives the vectors when the V-cycle is
+    set before it -- and every step also computes the ghost planes the next one reads (what the neighbour computes for its
+    own planes, bit for bit), instead of one exchange in front of every step.  The same iterates (FI_NO_DEEP_HALO: the
+    per-step form): equal iteration counts, equal BITS, fewer exchanges; levels whose slabs are thinner than the deep width
+    fall back by themselves.  And the undivided solve agrees."""
+    rng = np.random.default_rng(nranks + len(sizes))
+    n = 6000
+    pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+    val = rng.normal(size=n).astype(np.float32)
+    w = fi.Weights(model_2=0.5)
+    tol = 1e-8 if dtype == "f64" else 1e-5
+
+    def build(make):
+        f = make()
+        f.add_field_constraints(w)
+        f.set_levels(levels, 1e-4)
+        f.set_multigrid(True)
+        if mixed:
+            f.set_mixed_precision(True)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.assemble()
+        return f
+
+    out = []
+    for deep in (True, False):
+        if deep:
+            monkeypatch.delenv("FI_NO_DEEP_HALO", raising=False)
+        else:
+            monkeypatch.setenv("FI_NO_DEEP_HALO", "1")
+        g = build(lambda: fi.LatticeGroup(sizes, nranks, dtype=dtype))
+        x, it, rel = g.solve_cg(None, 0, tol)
+        st = g.stats()
+        assert g.true_residual() <= 1.5 * tol
+        out.append((x.copy(), it, st["coarse_iterations"], st["halo_exchanges"]))
+        del g
+    monkeypatch.delenv("FI_NO_DEEP_HALO", raising=False)
+    (xd, itd, cd, exd), (xs, its, cs, exs) = out
+    assert itd == its and cd == cs, (itd, its, cd, cs)
+    np.testing.assert_array_equal(xd, xs)
+    assert exd < exs, (exd, exs)        # 3 exchanges less per polynomial on every level thick enough
+    one = build(lambda: fi.LatticeField(sizes, dtype=dtype))
+    x1, it1, _ = one.solve_cg(None, 0, tol)
+    assert abs(it1 - itd) <= 2
+    assert np.abs(x1 - xd).max() <= (1e-5 if dtype == "f64" else 3e-3) * np.abs(x1).max()
