@@ -1432,14 +1432,13 @@ void* pinned(fi_ctx* c, int slot, size_t bytes)
 {
 	if (c->pin_bytes[slot] < bytes) {
 		if (c->pin[slot]) {
-			(void)hipHostFree(c->pin[slot]);
+			pinned_give(c->pin[slot], c->pin_bytes[slot]);
 			c->pin[slot] = nullptr;
 			c->pin_bytes[slot] = 0;
 		}
-		size_t want = 4096;
-		while (want < bytes) { want *= 2; }
-		FI_HIP_TRY(hipHostMalloc(&c->pin[slot], want, hipHostMallocDefault));
-		c->pin_bytes[slot] = want;
+		size_t cap = 0;
+		c->pin[slot] = pinned_take(bytes, &cap);
+		c->pin_bytes[slot] = cap;
 	}
 	return c->pin[slot];
 }

@@ -98,13 +98,13 @@ fi_ctx* create_ctx(int ndim, const int* sizes, int dtype, int rank, int nranks)
 		c->rank   = rank;
 		c->nranks = nranks;
 		FI_HIP_TRY(hipGetDevice(&c->device));
-		FI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->stream = stream_take();
 		c->halo = 1;
 		compute_geom(c, ndim, sizes);
 		c->scal.alloc(3 * sizeof(CgScalars));  // [0]: the state every kernel and the host look at, [1]: mid-iteration copy,
 		                                       // [2]: landing place of the dot products summed over slabs (rank sets)
 		FI_HIP_TRY(hipMemset(c->scal.p, 0, 2 * sizeof(CgScalars)));
-		FI_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->scal_host), sizeof(CgScalars), hipHostMallocDefault));
+		c->scal_host = static_cast<CgScalars*>(pinned_take(sizeof(CgScalars), &c->scal_host_cap));
 		// default Weights (field_interpolation.hpp:75-95)
 		c->w = fi_weights{1.0f, 1.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, FI_VALUE_LINEAR_INTERPOLATION,
 		                  FI_GRADIENT_CELL_EDGES};
@@ -178,30 +178,30 @@ int fi_ctx_destroy(fi_ctx* c)
 	c->pending_pool.clear();
 	for (auto e : c->ev) { (void)hipEventDestroy(e); }
 	for (auto e : c->ev_prec) { (void)hipEventDestroy(e); }
-	if (c->level_stream) { (void)hipStreamDestroy(c->level_stream); }
+	fi::stream_give(c->level_stream, drained);
 	if (c->ev_level) { (void)hipEventDestroy(c->ev_level); }
-	if (c->level_stream2) { (void)hipStreamDestroy(c->level_stream2); }
+	fi::stream_give(c->level_stream2, drained);
 	if (c->build_stream) {
-		(void)hipStreamDestroy(c->build_stream);
+		fi::stream_give(c->build_stream, drained);
 		(void)hipEventDestroy(c->ev_build);
 	}
 	if (c->ev_level2) { (void)hipEventDestroy(c->ev_level2); }
 	if (c->comm_stream) {
-		(void)hipStreamDestroy(c->comm_stream);
+		fi::stream_give(c->comm_stream, drained);
 		(void)hipEventDestroy(c->ev_ready);
 		(void)hipEventDestroy(c->ev_halo);
 	}
 	if (c->comm && c->owns_comm) { fi::comm_destroy(c->comm); }
-	if (c->scal_host) { (void)hipHostFree(c->scal_host); }
+	if (c->scal_host) { fi::pinned_give(c->scal_host, c->scal_host_cap); }
 	for (int s = 0; s < 3; ++s) {
-		if (c->pin[s]) { (void)hipHostFree(c->pin[s]); }
+		if (c->pin[s]) { fi::pinned_give(c->pin[s], c->pin_bytes[s]); }
 	}
 	if (c->ev_unwatched) { (void)hipEventDestroy(c->ev_unwatched); }
 	if (c->ev_asm0) {
 		(void)hipEventDestroy(c->ev_asm0);
 		(void)hipEventDestroy(c->ev_asm1);
 	}
-	if (c->stream && c->owns_stream) { (void)hipStreamDestroy(c->stream); }
+	if (c->stream && c->owns_stream) { fi::stream_give(c->stream, drained); }
 	delete c;
 	return FI_OK;
 }
@@ -521,7 +521,7 @@ int fi_assemble(fi_ctx* c)
 	}
 	if (beside) {
 		if (!c->level_stream) {
-			FI_HIP_TRY(hipStreamCreateWithFlags(&c->level_stream, hipStreamNonBlocking));
+			c->level_stream = fi::stream_take();
 			FI_HIP_TRY(hipEventCreateWithFlags(&c->ev_level, hipEventDisableTiming));
 		}
 		FI_HIP_TRY(hipEventRecord(c->ev_level, c->stream));  // the point batches were written on the solver stream
@@ -534,7 +534,7 @@ int fi_assemble(fi_ctx* c)
 		if (mixed64) {
 			fi::twin_prepare(c);
 			if (!c->level_stream2) {
-				FI_HIP_TRY(hipStreamCreateWithFlags(&c->level_stream2, hipStreamNonBlocking));
+				c->level_stream2 = fi::stream_take();
 				FI_HIP_TRY(hipEventCreateWithFlags(&c->ev_level2, hipEventDisableTiming));
 			}
 			FI_HIP_TRY(hipStreamWaitEvent(c->level_stream2, c->ev_level, 0));
@@ -542,6 +542,7 @@ int fi_assemble(fi_ctx* c)
 		auto guarded = [&](auto&& work, int* code, std::string* msg) {
 			try {
 				FI_HIP_TRY(hipSetDevice(c->device));
+				fi::AllocStream none(nullptr);  // (a helper's buffers: each level names its own stream, fi_levels.hip)
 				work();
 			} catch (const fi::Fail& f) {
 				*code = f.code;
@@ -584,6 +585,7 @@ int fi_assemble(fi_ctx* c)
 		int main_code = FI_OK;
 		c->defer_scaling_exchange = true;  // slabs: the one exchange of the assembly comes after the ranks have agreed (below)
 		try {
+			fi::AllocStream alloc_on(c->stream);  // (this chain's buffers are first used on the solver stream: fi_internal.h)
 			fi::assemble(c);
 			fi::generic_assemble(c);
 			fi::stencil_prepare(c);
@@ -599,6 +601,7 @@ int fi_assemble(fi_ctx* c)
 		// (its share of the assembly's one exchange comes with operator_finish_ghosts below).
 		if (lumped && main_code == FI_OK) {
 			try {
+				fi::AllocStream alloc_on(c->stream);
 				c->twin->defer_scaling_exchange = true;
 				fi::twin_assemble_lumped(c);
 			} catch (const fi::Fail& f) {
@@ -658,6 +661,7 @@ int fi_assemble(fi_ctx* c)
 		fi::operator_finish_ghosts(c);
 		for (fi_ctx* l = first_built; l; l = l->coarse) { fi::operator_finish_ghosts(l); }
 	} else {
+	fi::AllocStream alloc_on(c->stream);
 	fi::assemble(c);
 	fi::generic_assemble(c);
 	fi::stencil_prepare(c);
@@ -695,6 +699,7 @@ int fi_solve_cg(fi_ctx* c, const float* guess, int max_iterations, float tol, fl
 	fi::check_assembled(c);
 	fi::bind_device(c);
 	FI_REQUIRE(memory == FI_HOST || memory == FI_DEVICE, FI_ERR_INVALID, "bad memory kind %d", memory);
+	fi::AllocStream alloc_on(c->stream);  // (every level of a hierarchy solves on the finest level's stream)
 	if (c->dtype == FI_F64) {
 		fi::solve_cg_t<double>(c, guess, max_iterations, tol, out, iterations, rel_residual, memory);
 	} else {

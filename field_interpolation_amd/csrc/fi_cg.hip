@@ -5,6 +5,55 @@
 
 namespace fi {
 
+// ---- iteration counts across contexts (see fi_solver_internal.h) ------------------------------------------------------
+namespace {
+struct PredKey {
+	int    kind, dtype, ndim, gn[3], level, below, mixed, rows_only;
+	float  w[8];
+	double tol;
+	bool operator<(const PredKey& o) const { return std::memcmp(this, &o, sizeof(PredKey)) < 0; }
+};
+PredKey pred_key(const fi_ctx* c, int kind, double tol)
+{
+	PredKey k;
+	std::memset(&k, 0, sizeof(k));  // (padding bytes take part in the comparison)
+	k.kind  = kind;
+	k.dtype = c->dtype;
+	k.ndim  = c->g.ndim;
+	for (int d = 0; d < 3; ++d) { k.gn[d] = c->g.gn[d]; }
+	k.level = c->level;
+	for (const fi_ctx* l = (c->twin && c->twin->coarse ? c->twin->coarse : c->coarse); l; l = l->coarse) { ++k.below; }
+	k.mixed     = c->mixed;
+	k.rows_only = c->value_rows_only ? 1 : 0;
+	const float w[8] = {c->w.data_pos, c->w.data_gradient, c->w.model_0, c->w.model_1, c->w.model_2, c->w.model_3, c->w.model_4,
+	                    c->w.gradient_smoothness};
+	std::memcpy(k.w, w, sizeof(w));
+	k.tol = tol;
+	return k;
+}
+std::mutex g_pred_mutex;
+std::map<PredKey, int> g_pred;
+}  // namespace
+
+void remember_iterations(const fi_ctx* c, int kind, double tol, int iterations)
+{
+	if (c->nranks != 1 || iterations <= 0 || test_switch("FI_NO_LAMBDA_CACHE")) { return; }
+	std::lock_guard<std::mutex> lock(g_pred_mutex);
+	g_pred[pred_key(c, kind, tol)] = iterations;
+}
+
+// once per context and kind: afterwards the context's own history decides (a level whose prediction failed must be
+// able to watch its flag again)
+int recall_iterations(fi_ctx* c, int kind, double tol)
+{
+	if (c->pred_recalled[kind]) { return 0; }
+	c->pred_recalled[kind] = true;
+	if (c->nranks != 1 || test_switch("FI_NO_LAMBDA_CACHE") || test_switch("FI_LOOK_ALWAYS")) { return 0; }
+	std::lock_guard<std::mutex> lock(g_pred_mutex);
+	auto it = g_pred.find(pred_key(c, kind, tol));
+	return it == g_pred.end() ? 0 : it->second;
+}
+
 // ---- vector kernels (owned range is contiguous: the slowest axis is the decomposed one) ---------
 
 // r = b - q; p = Dinv r; partials: r.(Dinv r), r.r, b.b
@@ -447,7 +496,7 @@ bool overlap_possible(const fi_ctx* c)
 void exchange_begin(fi_ctx* c, void* v)
 {
 	if (!c->comm_stream) {
-		FI_HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+		c->comm_stream = stream_take();
 		FI_HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
 		FI_HIP_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
 	}
@@ -540,11 +589,19 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		const CgScalars* was = static_cast<const CgScalars*>(pinned(c0, 2, sizeof(CgScalars)));
 		const bool as_expected = (was->done == 1 || was->done == 5) && was->iter > 0 && was->iter <= c0->unwatched_expected;
 		c0->last_cg_iterations = as_expected ? was->iter : 0;  // (0: this solve watches its flag again and learns the new count)
+		c0->pred_recalled[0]   = true;
 	}
 	// Such a solve: a coarser level of an undivided lattice whose previous solve ended after n iterations with the same
 	// tolerance gets n iterations and no look at all -- the level below it is waiting for its result, and a look is a host
 	// round trip of ~40 us per level.  Should n not have been enough this time, the start guess is that much worse and the
 	// next solve of this level watches again.
+	if (c0->level > 0 && R.size() == 1 && c0->last_cg_iterations == 0) {  // a fresh context: what the one before it learnt
+		const int n = recall_iterations(c0, 0, tolerance);
+		if (n > 0) {
+			c0->last_cg_iterations = n;
+			c0->last_cg_tol        = tolerance;
+		}
+	}
 	const bool unwatched = c0->level > 0 && R.size() == 1 && c0->nranks == 1 && !c0->verify_residual && c0->last_cg_iterations > 0 &&
 	                       c0->last_cg_iterations <= max_iterations && c0->last_cg_iterations <= 64 && c0->last_cg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS");
 	c0->last_cg_tol = tolerance;
@@ -774,6 +831,7 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
 		c->last_cg_iterations = timed_out ? 0 : h.iter;  // the same on every rank: the scalars are sums over all of them
+		if (R.size() == 1 && c->level > 0 && !timed_out && (h.done == 1 || h.done == 5)) { remember_iterations(c, 0, tolerance, h.iter); }
 		// with the verified stop on, "converged" means b - A x itself met the tolerance (done == 5); a recurrence
 		// that converged while the true residual stagnated above it (fp32 on an ill-conditioned system) is not
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;

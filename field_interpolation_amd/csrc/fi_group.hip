@@ -24,7 +24,7 @@ int fi_group_create(fi_group** out, int ndim, const int* sizes, int dtype, int n
 		for (fi_ctx* c : g->members) {
 			ptrs.push_back(c->scal.as<fi::CgScalars>());
 			if (c != c0) {  // one stream for the whole group: program order is the synchronisation
-				(void)hipStreamDestroy(c->stream);
+				fi::stream_give(c->stream, true);  // (new, nothing on it)
 				c->stream      = c0->stream;
 				c->owns_stream = false;
 			}

@@ -130,7 +130,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 			generic_clear(co);
 		} else {
 			co = create_ctx(D, sizes, c->dtype, tail ? 0 : c->rank, co_nranks);
-			(void)hipStreamDestroy(co->stream);
+			stream_give(co->stream, true);  // (new, nothing on it)
 			co->stream      = c->stream;
 			co->owns_stream = false;
 			co->owns_comm   = false;
@@ -184,6 +184,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 	// config 4 16.2 -> 15.9 ms per step: there the fp64 finest level is the longest chain).  FI_SERIAL_LEVEL_CHAINS: one
 	// after the other (tests: the same bits).
 	auto assemble_level = [src](fi_ctx* co) {
+		AllocStream alloc_on(co->stream);  // (the level's chain runs on co->stream: its buffers' slack is zeroed there)
 		const int   l  = co->level;
 		const float ps = 1.0f / static_cast<float>(1 << l), ns = static_cast<float>(1 << l);
 		for (auto* b : src->batches) {
@@ -227,7 +228,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		for (size_t i = 1; i < built.size(); ++i) {
 			fi_ctx* co = built[i];
 			if (!co->build_stream) {
-				FI_HIP_TRY(hipStreamCreateWithFlags(&co->build_stream, hipStreamNonBlocking));
+				co->build_stream = stream_take();
 				FI_HIP_TRY(hipEventCreateWithFlags(&co->ev_build, hipEventDisableTiming));
 			}
 			FI_HIP_TRY(hipStreamWaitEvent(co->build_stream, go, 0));
@@ -384,7 +385,7 @@ fi_ctx* twin_prepare(fi_ctx* c)
 		generic_clear(t);
 	} else {
 		t = create_ctx(D, sizes, FI_F32, c->rank, c->nranks);
-		(void)hipStreamDestroy(t->stream);
+		stream_give(t->stream, true);  // (new, nothing on it)
 		t->stream      = c->stream;
 		t->owns_stream = false;
 		t->owns_comm   = false;
@@ -430,6 +431,7 @@ void twin_assemble(fi_ctx* c, hipStream_t build_stream)
 		t->stream = build_stream;
 		t->defer_scaling_exchange = true;  // a helper thread never talks to the neighbours
 	}
+	AllocStream alloc_on(t->stream);  // (the replica's chain runs on t->stream)
 	for (auto* b : c->batches) {
 		const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
 		const float* pw  = b->has_pw ? b->pw.as<float>() : nullptr;

@@ -1176,6 +1176,13 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	// likely takes as many iterations: no look at the stop flag before that count -- a look is a copy and a host round
 	// trip of 25-40 us in front of every V-cycle.  Should the solve be over earlier, the fp64 kernels exit on the flag and
 	// the cycles in between are wasted, nothing else; from the predicted count on every iteration looks again.
+	if (c0->last_mg_iterations == 0 && R.size() == 1 && c0->predictable_start) {  // a fresh context: what the one before it learnt
+		const int n = recall_iterations(c0, 1, tolerance);
+		if (n > 0) {
+			c0->last_mg_iterations = n;
+			c0->last_mg_tol        = tolerance;
+		}
+	}
 	const int predicted = (c0->predictable_start && c0->last_mg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS")) ? c0->last_mg_iterations : 0;
 	{  // (slabs: the exchanges of every level of the solve, counted by halo_exchange)
 		RankSet& top = mixed ? Tw : R;
@@ -1340,6 +1347,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		c->stats.iterations   = h.iter;
 		c->last_mg_iterations = timed_out || h.done == 2 ? 0 : h.iter;  // (the same on every rank: the scalars are sums over all)
 		c->last_mg_tol        = tolerance;
+		if (R.size() == 1 && c0->predictable_start && !timed_out && h.done != 2) { remember_iterations(c, 1, tolerance, h.iter); }
 		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
 		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
 		c->stats.restarts     = h.restarts;

@@ -7,10 +7,12 @@
 
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace fi {
 
 thread_local bool pool_quiescent = false;
+thread_local hipStream_t alloc_stream = nullptr;
 
 namespace {
 constexpr size_t kPoolBytes = size_t(8) << 30;
@@ -55,11 +57,104 @@ bool pool_give(void* p, size_t capacity, size_t used)
 	return true;
 }
 
+// ---- streams and pinned staging buffers of destroyed contexts -------------------------------------------------------------
+// hipStreamCreateWithFlags takes 0.4-6 ms, hipStreamDestroy 0.4-1.2 ms, hipHostMalloc / hipHostFree 0.1-0.25 ms (rocprofv3
+// --hip-runtime-trace of tools/r5_cold.py): a context of the headline solver -- five contexts with nine streams and a dozen
+// staging buffers between them -- paid 3-4 ms of its first assemble and 5-6 ms of its destruction for them.  A caller that
+// creates, solves and destroys per call (the reference's stateless solve_sparse_linear*, sparse_linear.cpp:194-196) now finds
+// the streams and buffers of the context before.  Streams enter drained (fi_ctx_destroy synchronises them first).
+namespace {
+struct HostPool {
+	std::vector<hipStream_t> streams;
+	std::multimap<size_t, void*> pinned;
+};
+std::map<int, HostPool> g_host;
+constexpr size_t kMaxPooledStreams = 64, kMaxPooledPinned = 128;
+}  // namespace
+
+hipStream_t stream_take()
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) == hipSuccess && !pool_off()) {
+		std::lock_guard<std::mutex> lock(g_mutex);
+		HostPool& H = g_host[dev];
+		if (!H.streams.empty()) {
+			hipStream_t st = H.streams.back();
+			H.streams.pop_back();
+			return st;
+		}
+	}
+	hipStream_t st = nullptr;
+	FI_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	return st;
+}
+
+void stream_give(hipStream_t st, bool drained)
+{
+	if (!st) { return; }
+	int dev = 0;
+	if (drained && !pool_off() && hipGetDevice(&dev) == hipSuccess) {
+		std::lock_guard<std::mutex> lock(g_mutex);
+		HostPool& H = g_host[dev];
+		if (H.streams.size() < kMaxPooledStreams) {
+			H.streams.push_back(st);
+			return;
+		}
+	}
+	(void)hipStreamDestroy(st);
+}
+
+void* pinned_take(size_t bytes, size_t* capacity)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) == hipSuccess && !pool_off()) {
+		std::lock_guard<std::mutex> lock(g_mutex);
+		HostPool& H = g_host[dev];
+		auto it = H.pinned.lower_bound(bytes);
+		if (it != H.pinned.end() && it->first <= 4 * (bytes < 4096 ? 4096 : bytes)) {
+			void* p = it->second;
+			*capacity = it->first;
+			H.pinned.erase(it);
+			return p;
+		}
+	}
+	size_t want = 4096;
+	while (want < bytes) { want *= 2; }
+	void* p = nullptr;
+	FI_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+	*capacity = want;
+	return p;
+}
+
+void pinned_give(void* p, size_t capacity)
+{
+	if (!p) { return; }
+	int dev = 0;
+	if (!pool_off() && hipGetDevice(&dev) == hipSuccess) {
+		std::lock_guard<std::mutex> lock(g_mutex);
+		HostPool& H = g_host[dev];
+		if (H.pinned.size() < kMaxPooledPinned) {
+			H.pinned.emplace(capacity, p);
+			return;
+		}
+	}
+	(void)hipHostFree(p);
+}
+
 size_t pool_trim(size_t keep_bytes)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { return 0; }
 	std::lock_guard<std::mutex> lock(g_mutex);
+	if (keep_bytes == 0) {  // "give everything back": the streams and staging buffers too
+		auto hit = g_host.find(dev);
+		if (hit != g_host.end()) {
+			for (hipStream_t st : hit->second.streams) { (void)hipStreamDestroy(st); }
+			for (auto& kv : hit->second.pinned) { (void)hipHostFree(kv.second); }
+			hit->second.streams.clear();
+			hit->second.pinned.clear();
+		}
+	}
 	auto pit = g_pools.find(dev);
 	if (pit == g_pools.end()) { return 0; }
 	DevicePool& P = pit->second;

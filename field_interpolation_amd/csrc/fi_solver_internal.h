@@ -503,6 +503,11 @@ void reset_scalars(RankSet& R, const CgScalars& init);
 bool timed_out_anywhere(RankSet& R, bool mine);
 bool all_ranks_ok(fi_ctx* c, bool mine);
 template <typename T> void cg_run(RankSet& R, int max_iterations, float tol);
+// iteration counts of finished solves, kept per process by lattice shape, model, level and tolerance: a context that lives
+// for one solve (the reference's stateless callers, sparse_linear.cpp:194-196) starts with the predictions the context before
+// it had learnt -- they decide when a solve first LOOKS at its stop flag, never what it computes
+void remember_iterations(const fi_ctx* c, int kind, double tol, int iterations);
+int  recall_iterations(fi_ctx* c, int kind, double tol);
 template <typename T> void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
                                       float* rel_residual, int memory);
 template <typename T> void tile_pass_run(RankSet& R, int tile_size);
