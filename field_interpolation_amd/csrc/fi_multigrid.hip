@@ -1183,7 +1183,11 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			c0->last_mg_tol        = tolerance;
 		}
 	}
-	const int predicted = (c0->predictable_start && c0->last_mg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS")) ? c0->last_mg_iterations : 0;
+	// (one iteration EARLIER than the previous solve ended: on changed data the count moves by one either way -- 512^3 with three
+	// data sets in turn took 6, 7, 6 iterations -- and a V-cycle launched behind an unseen stop is a whole cycle wasted (10 ms
+	// there) where a look costs 40 us)
+	const int predicted = (c0->predictable_start && c0->last_mg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS") && c0->last_mg_iterations > 1)
+	                          ? c0->last_mg_iterations - 1 : 0;
 	{  // (slabs: the exchanges of every level of the solve, counted by halo_exchange)
 		RankSet& top = mixed ? Tw : R;
 		for (fi_ctx* l = top[0]; l; l = l->coarse) { l->n_halo_exchanges = 0; }

@@ -60,6 +60,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <hip/hip_fp16.h>
+
 #include "fi_internal.h"
 #include "fi_stencil_common.h"
 
