@@ -51,7 +51,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_ROUND = "r4"       # profiles/<round>_traffic_<kernel>_c4.json: the PMC passes of the shipped kernels
+TRAFFIC_ROUND = "r5"       # profiles/<round>_traffic_<kernel>_c4.json: the PMC passes of the shipped kernels
 
 
 def measured_traffic(kind, config, side, points, dtype):
