@@ -685,13 +685,16 @@ __global__ __launch_bounds__(kThreads) void k_gather_cells3(Geom g, long ncell, 
 }
 
 // ---- the same sums for 3-D lattices, by TILES of lattice points in LDS ------------------------------------------------
-// One workgroup owns 64 x 4 x 2 owned points: it collects the cells that touch them (the cells are sorted by extended id,
-// x fastest: k_xtile_bounds gives the range of the tile's x in every (y, z) row of cells, a tile looks at 5 x 3 rows), orders them by the
+// One workgroup owns 64 x 4 x 4 owned points (round 5; 64 x 4 x 2 before: a tile is a chain of a dozen dependent phases --
+// range loads, record loads, eight colour rounds with a barrier each -- and the 256^3 fp64 level runs 16 rounds of such
+// workgroups: half as many, twice as large, 173 -> 155 us alone; 64 x 4 x 8: 186 us).  It collects the cells that touch them (the
+// cells are sorted by extended id, x fastest: k_xtile_bounds gives the range of the tile's x in every (y, z) row of cells, a tile
+// looks at 5 x 5 rows), orders them by the
 // parity colour of their origin, adds their records to the tile's accumulators colour after colour -- within a colour no
 // two cells share a corner -- and stores the tile with full lines.  The same sums in the same order as the 2^D colour
 // launches and the gather launch: the same bits.  No cell map, no zeroing of the arrays, and the time follows the occupied
 // cells, not the look-ups (256^3 fp64, 6 % of the cells occupied: gather 310 us + map 45 us + zeroing 42 us -> ... us).
-constexpr int kTileX = 64, kTileY = 4, kTileZ = 2;
+constexpr int kTileX = 64, kTileY = 4, kTileZ = 4;
 
 // xt[(row * (ntx + 1) + t) * 2 + which]: first cell of row `row` whose x origin is >= first + 64 t - 1 + which, `first` the
 // extended-local x of the lattice's first owned point.  The cells of the 64 points of tile t in that row -- origins one
