@@ -668,10 +668,10 @@ struct TailProgram {
 	enum { B = 0, X = 1, Rr = 2, W0 = 3, W1 = 4 };
 	std::vector<TailOp> ops;
 	std::vector<fi_ctx*> chain;
-	std::vector<int> base, nn;
+	std::vector<int> base, nn, vstride, guard;
 	bool ok = true;
 
-	int vec(int l, int v) const { return base[l] + v * nn[l]; }
+	int vec(int l, int v) const { return base[l] + guard[l] + v * vstride[l]; }  // point 0 of vector v (fi_tail.h: TailLevel)
 	void op(int kind, int level, int a, int b, int c, int out, int acc, const unsigned short* scale, double s0 = 0, double s1 = 0, double s2 = 0)
 	{
 		ops.push_back(TailOp{kind, level, a, b, c, out, acc, 0, scale, static_cast<float>(s0), static_cast<float>(s1), static_cast<float>(s2), 0});
@@ -792,10 +792,14 @@ bool tail_vcycle(RankSet& R, Vec b, Vec x)
 		TailProgram P;
 		int floats = 0;
 		for (fi_ctx* l = c; l; l = l->coarse) {
+			const int nn = static_cast<int>(l->g.nloc);
+			const int gd = 2 * (l->g.ndim > 2 ? l->g.gn[0] * l->g.gn[1] : l->g.gn[0]);
 			P.chain.push_back(l);
 			P.base.push_back(floats);
-			P.nn.push_back(static_cast<int>(l->g.nloc));
-			floats += kTailSlots * static_cast<int>(l->g.nloc);
+			P.nn.push_back(nn);
+			P.guard.push_back(gd);
+			P.vstride.push_back(nn + 2 * gd);
+			floats += tail_level_floats(l->g.ndim, l->g.gn);
 		}
 		P.cycle(0);
 		if (!P.ok || P.ops.empty() || static_cast<int>(P.chain.size()) > kTailMaxLevels || floats * sizeof(float) > 160u * 1024u) {
@@ -806,7 +810,11 @@ bool tail_vcycle(RankSet& R, Vec b, Vec x)
 		TailLevel* lv = reinterpret_cast<TailLevel*>(blob.data());
 		for (size_t k = 0; k < P.chain.size(); ++k) {
 			lv[k] = tail_level_of(P.chain[k]);
-			lv[k].base = P.base[k];
+			lv[k].base    = P.base[k] + P.guard[k];
+			lv[k].vstride = P.vstride[k];
+			lv[k].guard   = P.guard[k];
+			lv[k].ctab    = P.base[k] + kTailVectors * P.vstride[k];
+			lv[k].ktab    = lv[k].ctab + P.nn[k];
 			if (k + 1 < P.chain.size()) { lv[k].to_coarse = level_pair(P.chain[k], P.chain[k + 1]); }
 		}
 		std::memcpy(blob.data() + sizeof(TailLevel) * kTailMaxLevels, P.ops.data(), sizeof(TailOp) * P.ops.size());

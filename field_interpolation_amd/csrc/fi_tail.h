@@ -18,7 +18,6 @@ constexpr int64_t kTailMaxPoints = 4096;   // 64^2 / 16^3: five vectors of every
 constexpr int     kTailMaxLevels = 6;
 constexpr int     kTailThreads   = 1024;
 constexpr int     kTailVectors   = 5;      // per level: right-hand side, result, residual, two work vectors
-constexpr int     kTailSlots     = 6;      // ... and the points' packed coordinates (filled by the kernel's prologue)
 
 // One level as the engine sees it.  Operator = model rows matrix-free (model_0 / model_1 / model_2 from the global
 // coordinates, like the tiled kernels) + the data rows as 3^D diagonals (`dia`, built from the cell blocks by
@@ -27,11 +26,22 @@ struct TailLevel {
 	int      ndim;
 	int      n[3];
 	int      nn;           // unknowns
-	int      base;         // LDS offset (in floats) of this level's vectors: vector v lives at base + v * nn
+	// LDS layout of the level (offsets in floats): kTailVectors vectors of `vstride` = nn + 2 guard floats each -- vector v's
+	// point 0 at base + v * vstride, `guard` = two rows (2-D) / two planes (3-D) of zeros on either side, never written: a
+	// neighbour index needs no clamp, what lies beyond a vector only ever meets a zero coefficient --, then the points' packed
+	// coordinates (ctab, nn words) and the model rows' coefficients per coordinate (ktab: 5 floats per coordinate, axis after axis)
+	int      base, vstride, guard, ctab, ktab;
 	float    w0sq, w1sq, w2sq;
 	const float* dia;      // [3^D][nn] or null (no data)
 	LevelPair to_coarse;   // transfers to the next level of the tail (unused on the last one)
 };
+// floats of LDS a level of extents n takes
+inline int tail_level_floats(int ndim, const int* n)
+{
+	const int nn = n[0] * n[1] * (ndim > 2 ? n[2] : 1);
+	const int guard = 2 * (ndim > 2 ? n[0] * n[1] : n[0]);
+	return kTailVectors * (nn + 2 * guard) + nn + 5 * (n[0] + n[1] + (ndim > 2 ? n[2] : 0));
+}
 
 // The V-cycle as a straight-line program of stages, one workgroup barrier behind each.  a, b, c: input vectors, out / acc:
 // outputs -- LDS offsets in floats, -1: none; `scale`: the bfloat16 Jacobi-type scaling the stage uses (the polynomial
@@ -59,7 +69,7 @@ void tail_build_operator(fi_ctx* c);          // `dia` of an assembled level, on
 TailLevel tail_level_of(const fi_ctx* c);
 // runs the program (device array of `nops` stages over `nlev` levels, both in `prog`: TailLevel[kTailMaxLevels] then the ops):
 // b (global, top level) -> LDS vector 0 of level 0, the stages, LDS vector 1 of level 0 -> x (global); lds_floats: the sum of
-// kTailSlots * nn over the levels
+// tail_level_floats over the levels
 void tail_run(fi_ctx* top, const void* prog, int nlev, int nops, int lds_floats, const float* b, float* x);
 
 }  // namespace fi

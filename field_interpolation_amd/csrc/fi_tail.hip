@@ -71,48 +71,53 @@ extern __shared__ float fi_tail_lds[];
 template <int D, bool BOX>
 __device__ inline void load_around(const TailLevel& L, int off, int i, Around<D>& A)
 {
-	const int n0 = L.n[0], n01 = L.n[0] * L.n[1], hi = L.nn - 1;
+	// (no clamps: two rows / planes of zeros lie on either side of every vector, and whatever a neighbour index finds beyond
+	// the point's own row, plane or lattice meets a zero coefficient)
+	const int n0 = L.n[0], n01 = L.n[0] * L.n[1];
 	if (BOX) {
 #pragma unroll
 		for (int s = 0; s < (D == 2 ? 9 : 27); ++s) {
 			const int dx = s % 3 - 1, dy = (s / 3) % 3 - 1, dz = D > 2 ? s / 9 - 1 : 0;
-			A.box[s] = FI_TAIL_LDS(off, clampi(i + dx + dy * n0 + dz * n01, hi));
+			A.box[s] = FI_TAIL_LDS(off, i + dx + dy * n0 + dz * n01);
 		}
 	} else {  // the axis neighbours and the centre only
 		constexpr int ctr = D == 2 ? 4 : 13;
 		A.box[ctr]     = FI_TAIL_LDS(off, i);
-		A.box[ctr - 1] = FI_TAIL_LDS(off, clampi(i - 1, hi));
-		A.box[ctr + 1] = FI_TAIL_LDS(off, clampi(i + 1, hi));
-		A.box[ctr - 3] = FI_TAIL_LDS(off, clampi(i - n0, hi));
-		A.box[ctr + 3] = FI_TAIL_LDS(off, clampi(i + n0, hi));
+		A.box[ctr - 1] = FI_TAIL_LDS(off, i - 1);
+		A.box[ctr + 1] = FI_TAIL_LDS(off, i + 1);
+		A.box[ctr - 3] = FI_TAIL_LDS(off, i - n0);
+		A.box[ctr + 3] = FI_TAIL_LDS(off, i + n0);
 		if (D > 2) {
-			A.box[ctr - 9] = FI_TAIL_LDS(off, clampi(i - n01, hi));
-			A.box[ctr + 9] = FI_TAIL_LDS(off, clampi(i + n01, hi));
+			A.box[ctr - 9] = FI_TAIL_LDS(off, i - n01);
+			A.box[ctr + 9] = FI_TAIL_LDS(off, i + n01);
 		}
 	}
-	A.far[0] = FI_TAIL_LDS(off, clampi(i - 2, hi));
-	A.far[1] = FI_TAIL_LDS(off, clampi(i + 2, hi));
-	A.far[2] = FI_TAIL_LDS(off, clampi(i - 2 * n0, hi));
-	A.far[3] = FI_TAIL_LDS(off, clampi(i + 2 * n0, hi));
+	A.far[0] = FI_TAIL_LDS(off, i - 2);
+	A.far[1] = FI_TAIL_LDS(off, i + 2);
+	A.far[2] = FI_TAIL_LDS(off, i - 2 * n0);
+	A.far[3] = FI_TAIL_LDS(off, i + 2 * n0);
 	if (D > 2) {
-		A.far[4] = FI_TAIL_LDS(off, clampi(i - 2 * n01, hi));
-		A.far[5] = FI_TAIL_LDS(off, clampi(i + 2 * n01, hi));
+		A.far[4] = FI_TAIL_LDS(off, i - 2 * n01);
+		A.far[5] = FI_TAIL_LDS(off, i + 2 * n01);
 	}
 }
 
-// (A_model v)_i and the model diagonal of point i
+// (A_model v)_i and the model diagonal of point i: the five coefficients of the point's row along every axis come from
+// the level's table (axis_coefs of every coordinate, filled by the kernel's prologue)
 template <int D>
 __device__ inline float model_row(const TailLevel& L, const int* c, const Around<D>& A, float* diag)
 {
 	constexpr int ctr = D == 2 ? 4 : 13;
 	float acc = 0.0f, m = 0.0f;
+	int   at = L.ktab;
 #pragma unroll
 	for (int d = 0; d < D; ++d) {
-		float k[5];
-		axis_coefs(c[d], L.n[d], L.w0sq, L.w1sq, L.w2sq, k);
+		const int kk = at + 5 * c[d];
+		const float k0 = FI_TAIL_LDS(kk, 0), k1 = FI_TAIL_LDS(kk, 1), k2 = FI_TAIL_LDS(kk, 2), k3 = FI_TAIL_LDS(kk, 3), k4 = FI_TAIL_LDS(kk, 4);
 		const int st = d == 0 ? 1 : (d == 1 ? 3 : 9);  // the axis neighbour's place in the box
-		m += k[2];
-		acc += k[0] * A.far[2 * d] + k[1] * A.box[ctr - st] + k[2] * A.box[ctr] + k[3] * A.box[ctr + st] + k[4] * A.far[2 * d + 1];
+		m += k2;
+		acc += k0 * A.far[2 * d] + k1 * A.box[ctr - st] + k2 * A.box[ctr] + k3 * A.box[ctr + st] + k4 * A.far[2 * d + 1];
+		at += 5 * L.n[d];
 	}
 	*diag = m;
 	return acc;
@@ -133,7 +138,7 @@ __device__ inline void stage(const TailLevel* __restrict__ levels, const TailOp&
 {
 	constexpr int nthreads = kTailThreads;
 	const TailLevel& L = levels[op.level];
-	const int ctab = L.base + kTailVectors * L.nn;
+	const int ctab = L.ctab;
 	const bool data = L.dia != nullptr;
 	switch (op.kind) {
 	case kTailScale:
@@ -212,7 +217,7 @@ __device__ inline void stage(const TailLevel* __restrict__ levels, const TailOp&
 	case kTailRestrict: {
 		const LevelPair& P = L.to_coarse;
 		const TailLevel& C = levels[op.level + 1];
-		const int ctab_c = C.base + kTailVectors * C.nn;
+		const int ctab_c = C.ctab;
 		for (int j = tid; j < C.nn; j += nthreads) {
 			int c[3];
 			unpack_coords<D>(__float_as_int(FI_TAIL_LDS(ctab_c, j)), c);
@@ -269,19 +274,32 @@ __device__ inline void stage(const TailLevel* __restrict__ levels, const TailOp&
 // no early exit: every wave reaches every barrier.
 template <int D>
 __global__ __launch_bounds__(kTailThreads) void k_tail(const TailLevel* __restrict__ levels, const TailOp* __restrict__ ops, int nlev, int nops,
-                                                        const float* __restrict__ b, float* __restrict__ x)
+                                                        int lds_floats, const float* __restrict__ b, float* __restrict__ x)
 {
 	float* const lds = fi_tail_lds;
 	const int tid = threadIdx.x;
 	const int nn0 = levels[0].nn, base0 = levels[0].base;
+	// everything zero first (the guard zones stay so), then the right-hand side, the points' coordinates and the model rows'
+	// coefficients per coordinate -- once per launch
+	for (int i = tid; i < lds_floats; i += kTailThreads) { lds[i] = 0.0f; }
+	__syncthreads();
 	for (int i = tid; i < nn0; i += kTailThreads) { lds[base0 + i] = b[i]; }
-	for (int l = 0; l < nlev; ++l) {  // the points' coordinates, once
+	for (int l = 0; l < nlev; ++l) {
 		const TailLevel& L = levels[l];
-		const int ctab = L.base + kTailVectors * L.nn;
 		for (int i = tid; i < L.nn; i += kTailThreads) {
 			const int cx = i % L.n[0], t = i / L.n[0];
 			const int cy = D > 2 ? t % L.n[1] : t, cz = D > 2 ? t / L.n[1] : 0;
-			lds[ctab + i] = __int_as_float(cx | (cy << 12) | (cz << 24));
+			lds[L.ctab + i] = __int_as_float(cx | (cy << 12) | (cz << 24));
+		}
+		int at = L.ktab;
+		for (int d = 0; d < D; ++d) {
+			for (int cc = tid; cc < L.n[d]; cc += kTailThreads) {
+				float k[5];
+				axis_coefs(cc, L.n[d], L.w0sq, L.w1sq, L.w2sq, k);
+#pragma unroll
+				for (int j = 0; j < 5; ++j) { lds[at + 5 * cc + j] = k[j]; }
+			}
+			at += 5 * L.n[d];
 		}
 	}
 	__syncthreads();
@@ -290,7 +308,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(const TailLevel* __restri
 		stage<D>(levels, op, tid);
 		__syncthreads();
 	}
-	for (int i = tid; i < nn0; i += kTailThreads) { x[i] = lds[base0 + nn0 + i]; }
+	for (int i = tid; i < nn0; i += kTailThreads) { x[i] = lds[base0 + levels[0].vstride + i]; }
 }
 #undef FI_TAIL_LDS
 
@@ -423,9 +441,9 @@ void tail_run(fi_ctx* top, const void* prog, int nlev, int nops, int lds_floats,
 	const TailLevel* levels = static_cast<const TailLevel*>(prog);
 	const TailOp*    ops    = reinterpret_cast<const TailOp*>(levels + kTailMaxLevels);
 	if (D == 2) {
-		hipLaunchKernelGGL(k_tail<2>, dim3(1), dim3(kTailThreads), lds_bytes, top->stream, levels, ops, nlev, nops, b, x);
+		hipLaunchKernelGGL(k_tail<2>, dim3(1), dim3(kTailThreads), lds_bytes, top->stream, levels, ops, nlev, nops, lds_floats, b, x);
 	} else {
-		hipLaunchKernelGGL(k_tail<3>, dim3(1), dim3(kTailThreads), lds_bytes, top->stream, levels, ops, nlev, nops, b, x);
+		hipLaunchKernelGGL(k_tail<3>, dim3(1), dim3(kTailThreads), lds_bytes, top->stream, levels, ops, nlev, nops, lds_floats, b, x);
 	}
 	FI_HIP_TRY(hipGetLastError());
 }
