@@ -416,16 +416,14 @@ struct fi_ctx {
 	// assembly temporaries, kept between fi_assemble calls (hipMalloc/hipFree are slow and synchronising)
 	fi::DevBuf scratch[36];
 
-	// the small-level engine (fi_tail.h): this level and every level below it run their share of a V-cycle in one
-	// cooperative launch.  tail_dia: the data rows as 3^D diagonals; tail_prog: the levels' table and the stages of the cycle
-	// (built at the first cycle after an assemble / a change of the smoothers' bounds)
+	// the small-level engine (fi_tail.h): this level and every level below it (all of <= 4 096 unknowns) run their share of a
+	// V-cycle in one launch of one workgroup.  tail_dia: the data rows as 3^D diagonals; tail_prog: the levels' table and the
+	// stages of the cycle (built at the first cycle after an assemble / a change of the smoothers' bounds)
 	bool       tail_ok = false;
-	fi::DevBuf tail_dia, tail_map, tail_prog, tail_bar;
+	fi::DevBuf tail_dia, tail_map, tail_prog;
 	bool       tail_prog_valid = false;
 	int        tail_nlev = 0, tail_nops = 0;
-	int64_t    tail_widest = 0;
-	const void* tail_prog_b = nullptr;  // the right-hand side / result vectors the program was built for
-	const void* tail_prog_x = nullptr;
+	int        tail_lds_floats = 0;  // LDS the program's levels take (fi_tail.h: tail_level_floats)
 
 	fi::Comm*  comm = nullptr;
 	hipStream_t comm_stream = nullptr;   // slabs over RCCL: the halo exchange runs here beside the interior launch

@@ -823,10 +823,10 @@ bool tail_vcycle(RankSet& R, Vec b, Vec x)
 		FI_HIP_TRY(hipStreamSynchronize(c->stream));  // (the host buffer dies here)
 		c->tail_nlev       = static_cast<int>(P.chain.size());
 		c->tail_nops       = static_cast<int>(P.ops.size());
-		c->tail_widest     = floats;
+		c->tail_lds_floats = floats;
 		c->tail_prog_valid = true;
 	}
-	tail_run(c, c->tail_prog.p, c->tail_nlev, c->tail_nops, static_cast<int>(c->tail_widest), (c->*b).as<float>(), (c->*x).as<float>());
+	tail_run(c, c->tail_prog.p, c->tail_nlev, c->tail_nops, c->tail_lds_floats, (c->*b).as<float>(), (c->*x).as<float>());
 	return true;
 }
 
