@@ -264,6 +264,40 @@ def test_small_levels_in_one_workgroup_equal_the_tiled_kernels(fi, monkeypatch, 
     assert rel_inf(out[0][0], out[1][0]) <= (1e-5 if mixed else 3e-4)
 
 
+@pytest.mark.parametrize("sizes,kw", [([64, 64, 64], dict(model_2=0.5)), ([72, 60, 56], dict(model_1=0.4, model_2=0.5)),
+                                      ([48, 52, 44], dict(model_1=0.6, model_2=0.0)), ([80, 40, 36], dict(model_0=0.1, model_1=0.2, model_2=0.7))])
+def test_small_levels_polynomial_steps_without_the_march(fi, monkeypatch, sizes, kw):
+    """On fp32 levels of <= 2^19 points the steps of the V-cycle's polynomial smoother run as k_cheb_direct3 -- a thread per
+    point, one round of neighbour loads -- instead of the z-marching kernel (FI_NO_DIRECT_STEP): the same step (operand
+    formed on load or stored, every combination of model_0 / model_1 / model_2), so V-cycle PCG takes the same iterations
+    (rounding may move the count by one) to the same solution.  Value rows: the levels smooth with the polynomial."""
+    rng = np.random.default_rng(sum(sizes))
+    n = 5000
+    pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+    val = rng.normal(size=n).astype(np.float32)
+    w = fi.Weights(**kw)
+    out = []
+    for no_direct in (False, True):
+        if no_direct:
+            monkeypatch.setenv("FI_NO_DIRECT_STEP", "1")
+        else:
+            monkeypatch.delenv("FI_NO_DIRECT_STEP", raising=False)
+        f = fi.LatticeField(sizes, dtype="f64")
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.set_levels(2, 1e-4)
+        f.set_multigrid(True)
+        f.set_mixed_precision(True)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-8)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.2e-8
+        out.append((f.solution_f64(), it))
+        del f
+    monkeypatch.delenv("FI_NO_DIRECT_STEP", raising=False)
+    assert abs(out[0][1] - out[1][1]) <= 1, (out[0][1], out[1][1])
+    assert rel_inf(out[0][0], out[1][0]) <= 1e-5
+
+
 def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
     """fi_assemble builds the coarser levels on a helper thread and a second stream while the calling thread assembles
     the finest level; FI_SERIAL_LEVELS builds them afterwards on the solver stream.  Same kernels on the same data: the
