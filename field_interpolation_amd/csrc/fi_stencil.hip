@@ -852,6 +852,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 			xload = load_own(z + 5);
 			FI_STAMP(s, 3);
 			// layer z into the accumulation planes of z and z+1
+			// (the waves that scatter are the ones the step's barrier waits for: they issue ahead of the other workgroups' waves
+			// on their SIMD -- 256^3 fp32 52.3 -> 50.0 us, fp64 105.3 -> 102.8 us per apply)
+			__builtin_amdgcn_s_setprio(1);
 			if (layer_dense(s + 1)) {
 				const int o = (s + 1) * 4 + band;
 				if (kDensePF) {
@@ -868,6 +871,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 				const uint32_t re = uni(layR[o + 4]), rs = uni(layR[o]) + 64u;
 				cells_scatter(rs < re ? rs : re, re, uni(layB[o]), uni(layB[o + 4]), b0, b1, b0, b1, true);
 			}
+			__builtin_amdgcn_s_setprio(0);
 			FI_STAMP(s, 4);
 			prefetch_rows(s + 1 + PR, pf);
 		}
@@ -1184,7 +1188,11 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 	int cus = 256;
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
 	const bool fused = !plain && c->cells.ncell > 0 && !test_switch("FI_NO_FUSE");
-	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : fused_waves<T>(w.model_1 > 0, w.model_2 > 0, c->cells.pack);
+	// resident workgroups per CU.  fp32: what the variant is register-allocated for.  fp64: every fused variant lands at
+	// 162-168 VGPRs and 46-48 KB of LDS under its bound of 2 (see fused_waves) -- THREE fit a CU, and a grid sized for two
+	// left a third of the wave slots empty: 256^3 fp64 with config 4's data 64 planes x 512 workgroups 107 us, 43 planes x
+	// 768 workgroups 92.7 us (profiles/r5_ablation.md section 14; tests/test_kernel_resources.py pins the occupancy)
+	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : (sizeof(T) == 8 ? 3 : fused_waves<T>(w.model_1 > 0, w.model_2 > 0, c->cells.pack));
 	// the fused variant stages the list bounds of at most 64 + 2 layers in LDS (s_lay); without data cells the chunk
 	// may be as long as one round of workgroups allows (512^3: 128 planes, 1024 workgroups)
 	P->zc     = pick_chunk(P->tiles_x * P->tiles_y, nz_own, (cus > 0 ? cus : 256) * wgs_per_cu, forced_zc, fused ? 64 : 256);

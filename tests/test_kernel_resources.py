@@ -55,6 +55,12 @@ def test_marching_kernel_budget():
     # the bench variant: fp32, model_2 only, fused -- three workgroups per CU
     bench = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb1ELi32ELb0ELb0ELb0E" in n]
     assert len(bench) == 1 and bench[0]["VGPRs"] <= 168 and bench[0]["Occupancy [waves/SIMD]"] == 3
+    # the fp64 fused variants without the epilogue (the CG's operator apply): THREE workgroups per CU by registers and by
+    # LDS -- march_setup sizes their grids for three (fi_stencil.hip)
+    f64 = [r for n, r in rep.items() if "march3dId" in n and r["LDS Size [bytes/block]"] > 30000 and "ELb0ELb0EEEv" in n]
+    assert len(f64) == 12
+    for r in f64:
+        assert r["Occupancy [waves/SIMD]"] == 3 and r["LDS Size [bytes/block]"] * 3 <= 160 * 1024
     # the Chebyshev step of the bench: fp32, model_2 only, plain + epilogue -- four workgroups per CU, no spills
     for pro in "01":   # ... and its first step, which forms the operand while it loads r and the scaling
         cheb = [r for n, r in rep.items() if "march3dIfLb0ELb1ELb0ELi32ELb0ELb1ELb%sE" % pro in n]

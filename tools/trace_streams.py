@@ -27,6 +27,7 @@ for r in sel:
     if (s - t0) / 1e3 > tmax: break
     byq.setdefault(r[qkey], []).append(((s - t0) / 1e3, (e - s) / 1e3, short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
 for q, ks in byq.items():
+    print("   queues of this stream:", sorted({r["Queue_Id"] for r in sel if r[qkey] == q}))
     print("\n== %s %s: %d kernels, first %.1f us, last ends %.1f us, busy %.1f us" % (qkey, q, len(ks), ks[0][0], ks[-1][0] + ks[-1][1], sum(k[1] for k in ks)))
     prev = ks[0][0]
     for (s, dur, name, grid) in ks:
