@@ -379,13 +379,26 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		}
 		return d;
 	};
+	// bfloat16 vectors (ChebEpi::fmt): a load leaves the RAW bits in the low half of its registers, and they become floats
+	// where the values are first used (decode_own / write_plane / the epilogue) -- NOT behind the load: a conversion there is
+	// a use, and the wave waited (s_waitcnt vmcnt(0): for every load and store in flight) for the plane it had just
+	// requested 5 steps ahead, for the halo and for z_prev, three exposed memory latencies per plane step (round 4's bfloat16
+	// storage took 27 % of the bytes and 16 % of the time off a step for this reason; profiles/r5_ablation.md section 15)
+	auto raw16 = [](const DV16& d) -> V {
+		V v;
+		*reinterpret_cast<DV16*>(&v) = d;
+		return v;
+	};
 	auto load_own = [&](int lz) -> V {
 		if (Z16 && (E.fmt & 1)) {
 			const unsigned short* xp = reinterpret_cast<const unsigned short*>(x) + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
-			return from16(*reinterpret_cast<const DV16*>(xp + xoff));
+			return raw16(*reinterpret_cast<const DV16*>(xp + xoff));
 		}
 		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
 		return *reinterpret_cast<const V*>(xp + xoff);
+	};
+	auto decode_own = [&](V& v) {
+		if (Z16 && (E.fmt & 1)) { v = from16(*reinterpret_cast<const DV16*>(&v)); }
 	};
 	auto load_halo = [&](int lz, HaloRegs& h) {
 		const T* xp = x + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
@@ -394,9 +407,9 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 #endif
 		if (Z16 && (E.fmt & 1)) {
 			const unsigned short* xq = reinterpret_cast<const unsigned short*>(x) + static_cast<int64_t>(clamp_plane(lz)) * P.plane;
-			const V hv = from16(*reinterpret_cast<const DV16*>(xq + hvg));
+			const V hv = raw16(*reinterpret_cast<const DV16*>(xq + hvg));  // (raw bits: decoded by write_plane)
 			h.vec = *reinterpret_cast<const NV*>(&hv);
-			h.sc  = static_cast<T>(__uint_as_float(static_cast<unsigned int>(xq[hsg]) << 16));
+			h.sc  = static_cast<T>(__uint_as_float(static_cast<unsigned int>(xq[hsg])));
 		} else {
 			h.vec = *reinterpret_cast<const NV*>(xp + hvg);
 			h.sc  = xp[hsg];
@@ -422,9 +435,15 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 #pragma unroll
 		for (int j = 0; j < VX; ++j) { pv[j] = E.pro_scale * dinv_of(d, j) * pv[j]; }
 	};
-	auto write_plane = [&](int buf, const V& own, const HaloRegs& h) {
+	auto write_plane = [&](int buf, const V& own, const HaloRegs& hraw) {
 		T* base = &xs[buf][0][0];
 		*reinterpret_cast<V*>(&xs[buf][ly][lx]) = own;
+		HaloRegs h = hraw;
+		if (Z16 && (E.fmt & 1)) {  // the halo's raw bfloat16 bits (load_halo)
+			const V hv = from16(*reinterpret_cast<const DV16*>(&hraw.vec));
+			h.vec = *reinterpret_cast<const NV*>(&hv);
+			h.sc  = static_cast<T>(__uint_as_float(__float_as_uint(static_cast<float>(hraw.sc)) << 16));
+		}
 		if (PRO) {
 			NV hv;
 #pragma unroll
@@ -493,11 +512,29 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		T out[8];
 #pragma unroll
 		for (int i = 0; i < 8; ++i) { out[i] = a[i] * t; }
-		// the second row of a two-row cell sits in the lane next to the first: same addresses, so it is added in a
-		// pass of its own (wave-uniform branch; LDS instructions of a wave execute in order)
+		// The second row of a two-row cell sits in the lane next to the first and goes to the same addresses: the first row's
+		// lane takes its products over a DPP shift (VALU: no LDS round trip) and adds both at once.  A pass of its own for
+		// the second rows -- round 2-4 -- cost the scattering wave two more dependent LDS round trips in every layer that
+		// holds ONE such cell (60 % of config 4's layers), on the path the step's barrier waits for.  (A second row in lane 0
+		// has its partner in the previous batch of 64: it adds by itself.)
 		const bool second = ((pos >> 8) & 0xFFu) != 0u;
-		put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok, !second);
-		if (__ballot(second) != 0ull) { put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok, second); }
+		if (__ballot(second) != 0ull) {
+			const int nxt = __builtin_amdgcn_update_dpp(0, second ? 1 : 0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				T o;
+				if constexpr (sizeof(T) == 8) {
+					const long long b = __double_as_longlong(static_cast<double>(out[i]));
+					const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(b), 0x130, 0xF, 0xF, false);
+					const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(b >> 32), 0x130, 0xF, 0xF, false);
+					o = static_cast<T>(__longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo)));
+				} else {
+					o = static_cast<T>(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(static_cast<float>(out[i])), 0x130, 0xF, 0xF, false)));
+				}
+				if (nxt) { out[i] += o; }
+			}
+		}
+		put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok, !(second && lane > 0));
 	};
 	auto load_row = [&](uint32_t r, uint32_t* pos, T* a) {
 		*pos = L.pos_row[r];
@@ -628,7 +665,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	auto load_epi = [&](int lz, EpiRegs& e) {
 		const int64_t o = static_cast<int64_t>(clamp_plane(lz)) * P.plane + xoff;
 		if (Z16 && (E.fmt & 2)) {
-			e.zp = from16(*reinterpret_cast<const DV16*>(reinterpret_cast<const unsigned short*>(E.zprev) + o));
+			e.zp = raw16(*reinterpret_cast<const DV16*>(reinterpret_cast<const unsigned short*>(E.zprev) + o));  // (decoded by epi_zp)
 		} else {
 			e.zp = *reinterpret_cast<const V*>(E.zprev + o);  // never null: the host passes z itself with c1 = 0 on the first step
 		}
@@ -636,9 +673,14 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		e.dv = *reinterpret_cast<const DV16*>(E.dinv + o);
 	};
 
+	auto epi_zp = [&](const EpiRegs& e) -> V {  // z_prev of the epilogue's operand set as floats
+		if (Z16 && (E.fmt & 2)) { return from16(*reinterpret_cast<const DV16*>(&e.zp)); }
+		return e.zp;
+	};
 	// modes 2 / 3 for one completed plane: zc = the plane's z values, q = A z (full operator)
 	auto epi_full = [&](const EpiRegs& e, const T* zc, const T* q, T* pz) -> T {
-		const T* zp = reinterpret_cast<const T*>(&e.zp);
+		const V  zpv = epi_zp(e);
+		const T* zp = reinterpret_cast<const T*>(&zpv);
 		const T* rv = reinterpret_cast<const T*>(&e.rv);
 		T dv[VX];
 #pragma unroll
@@ -680,6 +722,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	// PRO: the scaling of the same planes, slot for slot; a slot is turned into the operand (form_own) two steps before
 	// it becomes the centre plane -- when it is first needed, as x(z+2) of the z stencil -- slots 0 and 1 here
 	DV16 Q0{}, Q1{}, Q2{}, Q3{}, Q4{}, Q5{};
+	decode_own(X0);  // (slots 2.. are decoded by the step that first uses them, as x(z+2))
+	decode_own(X1);
 	if (PRO) {
 		Q0 = load_own_d(z_begin); Q1 = load_own_d(z_begin + 1); Q2 = load_own_d(z_begin + 2);
 		Q3 = load_own_d(z_begin + 3); Q4 = load_own_d(z_begin + 4);
@@ -740,6 +784,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	};
 	{
 		V xa = load_own(z_begin - 2), xb = load_own(z_begin - 1);
+		decode_own(xa);
+		decode_own(xb);
 		if (PRO) {
 			form_own(xa, load_own_d(z_begin - 2));
 			form_own(xb, load_own_d(z_begin - 1));
@@ -799,6 +845,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	                const T* uA, const T* uB, T* uC, const T* dA, T* dC,
 	                const DV16& qc, const DV16& q2, DV16& qload) {
 		const int z = z_begin + s;
+		decode_own(xp2);
 		if (PRO) { form_own(xp2, q2); }
 		FI_STAMP(s, 0);
 		// stage plane z+1 into the LDS ring (needed by the cells of layer z) and refill its halo set HR planes ahead
@@ -975,7 +1022,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 				                ((g + 2 < P.gz) ? T(1) : T(0)));
 			}
 			if (HAS1) { mz += C.w1sq * (((gzc - 1 >= 0) ? T(1) : T(0)) + ((gzc + 1 < P.gz) ? T(1) : T(0))); }
-			const T* zp = reinterpret_cast<const T*>(&EP.zp);
+			const V  zpv = epi_zp(EP);
+			const T* zp = reinterpret_cast<const T*>(&zpv);
 			const T* rv = reinterpret_cast<const T*>(&EP.rv);
 			T dv[VX];
 #pragma unroll
@@ -1098,7 +1146,10 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 
 #ifdef FI_STAMPS
 	__syncthreads();
-	if (wg == (P.dbg >> 8)) {
+#ifndef FI_STAMPS_SEL
+#define FI_STAMPS_SEL true  // (which launches report: an expression over the kernel's template flags and arguments)
+#endif
+	if (wg == (P.dbg >> 8) && (FI_STAMPS_SEL)) {
 		for (int i = threadIdx.x; i < 4 * 64 * 8; i += kThreads) { g_stamp[i] = s_stamp[i / 512][i % 512]; }
 	}
 #endif

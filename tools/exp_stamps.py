@@ -13,7 +13,7 @@ wgsel = int(os.environ.get("WG", "300"))
 os.environ["FI_DBG"] = str(wgsel << 8)
 nodata = os.environ.get("NODATA")
 sizes, w, pos, val = synth.config4(side=side, num_points=int(1e6 * (side / 256) ** 3), seed=3)
-f = fi.LatticeField(sizes, dtype="f32")
+f = fi.LatticeField(sizes, dtype=os.environ.get("DT", "f32"))
 f.add_field_constraints(w)
 if not nodata:
     f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
