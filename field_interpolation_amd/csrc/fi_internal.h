@@ -489,7 +489,8 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
                        double* partial, int part = 0, double zprev_scale = 0.0, double pro_scale = 0.0,
                        const unsigned short* scaling = nullptr,   // scaling: bfloat16 array (default: the context's dinv16)
                        int extend = 0,    // slabs, deep exchange: the step also covers `extend` ghost planes on either side
-                       int fmt = 0);      // bfloat16 storage of z (bit 0), z_prev (bit 1), z_new (bit 2): fp32 3-D levels, ChebEpi::fmt
+                       int fmt = 0,       // bfloat16 storage of z (bit 0), z_prev (bit 1), z_new (bit 2): fp32 3-D levels, ChebEpi::fmt
+                       const void* acc = nullptr);  // z_new = acc + the step's result (ChebEpi::acc; may be znew itself)
 int  stencil_cheb_partials_max(const fi_ctx* c);  // room for the partials of a step extended over the whole ghost zone
 // small undivided fp32 levels: a step whose caller wants no partials (partial == nullptr) runs as one thread per point with
 // direct neighbour loads instead of the z-marching kernel (fi_stencil.hip, k_cheb_direct3)

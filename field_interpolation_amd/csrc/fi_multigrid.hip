@@ -548,12 +548,16 @@ bool poly_smoother_ok(const RankSet& R)
 	return true;
 }
 
-// z = M r through the work vectors za / zb; returns the one that holds the result (ghost planes not exchanged)
+// z = M r through the work vectors za / zb; returns the one that holds the result (ghost planes not exchanged).
+// onto: the vector the result is ADDED to by the polynomial's last step itself (x += M r: the post-smoothing; returns onto) --
+// one launch and three lattice passes less than a sum of its own; taken when the last step is not the one that forms its
+// operand on load, else the result comes back in a work vector as without it.
 template <typename T>
-Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr, int* chain_launches = nullptr)
+Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr, int* chain_launches = nullptr, Vec onto = nullptr)
 {
 	fi_ctx* c0 = R[0];
 	const int    terms = mg_poly_terms(c0);
+	if (onto && (terms < 3 || test_switch("FI_NO_STEP_ONTO"))) { onto = nullptr; }
 	const double lam = c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0;
 	const double hi = 1.1 * lam, lo = hi / mg_poly_ratio(c0);
 	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
@@ -608,17 +612,17 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 		for (int k = 1; k <= n; ++k) {
 			const double rho_new = 1.0 / (2.0 * sigma - rho);
 			const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
-			void* out = k == n ? (c->*zb).p : where(k);
+			void* out = k == n ? (onto ? (c->*onto).p : (c->*zb).p) : where(k);
 			const int fmt = (k > 1 ? 1 : 0) | (k > 2 ? 2 : 0) | (k < n ? 4 : 0);
 			if (k == 1) {
 				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, out, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc, 0, fmt);
 			} else {
 				stencil_cheb_step(c, where(k - 1), k == 2 ? (c->*r).p : where(k - 2), (c->*r).p, out, c1, c2, region2(c), 0,
-				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc, 0, fmt);
+				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc, 0, fmt, k == n && onto ? (c->*onto).p : nullptr);
 			}
 			rho = rho_new;
 		}
-		return zb;
+		return onto ? onto : zb;
 	}
 	// Deep exchange over slabs (the polynomial PCG's, fi_poly.hip, for the V-cycle's smoother): fi_assemble has given the
 	// vectors 2 (d - 1) ghost planes; r's travel ONCE per polynomial, step k then also computes its 2 (d - 1 - k) nearest ghost
@@ -645,14 +649,15 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc, ext);
 			} else {
 				// the second step's z_prev is z_0 = Dinv r / theta, recomputed from r and the scaling
-				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, (c->*r).p, (c->*zout).p, c1, c2, region2(c), 0,
-				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc, ext);
+				const bool last_onto = onto && k == terms - 1;  // (z_prev is read from zout, the result goes onto `onto`)
+				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, (c->*r).p, last_onto ? (c->*onto).p : (c->*zout).p, c1, c2,
+				                  region2(c), 0, k == 2 ? 1.0 / theta : 0.0, 0.0, sc, ext, 0, last_onto ? (c->*onto).p : nullptr);
 			}
 		}
 		std::swap(zin, zout);
 		rho = rho_new;
 	}
-	return zin;
+	return onto ? onto : zin;
 }
 
 // ---- the V-cycle of the hierarchy's tail as a program of the small-level engine (fi_tail.h) ----------------------------
@@ -863,7 +868,8 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	};
 	auto post_smooth = [&]() {  // x += M (b - A x)
 		residual();
-		const Vec d = poly_chain<T>(R, &fi_ctx::mg_r, &fi_ctx::mg_d, &fi_ctx::q);
+		const Vec d = poly_chain<T>(R, &fi_ctx::mg_r, &fi_ctx::mg_d, &fi_ctx::q, nullptr, nullptr, x);
+		if (d == x) { return; }  // (the last step has added its result onto x)
 		for (fi_ctx* c : R) {
 			hipLaunchKernelGGL((k_add_vec<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, d),
 			                   vown<T>(c, x));

@@ -148,6 +148,9 @@ struct ChebEpi {
 	                    // counts to 1e-9), and a step moves 8-14 bytes per point instead of 10-18.
 	int      round16;   // timing builds (FI_Z16): the step's result rounded to bfloat16 (1) / half (2) precision -- what 16-bit
 	                    // storage of the polynomial's iterates would do to the preconditioner (profiles/r4_ablation.md section 9)
+	const T* acc;       // mode 0 without the operand formed on load, non-null: z_new = acc + (the step's result) -- the LAST step of
+	                    // a smoother's polynomial adds the correction onto x itself (acc == znew: x += M (b - A x) with no pass of
+	                    // its own for the sum; fp32 / fp64 storage, never bfloat16)
 };
 
 struct CellLists {
@@ -659,6 +662,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 	struct EpiRegs {
 		V    zp, rv;
 		DV16 dv;
+		V    av;  // ChebEpi::acc
 	};
 	// operands of plane lz (clamped like every load that crosses a step): issued right behind the epilogue that
 	// consumed the previous set, used one step later
@@ -671,6 +675,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		}
 		e.rv = *reinterpret_cast<const V*>(E.r + o);
 		e.dv = *reinterpret_cast<const DV16*>(E.dinv + o);
+		if (!CELLS && E.acc) { e.av = *reinterpret_cast<const V*>(E.acc + o); }
 	};
 
 	auto epi_zp = [&](const EpiRegs& e) -> V {  // z_prev of the epilogue's operand set as floats
@@ -1053,6 +1058,11 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 					const T zq = E.zp_scale != T(0) ? E.zp_scale * dv[j] * zp[j] : zp[j];
 					pz[j] = E.a * pc[j] - E.c1 * zq + E.c2 * (dv[j] * rv[j] - sv);
 					rz += rv[j] * pz[j];
+				}
+				if (E.acc) {
+					const T* av = reinterpret_cast<const T*>(&EP.av);
+#pragma unroll
+					for (int j = 0; j < VX; ++j) { pz[j] += av[j]; }
 				}
 			}
 #ifdef FI_TIMING_BUILD
@@ -1521,6 +1531,7 @@ __global__ __launch_bounds__(kThreads) void k_cheb_direct3(int nx, int ny, int n
 	const float dv = bf16_of(E.dinv[i]);
 	const float rv = PRO ? 0.0f : E.r[i];
 	const float zp = PRO ? 0.0f : E.zprev[i];
+	const float av = (!PRO && E.acc) ? E.acc[i] : 0.0f;
 	if (stop) { return; }
 	const float pc = v[0][2];
 	float acc2 = 0.0f, acc1 = 0.0f, m2 = 0.0f, m1 = 0.0f;
@@ -1557,7 +1568,7 @@ __global__ __launch_bounds__(kThreads) void k_cheb_direct3(int nx, int ny, int n
 		zn = E.a * pc + E.c2 * (pc * (1.0f / E.pro_scale) - sv);
 	} else {
 		const float zq = E.zp_scale != 0.0f ? E.zp_scale * dv * zp : zp;
-		zn = E.a * pc - E.c1 * zq + E.c2 * (dv * rv - sv);
+		zn = E.a * pc - E.c1 * zq + E.c2 * (dv * rv - sv) + av;
 	}
 	E.znew[i] = zn;
 }
@@ -1577,8 +1588,11 @@ int  stencil_cheb_partials_max(const fi_ctx* c)
 	return extended_params(c->march.Pplain, c->nranks > 1 ? c->halo : 0).nwg;
 }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
-                       double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling, int extend, int fmt)
+                       double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling, int extend, int fmt,
+                       const void* acc)
 {
+	FI_REQUIRE(!acc || (!c->tile2.valid && pro_scale == 0.0 && !(fmt & 4)), FI_ERR_STATE,
+	           "polynomial step onto a vector: 3-D levels, not the step that forms its operand on load, fp32 / fp64 result");
 	FI_REQUIRE(fmt == 0 || (!c->tile2.valid && c->dtype == FI_F32 && c->g.gn[0] % 4 == 0), FI_ERR_STATE,
 	           "bfloat16 iterates: fp32 3-D levels with rows of whole 16-byte groups");
 	// pro_scale != 0 (the first step, z_prev = 0): `z` is r and the kernel forms z_0 = pro_scale * Dinv * r on load
@@ -1595,7 +1609,7 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	if (!partial && part == 0 && extend == 0 && fmt == 0 && stencil_cheb_direct(c)) {  // small levels: one round of loads per point
 		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
 		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
-		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), 0, 0};
+		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), 0, 0, static_cast<const float*>(acc)};
 		const MarchCoef<float> C = march_coef<float>(c->w);
 		const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
 		const int  nx = c->g.n[0], ny = c->g.n[1], nz = c->g.n[2];
@@ -1615,12 +1629,12 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	}
 	if (c->dtype == FI_F64) {
 		ChebEpi<double> E{static_cast<const double*>(zp), static_cast<const double*>(r), d16, static_cast<double*>(znew), 1.0 + c1,
-		                  has_prev ? c1 : 0.0, c2, 0, pro_scale, zprev_scale};
+		                  has_prev ? c1 : 0.0, c2, 0, pro_scale, zprev_scale, 0, 0, static_cast<const double*>(acc)};
 		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part, pro_scale != 0.0, extend);
 	} else {
 		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
 		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
-		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), fmt, 0};
+		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), fmt, 0, static_cast<const float*>(acc)};
 		if (const char* e = tuning_switch("FI_Z16")) { E.round16 = c->level == 0 ? atoi(e) : 0; }
 		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part, pro_scale != 0.0, extend);
 	}

@@ -298,6 +298,42 @@ def test_small_levels_polynomial_steps_without_the_march(fi, monkeypatch, sizes,
     assert rel_inf(out[0][0], out[1][0]) <= 1e-5
 
 
+@pytest.mark.parametrize("sizes,kw,dtype,mixed", [([160, 144, 136], dict(model_2=0.5), "f64", True),      # bfloat16 iterates on the finest level
+                                                  ([72, 60, 56], dict(model_1=0.4, model_2=0.5), "f64", True),   # small levels: k_cheb_direct3
+                                                  ([96, 80, 72], dict(model_0=0.1, model_2=0.7), "f32", False),
+                                                  ([64, 56, 48], dict(model_1=0.5, model_2=0.0), "f64", False)])  # the V-cycle in fp64
+def test_post_smoothing_added_by_the_polynomials_last_step(fi, monkeypatch, sizes, kw, dtype, mixed):
+    """x += M (b - A x): the last step of the post-smoothing's polynomial adds its result onto x itself (ChebEpi::acc) instead
+    of leaving it to a sum of its own (FI_NO_STEP_ONTO) -- the same additions in the same order: bit-equal solves."""
+    rng = np.random.default_rng(sum(sizes) + 5)
+    n = 20000
+    pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+    val = rng.normal(size=n).astype(np.float32)
+    w = fi.Weights(**kw)
+    out = []
+    for separate in (False, True):
+        if separate:
+            monkeypatch.setenv("FI_NO_STEP_ONTO", "1")
+        else:
+            monkeypatch.delenv("FI_NO_STEP_ONTO", raising=False)
+        f = fi.LatticeField(sizes, dtype=dtype)
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.set_levels(2, 1e-4)
+        f.set_multigrid(True)
+        if mixed:
+            f.set_mixed_precision(True)
+        f.assemble()
+        tol = 1e-8 if dtype == "f64" else 1e-5
+        x, it, rel = f.solve_cg(None, 0, tol)
+        assert f.stats()["converged"] == 1
+        out.append((np.array(f.solution_f64() if dtype == "f64" else x), it))
+        del f
+    monkeypatch.delenv("FI_NO_STEP_ONTO", raising=False)
+    assert out[0][1] == out[1][1], (out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
     """fi_assemble builds the coarser levels on a helper thread and a second stream while the calling thread assembles
     the finest level; FI_SERIAL_LEVELS builds them afterwards on the solver stream.  Same kernels on the same data: the
