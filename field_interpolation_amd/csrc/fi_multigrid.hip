@@ -246,8 +246,11 @@ __global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgS
 	const double alpha = sc->alpha;
 	const double inv = 1.0 / mixed_scale(sc);  // sc->rr is still the previous norm: k_mg_logic(kMgResid) records this scale
 	double acc[1] = {0};
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
-	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+	// a workgroup walks ONE contiguous piece of the seven streams (512^3: 1.68 -> 1.48 ms against a grid-stride loop whose
+	// workgroups touch 2 048 places of every stream at once; 256^3: the same 150 us)
+	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;
+	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
+	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
 		x[i] += alpha * p[i];
 		const double ri = r[i] - alpha * q[i];
 		r[i]   = ri;
@@ -278,8 +281,9 @@ __global__ __launch_bounds__(kThreads) void k_mg_direction_mixed(int64_t n, cons
 {
 	const double beta = first ? 0.0 : sc->beta;
 	const double s = twin_scale(sc);
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
-	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;  // (contiguous pieces: k_mg_step_mixed)
+	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
+	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
 		p[i] = s * static_cast<double>(z32[i]) + beta * p[i];
 	}
 }
@@ -291,8 +295,9 @@ __global__ __launch_bounds__(kThreads) void k_resid_norms(int64_t n, const T* __
                                                            double* __restrict__ partial_rr, double* __restrict__ partial_bb)
 {
 	double acc[2] = {0, 0};
-	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
-	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
+	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;  // (contiguous pieces: k_mg_step_mixed)
+	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
+	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
 		const T bi = b[i];
 		const T ri = bi - q[i];
 		r[i] = ri;

@@ -1493,7 +1493,10 @@ namespace fi {
 // operand formed on load) as ONE round of loads per point: 13 neighbours through L1 / L2, the same arithmetic (u = S x
 // masked from the global coordinates, S^T u, the model diagonal from the same masks).  Undivided fp32 levels, whole lattice,
 // fp32 iterates, no dot-product partials (the V-cycle's smoother takes none).
-constexpr int64_t kDirectMaxPoints = int64_t(1) << 19;
+#ifndef FI_DIRECT_MAX_LOG2
+#define FI_DIRECT_MAX_LOG2 19
+#endif
+constexpr int64_t kDirectMaxPoints = int64_t(1) << FI_DIRECT_MAX_LOG2;
 __device__ inline float bf16_of(unsigned short v) { return __uint_as_float(static_cast<unsigned int>(v) << 16); }
 
 template <bool HAS1, bool HAS2, bool PRO>
