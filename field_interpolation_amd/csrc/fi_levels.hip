@@ -154,6 +154,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		}
 		co->min_slab = min_slab;
 		co->comm = tail ? nullptr : c->comm;
+		co->mg_mode     = c->mg_mode;  // (before the level is assembled: march_setup sizes its grids by the kernels a V-cycle runs)
 		co->mg_smoother = c->mg_smoother;
 		co->mg_safe     = c->mg_safe;
 		co->mg_terms    = c->mg_terms;

@@ -1253,7 +1253,13 @@ bool march_setup(const fi_ctx* c, MarchParams* P, int forced_zc = 0, bool plain 
 	// 162-168 VGPRs and 46-48 KB of LDS under its bound of 2 (see fused_waves) -- THREE fit a CU, and a grid sized for two
 	// left a third of the wave slots empty: 256^3 fp64 with config 4's data 64 planes x 512 workgroups 107 us, 43 planes x
 	// 768 workgroups 92.7 us (profiles/r5_ablation.md section 14; tests/test_kernel_resources.py pins the occupancy)
-	const int  wgs_per_cu = !fused ? FI_BASE_WAVES : (sizeof(T) == 8 ? 3 : fused_waves<T>(w.model_1 > 0, w.model_2 > 0, c->cells.pack));
+	// fp32 levels of a V-cycle: their cells are applied by the fused variant WITH the smoother's epilogue (residuals, the
+	// full-operator smoother's steps: 2-10 launches per cycle against one plain apply per CG iteration), which is
+	// register-allocated for two workgroups per CU -- a grid sized for three ran its last third as a second round
+	// (config 4's 128^3 level: 688 workgroups on 512 slots, 48 us per residual)
+	const bool epi_level  = fused && sizeof(T) == 4 && c->mg_mode == 1 && !test_switch("FI_NO_EPI_SIZING");
+	const int  wgs_per_cu = !fused ? FI_BASE_WAVES
+	                               : (sizeof(T) == 8 ? 3 : (epi_level ? 2 : fused_waves<T>(w.model_1 > 0, w.model_2 > 0, c->cells.pack)));
 	// the fused variant stages the list bounds of at most 64 + 2 layers in LDS (s_lay); without data cells the chunk
 	// may be as long as one round of workgroups allows (512^3: 128 planes, 1024 workgroups)
 	P->zc     = pick_chunk(P->tiles_x * P->tiles_y, nz_own, (cus > 0 ? cus : 256) * wgs_per_cu, forced_zc, fused ? 64 : 256);
