@@ -422,6 +422,8 @@ struct fi_ctx {
 	bool       tail_ok = false;
 	fi::DevBuf tail_dia, tail_map, tail_prog;
 	bool       tail_prog_valid = false;
+	bool       dia_valid = false;  // tail_dia holds THIS assembly's data rows (fi_levels.hip: levels of up to 2^19 points keep them for
+	                               // the full operator's direct launches, fi_stencil.hip k_full_direct3, not for the engine alone)
 	int        tail_nlev = 0, tail_nops = 0;
 	int        tail_lds_floats = 0;  // LDS the program's levels take (fi_tail.h: tail_level_floats)
 
@@ -495,6 +497,7 @@ int  stencil_cheb_partials_max(const fi_ctx* c);  // room for the partials of a 
 // small undivided fp32 levels: a step whose caller wants no partials (partial == nullptr) runs as one thread per point with
 // direct neighbour loads instead of the z-marching kernel (fi_stencil.hip, k_cheb_direct3)
 bool stencil_cheb_direct(const fi_ctx* c);
+bool stencil_full_direct_wanted(const fi_ctx* c);  // the level's data rows are worth keeping as diagonals (asked while the level is assembled)
 void stencil_power_step(fi_ctx* c, const void* v, void* vnew, double* partial);
 // z_new = a z - c1 z_prev + c2 Dinv (r - A z) on the FULL operator (residual: z_new = r - A z) in one pass of the
 // marching kernel(s) over the lattice; z with valid ghost planes.  Dinv is the context's bfloat16 copy (dinv16).

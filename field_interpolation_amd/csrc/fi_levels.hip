@@ -207,7 +207,10 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		operator_prepare(co, co->dtype == FI_F32 && co->g.ndim == 3 && co->mg_smoother == 1 && co->value_rows_only && !co->any_trip &&
 		                         co->march.valid && !co->march.wide && co->nranks == 1 && !test_switch("FI_MG_FULL_SMOOTHER"));
 		co->tail_prog_valid = false;
-		if (tail_level_supported(co)) { tail_build_operator(co); }  // the small-level engine's view of the data rows
+		co->dia_valid = false;
+		// the data rows as 3^D diagonals: the small-level engine's view of them, and what the full operator's direct launches
+		// on levels of up to 2^19 points read (fi_stencil.hip, k_full_direct3)
+		if (tail_level_supported(co) || stencil_full_direct_wanted(co)) { tail_build_operator(co); }
 		co->assembled = true;
 		co->vectors_ready = co->vectors_ready && co->max_blocks >= apply_num_partials(co);
 		co->stats.num_unknowns = co->g.nown;

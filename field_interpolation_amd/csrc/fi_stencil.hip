@@ -1479,7 +1479,14 @@ void stencil_prepare_slab_lists(fi_ctx* c)
 }
 
 // Number of p.q partials the stencil kernel writes, or 0 when the generic kernel must run.
-int stencil_partials(const fi_ctx* c) { return c->march.valid ? c->march.P.nwg : tile2d_partials(c); }
+namespace {
+bool full_direct_now(const fi_ctx* c);  // (the level's full operator runs as k_full_direct3: below)
+}
+int stencil_partials(const fi_ctx* c)
+{
+	if (full_direct_now(c)) { return static_cast<int>((c->g.nloc + kThreads - 1) / kThreads); }  // (k_full_direct3: one per workgroup)
+	return c->march.valid ? c->march.P.nwg : tile2d_partials(c);
+}
 
 bool cells_fused(const fi_ctx* c) { return (c->march.valid && c->march.fused) || (c->tile2.valid && c->tile2.fused); }
 
@@ -1588,6 +1595,135 @@ bool stencil_cheb_direct(const fi_ctx* c)
 	       !test_switch("FI_NO_DIRECT_STEP");
 }
 
+// ---- the FULL operator on small levels: one thread per point, the data rows as 27 diagonals -------------------------------
+// A 64^3 level of a cascade holds 4 points per cell, a 32^3 level 30: every cell is a packed 8 x 8 block, and the marching
+// kernel walks its workgroups through single planes (zc = 1: 1 + 5 plane steps, every layer's blocks multiplied by the two
+// workgroups that share it) -- 35 / 24 / 19 us per residual in config 4's cycle for 36 MB / 5 MB of blocks.  The same
+// level's operator as A_model (the 13-point star from masks, as k_cheb_direct3) + 27 diagonals of the data term
+// (fi_tail.hip: tail_build_operator, summed in a fixed order when the level is assembled) is one round of coalesced loads
+// per point.  ChebEpi modes 2 (the full-operator smoother's step) and 3 (residual); fp32 undivided levels of <= 2^19
+// points whose cells are assembled as a level of a hierarchy (fi_levels.hip).  Not the bits of the marching kernel (another
+// order of the data term's sums): tests compare iteration counts and solutions (FI_NO_DIRECT_FULL).
+template <bool HAS1, bool HAS2>
+__global__ __launch_bounds__(kThreads) void k_full_direct3(int nx, int ny, int nz, MarchCoef<float> C, const float* __restrict__ z,
+                                                            const float* __restrict__ dia, ChebEpi<float> E, const int* __restrict__ done,
+                                                            double* __restrict__ partial)
+{
+	const int n = nx * ny * nz;
+	const int i_raw = static_cast<int>(blockIdx.x) * kThreads + threadIdx.x;
+	const bool live = i_raw < n;
+	const int i = live ? i_raw : n - 1;  // (every thread stays for the workgroup's sum; the last point stands in for loads)
+	const int cx = i % nx;
+	const int t  = i / nx;
+	const int cy = t % ny, cz = t / ny;
+	const int cc[3] = {cx, cy, cz}, nn[3] = {nx, ny, nz};
+	const int st[3] = {1, nx, nx * ny};
+	const int stop = done ? *done : 0;
+	// clamped steps to the neighbours at -1 / +1 along every axis (a clamped value meets a zero diagonal / a zero mask)
+	int dm[3], dp[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		dm[d] = cc[d] > 0 ? -st[d] : 0;
+		dp[d] = cc[d] + 1 < nn[d] ? st[d] : 0;
+	}
+	float xb[3][3][3], dg[27];
+#pragma unroll
+	for (int s = 0; s < 27; ++s) { dg[s] = dia[static_cast<int64_t>(s) * n + i]; }
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+#pragma unroll
+		for (int b = 0; b < 3; ++b) {
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const int j = i + (a == 0 ? dm[2] : (a == 2 ? dp[2] : 0)) + (b == 0 ? dm[1] : (b == 2 ? dp[1] : 0)) + (c == 0 ? dm[0] : (c == 2 ? dp[0] : 0));
+				xb[a][b][c] = z[j];
+			}
+		}
+	}
+	float far[3][2];  // the neighbours at -2 / +2 (model_2)
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		far[d][0] = HAS2 ? z[i + (cc[d] >= 2 ? -2 * st[d] : -cc[d] * st[d])] : 0.0f;
+		far[d][1] = HAS2 ? z[i + (cc[d] + 2 < nn[d] ? 2 * st[d] : (nn[d] - 1 - cc[d]) * st[d])] : 0.0f;
+	}
+	const float dv = E.mode == 2 ? bf16_of(E.dinv[i]) : 0.0f;
+	const float rv = E.mode == 5 ? 0.0f : E.r[i];
+	const float zp = E.mode == 2 ? E.zprev[i] : 0.0f;
+	if (stop) { return; }  // (workgroup-uniform)
+	const float pc = xb[1][1][1];
+	float acc2 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const int c = cc[d], nd = nn[d];
+		const float wm = d == 0 ? xb[1][1][0] : (d == 1 ? xb[1][0][1] : xb[0][1][1]);
+		const float wp = d == 0 ? xb[1][1][2] : (d == 1 ? xb[1][2][1] : xb[2][1][1]);
+		const float w[5] = {far[d][0], wm, pc, wp, far[d][1]};
+		if (HAS2) {
+			const float e0 = (c - 2 >= 0 && c < nd) ? 1.0f : 0.0f, e1 = (c - 1 >= 0 && c + 1 < nd) ? 1.0f : 0.0f, e2 = (c + 2 < nd) ? 1.0f : 0.0f;
+			const float u0 = e0 * (w[0] - 2.0f * w[1] + w[2]), u1 = e1 * (w[1] - 2.0f * w[2] + w[3]), u2 = e2 * (w[2] - 2.0f * w[3] + w[4]);
+			acc2 += u0 - 2.0f * u1 + u2;
+		}
+		if (HAS1) {
+			const float f0 = (c - 1 >= 0) ? 1.0f : 0.0f, f1 = (c + 1 < nd) ? 1.0f : 0.0f;
+			const float d0 = f0 * (w[2] - w[1]), d1 = f1 * (w[3] - w[2]);
+			acc1 += d0 - d1;
+		}
+	}
+	float q = C.w0x3 * pc;
+	if (HAS2) { q += C.w2sq * acc2; }
+	if (HAS1) { q += C.w1sq * acc1; }
+	float data = 0.0f;
+#pragma unroll
+	for (int s = 0; s < 27; ++s) { data += dg[s] * xb[s / 9][(s / 3) % 3][s % 3]; }
+	q += data;
+	float zn;
+	if (E.mode == 5) {  // the plain product y = A x, with the workgroup's share of x . A x
+		zn = q;
+	} else if (E.mode == 3) {
+		zn = rv - q;
+	} else {
+		zn = E.a * pc - E.c1 * zp + E.c2 * (dv * (rv - q));
+	}
+	if (live) { E.znew[i] = zn; }
+	if (partial) {
+		__shared__ double red[kThreads / 64];
+		const double w = wave_sum(live ? static_cast<double>(pc) * static_cast<double>(q) : 0.0);
+		if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = w; }
+		__syncthreads();
+		if (threadIdx.x == 0) { partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3]; }
+	}
+}
+
+namespace {
+bool full_direct_now(const fi_ctx* c) { return c->dia_valid && c->tail_dia.p && stencil_cheb_direct(c) && stencil_full_direct_wanted(c); }
+void full_direct_launch(fi_ctx* c, const float* x, const ChebEpi<float>& E, double* partial)
+{
+	const MarchCoef<float> C = march_coef<float>(c->w);
+	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
+	const int  nx = c->g.n[0], ny = c->g.n[1], nz = c->g.n[2];
+	const dim3 grid(static_cast<unsigned>((c->g.nloc + kThreads - 1) / kThreads));
+	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, grid, dim3(kThreads), 0, c->stream, nx, ny, nz, C, x, c->tail_dia.as<float>(), E, done, partial);
+	};
+	if (h1 && h2) {
+		launch(k_full_direct3<true, true>);
+	} else if (h2) {
+		launch(k_full_direct3<false, true>);
+	} else {
+		launch(k_full_direct3<true, false>);
+	}
+	FI_HIP_TRY(hipGetLastError());
+}
+}  // namespace
+
+bool stencil_full_direct_wanted(const fi_ctx* c)
+{
+	return c->dtype == FI_F32 && c->g.ndim == 3 && c->nranks == 1 && c->g.nown == c->g.nloc && c->g.nloc <= kDirectMaxPoints && c->mg_mode == 1 &&
+	       c->cells.ncell > 0 && c->generic.ntrip == 0 && !(c->w.model_3 > 0 || c->w.model_4 > 0 || c->w.gradient_smoothness > 0) &&
+	       (c->w.model_1 > 0 || c->w.model_2 > 0) && !test_switch("FI_NO_DIRECT_FULL");
+}
+
 // Chebyshev step through the marching kernel (see ChebEpi); false when the kernel does not apply to this context.
 bool stencil_cheb_available(const fi_ctx* c) { return (c->march.valid && !c->march.wide) || c->tile2.valid; }  // (2-D: the tile kernel)
 int  stencil_cheb_partials(const fi_ctx* c) { return c->march.valid ? c->march.Pplain.nwg : tile2d_partials(c); }
@@ -1689,6 +1825,10 @@ void stencil_full_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	ChebEpi<float> E{static_cast<const float*>(zprev ? zprev : z), static_cast<const float*>(r), c->dinv16.as<unsigned short>(),
 	                 static_cast<float*>(znew), static_cast<float>(a), static_cast<float>(zprev ? c1 : 0.0),
 	                 static_cast<float>(c2), residual ? 3 : 2, 0.0f, 0.0f};
+	if (full_direct_now(c)) {  // small levels: the data rows as diagonals
+		full_direct_launch(c, zf, E, nullptr);
+		return;
+	}
 	march_launch<float>(c, zf, nullptr, nullptr, &E);
 }
 
@@ -1730,6 +1870,12 @@ bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial)
 {
 	if (c->tile2.valid) { return tile2d_apply(c, x, y, partial); }
 	if (!c->march.valid) { return false; }
+	if (full_direct_now(c)) {
+		ChebEpi<float> E{static_cast<const float*>(x), static_cast<const float*>(x), c->dinv16.as<unsigned short>(), static_cast<float*>(y), 0.0f,
+		                 0.0f, 0.0f, 5, 0.0f, 0.0f};
+		full_direct_launch(c, static_cast<const float*>(x), E, partial);
+		return true;
+	}
 	if (c->dtype == FI_F64) {
 		march_launch<double>(c, static_cast<const double*>(x), static_cast<double*>(y), partial);
 	} else {

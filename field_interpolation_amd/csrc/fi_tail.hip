@@ -386,6 +386,7 @@ void tail_build_operator(fi_ctx* c)
 	const int64_t nn = g.nloc;
 	const int D = g.ndim, ns = ipow3(D);
 	c->tail_prog_valid = false;
+	c->dia_valid = false;
 	if (c->cells.ncell <= 0) {
 		c->tail_dia.release();
 		return;
@@ -407,6 +408,7 @@ void tail_build_operator(fi_ctx* c)
 		                   c->cells.blk.as<float>(), c->tail_dia.as<float>());
 	}
 	FI_HIP_TRY(hipGetLastError());
+	c->dia_valid = true;
 }
 
 TailLevel tail_level_of(const fi_ctx* c)

@@ -334,6 +334,55 @@ def test_post_smoothing_added_by_the_polynomials_last_step(fi, monkeypatch, size
     assert np.array_equal(out[0][0], out[1][0])
 
 
+@pytest.mark.parametrize("sizes,kw,oriented,mixed", [([128, 128, 128], dict(model_2=0.5), False, True),          # config 4's shape: levels 64^3, 32^3
+                                                     ([96, 80, 72], dict(model_1=0.4, model_2=0.5), False, True),
+                                                     ([88, 72, 80], dict(model_1=0.6, model_2=0.0), False, False),   # fp32 V-cycle PCG
+                                                     ([96, 96, 96], dict(), True, True)])                            # an SDF: the full-operator smoother
+def test_small_levels_full_operator_as_diagonals(fi, monkeypatch, sizes, kw, oriented, mixed):
+    """fp32 levels of <= 2^19 points apply their FULL operator (V-cycle residuals, the full-operator smoother's steps) as the
+    model star + 27 diagonals of the data rows, a thread per point (k_full_direct3), instead of walking the z-marching kernel
+    through single planes of packed cells (FI_NO_DIRECT_FULL): the same operator, another order of sums -- the same iteration
+    counts (+-1) and the same solution."""
+    rng = np.random.default_rng(sum(sizes) + 3)
+    w = fi.Weights(**kw)
+    if oriented:
+        n = 6000
+        centre = np.array(sizes, np.float32) / 2.0
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pos = (centre + 0.3 * min(sizes) * d).astype(np.float32)
+        nrm, val = d, None
+    else:
+        n = 40000
+        pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+        nrm, val = None, rng.normal(size=n).astype(np.float32)
+    out = []
+    for no_direct in (False, True):
+        if no_direct:
+            monkeypatch.setenv("FI_NO_DIRECT_FULL", "1")
+        else:
+            monkeypatch.delenv("FI_NO_DIRECT_FULL", raising=False)
+        f = fi.LatticeField(sizes, dtype="f64" if mixed else "f32")
+        f.add_field_constraints(w)
+        if oriented:
+            f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
+        else:
+            f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.set_levels(2, 1e-4)
+        f.set_multigrid(True)
+        if mixed:
+            f.set_mixed_precision(True)
+        f.assemble()
+        tol = 1e-8 if mixed else 2e-5
+        x, it, rel = f.solve_cg(None, 0, tol)
+        assert f.stats()["converged"] == 1
+        out.append((np.array(f.solution_f64() if mixed else x, dtype=np.float64), it))
+        del f
+    monkeypatch.delenv("FI_NO_DIRECT_FULL", raising=False)
+    assert abs(out[0][1] - out[1][1]) <= 1, (out[0][1], out[1][1])
+    assert rel_inf(out[0][0], out[1][0]) <= (1e-5 if mixed else 2e-3)
+
+
 def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
     """fi_assemble builds the coarser levels on a helper thread and a second stream while the calling thread assembles
     the finest level; FI_SERIAL_LEVELS builds them afterwards on the solver stream.  Same kernels on the same data: the
