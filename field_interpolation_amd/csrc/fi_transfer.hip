@@ -119,6 +119,24 @@ __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __r
 	T acc[2][2][2];
 #pragma unroll
 	for (int q = 0; q < 8; ++q) { acc[q >> 2][(q >> 1) & 1][q & 1] = T(0); }
+	// Rows of whole pairs (even extent along x): a thread's two points of a row travel as ONE access, and in mode 1 the four
+	// pairs it adds onto are requested HERE, before the 27 coarse loads, not after the sums (two 4-byte accesses per row with a
+	// stride of two points between lanes touched every line twice, and the old values were waited for at the very end:
+	// 256^3 from 128^3 43 -> ... us)
+	struct alignas(2 * sizeof(T)) Pair { T a, b; };
+	const bool pairs = (L.nf[0] & 1) == 0;
+	Pair old4[2][2];
+#pragma unroll
+	for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+		for (int pyb = 0; pyb < 2; ++pyb) {
+			old4[pz][pyb] = Pair{T(0), T(0)};
+			if (pairs && mode && live[2][pz] && live[1][pyb]) {
+				const int64_t i = (static_cast<int64_t>(2 * jz + pz - L.f_base) * L.nf[1] + (2 * jy + pyb)) * L.nf[0] + 2 * jx;
+				old4[pz][pyb] = *reinterpret_cast<const Pair*>(fine + i);
+			}
+		}
+	}
 	// every load unconditional; a plane without weight (it may lie beyond the slab's ghost plane) is replaced by coarse
 	// plane jz, which every live parity draws on
 	const int safe_z = (jz > L.nc[2] - 1 ? L.nc[2] - 1 : jz) - L.c_base;
@@ -151,6 +169,10 @@ __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __r
 		for (int pyb = 0; pyb < 2; ++pyb) {
 			if (!live[2][pz] || !live[1][pyb]) { continue; }
 			const int64_t i = (static_cast<int64_t>(2 * jz + pz - L.f_base) * L.nf[1] + (2 * jy + pyb)) * L.nf[0] + 2 * jx;
+			if (pairs) {  // (the same sums: old + acc)
+				*reinterpret_cast<Pair*>(fine + i) = Pair{old4[pz][pyb].a + acc[pz][pyb][0], old4[pz][pyb].b + acc[pz][pyb][1]};
+				continue;
+			}
 			fine[i] = mode ? fine[i] + acc[pz][pyb][0] : acc[pz][pyb][0];
 			if (live[0][1]) { fine[i + 1] = mode ? fine[i + 1] + acc[pz][pyb][1] : acc[pz][pyb][1]; }
 		}
@@ -537,6 +559,76 @@ __global__ __launch_bounds__(kThreads) void k_restrict3_xy_tiled(LevelPair L, in
 		tmp[(static_cast<int64_t>(fz) * L.nc[1] + cy) * L.nc[0] + cx] = acc;
 	}
 }
+// The x / y pass on lattices halved cell-centred along x and y (even extents: 256^3 .. 8^3 of configs 4 / 5), without LDS
+// and without a barrier: a thread owns TWO coarse columns -- the four fine points of one 16-byte load, plus its two
+// neighbours' edge points through the cache -- and walks 2 R + 4 fine rows for R coarse rows of them, every row restricted
+// along x once and spread over the (at most three) coarse rows it belongs to.  The weights are restrict_taps' own (the end
+// rows / columns with their 5/4 and -1/4), dropped into windows of six; the sums run in another order than the tiled
+// kernel's (same weights).  25 LDS reads, their index arithmetic and the tile's 11 loads per thread made that one
+// instruction-bound: 42 us for 84 MB at 256^3 -> 128^3.
+constexpr int kRowsR = 8;
+template <typename T>
+__device__ inline void restrict_window6(int c, int nf, int nc, int base, T* W)
+{
+	int f[kRTaps];
+	T   w[kRTaps];
+	restrict_taps<T>(c, nf, nc, 1, base, f, w);
+#pragma unroll
+	for (int s = 0; s < 6; ++s) {
+		T acc = T(0);
+#pragma unroll
+		for (int k = 0; k < kRTaps; ++k) { acc += (f[k] == s) ? w[k] : T(0); }
+		W[s] = acc;
+	}
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_restrict3_xy_rows(LevelPair L, const T* __restrict__ fine, T* __restrict__ tmp)
+{
+	constexpr int R = kRowsR;
+	typedef T V4 __attribute__((ext_vector_type(4)));
+	typedef T V2 __attribute__((ext_vector_type(2)));
+	const int g   = static_cast<int>(blockIdx.x) * 64 + (threadIdx.x & 63);             // fine columns 4g .. 4g+3
+	const int cyb = (static_cast<int>(blockIdx.y) * (kThreads / 64) + (threadIdx.x >> 6)) * R;  // first coarse row (wave-uniform)
+	if (4 * g >= L.nf[0] || cyb >= L.nc[1]) { return; }
+	const int fz = static_cast<int>(blockIdx.z);
+	T We[6], Wo[6];
+	restrict_window6<T>(2 * g, L.nf[0], L.nc[0], 4 * g - 1, We);
+	restrict_window6<T>(2 * g + 1, L.nf[0], L.nc[0], 4 * g - 1, Wo);
+	const int xl = 4 * g - 1 < 0 ? 0 : 4 * g - 1, xr = 4 * g + 4 > L.nf[0] - 1 ? L.nf[0] - 1 : 4 * g + 4;
+	const T* plane = fine + static_cast<int64_t>(fz) * L.nf[0] * L.nf[1];
+	T oe[R], oo[R];
+#pragma unroll
+	for (int j = 0; j < R; ++j) { oe[j] = T(0); oo[j] = T(0); }
+	T Wy[R][6];
+#pragma unroll
+	for (int j = 0; j < R; ++j) {
+		const int cy = cyb + j < L.nc[1] ? cyb + j : L.nc[1] - 1;
+		restrict_window6<T>(cy, L.nf[1], L.nc[1], 2 * cy - 2, Wy[j]);
+	}
+#pragma unroll
+	for (int k = 0; k < 2 * R + 4; ++k) {
+		int fy = 2 * cyb - 2 + k;
+		fy = fy < 0 ? 0 : (fy > L.nf[1] - 1 ? L.nf[1] - 1 : fy);  // (a clamped row meets weights of zero only)
+		const T* row = plane + static_cast<int64_t>(fy) * L.nf[0];
+		const V4 v = *reinterpret_cast<const V4*>(row + 4 * g);
+		const T  a = row[xl], b = row[xr];
+		const T e = We[0] * a + We[1] * v[0] + We[2] * v[1] + We[3] * v[2] + We[4] * v[3] + We[5] * b;
+		const T o = Wo[0] * a + Wo[1] * v[0] + Wo[2] * v[1] + Wo[3] * v[2] + Wo[4] * v[3] + Wo[5] * b;
+#pragma unroll
+		for (int j = 0; j < R; ++j) {
+			if (k - 2 * j >= 0 && k - 2 * j < 6) {  // (static)
+				oe[j] += Wy[j][k - 2 * j] * e;
+				oo[j] += Wy[j][k - 2 * j] * o;
+			}
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < R; ++j) {
+		if (cyb + j < L.nc[1]) {
+			*reinterpret_cast<V2*>(tmp + (static_cast<int64_t>(fz) * L.nc[1] + (cyb + j)) * L.nc[0] + 2 * g) = V2{oe[j], oo[j]};
+		}
+	}
+}
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict3_z(LevelPair L, const T* __restrict__ tmp, T* __restrict__ coarse)
 {
@@ -563,7 +655,12 @@ void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t s
 {
 	if (L.ndim == 3 && tmp && f_local_planes > 0 && !test_switch("FI_ONE_PASS_RESTRICT")) {
 		const int64_t n_xy = static_cast<int64_t>(L.nc[0]) * L.nc[1] * f_local_planes, n_z = static_cast<int64_t>(L.nc[0]) * L.nc[1] * L.c_planes;
-		if (L.nc[0] >= 32 && f_local_planes <= 65535 && !test_switch("FI_FLAT_RESTRICT")) {
+		const bool halves = L.cc[0] && L.cc[1] && L.nf[0] == 2 * L.nc[0] && L.nf[1] == 2 * L.nc[1] && L.nf[0] % 4 == 0 && L.nc[0] >= 8 && L.nc[1] >= 8;
+		if (halves && L.nc[0] >= 32 && f_local_planes <= 65535 && !test_switch("FI_FLAT_RESTRICT") && !test_switch("FI_TILED_RESTRICT")) {
+			constexpr int rows_per_wg = (kThreads / 64) * kRowsR;
+			hipLaunchKernelGGL((k_restrict3_xy_rows<T>), dim3((L.nf[0] / 4 + 63) / 64, (L.nc[1] + rows_per_wg - 1) / rows_per_wg, f_local_planes),
+			                   dim3(kThreads), 0, st, L, fine, tmp);
+		} else if (L.nc[0] >= 32 && f_local_planes <= 65535 && !test_switch("FI_FLAT_RESTRICT")) {
 			hipLaunchKernelGGL((k_restrict3_xy_tiled<T>), dim3((L.nc[0] + 63) / 64, (L.nc[1] + 7) / 8, f_local_planes), dim3(kThreads), 0, st,
 			                   L, f_local_planes, fine, tmp);
 		} else {
