@@ -178,6 +178,98 @@ __global__ __launch_bounds__(kThreads) void k_prolong3(LevelPair L, const T* __r
 		}
 	}
 }
+// The same interpolation on undivided lattices halved cell-centred along all three axes (even extents: the levels of
+// configs 4 / 5), a thread per TWO coarse columns and R coarse rows of one coarse plane: every coarse row of the three
+// planes it draws on is interpolated along x ONCE into the four fine columns of a 16-byte store, combined along z for the
+// two fine planes, and a window of three such rows gives the fine rows 2 cy, 2 cy + 1 -- 9 (R + 2) loads for 16 R fine points
+// where a thread per 2 x 2 x 2 block issued 27 for 8.  The weights are prolong_taps' own (the end points' 5/4, -1/4).
+#ifndef FI_PRO_ROWS
+#define FI_PRO_ROWS 4
+#endif
+constexpr int kProRows = FI_PRO_ROWS;
+template <typename T>
+__device__ inline void prolong_window(int f, int nc, int u0, int nslots, T* W)  // cell-centred taps of fine index f on slots u0 ..
+{
+	int i0, i1;
+	T   w0, w1;
+	prolong_taps<T>(f, nc, 1, &i0, &i1, &w0, &w1);
+#pragma unroll
+	for (int s = 0; s < 4; ++s) {
+		if (s < nslots) { W[s] = (i0 - u0 == s ? w0 : T(0)) + (i1 - u0 == s ? w1 : T(0)); }
+	}
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_prolong3_rows(LevelPair L, const T* __restrict__ coarse, T* __restrict__ fine, int mode)
+{
+#pragma clang fp contract(fast)  // (this file is compiled without contraction; these sums need no particular rounding)
+	constexpr int R = kProRows;
+	typedef T V4 __attribute__((ext_vector_type(4)));
+	typedef T V2 __attribute__((ext_vector_type(2)));
+	const int g   = static_cast<int>(blockIdx.x) * 64 + (threadIdx.x & 63);                     // coarse columns 2g, 2g+1
+	const int cyb = (static_cast<int>(blockIdx.y) * (kThreads / 64) + (threadIdx.x >> 6)) * R;  // first coarse row (wave-uniform)
+	if (2 * g >= L.nc[0] || cyb >= L.nc[1]) { return; }
+	const int jz = static_cast<int>(blockIdx.z);
+	T Wx[4][4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) { prolong_window<T>(4 * g + q, L.nc[0], 2 * g - 1, 4, Wx[q]); }
+	T Wz[2][3];
+#pragma unroll
+	for (int pz = 0; pz < 2; ++pz) { prolong_window<T>(2 * jz + pz, L.nc[2], jz - 1, 3, Wz[pz]); }
+	const int xl = 2 * g - 1 < 0 ? 0 : 2 * g - 1, xr = 2 * g + 2 > L.nc[0] - 1 ? L.nc[0] - 1 : 2 * g + 2;
+	const int64_t csy = L.nc[0], csz = static_cast<int64_t>(L.nc[0]) * L.nc[1];
+	const T* cpl[3];
+#pragma unroll
+	for (int p = 0; p < 3; ++p) {
+		const int cz = jz - 1 + p;
+		cpl[p] = coarse + csz * (cz < 0 ? 0 : (cz > L.nc[2] - 1 ? L.nc[2] - 1 : cz));  // (a clamped plane meets a weight of zero)
+	}
+	T zc[R + 2][2][4];  // rows cyb-1 .. cyb+R, interpolated along x and combined along z for the two fine planes
+#pragma unroll
+	for (int k = 0; k < R + 2; ++k) {
+		int cy = cyb - 1 + k;
+		cy = cy < 0 ? 0 : (cy > L.nc[1] - 1 ? L.nc[1] - 1 : cy);
+#pragma unroll
+		for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { zc[k][pz][q] = T(0); }
+		}
+#pragma unroll
+		for (int p = 0; p < 3; ++p) {
+			const T* row = cpl[p] + csy * cy;
+			const V2 v = *reinterpret_cast<const V2*>(row + 2 * g);
+			const T  a = row[xl], b = row[xr];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const T xi = Wx[q][0] * a + Wx[q][1] * v[0] + Wx[q][2] * v[1] + Wx[q][3] * b;
+				zc[k][0][q] += Wz[0][p] * xi;
+				zc[k][1][q] += Wz[1][p] * xi;
+			}
+		}
+		if (k >= 2) {  // coarse row cyb + k - 2 has its three rows: its two fine rows of both fine planes
+			const int cyo = cyb + k - 2;
+			if (cyo < L.nc[1]) {
+#pragma unroll
+				for (int py = 0; py < 2; ++py) {
+					T Wy[3];
+					prolong_window<T>(2 * cyo + py, L.nc[1], cyo - 1, 3, Wy);
+#pragma unroll
+					for (int pz = 0; pz < 2; ++pz) {
+						V4 out;
+#pragma unroll
+						for (int q = 0; q < 4; ++q) { out[q] = Wy[0] * zc[k - 2][pz][q] + Wy[1] * zc[k - 1][pz][q] + Wy[2] * zc[k][pz][q]; }
+						T* dst = fine + (static_cast<int64_t>(2 * jz + pz) * L.nf[1] + (2 * cyo + py)) * L.nf[0] + 4 * g;
+						if (mode) {
+							const V4 old = *reinterpret_cast<const V4*>(dst);
+							out += old;
+						}
+						*reinterpret_cast<V4*>(dst) = out;
+					}
+				}
+			}
+		}
+	}
+}
+
 // 2-D form (the generic kernel indexes its coordinate arrays by the runtime axis -- scratch memory: 127 us per call at
 // 4096^2 against the 25 us two lattice passes take).  A thread owns the fine points 2t and 2t+1 of a row; y is the
 // decomposed axis.
@@ -369,7 +461,14 @@ void launch_prolong(const LevelPair& L, const T* coarse, T* fine, int mode, hipS
 	if (L.ndim == 3) {
 		const int64_t blocks8 = static_cast<int64_t>((L.nf[0] + 1) / 2) * ((L.nf[1] + 1) / 2) *
 		                        (((L.f_z0 + L.f_planes - 1) >> 1) - (L.f_z0 >> 1) + 1);
-		if (L.f_planes > 0) {
+		const bool halves = L.cc[0] && L.cc[1] && L.cc[2] && L.nf[0] == 2 * L.nc[0] && L.nf[1] == 2 * L.nc[1] && L.nf[2] == 2 * L.nc[2] &&
+		                    L.nc[0] % 2 == 0 && L.nc[0] >= 128 && L.nc[1] >= 64 && L.nc[2] >= 64 && L.f_base == 0 && L.c_base == 0 && L.f_z0 == 0 &&
+		                    L.f_planes == L.nf[2] && L.nc[2] <= 65535 && !test_switch("FI_BLOCK_PROLONG");
+		if (halves) {
+			constexpr int rows_per_wg = (kThreads / 64) * kProRows;
+			hipLaunchKernelGGL((k_prolong3_rows<T>), dim3((L.nc[0] / 2 + 63) / 64, (L.nc[1] + rows_per_wg - 1) / rows_per_wg, L.nc[2]), dim3(kThreads), 0,
+			                   st, L, coarse, fine, mode);
+		} else if (L.f_planes > 0) {
 			hipLaunchKernelGGL((k_prolong3<T>), dim3(static_cast<unsigned>((blocks8 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
 			                   coarse, fine, mode);
 		}
@@ -394,6 +493,87 @@ void launch_prolong(const LevelPair& L, const T* coarse, T* fine, int mode, hipS
 // (weight 1/2; the last coarse point also takes the full weight of a fine point beyond it).  Cell-centred axis: fine
 // 2c-1 .. 2c+2 with (1/4, 3/4, 3/4, 1/4); the end points' extrapolation puts 5/4 of fine 0 on coarse 0 and -1/4 of it on
 // coarse 1 (mirrored at the other end): five taps.  Indices are relative to `base` and clamped where the weight is 0.
+// The cubic interpolation of the start in the row form of k_prolong3_rows (undivided lattices halved cell-centred along all
+// axes): a thread owns two coarse columns (four fine ones) and R coarse rows of one coarse plane; windows of 6 (x) / 5 (y, z)
+// coarse points carry cubic_taps' weights, the ends' linear taps included.  15 (R + 4) eight-byte loads for 16 R fine points
+// where a thread per 2 x 2 x 2 block issued 125 for 8 (256^3 from 128^3, fp64 result: 91 -> ... us).
+template <typename T, typename TO>
+__global__ __launch_bounds__(kThreads) void k_prolong3_cubic_rows(LevelPair L, const T* __restrict__ coarse, TO* __restrict__ fine)
+{
+#pragma clang fp contract(fast)
+	constexpr int R = kProRows;
+	typedef T  V2 __attribute__((ext_vector_type(2)));
+	typedef TO O2 __attribute__((ext_vector_type(2)));
+	const int g   = static_cast<int>(blockIdx.x) * 64 + (threadIdx.x & 63);                     // coarse columns 2g, 2g+1
+	const int cyb = (static_cast<int>(blockIdx.y) * (kThreads / 64) + (threadIdx.x >> 6)) * R;  // first coarse row (wave-uniform)
+	if (2 * g >= L.nc[0] || cyb >= L.nc[1]) { return; }
+	const int jz = static_cast<int>(blockIdx.z);
+	T Wx[4][6];  // fine column 4g+q on the coarse slots 2g-2 .. 2g+3
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		T w5[5];
+		cubic_window<T>(4 * g + q, L.nc[0], 1, 2 * g + (q >> 1) - 2, true, w5);
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { Wx[q][s] = (s - (q >> 1) >= 0 && s - (q >> 1) < 5) ? w5[s - (q >> 1) < 0 ? 0 : (s - (q >> 1) > 4 ? 4 : s - (q >> 1))] : T(0); }
+	}
+	T Wz[2][5];
+#pragma unroll
+	for (int pz = 0; pz < 2; ++pz) { cubic_window<T>(2 * jz + pz, L.nc[2], 1, jz - 2, true, Wz[pz]); }
+	const int64_t csy = L.nc[0], csz = static_cast<int64_t>(L.nc[0]) * L.nc[1];
+	// the three pairs of a row: whole pairs are inside the lattice or outside it (even extent); an outside pair is read at a
+	// clamped place and meets weights of zero
+	const int p0 = 2 * g - 2 < 0 ? 0 : 2 * g - 2, p2 = 2 * g + 2 > L.nc[0] - 2 ? L.nc[0] - 2 : 2 * g + 2;
+	const T* cpl[5];
+#pragma unroll
+	for (int p = 0; p < 5; ++p) {
+		const int cz = jz - 2 + p;
+		cpl[p] = coarse + csz * (cz < 0 ? 0 : (cz > L.nc[2] - 1 ? L.nc[2] - 1 : cz));
+	}
+	T zc[R + 4][2][4];  // rows cyb-2 .. cyb+R+1, interpolated along x and combined along z for the two fine planes
+#pragma unroll
+	for (int k = 0; k < R + 4; ++k) {
+		int cy = cyb - 2 + k;
+		cy = cy < 0 ? 0 : (cy > L.nc[1] - 1 ? L.nc[1] - 1 : cy);
+#pragma unroll
+		for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { zc[k][pz][q] = T(0); }
+		}
+#pragma unroll
+		for (int p = 0; p < 5; ++p) {
+			const T* row = cpl[p] + csy * cy;
+			const V2 a = *reinterpret_cast<const V2*>(row + p0), v = *reinterpret_cast<const V2*>(row + 2 * g), b = *reinterpret_cast<const V2*>(row + p2);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const T xi = Wx[q][0] * a[0] + Wx[q][1] * a[1] + Wx[q][2] * v[0] + Wx[q][3] * v[1] + Wx[q][4] * b[0] + Wx[q][5] * b[1];
+				zc[k][0][q] += Wz[0][p] * xi;
+				zc[k][1][q] += Wz[1][p] * xi;
+			}
+		}
+		if (k >= 4) {  // coarse row cyb + k - 4 has its five rows
+			const int cyo = cyb + k - 4;
+			if (cyo < L.nc[1]) {
+#pragma unroll
+				for (int py = 0; py < 2; ++py) {
+					T Wy[5];
+					cubic_window<T>(2 * cyo + py, L.nc[1], 1, cyo - 2, true, Wy);
+#pragma unroll
+					for (int pz = 0; pz < 2; ++pz) {
+						T out[4];
+#pragma unroll
+						for (int q = 0; q < 4; ++q) {
+							out[q] = Wy[0] * zc[k - 4][pz][q] + Wy[1] * zc[k - 3][pz][q] + Wy[2] * zc[k - 2][pz][q] + Wy[3] * zc[k - 1][pz][q] + Wy[4] * zc[k][pz][q];
+						}
+						TO* dst = fine + (static_cast<int64_t>(2 * jz + pz) * L.nf[1] + (2 * cyo + py)) * L.nf[0] + 4 * g;
+						*reinterpret_cast<O2*>(dst)     = O2{static_cast<TO>(out[0]), static_cast<TO>(out[1])};
+						*reinterpret_cast<O2*>(dst + 2) = O2{static_cast<TO>(out[2]), static_cast<TO>(out[3])};
+					}
+				}
+			}
+		}
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict(LevelPair L, const T* __restrict__ fine, T* __restrict__ coarse)
 {
@@ -584,6 +764,7 @@ __device__ inline void restrict_window6(int c, int nf, int nc, int base, T* W)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_restrict3_xy_rows(LevelPair L, const T* __restrict__ fine, T* __restrict__ tmp)
 {
+#pragma clang fp contract(fast)  // (this file is compiled without contraction; these sums need no particular rounding)
 	constexpr int R = kRowsR;
 	typedef T V4 __attribute__((ext_vector_type(4)));
 	typedef T V2 __attribute__((ext_vector_type(2)));
@@ -695,7 +876,14 @@ void launch_prolong_cubic(const LevelPair& L, const T* coarse, TO* fine, hipStre
 {
 	const int64_t blocks8 = static_cast<int64_t>((L.nf[0] + 1) / 2) * ((L.nf[1] + 1) / 2) *
 	                        (((L.f_z0 + L.f_planes - 1) >> 1) - (L.f_z0 >> 1) + 1);
-	if (L.f_planes > 0) {
+	const bool halves = L.cc[0] && L.cc[1] && L.cc[2] && L.nf[0] == 2 * L.nc[0] && L.nf[1] == 2 * L.nc[1] && L.nf[2] == 2 * L.nc[2] &&
+	                    L.nc[0] % 2 == 0 && L.nc[0] >= 128 && L.nc[1] >= 64 && L.nc[2] >= 64 && L.f_base == 0 && L.c_base == 0 && L.f_z0 == 0 &&
+	                    L.f_planes == L.nf[2] && L.nc[2] <= 65535 && !test_switch("FI_BLOCK_PROLONG");
+	if (halves) {
+		constexpr int rows_per_wg = (kThreads / 64) * kProRows;
+		hipLaunchKernelGGL((k_prolong3_cubic_rows<T, TO>), dim3((L.nc[0] / 2 + 63) / 64, (L.nc[1] + rows_per_wg - 1) / rows_per_wg, L.nc[2]),
+		                   dim3(kThreads), 0, st, L, coarse, fine);
+	} else if (L.f_planes > 0) {
 		hipLaunchKernelGGL((k_prolong3_cubic<T, TO>), dim3(static_cast<unsigned>((blocks8 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
 		                   coarse, fine);
 	}

@@ -383,6 +383,42 @@ def test_small_levels_full_operator_as_diagonals(fi, monkeypatch, sizes, kw, ori
     assert rel_inf(out[0][0], out[1][0]) <= (1e-5 if mixed else 2e-3)
 
 
+@pytest.mark.parametrize("sizes", [[256, 128, 128], [128, 96, 64]])
+def test_row_form_transfers_equal_the_block_form(fi, monkeypatch, sizes):
+    """On lattices halved cell-centred (even extents) the V-cycle's restriction (x / y pass) and interpolation and the start's
+    cubic interpolation run in a ROW form -- a thread per two coarse columns walking rows, whole 16-byte accesses, no LDS
+    (k_restrict3_xy_rows, k_prolong3_rows, k_prolong3_cubic_rows; the interpolations from 128 x 64 x 64 coarse points up) --
+    with the weights of restrict_taps / prolong_taps / cubic_taps in another order of sums than the tiled and per-block
+    kernels (FI_TILED_RESTRICT, FI_BLOCK_PROLONG): the same iteration counts and the same solution."""
+    rng = np.random.default_rng(sum(sizes) + 9)
+    n = 60000
+    pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+    val = rng.normal(size=n).astype(np.float32)
+    w = fi.Weights(model_2=0.5)
+    out = []
+    for block in (False, True):
+        for k in ("FI_TILED_RESTRICT", "FI_BLOCK_PROLONG"):
+            if block:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        f = fi.LatticeField(sizes, dtype="f64")
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.set_levels(2, 1e-4)
+        f.set_multigrid(True)
+        f.set_mixed_precision(True)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-8)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.2e-8
+        out.append((np.array(f.solution_f64()), it))
+        del f
+    for k in ("FI_TILED_RESTRICT", "FI_BLOCK_PROLONG"):
+        monkeypatch.delenv(k, raising=False)
+    assert abs(out[0][1] - out[1][1]) <= 1, (out[0][1], out[1][1])
+    assert rel_inf(out[0][0], out[1][0]) <= 1e-5
+
+
 def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
     """fi_assemble builds the coarser levels on a helper thread and a second stream while the calling thread assembles
     the finest level; FI_SERIAL_LEVELS builds them afterwards on the solver stream.  Same kernels on the same data: the
