@@ -42,9 +42,9 @@ def test_marching_kernel_budget():
         epi = "ELb1ELb0EEEv" in name or "ELb1ELb1EEEv" in name
         # (SGPR spills go to VGPR lanes, not to memory: the both-models variants keep 11-19 lane masks and bounds there,
         # the fused ones with the smoother's epilogue up to 40; the plain ones with the epilogue carry the storage format of
-        # the polynomial's iterates as uniform state since round 4: 34 with both models on, 44 since round 5 -- the format is
+        # the polynomial's iterates as uniform state since round 4: 34 with both models on, 50 since round 5 -- the format is
         # looked at where a loaded vector is first used as well as where it is loaded)
-        assert r["SGPRs Spill"] <= ((40 if r["LDS Size [bytes/block]"] > 30000 else 48) if epi else 24) and r["AGPRs"] == 0, name
+        assert r["SGPRs Spill"] <= ((40 if r["LDS Size [bytes/block]"] > 30000 else 56) if epi else 24) and r["AGPRs"] == 0, name
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, name
         if r["LDS Size [bytes/block]"] > 30000:           # fused variants: 3 workgroups per CU (2 with both models)
             assert r["LDS Size [bytes/block]"] * 3 <= 160 * 1024, name
