@@ -419,6 +419,10 @@ struct fi_ctx {
 	// the small-level engine (fi_tail.h): this level and every level below it (all of <= 4 096 unknowns) run their share of a
 	// V-cycle in one launch of one workgroup.  tail_dia: the data rows as 3^D diagonals; tail_prog: the levels' table and the
 	// stages of the cycle (built at the first cycle after an assemble / a change of the smoothers' bounds)
+	// fp32 replica of a mixed-precision solve: the fp64 CG's r . z is b . x of the V-cycle, and the cycle's last launch on the
+	// finest level (the post-smoothing polynomial's last step) can sum it on the way (ChebEpi::dotv): bx_dot_wanted is set by
+	// cg_run_mg, bx_dot_done by the cycle that delivered the partials (fi_multigrid.hip)
+	bool       bx_dot_wanted = false, bx_dot_done = false;
 	bool       tail_ok = false;
 	fi::DevBuf tail_dia, tail_map, tail_prog;
 	bool       tail_prog_valid = false;
@@ -492,7 +496,8 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
                        const unsigned short* scaling = nullptr,   // scaling: bfloat16 array (default: the context's dinv16)
                        int extend = 0,    // slabs, deep exchange: the step also covers `extend` ghost planes on either side
                        int fmt = 0,       // bfloat16 storage of z (bit 0), z_prev (bit 1), z_new (bit 2): fp32 3-D levels, ChebEpi::fmt
-                       const void* acc = nullptr);  // z_new = acc + the step's result (ChebEpi::acc; may be znew itself)
+                       const void* acc = nullptr,   // z_new = acc + the step's result (ChebEpi::acc; may be znew itself)
+                       const void* dotv = nullptr); // the partials are those of dotv . z_new instead of r . z_new (ChebEpi::dotv)
 int  stencil_cheb_partials_max(const fi_ctx* c);  // room for the partials of a step extended over the whole ghost zone
 // small undivided fp32 levels: a step whose caller wants no partials (partial == nullptr) runs as one thread per point with
 // direct neighbour loads instead of the z-marching kernel (fi_stencil.hip, k_cheb_direct3)

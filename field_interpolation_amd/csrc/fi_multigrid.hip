@@ -558,11 +558,16 @@ bool poly_smoother_ok(const RankSet& R)
 // one launch and three lattice passes less than a sum of its own; taken when the last step is not the one that forms its
 // operand on load, else the result comes back in a work vector as without it.
 template <typename T>
-Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr, int* chain_launches = nullptr, Vec onto = nullptr)
+Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr, int* chain_launches = nullptr, Vec onto = nullptr,
+               Vec dotv = nullptr)
 {
 	fi_ctx* c0 = R[0];
 	const int    terms = mg_poly_terms(c0);
 	if (onto && (terms < 3 || test_switch("FI_NO_STEP_ONTO"))) { onto = nullptr; }
+	// dotv: the last step's partials are those of dotv . (onto after the sum) -- asked for by the top of a replica's cycle
+	// (vcycle), delivered when that step runs in the marching kernel on one undivided context
+	if (dotv && !(onto && R.size() == 1 && c0->nranks == 1 && c0->march.valid && !stencil_cheb_direct(c0))) { dotv = nullptr; }
+	c0->bx_dot_done = dotv != nullptr;
 	const double lam = c0->poly_lambda > 1.0 ? c0->poly_lambda : 1.0;
 	const double hi = 1.1 * lam, lo = hi / mg_poly_ratio(c0);
 	const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
@@ -623,7 +628,8 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 				stencil_cheb_step(c, (c->*r).p, nullptr, (c->*r).p, out, c1, c2, region2(c), 0, 0.0, 1.0 / theta, sc, 0, fmt);
 			} else {
 				stencil_cheb_step(c, where(k - 1), k == 2 ? (c->*r).p : where(k - 2), (c->*r).p, out, c1, c2, region2(c), 0,
-				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc, 0, fmt, k == n && onto ? (c->*onto).p : nullptr);
+				                  k == 2 ? 1.0 / theta : 0.0, 0.0, sc, 0, fmt, k == n && onto ? (c->*onto).p : nullptr,
+				                  k == n && dotv ? (c->*dotv).p : nullptr);
 			}
 			rho = rho_new;
 		}
@@ -656,7 +662,8 @@ Vec poly_chain(RankSet& R, Vec r, Vec za, Vec zb, double* chain_bytes = nullptr,
 				// the second step's z_prev is z_0 = Dinv r / theta, recomputed from r and the scaling
 				const bool last_onto = onto && k == terms - 1;  // (z_prev is read from zout, the result goes onto `onto`)
 				stencil_cheb_step(c, (c->*zin).p, k == 1 ? nullptr : (c->*zout).p, (c->*r).p, last_onto ? (c->*onto).p : (c->*zout).p, c1, c2,
-				                  region2(c), 0, k == 2 ? 1.0 / theta : 0.0, 0.0, sc, ext, 0, last_onto ? (c->*onto).p : nullptr);
+				                  region2(c), 0, k == 2 ? 1.0 / theta : 0.0, 0.0, sc, ext, 0, last_onto ? (c->*onto).p : nullptr,
+				                  last_onto && dotv ? (c->*dotv).p : nullptr);
 			}
 		}
 		std::swap(zin, zout);
@@ -873,7 +880,9 @@ void vcycle(RankSet& R, Vec b, Vec x)
 	};
 	auto post_smooth = [&]() {  // x += M (b - A x)
 		residual();
-		const Vec d = poly_chain<T>(R, &fi_ctx::mg_r, &fi_ctx::mg_d, &fi_ctx::q, nullptr, nullptr, x);
+		// (the top of a replica's cycle: b . x, the fp64 CG's r . z, leaves the last step as its partials when asked for)
+		const bool want_bx = R[0]->level == 0 && R[0]->bx_dot_wanted && R[0]->coarse != nullptr;
+		const Vec d = poly_chain<T>(R, &fi_ctx::mg_r, &fi_ctx::mg_d, &fi_ctx::q, nullptr, nullptr, x, want_bx ? b : nullptr);
 		if (d == x) { return; }  // (the last step has added its result onto x)
 		for (fi_ctx* c : R) {
 			hipLaunchKernelGGL((k_add_vec<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, d),
@@ -1153,7 +1162,23 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			                   c->partial.as<double>());
 		}
 	};
+	// mixed precision on one undivided context: r . z = t^2 (b . x of the replica's cycle), summed by the cycle's last launch
+	// (ChebEpi::dotv) where that launch is the marching kernel's -- no pass of its own over r and z (k_dot_mixed)
+	if (mixed) {
+		for (fi_ctx* t : Tw) { t->bx_dot_wanted = R.size() == 1 && c0->nranks == 1 && !test_switch("FI_NO_TWIN_DOT"); }
+	}
+	auto twin_dot = [&]() { return mixed && Tw[0]->bx_dot_wanted && Tw[0]->bx_dot_done; };
+	auto reduce_rz = [&](int phase) {
+		if (twin_dot()) {
+			fi_ctx* t = Tw[0];
+			hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, c0->stream, sc0,
+			                   t->partial.as<double>() + 2 * static_cast<size_t>(t->max_blocks), stencil_cheb_partials(t), phase, 1);
+			return;
+		}
+		mg_reduce(R, nbv, phase);
+	};
 	auto dot_rz = [&]() {  // partials of r . z
+		if (twin_dot()) { return; }
 		if constexpr (std::is_same<T, double>::value) {
 			if (mixed) {
 				for (size_t i = 0; i < R.size(); ++i) {
@@ -1238,9 +1263,10 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		first_restart = false;
 		const int flag = look ? read_flag() : 0;
 		if (flag) { return flag; }
+		if (mixed) { Tw[0]->bx_dot_done = false; }
 		precondition<T>(R, Tw, Rv, Z, false);
 		dot_rz();
-		mg_reduce(R, nbv, kMgInitRz);
+		reduce_rz(kMgInitRz);
 		direction(1);
 		return 0;
 	};
@@ -1320,9 +1346,10 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		++steps;
 		done = steps < predicted ? 0 : read_flag();
 		if (done) { continue; }
+		if (mixed) { Tw[0]->bx_dot_done = false; }
 		precondition<T>(R, Tw, Rv, Z, stepped);
 		dot_rz();
-		mg_reduce(R, nbv, kMgBeta);
+		reduce_rz(kMgBeta);
 		direction(0);
 		FI_HIP_TRY(hipGetLastError());
 	}

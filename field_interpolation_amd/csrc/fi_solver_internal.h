@@ -386,7 +386,7 @@ __device__ inline double twin_scale(const CgScalars* sc) { return sc->tscale > 0
 // scalar steps of the preconditioned recurrence (single block, thread 0)
 enum MgPhase { kMgInitRz = 10, kMgAlpha = 11, kMgResid = 12, kMgBeta = 13, kMgInitRr = 14 };
 __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const double* __restrict__ partial, int count,
-                                                        int phase)
+                                                        int phase, int twin_sum = 0)
 {
 	if (sc->done && phase != kMgInitRr && phase != kMgInitRz) { return; }
 	// (eight loads in flight per thread: a 4096^2 lattice hands over 16 384 partials, and one load per trip of the loop made
@@ -405,7 +405,9 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x != 0) { return; }
-	const double s = partial ? out[0] : sc->sums[0];  // no partials: the sum over blocks and ranks is in sums[0]
+	double s = partial ? out[0] : sc->sums[0];  // no partials: the sum over blocks and ranks is in sums[0]
+	// twin_sum: the partials are the fp32 replica's b . x (ChebEpi::dotv) with b = r / t and x = z / t, t = CgScalars::tscale
+	if (twin_sum) { s *= twin_scale(sc) * twin_scale(sc); }
 	switch (phase) {
 	case kMgInitRr:  // sums: r.r (partial 0) -- b.b was stored by the caller in sums[2]
 		sc->rr = s;

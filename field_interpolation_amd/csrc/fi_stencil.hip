@@ -151,6 +151,8 @@ struct ChebEpi {
 	const T* acc;       // mode 0 without the operand formed on load, non-null: z_new = acc + (the step's result) -- the LAST step of
 	                    // a smoother's polynomial adds the correction onto x itself (acc == znew: x += M (b - A x) with no pass of
 	                    // its own for the sum; fp32 / fp64 storage, never bfloat16)
+	const T* dotv;      // with acc, non-null: the launch's partials are those of dotv . z_new (z_new after the sum) instead of r . z_new --
+	                    // the V-cycle's b . x, which is the fp64 CG's r . z, summed by the cycle's last launch (marching kernel only)
 };
 
 struct CellLists {
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		V    zp, rv;
 		DV16 dv;
 		V    av;  // ChebEpi::acc
+		V    bv;  // ChebEpi::dotv
 	};
 	// operands of plane lz (clamped like every load that crosses a step): issued right behind the epilogue that
 	// consumed the previous set, used one step later
@@ -675,7 +678,10 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 		}
 		e.rv = *reinterpret_cast<const V*>(E.r + o);
 		e.dv = *reinterpret_cast<const DV16*>(E.dinv + o);
-		if (!CELLS && E.acc) { e.av = *reinterpret_cast<const V*>(E.acc + o); }
+		if (!CELLS && E.acc) {
+			e.av = *reinterpret_cast<const V*>(E.acc + o);
+			if (E.dotv) { e.bv = *reinterpret_cast<const V*>(E.dotv + o); }
+		}
 	};
 
 	auto epi_zp = [&](const EpiRegs& e) -> V {  // z_prev of the epilogue's operand set as floats
@@ -1063,6 +1069,12 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 					const T* av = reinterpret_cast<const T*>(&EP.av);
 #pragma unroll
 					for (int j = 0; j < VX; ++j) { pz[j] += av[j]; }
+					if (E.dotv) {
+						const T* bv = reinterpret_cast<const T*>(&EP.bv);
+						rz = T(0);
+#pragma unroll
+						for (int j = 0; j < VX; ++j) { rz += bv[j] * pz[j]; }
+					}
 				}
 			}
 #ifdef FI_TIMING_BUILD
@@ -1087,7 +1099,8 @@ __global__ __launch_bounds__(kThreads, CELLS ? (EPI ? 2 : fused_waves<T>(HAS1, H
 				}
 				dot_acc += static_cast<double>(rz);
 			} else if (tail) {
-				store_tail(E.znew + static_cast<int64_t>(z) * P.plane, (PRO || E.mode == 1) ? pz : rv, pz);
+				store_tail(E.znew + static_cast<int64_t>(z) * P.plane,
+				           (PRO || E.mode == 1) ? pz : ((E.acc && E.dotv) ? reinterpret_cast<const T*>(&EP.bv) : rv), pz);
 			}
 			if (!PRO) { load_epi(z + 1, EP); }
 		} else if (active) {
@@ -1734,10 +1747,11 @@ int  stencil_cheb_partials_max(const fi_ctx* c)
 }
 void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* r, void* znew, double c1, double c2,
                        double* partial, int part, double zprev_scale, double pro_scale, const unsigned short* scaling, int extend, int fmt,
-                       const void* acc)
+                       const void* acc, const void* dotv)
 {
 	FI_REQUIRE(!acc || (!c->tile2.valid && pro_scale == 0.0 && !(fmt & 4)), FI_ERR_STATE,
 	           "polynomial step onto a vector: 3-D levels, not the step that forms its operand on load, fp32 / fp64 result");
+	FI_REQUIRE(!dotv || (acc && partial && !stencil_cheb_direct(c)), FI_ERR_STATE, "b . x partials: the marching kernel's last step onto x");
 	FI_REQUIRE(fmt == 0 || (!c->tile2.valid && c->dtype == FI_F32 && c->g.gn[0] % 4 == 0), FI_ERR_STATE,
 	           "bfloat16 iterates: fp32 3-D levels with rows of whole 16-byte groups");
 	// pro_scale != 0 (the first step, z_prev = 0): `z` is r and the kernel forms z_0 = pro_scale * Dinv * r on load
@@ -1774,12 +1788,13 @@ void stencil_cheb_step(fi_ctx* c, const void* z, const void* zprev, const void* 
 	}
 	if (c->dtype == FI_F64) {
 		ChebEpi<double> E{static_cast<const double*>(zp), static_cast<const double*>(r), d16, static_cast<double*>(znew), 1.0 + c1,
-		                  has_prev ? c1 : 0.0, c2, 0, pro_scale, zprev_scale, 0, 0, static_cast<const double*>(acc)};
+		                  has_prev ? c1 : 0.0, c2, 0, pro_scale, zprev_scale, 0, 0, static_cast<const double*>(acc), static_cast<const double*>(dotv)};
 		march_launch_epi<double>(c, static_cast<const double*>(z), E, partial, part, pro_scale != 0.0, extend);
 	} else {
 		ChebEpi<float> E{static_cast<const float*>(zp), static_cast<const float*>(r), d16, static_cast<float*>(znew),
 		                 static_cast<float>(1.0 + c1), static_cast<float>(has_prev ? c1 : 0.0), static_cast<float>(c2), 0,
-		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), fmt, 0, static_cast<const float*>(acc)};
+		                 static_cast<float>(pro_scale), static_cast<float>(zprev_scale), fmt, 0, static_cast<const float*>(acc),
+		                 static_cast<const float*>(dotv)};
 		if (const char* e = tuning_switch("FI_Z16")) { E.round16 = c->level == 0 ? atoi(e) : 0; }
 		march_launch_epi<float>(c, static_cast<const float*>(z), E, partial, part, pro_scale != 0.0, extend);
 	}

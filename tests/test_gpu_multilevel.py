@@ -304,7 +304,9 @@ def test_small_levels_polynomial_steps_without_the_march(fi, monkeypatch, sizes,
                                                   ([64, 56, 48], dict(model_1=0.5, model_2=0.0), "f64", False)])  # the V-cycle in fp64
 def test_post_smoothing_added_by_the_polynomials_last_step(fi, monkeypatch, sizes, kw, dtype, mixed):
     """x += M (b - A x): the last step of the post-smoothing's polynomial adds its result onto x itself (ChebEpi::acc) instead
-    of leaving it to a sum of its own (FI_NO_STEP_ONTO) -- the same additions in the same order: bit-equal solves."""
+    of leaving it to a sum of its own (FI_NO_STEP_ONTO) -- the same additions in the same order: bit-equal solves.  (Both legs
+    with the CG's r . z from its own pass, FI_NO_TWIN_DOT: the partials that last step can deliver round r to fp32 first.)"""
+    monkeypatch.setenv("FI_NO_TWIN_DOT", "1")
     rng = np.random.default_rng(sum(sizes) + 5)
     n = 20000
     pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
@@ -417,6 +419,39 @@ def test_row_form_transfers_equal_the_block_form(fi, monkeypatch, sizes):
         monkeypatch.delenv(k, raising=False)
     assert abs(out[0][1] - out[1][1]) <= 1, (out[0][1], out[1][1])
     assert rel_inf(out[0][0], out[1][0]) <= 1e-5
+
+
+@pytest.mark.parametrize("sizes,kw", [([160, 144, 136], dict(model_2=0.5)), ([136, 128, 132], dict(model_1=0.3, model_2=0.6))])
+def test_r_dot_z_from_the_cycles_last_launch(fi, monkeypatch, sizes, kw):
+    """Mixed precision on one undivided context: the fp64 CG's r . z is t^2 (b . x) of the fp32 replica's cycle, and the cycle's
+    last launch -- the post-smoothing polynomial's last step -- sums b . x on the way (ChebEpi::dotv) instead of a pass of its
+    own over r and z (k_dot_mixed, FI_NO_TWIN_DOT).  r enters rounded to fp32 there: the same iteration counts, the same
+    solution to the solve's tolerance, the same verified residual."""
+    rng = np.random.default_rng(sum(sizes) + 11)
+    n = 30000
+    pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+    val = rng.normal(size=n).astype(np.float32)
+    w = fi.Weights(**kw)
+    out = []
+    for own_pass in (False, True):
+        if own_pass:
+            monkeypatch.setenv("FI_NO_TWIN_DOT", "1")
+        else:
+            monkeypatch.delenv("FI_NO_TWIN_DOT", raising=False)
+        f = fi.LatticeField(sizes, dtype="f64")
+        f.add_field_constraints(w)
+        f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+        f.set_levels(2, 1e-4)
+        f.set_multigrid(True)
+        f.set_mixed_precision(True)
+        f.assemble()
+        x, it, rel = f.solve_cg(None, 0, 1e-9)
+        assert f.stats()["converged"] == 1 and f.true_residual() <= 1.2e-9
+        out.append((np.array(f.solution_f64()), it))
+        del f
+    monkeypatch.delenv("FI_NO_TWIN_DOT", raising=False)
+    assert abs(out[0][1] - out[1][1]) <= 1, (out[0][1], out[1][1])
+    assert rel_inf(out[0][0], out[1][0]) <= 1e-6
 
 
 def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
