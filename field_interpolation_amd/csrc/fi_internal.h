@@ -209,6 +209,8 @@ struct MarchParams {
 struct MarchState {
 	bool        valid = false;  // the marching kernel applies to this context
 	bool        fused = false;  // cell blocks are applied inside the marching kernel
+	bool        no_lists = false;  // ... but never by IT: a small level of a hierarchy whose full operator runs as k_full_direct3
+	                               // (diagonals) keeps no per-workgroup cell lists (fi_stencil.hip, stencil_prepare)
 	bool        wide = false;   // the model has rows the marching kernel does not carry (model_3, model_4, gradient_smoothness,
 	                            // field_interpolation.cpp:282-315): it applies model_0/1/2 and the cells, k_add_wide3 (fi_operator.hip)
 	                            // adds the rest onto its result.  Whoever takes the marching kernel for the WHOLE operator -- the

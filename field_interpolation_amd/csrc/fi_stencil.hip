@@ -1307,6 +1307,7 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 	const MarchParams& P = c->march.P;
 	const MarchCoef<T> C = march_coef<T>(c->w);
 	const MarchState& m = c->march;
+	FI_REQUIRE(!(CELLS && m.no_lists), FI_ERR_STATE, "the marching kernel was asked for the cells of a level that keeps diagonals only");
 	CellLists L{m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(),
 	            m.coef_row.p, m.coef_blk.p};
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
@@ -1447,7 +1448,21 @@ void stencil_prepare(fi_ctx* c)
 	c->tile2.valid = c->tile2.fused = false;
 	if (c->g.ndim == 2) { tile2d_prepare(c); }
 	if (!m.valid) { return; }
-	if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE")) {
+	m.no_lists = false;
+	if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE") && c->level > 0 && stencil_cheb_direct(c) && stencil_full_direct_wanted(c) &&
+	    !test_switch("FI_KEEP_CELL_LISTS")) {
+		// A small level of a V-cycle hierarchy: every launch that applies its cells -- residuals, the full-operator smoother,
+		// the start's products -- runs as k_full_direct3 on the diagonals fi_levels.hip builds right after this; the marching
+		// kernel's per-workgroup cell lists (six kernels, two scans, a host round trip and the copy of every record: 180-200 us
+		// of a 64^3 / 32^3 level's assembly chain in config 4) would never be read.  From here on the level's operator is the
+		// diagonals', whatever the switches say at solve time (full_direct_now).
+		m.fused      = true;
+		m.no_lists   = true;
+		m.n_wg_cells = m.P.nwg;
+		m.n_wg_plain = 0;
+		m.cells_row  = 0;
+		m.cells_blk  = c->cells.ncell;
+	} else if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE")) {
 		c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
 		m.fused = true;
 		// Surface-type data: fewer than half of the workgroups hold cells, and those are long latency-bound columns
@@ -1708,7 +1723,14 @@ __global__ __launch_bounds__(kThreads) void k_full_direct3(int nx, int ny, int n
 }
 
 namespace {
-bool full_direct_now(const fi_ctx* c) { return c->dia_valid && c->tail_dia.p && stencil_cheb_direct(c) && stencil_full_direct_wanted(c); }
+bool full_direct_now(const fi_ctx* c)
+{
+	if (c->march.valid && c->march.no_lists) {  // (decided at assembly: the level has nothing else to apply its cells with)
+		FI_REQUIRE(c->dia_valid && c->tail_dia.p, FI_ERR_STATE, "a level without cell lists has lost its diagonals");
+		return true;
+	}
+	return c->dia_valid && c->tail_dia.p && stencil_cheb_direct(c) && stencil_full_direct_wanted(c);
+}
 void full_direct_launch(fi_ctx* c, const float* x, const ChebEpi<float>& E, double* partial)
 {
 	const MarchCoef<float> C = march_coef<float>(c->w);
