@@ -1729,7 +1729,8 @@ bool full_direct_now(const fi_ctx* c)
 		FI_REQUIRE(c->dia_valid && c->tail_dia.p, FI_ERR_STATE, "a level without cell lists has lost its diagonals");
 		return true;
 	}
-	return c->dia_valid && c->tail_dia.p && stencil_cheb_direct(c) && stencil_full_direct_wanted(c);
+	// (march.fused: with FI_NO_FUSE the cells go through the kernel of their own behind the model rows, not through the diagonals too)
+	return c->dia_valid && c->tail_dia.p && c->march.fused && stencil_cheb_direct(c) && stencil_full_direct_wanted(c);
 }
 void full_direct_launch(fi_ctx* c, const float* x, const ChebEpi<float>& E, double* partial)
 {

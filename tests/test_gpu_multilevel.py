@@ -454,6 +454,31 @@ def test_r_dot_z_from_the_cycles_last_launch(fi, monkeypatch, sizes, kw):
     assert rel_inf(out[0][0], out[1][0]) <= 1e-6
 
 
+def test_levels_on_diagonals_serve_every_solver_of_the_context(fi):
+    """Levels of a V-cycle hierarchy whose full operator runs on diagonals keep no cell lists for the marching kernel
+    (MarchState::no_lists).  The solver may change after the assembly -- V-cycle PCG off: coarse-to-fine start + Jacobi-PCG on the
+    same levels -- and the levels must serve it all the same (their operator stays the diagonals')."""
+    sizes = [96, 80, 72]
+    rng = np.random.default_rng(77)
+    n = 30000
+    pos = np.stack([rng.uniform(0.0, s - 1.0, n) for s in sizes], 1).astype(np.float32)
+    val = rng.normal(size=n).astype(np.float32)
+    w = fi.Weights(model_2=0.5)
+    f = fi.LatticeField(sizes, dtype="f64")
+    f.add_field_constraints(w)
+    f.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    f.set_levels(2, 1e-4)
+    f.set_multigrid(True)
+    f.assemble()
+    x1, it1, rel1 = f.solve_cg(None, 0, 1e-8)
+    assert f.stats()["converged"] == 1
+    a = np.array(f.solution_f64())
+    f.set_multigrid(False)                      # no re-assembly: the same levels, now under the start + Jacobi-PCG
+    x2, it2, rel2 = f.solve_cg(None, 0, 1e-8)
+    assert f.stats()["converged"] == 1 and f.stats()["coarse_iterations"] > 0 and it2 > it1
+    assert rel_inf(a, np.array(f.solution_f64())) <= 1e-5
+
+
 def test_levels_built_beside_the_finest_level_are_the_same_levels(fi, monkeypatch):
     """fi_assemble builds the coarser levels on a helper thread and a second stream while the calling thread assembles
     the finest level; FI_SERIAL_LEVELS builds them afterwards on the solver stream.  Same kernels on the same data: the
