@@ -829,6 +829,31 @@ __global__ __launch_bounds__(kThreads) void k_restrict3_z(LevelPair L, const T* 
 	coarse[(static_cast<int64_t>(cz - L.c_base)) * cplane + o] = acc;
 }
 
+// the z pass with four coarse points of a row per thread (rows of whole 16-byte groups): the same sums in the same order
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_restrict3_z4(LevelPair L, const T* __restrict__ tmp, T* __restrict__ coarse)
+{
+	typedef T V4 __attribute__((ext_vector_type(4)));
+	const int64_t cplane = static_cast<int64_t>(L.nc[0]) * L.nc[1], q4 = cplane / 4;
+	const int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+	if (t >= q4 * L.c_planes) { return; }
+	const int64_t o  = (t % q4) * 4;
+	const int     cz = static_cast<int>(t / q4) + L.c_z0;  // global plane
+	int fz[kRTaps];
+	T   wz[kRTaps];
+	restrict_taps<T>(cz, L.nf[2], L.nc[2], L.cc[2], L.f_base, fz, wz);
+	V4 acc = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+	for (int k = 0; k < kRTaps; ++k) {
+		if (wz[k] != T(0)) {  // (a plane without weight may lie outside the slab)
+			const V4 v = *reinterpret_cast<const V4*>(tmp + fz[k] * cplane + o);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { acc[j] += wz[k] * v[j]; }
+		}
+	}
+	*reinterpret_cast<V4*>(coarse + (static_cast<int64_t>(cz - L.c_base)) * cplane + o) = acc;
+}
+
 // tmp (3-D, optional): a work array of the fine level with room for (local fine planes) x nc[1] x nc[0] values -- any of
 // the fine level's lattice vectors will do -- selects the two-pass form; f_local_planes = the fine level's local planes
 template <typename T>
@@ -848,7 +873,10 @@ void launch_restrict(const LevelPair& L, const T* fine, T* coarse, hipStream_t s
 			hipLaunchKernelGGL((k_restrict3_xy<T>), dim3(static_cast<unsigned>((n_xy + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L,
 			                   f_local_planes, fine, tmp);
 		}
-		if (n_z > 0) {
+		if (n_z > 0 && L.nc[0] % 4 == 0 && n_z >= (1 << 18)) {
+			hipLaunchKernelGGL((k_restrict3_z4<T>), dim3(static_cast<unsigned>((n_z / 4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L, tmp,
+			                   coarse);
+		} else if (n_z > 0) {
 			hipLaunchKernelGGL((k_restrict3_z<T>), dim3(static_cast<unsigned>((n_z + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, L, tmp,
 			                   coarse);
 		}
