@@ -251,10 +251,13 @@ __global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgS
 	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;
 	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
 	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
-		x[i] += alpha * p[i];
-		const double ri = r[i] - alpha * q[i];
-		r[i]   = ri;
-		r32[i] = static_cast<float>(ri * inv);
+		// streaming accesses (nontemporal: the seven streams of 134 / 67 MB pass through once; kept out of the L2's working set
+		// the kernel runs at 6.3 instead of 5.7 TB/s and the V-cycle's first launches behind it find their halo lines still cached)
+		const double xi = __builtin_nontemporal_load(x + i) + alpha * __builtin_nontemporal_load(p + i);
+		__builtin_nontemporal_store(xi, x + i);
+		const double ri = __builtin_nontemporal_load(r + i) - alpha * __builtin_nontemporal_load(q + i);
+		__builtin_nontemporal_store(ri, r + i);
+		__builtin_nontemporal_store(static_cast<float>(ri * inv), r32 + i);
 		acc[0] += ri * ri;
 	}
 	double out[1];
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void k_dot_mixed(int64_t n, const CgScala
 	double acc[1] = {0};
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		acc[0] += r[i] * (s * static_cast<double>(z32[i]));
+		acc[0] += __builtin_nontemporal_load(r + i) * (s * static_cast<double>(__builtin_nontemporal_load(z32 + i)));
 	}
 	double out[1];
 	block_sum<1>(acc, out);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_direction_mixed(int64_t n, cons
 	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;  // (contiguous pieces: k_mg_step_mixed)
 	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
 	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
-		p[i] = s * static_cast<double>(z32[i]) + beta * p[i];
+		__builtin_nontemporal_store(s * static_cast<double>(__builtin_nontemporal_load(z32 + i)) + beta * __builtin_nontemporal_load(p + i), p + i);
 	}
 }
 
@@ -298,9 +301,9 @@ __global__ __launch_bounds__(kThreads) void k_resid_norms(int64_t n, const T* __
 	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;  // (contiguous pieces: k_mg_step_mixed)
 	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
 	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
-		const T bi = b[i];
-		const T ri = bi - q[i];
-		r[i] = ri;
+		const T bi = __builtin_nontemporal_load(b + i);
+		const T ri = bi - __builtin_nontemporal_load(q + i);
+		__builtin_nontemporal_store(ri, r + i);
 		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
 		acc[1] += static_cast<double>(bi) * static_cast<double>(bi);
 	}
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(kThreads) void k_to_twin(int64_t n, const CgScalars
 	const double inv = 1.0 / twin_scale(sc);
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		r32[i] = static_cast<float>(r[i] * inv);
+		__builtin_nontemporal_store(static_cast<float>(__builtin_nontemporal_load(r + i) * inv), r32 + i);
 	}
 }
 
