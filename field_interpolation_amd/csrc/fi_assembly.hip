@@ -904,9 +904,11 @@ __global__ __launch_bounds__(kThreads) void k_tile_sums3(Geom g, const uint32_t*
 		if (x0 + px >= ext0 || y0 + py >= ext1 || z0 + pz >= ext2) { continue; }
 		const int64_t idx = (g.own_lo[0] + x0 + px) * g.stride[0] + (g.own_lo[1] + y0 + py) * g.stride[1] +
 		                    (g.own_lo[2] + z0 + pz) * g.stride[2];
-		atb[idx]  = acc_b[i];
-		diag[idx] = acc_d[i];
-		if (lump) { lump[idx] = acc_l[i]; }
+		// (every owned point, written once and read much later: streaming stores keep these 335 MB out of the L2 the other
+		// assembly chains' sorts and scans work in)
+		__builtin_nontemporal_store(acc_b[i], atb + idx);
+		__builtin_nontemporal_store(acc_d[i], diag + idx);
+		if (lump) { __builtin_nontemporal_store(acc_l[i], lump + idx); }
 	}
 }
 

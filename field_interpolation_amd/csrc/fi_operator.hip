@@ -543,17 +543,17 @@ __global__ __launch_bounds__(kThreads) void k_model_diag3(Geom g, ModelCoef<T> m
 			}
 		}
 		const T d = in[j] + acc;
-		diag[idx] = d;
+		__builtin_nontemporal_store(d, diag + idx);  // (streaming stores: see k_tile_sums3)
 		if (dinv) {
 			const T v = (d != T(0)) ? T(1) / d : T(1);
-			dinv[idx] = v;
-			d16[idx]  = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
+			__builtin_nontemporal_store(v, dinv + idx);
+			__builtin_nontemporal_store(static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16), d16 + idx);
 		}
 		if (d16s) {  // the polynomial smoother's scaling in the same pass (k_safe_scaling: the same m, the same sums)
 			const T dd = d > acc ? d - acc : T(0);
 			const T sc = acc + factor * dd;
 			const T v  = (sc > T(0)) ? T(1) / sc : T(1);
-			d16s[idx] = static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16);
+			__builtin_nontemporal_store(static_cast<unsigned short>(__float_as_uint(static_cast<float>(v)) >> 16), d16s + idx);
 		}
 	}
 }
