@@ -234,9 +234,26 @@ __global__ __launch_bounds__(kThreads) void k_mg_direction(int64_t n, const CgSc
 	}
 }
 
+// Streaming accesses for vectors that pass through ONCE and do not fit the L2 (8 x 4 MB): nontemporal loads / stores keep them
+// out of its working set -- the kernels themselves run at 6.3 instead of 5.7 TB/s and the stencil kernels behind them find
+// their halo lines still cached (profiles/r5_ablation.md section 26).  Vectors of fewer than kStreamMin points stay cached:
+// a 1024^2 lattice's fp64 vectors (8 MB each) are served from the L2 iteration after iteration.
+constexpr int64_t kStreamMin = int64_t(1) << 22;
+template <bool NT, typename U>
+__device__ inline U ldv(const U* p)
+{
+	if constexpr (NT) { return __builtin_nontemporal_load(p); } else { return *p; }
+}
+template <bool NT, typename U>
+__device__ inline void stv(U v, U* p)
+{
+	if constexpr (NT) { __builtin_nontemporal_store(v, p); } else { *p = v; }
+}
+
 // Mixed precision (CG in fp64, V-cycle on the fp32 replica): the fp32 copy of the residual leaves k_mg_step with the
 // update itself, and the fp64 copy of z = V(r) is never formed -- r.z and the new direction read the fp32 result.
 // Per step 3 fp64 lattice passes less than k_mg_step + k_to_twin + k_from_twin + k_dot + k_mg_direction.
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgScalars* __restrict__ sc,
                                                              const double* __restrict__ p, const double* __restrict__ q,
                                                              double* __restrict__ x, double* __restrict__ r,
@@ -251,13 +268,11 @@ __global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgS
 	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;
 	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
 	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
-		// streaming accesses (nontemporal: the seven streams of 134 / 67 MB pass through once; kept out of the L2's working set
-		// the kernel runs at 6.3 instead of 5.7 TB/s and the V-cycle's first launches behind it find their halo lines still cached)
-		const double xi = __builtin_nontemporal_load(x + i) + alpha * __builtin_nontemporal_load(p + i);
-		__builtin_nontemporal_store(xi, x + i);
-		const double ri = __builtin_nontemporal_load(r + i) - alpha * __builtin_nontemporal_load(q + i);
-		__builtin_nontemporal_store(ri, r + i);
-		__builtin_nontemporal_store(static_cast<float>(ri * inv), r32 + i);
+		const double xi = ldv<NT>(x + i) + alpha * ldv<NT>(p + i);
+		stv<NT>(xi, x + i);
+		const double ri = ldv<NT>(r + i) - alpha * ldv<NT>(q + i);
+		stv<NT>(ri, r + i);
+		stv<NT>(static_cast<float>(ri * inv), r32 + i);
 		acc[0] += ri * ri;
 	}
 	double out[1];
@@ -265,6 +280,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgS
 	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
 }
 // partial of r . (s z32)
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_dot_mixed(int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ r,
                                                          const float* __restrict__ z32, double* __restrict__ partial)
 {
@@ -272,13 +288,14 @@ __global__ __launch_bounds__(kThreads) void k_dot_mixed(int64_t n, const CgScala
 	double acc[1] = {0};
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		acc[0] += __builtin_nontemporal_load(r + i) * (s * static_cast<double>(__builtin_nontemporal_load(z32 + i)));
+		acc[0] += ldv<NT>(r + i) * (s * static_cast<double>(ldv<NT>(z32 + i)));
 	}
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
 }
 // p = s z32 + beta p
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_mg_direction_mixed(int64_t n, const CgScalars* __restrict__ sc,
                                                                   const float* __restrict__ z32, double* __restrict__ p, int first)
 {
@@ -287,13 +304,13 @@ __global__ __launch_bounds__(kThreads) void k_mg_direction_mixed(int64_t n, cons
 	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;  // (contiguous pieces: k_mg_step_mixed)
 	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
 	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
-		__builtin_nontemporal_store(s * static_cast<double>(__builtin_nontemporal_load(z32 + i)) + beta * __builtin_nontemporal_load(p + i), p + i);
+		stv<NT>(s * static_cast<double>(ldv<NT>(z32 + i)) + beta * ldv<NT>(p + i), p + i);
 	}
 }
 
 // r = b - q with the partials of r.r and b.b in the same pass (the start and the verification of V-cycle PCG on an
 // undivided lattice: k_sub + two k_dot + their one-block sums were five launches and three more lattice passes)
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(kThreads) void k_resid_norms(int64_t n, const T* __restrict__ b, const T* __restrict__ q, T* __restrict__ r,
                                                            double* __restrict__ partial_rr, double* __restrict__ partial_bb)
 {
@@ -301,9 +318,9 @@ __global__ __launch_bounds__(kThreads) void k_resid_norms(int64_t n, const T* __
 	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;  // (contiguous pieces: k_mg_step_mixed)
 	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
 	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
-		const T bi = __builtin_nontemporal_load(b + i);
-		const T ri = bi - __builtin_nontemporal_load(q + i);
-		__builtin_nontemporal_store(ri, r + i);
+		const T bi = ldv<NT>(b + i);
+		const T ri = bi - ldv<NT>(q + i);
+		stv<NT>(ri, r + i);
 		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
 		acc[1] += static_cast<double>(bi) * static_cast<double>(bi);
 	}
@@ -1045,13 +1062,14 @@ void mg_prepare(RankSet& R, bool clear_finest)
 	}
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_to_twin(int64_t n, const CgScalars* __restrict__ sc, const double* __restrict__ r,
                                                        float* __restrict__ r32)
 {
 	const double inv = 1.0 / twin_scale(sc);
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		__builtin_nontemporal_store(static_cast<float>(__builtin_nontemporal_load(r + i) * inv), r32 + i);
+		stv<NT>(static_cast<float>(ldv<NT>(r + i) * inv), r32 + i);
 	}
 }
 
@@ -1074,7 +1092,7 @@ void precondition<double>(RankSet& R, RankSet& Tw, Vec r, Vec z, bool have_r32)
 		for (size_t i = 0; i < R.size(); ++i) {
 			fi_ctx* c = R[i];
 			fi_ctx* t = Tw[i];
-			hipLaunchKernelGGL(k_to_twin, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
+			hipLaunchKernelGGL(c->g.nown >= kStreamMin ? k_to_twin<true> : k_to_twin<false>, dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown,
 			                   c->scal.as<CgScalars>(), vown<double>(c, r), vown<float>(t, &fi_ctx::r));
 		}
 	}
@@ -1186,7 +1204,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			if (mixed) {
 				for (size_t i = 0; i < R.size(); ++i) {
 					fi_ctx* c = R[i];
-					hipLaunchKernelGGL(k_dot_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+					hipLaunchKernelGGL(c->g.nown >= kStreamMin ? k_dot_mixed<true> : k_dot_mixed<false>, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
 					                   vown<double>(c, Rv), vown<float>(Tw[i], &fi_ctx::mg_x), c->partial.as<double>());
 				}
 				return;
@@ -1199,7 +1217,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			if (mixed) {
 				for (size_t i = 0; i < R.size(); ++i) {
 					fi_ctx* c = R[i];
-					hipLaunchKernelGGL(k_mg_direction_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
+					hipLaunchKernelGGL(c->g.nown >= kStreamMin ? k_mg_direction_mixed<true> : k_mg_direction_mixed<false>, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown,
 					                   c->scal.as<CgScalars>(), vown<float>(Tw[i], &fi_ctx::mg_x), vown<double>(c, P), first);
 				}
 				return;
@@ -1247,7 +1265,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		if (R.size() == 1 && c0->nranks == 1) {  // undivided lattice: one pass for r, r.r and b.b
 			double* prr = c0->partial.as<double>();
 			double* pbb = prr + static_cast<size_t>(c0->max_blocks);
-			hipLaunchKernelGGL((k_resid_norms<T>), dim3(nbv(c0)), dim3(kThreads), 0, st, c0->g.nown, vown<T>(c0, B), vown<T>(c0, Q),
+			hipLaunchKernelGGL((c0->g.nown >= kStreamMin ? k_resid_norms<T, true> : k_resid_norms<T, false>), dim3(nbv(c0)), dim3(kThreads), 0, st, c0->g.nown, vown<T>(c0, B), vown<T>(c0, Q),
 			                   vown<T>(c0, Rv), prr, pbb);
 			hipLaunchKernelGGL(k_sum_to_slot2, dim3(1), dim3(kThreads), 0, st, sc0, pbb, nbv(c0));
 			mg_reduce(R, nbv, kMgInitRr);
@@ -1332,7 +1350,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 			if (mixed) {
 				for (size_t i = 0; i < R.size(); ++i) {
 					fi_ctx* c = R[i];
-					hipLaunchKernelGGL(k_mg_step_mixed, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
+					hipLaunchKernelGGL(c->g.nown >= kStreamMin ? k_mg_step_mixed<true> : k_mg_step_mixed<false>, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
 					                   vown<double>(c, P), vown<double>(c, Q), vown<double>(c, X), vown<double>(c, Rv),
 					                   vown<float>(Tw[i], &fi_ctx::r), c->partial.as<double>());
 				}
