@@ -211,6 +211,10 @@ int fi_memory_pool(long long keep_bytes, long long* cached_bytes)
 	FI_API_BEGIN
 	const size_t keep = keep_bytes < 0 ? ~size_t(0) : static_cast<size_t>(keep_bytes);
 	const size_t left = fi::pool_trim(keep);
+	if (keep == 0) {  // "nothing left over from earlier contexts": neither their blocks nor what they learnt
+		fi::forget_iterations();
+		fi::forget_lambdas();
+	}
 	if (cached_bytes) { *cached_bytes = static_cast<long long>(left); }
 	FI_API_END
 }

@@ -54,6 +54,13 @@ int recall_iterations(fi_ctx* c, int kind, double tol)
 	return it == g_pred.end() ? 0 : it->second;
 }
 
+// fi_memory_pool(0): a process that wants nothing left over from earlier contexts (bench.py's cold step) forgets the counts too
+void forget_iterations()
+{
+	std::lock_guard<std::mutex> lock(g_pred_mutex);
+	g_pred.clear();
+}
+
 // ---- vector kernels (owned range is contiguous: the slowest axis is the decomposed one) ---------
 
 // r = b - q; p = Dinv r; partials: r.(Dinv r), r.r, b.b
@@ -590,19 +597,24 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		const bool as_expected = (was->done == 1 || was->done == 5) && was->iter > 0 && was->iter <= c0->unwatched_expected;
 		c0->last_cg_iterations = as_expected ? was->iter : 0;  // (0: this solve watches its flag again and learns the new count)
 		c0->pred_recalled[0]   = true;
+		c0->cg_count_recalled  = false;
 	}
 	// Such a solve: a coarser level of an undivided lattice whose previous solve ended after n iterations with the same
 	// tolerance gets n iterations and no look at all -- the level below it is waiting for its result, and a look is a host
 	// round trip of ~40 us per level.  Should n not have been enough this time, the start guess is that much worse and the
 	// next solve of this level watches again.
+	// A count recalled from ANOTHER context (same lattice, model, level and tolerance -- the key knows nothing of the data)
+	// only schedules this solve's first look at the flag: the solve is watched, so what a fresh context computes never
+	// depends on what the process solved before.  "No look at all" is for a context's own history.
 	if (c0->level > 0 && R.size() == 1 && c0->last_cg_iterations == 0) {  // a fresh context: what the one before it learnt
 		const int n = recall_iterations(c0, 0, tolerance);
 		if (n > 0) {
 			c0->last_cg_iterations = n;
 			c0->last_cg_tol        = tolerance;
+			c0->cg_count_recalled  = true;
 		}
 	}
-	const bool unwatched = c0->level > 0 && R.size() == 1 && c0->nranks == 1 && !c0->verify_residual && c0->last_cg_iterations > 0 &&
+	const bool unwatched = c0->level > 0 && R.size() == 1 && c0->nranks == 1 && !c0->verify_residual && c0->last_cg_iterations > 0 && !c0->cg_count_recalled &&
 	                       c0->last_cg_iterations <= max_iterations && c0->last_cg_iterations <= 64 && c0->last_cg_tol == tolerance && !test_switch("FI_LOOK_ALWAYS");
 	c0->last_cg_tol = tolerance;
 
@@ -831,6 +843,7 @@ void cg_run(RankSet& R, int max_iterations, float tol)
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
 		c->last_cg_iterations = timed_out ? 0 : h.iter;  // the same on every rank: the scalars are sums over all of them
+		c->cg_count_recalled  = false;                   // (this context's own history from here on)
 		if (R.size() == 1 && c->level > 0 && !timed_out && (h.done == 1 || h.done == 5)) { remember_iterations(c, 0, tolerance, h.iter); }
 		// with the verified stop on, "converged" means b - A x itself met the tolerance (done == 5); a recurrence
 		// that converged while the true residual stagnated above it (fp32 on an ill-conditioned system) is not

@@ -209,6 +209,7 @@ struct MarchParams {
 struct MarchState {
 	bool        valid = false;  // the marching kernel applies to this context
 	bool        fused = false;  // cell blocks are applied inside the marching kernel
+	bool        strip_lists = false;  // ... by the strip kernel (fi_strip.hip): the lists live in fi_ctx::strip, this state keeps none
 	bool        no_lists = false;  // ... but never by IT: a small level of a hierarchy whose full operator runs as k_full_direct3
 	                               // (diagonals) keeps no per-workgroup cell lists (fi_stencil.hip, stencil_prepare)
 	bool        wide = false;   // the model has rows the marching kernel does not carry (model_3, model_4, gradient_smoothness,
@@ -340,6 +341,8 @@ struct fi_ctx {
 	float      pos_shift[3] = {0, 0, 0};
 	fi::CellData              cells;
 	fi::MarchState            march;
+	fi::MarchState            strip;   // fi_strip.hip: the apply of undivided 3-D fp64 lattices as wave-private strips (P: tx x ty = one
+	                                   // wave's strip, nwg = waves of the launch; the lists as the marching kernel's, per strip)
 	fi::Tile2State            tile2;
 	fi::GenericRows           generic;
 
@@ -401,6 +404,8 @@ struct fi_ctx {
 	hipEvent_t ev_unwatched = nullptr;
 	int        last_cg_iterations = 0;     // of the previous Jacobi-PCG solve of this context (coarser levels: first look at the stop flag)
 	bool       pred_recalled[2] = {false, false};  // a fresh context has asked the process-wide record of iteration counts once
+	bool       cg_count_recalled = false;  // last_cg_iterations came from that record, not from a solve of this context: the next
+	                                       // solve is scheduled by it but WATCHED (cg_run)
 	                                       // (fi_cg.hip, recall_iterations: [0] Jacobi-PCG, [1] V-cycle PCG)
 	int        last_outer_iterations = 0;  // of the previous polynomial-PCG solve of this context (first look at the stop flag)
 	int        mg_mode = 0;       // 0: Jacobi-PCG (+ cascade start when levels exist); 1: V-cycle preconditioned CG
@@ -487,6 +492,11 @@ bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial);
 // part 1: the workgroups that read no ghost plane, part 2: the others (first and last z-chunk); false when the context's
 // apply is not one launch over all workgroups (then the caller exchanges first and applies in one go)
 bool stencil_apply_part(fi_ctx* c, const void* x, void* y, double* partial, int part);
+
+// fi_strip.hip
+bool strip_wanted(const fi_ctx* c);
+void strip_setup(fi_ctx* c);       // fi_ctx::strip.P (valid only where the kernel applies); called by stencil_prepare
+void strip_apply(fi_ctx* c, const void* x, void* y, double* partial);
 
 bool cells_fused(const fi_ctx* c);  // the stencil kernel of this context also applies the cell blocks
 // one step of the Chebyshev polynomial preconditioner / of the power method through the plain marching kernel

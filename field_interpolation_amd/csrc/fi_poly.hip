@@ -318,6 +318,12 @@ void remember_lambda(const fi_ctx* c)
 	if (c->poly_lambda > v) { v = c->poly_lambda; }
 }
 
+void forget_lambdas()  // fi_memory_pool(0): the next context runs its power method again
+{
+	std::lock_guard<std::mutex> lock(g_lambda_mutex);
+	g_lambda_cache.clear();
+}
+
 template <typename T>
 void estimate_poly_lambda(RankSet& R)
 {

@@ -507,9 +507,13 @@ bool all_ranks_ok(fi_ctx* c, bool mine);
 template <typename T> void cg_run(RankSet& R, int max_iterations, float tol);
 // iteration counts of finished solves, kept per process by lattice shape, model, level and tolerance: a context that lives
 // for one solve (the reference's stateless callers, sparse_linear.cpp:194-196) starts with the predictions the context before
-// it had learnt -- they decide when a solve first LOOKS at its stop flag, never what it computes
+// it had learnt -- they decide when a solve first LOOKS at its stop flag, never what it computes: a solve scheduled by a
+// recalled count is watched like any other, only a context's OWN previous solve lets a coarse level run without a look
+// (cg_run, `unwatched`).  fi_memory_pool(0) clears the record (and the cached eigenvalue bounds of fi_poly.hip).
 void remember_iterations(const fi_ctx* c, int kind, double tol, int iterations);
 int  recall_iterations(fi_ctx* c, int kind, double tol);
+void forget_iterations();
+void forget_lambdas();
 template <typename T> void solve_cg_t(fi_ctx* c, const float* guess, int max_iterations, float tol, float* out, int* iterations,
                                       float* rel_residual, int memory);
 template <typename T> void tile_pass_run(RankSet& R, int tile_size);

@@ -1310,6 +1310,7 @@ void march_launch_cells(fi_ctx* c, const T* x, T* y, double* partial, const uint
 	const MarchCoef<T> C = march_coef<T>(c->w);
 	const MarchState& m = c->march;
 	FI_REQUIRE(!(CELLS && m.no_lists), FI_ERR_STATE, "the marching kernel was asked for the cells of a level that keeps diagonals only");
+	FI_REQUIRE(!(CELLS && m.strip_lists), FI_ERR_STATE, "the marching kernel was asked for the cells of a context whose lists are the strip kernel's");
 	CellLists L{m.lay_row.as<uint32_t>(), m.lay_blk.as<uint32_t>(), m.pos_row.as<uint32_t>(), m.pos_blk.as<uint32_t>(),
 	            m.coef_row.p, m.coef_blk.p};
 	const int* done = c->scal.p ? &c->scal.as<CgScalars>()->done : nullptr;
@@ -1451,6 +1452,26 @@ void stencil_prepare(fi_ctx* c)
 	if (c->g.ndim == 2) { tile2d_prepare(c); }
 	if (!m.valid) { return; }
 	m.no_lists = false;
+	m.strip_lists = false;
+	strip_setup(c);
+	if (c->strip.valid) {
+		// the context's apply runs as wave-private strips (fi_strip.hip): the cell lists are built for THAT decomposition, the
+		// marching kernel keeps none (its plain variant still serves the epilogue launches of this context)
+		if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE")) {
+			build_cell_lists<double>(c, c->strip);
+			c->strip.fused = true;
+			m.fused        = true;
+			m.strip_lists  = true;
+			m.n_row = c->strip.n_row;
+			m.n_blk = c->strip.n_blk;
+			m.cells_row  = c->strip.cells_row;
+			m.cells_blk  = c->strip.cells_blk;
+			m.n_wg_cells = m.P.nwg;
+			m.n_wg_plain = 0;
+		}
+		stencil_prepare_slab_lists(c);
+		return;
+	}
 	if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE") && c->level > 0 && stencil_cheb_direct(c) && stencil_full_direct_wanted(c) &&
 	    !test_switch("FI_KEEP_CELL_LISTS")) {
 		// A small level of a V-cycle hierarchy: every launch that applies its cells -- residuals, the full-operator smoother,
@@ -1465,14 +1486,14 @@ void stencil_prepare(fi_ctx* c)
 		m.cells_row  = 0;
 		m.cells_blk  = c->cells.ncell;
 	} else if (c->cells.ncell > 0 && !test_switch("FI_NO_FUSE")) {
-		c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
+		c->dtype == FI_F64 ? build_cell_lists<double>(c, m) : build_cell_lists<float>(c, m);
 		m.fused = true;
 		// Surface-type data: fewer than half of the workgroups hold cells, and those are long latency-bound columns
 		// (march_launch runs them in a launch of their own).  Short chunks turn them into 4-8 times as many
 		// workgroups: 512^3 SDF data 476 -> 398 us, 256^3 98 -> 62 us.  The lists are rebuilt for the new chunking.
 		if (m.n_wg_cells * 2 < m.P.nwg && m.P.zc > 8 && !test_switch("FI_ZC") && !tuning_switch("FI_NO_SPLIT")) {
 			c->dtype == FI_F64 ? march_setup<double>(c, &m.P, 8) : march_setup<float>(c, &m.P, 8);
-			c->dtype == FI_F64 ? build_cell_lists<double>(c) : build_cell_lists<float>(c);
+			c->dtype == FI_F64 ? build_cell_lists<double>(c, m) : build_cell_lists<float>(c, m);
 		}
 	}
 	stencil_prepare_slab_lists(c);
@@ -1515,6 +1536,7 @@ bool full_direct_now(const fi_ctx* c);  // (the level's full operator runs as k_
 int stencil_partials(const fi_ctx* c)
 {
 	if (full_direct_now(c)) { return static_cast<int>((c->g.nloc + kThreads - 1) / kThreads); }  // (k_full_direct3: one per workgroup)
+	if (c->march.valid && c->strip.valid) { return c->strip.P.nwg; }  // (fi_strip.hip: one per wave)
 	return c->march.valid ? c->march.P.nwg : tile2d_partials(c);
 }
 
@@ -1914,6 +1936,10 @@ bool stencil_apply(fi_ctx* c, const void* x, void* y, double* partial)
 		ChebEpi<float> E{static_cast<const float*>(x), static_cast<const float*>(x), c->dinv16.as<unsigned short>(), static_cast<float*>(y), 0.0f,
 		                 0.0f, 0.0f, 5, 0.0f, 0.0f};
 		full_direct_launch(c, static_cast<const float*>(x), E, partial);
+		return true;
+	}
+	if (c->strip.valid) {
+		strip_apply(c, x, y, partial);
 		return true;
 	}
 	if (c->dtype == FI_F64) {

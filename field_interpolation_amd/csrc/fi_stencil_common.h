@@ -25,7 +25,8 @@ struct VecOf<double> {
 
 
 // per-workgroup record lists of the fused kernel from the context's cells (fi_stencil_lists.hip); T = the context's precision
+// (m: the context's marching state, or its strip state -- fi_strip.hip -- whose "workgroup" is one wave's strip)
 template <typename T>
-void build_cell_lists(fi_ctx* c);
+void build_cell_lists(fi_ctx* c, MarchState& m);
 
 }  // namespace fi

@@ -522,9 +522,8 @@ __global__ __launch_bounds__(kThreads) void k_classify_wg(int nwg, int per_wg, c
 }  // namespace
 
 template <typename T>
-void build_cell_lists(fi_ctx* c)
+void build_cell_lists(fi_ctx* c, MarchState& m)
 {
-	MarchState& m = c->march;
 	const MarchParams& P = m.P;
 	const int64_t ncell = c->cells.ncell;
 	const int64_t nbuckets = static_cast<int64_t>(P.nwg) * (P.zc + 1) * 4;  // (workgroup, layer, band of origin rows)
@@ -728,7 +727,7 @@ void build_cell_lists(fi_ctx* c)
 }
 
 
-template void build_cell_lists<float>(fi_ctx*);
-template void build_cell_lists<double>(fi_ctx*);
+template void build_cell_lists<float>(fi_ctx*, MarchState&);
+template void build_cell_lists<double>(fi_ctx*, MarchState&);
 
 }  // namespace fi
