@@ -49,6 +49,7 @@ constexpr int kOwn  = 4;  // ring of own planes: 3 live + 1 step of lead (tools/
 #endif
 constexpr int kHal  = FI_STRIP_HAL;  // sets of halo registers = steps of lead
 constexpr int kMaxZc = 128;  // longest chunk (planes per wave)
+constexpr int kRing  = 4;    // accumulation planes of the data term in LDS: the cell wave runs up to kRing - 1 layers ahead
 
 template <typename T>
 struct StripCoef {
@@ -94,8 +95,19 @@ __device__ inline T lane_shift(T edge, T v)
 	}
 }
 
-template <typename T, bool HAS1, bool HAS2, bool CELLS, int RY>
-__global__ __launch_bounds__(kWave, CELLS ? FI_STRIP_WPS_CELLS : 1) void k_apply_strip3d(MarchParams P, StripCoef<T> C, StripLists L, const T* __restrict__ x,
+// CELLS: a workgroup is TWO waves with fixed roles.  Wave 0 marches the strip (everything above); wave 1 is the strip's CELL
+// wave: it walks the strip's record lists layer by layer, up to kRing - 1 layers ahead of the march, and adds the corner
+// products into the LDS accumulation ring; the march collects a plane when the cell wave has published its second layer and
+// hands the slot back.  Two words in LDS carry the progress (layers done / planes collected); each is written by one wave and
+// polled by the other -- no barrier after the prologue, no atomics on the words.  Why two waves: with one wave per SIMD the
+// cell path's round trips (a record is an HBM miss, its corner values an L2 round trip, the LDS adds) had nothing to hide
+// behind -- the single-wave form cost 0.6 us of every 2.3 us step at 512^3 (profiles/r6_ablation.md); a wave of its own runs
+// them ahead of time, beside the march instead of inside it.  Both roles stay under 256 registers: two waves per SIMD.
+// PACK: the context keeps its cells of >= 3 rows as packed blocks (CellData::pack: an SDF, the coarse levels of a cascade) --
+// the cell wave's pipeline then carries the first 64 BLOCK records of a layer (and fetches row records where it uses them);
+// otherwise the first 64 row records (and the rare block records where it uses them).
+template <typename T, bool HAS1, bool HAS2, bool CELLS, int RY, bool PACK = false>
+__global__ __launch_bounds__(CELLS ? 2 * kWave : kWave, CELLS ? 2 : 1) void k_apply_strip3d(MarchParams P, StripCoef<T> C, StripLists L, const T* __restrict__ x,
                                                             T* __restrict__ y, double* __restrict__ partial, const int* __restrict__ done)
 {
 	using V = typename VecOf<T>::V;
@@ -104,20 +116,29 @@ __global__ __launch_bounds__(kWave, CELLS ? FI_STRIP_WPS_CELLS : 1) void k_apply
 	constexpr int U  = (kOwn % kHal == 0) ? kOwn : kOwn * kHal;  // instantiations of the step: every ring index a constant
 	typedef T PairU __attribute__((ext_vector_type(2), aligned(8)));  // two neighbouring points at any even / odd column
 
-	// accumulation planes of the data term: [plane ring of 2][corner y-bit][RY][TX], and the write-only target of corner
+	// accumulation planes of the data term: a ring of kRing lattice planes [RY][TX], and the write-only target of corner
 	// products that fall outside the strip
-	__shared__ __attribute__((aligned(16))) T yb[CELLS ? 2 : 1][CELLS ? RY : 1][CELLS ? TX : VX];
-	__shared__ T ydump[CELLS ? kWave : 1];
-	// this strip's record bounds, one pair per layer (a strip takes all 4 bands of a layer as one list): staged once -- a
-	// global load per plane step would put its latency (and, in order, every older load's) on every step of the march
-	__shared__ uint32_t s_lay[2][CELLS ? kMaxZc + 2 : 1];
+	// (with a ring of halo points -- rows -1 .. RY, columns -1 .. TX at column index + 2, so that the strip's own points sit at
+	// 16-byte offsets: EVERY corner of every listed cell has a slot, the cell wave adds without a bounds test, and the march
+	// collects the strip's own points only; what gathers in the halo belongs to the neighbouring strips' own lists)
+	constexpr int PW = TX + 4, PS = (RY + 2) * PW;  // row pitch and plane stride of the ring, in points
+	__shared__ __attribute__((aligned(16))) T yb[CELLS ? kRing * PS : VX];
+	__shared__ T ydump[CELLS ? PW + 8 : 1];
+	// this strip's record bounds, one pair per layer (a strip takes all 4 bands of a layer as one list): staged once
+	__shared__ uint32_t s_lay[2][CELLS ? kMaxZc + 3 : 1];
+	// (relaxed workgroup-scope atomics on plain LDS words, NOT volatile: the address-space inference leaves volatile accesses
+	// generic, and a FLAT load / store of the word drained every global load in flight -- s_waitcnt vmcnt(0) -- twice per
+	// plane step in both waves: the first form of this kernel lost 40 % to that)
+	__shared__ int s_flag[2];  // [0]: layers the cell wave has finished; [1]: planes the march has collected
+	__shared__ int s_role;              // the role of wave 0 (0: the march)
 
 	if (done && *done) { return; }
 	// XCD-aware order: blocks b, b + 8, ... (one XCD, one L2) take neighbouring strips
 	const int per  = (P.nwg + 7) / 8;
 	const int slot = (blockIdx.x % 8) * per + blockIdx.x / 8;
 	if (slot >= P.nwg) { return; }
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wave = CELLS ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) : 0;
 	const int strips_xy = P.tiles_x * P.tiles_y;
 	const int chunk = slot / strips_xy, sxy = slot % strips_xy;
 	const int x0 = (sxy % P.tiles_x) * TX, y0 = (sxy / P.tiles_x) * RY;
@@ -126,7 +147,356 @@ __global__ __launch_bounds__(kWave, CELLS ? FI_STRIP_WPS_CELLS : 1) void k_apply
 	const int z_begin = P.own_z0 + chunk * P.zc;
 	const int z_end   = z_begin + P.zc < P.own_z1 ? z_begin + P.zc : P.own_z1;
 	const int nsteps  = z_end - z_begin;
+	auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+	auto row_lo = [&](int l) { return uni(s_lay[0][l]); };
+	auto blk_lo = [&](int l) { return uni(s_lay[1][l]); };
+	auto wait_ge = [&](int which, int v) {  // until the other wave's progress word has reached v
+		while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_flag[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v) {
+			__builtin_amdgcn_s_sleep(2);
+		}
+		asm volatile("" ::: "memory");  // (nothing that follows is read or added ahead of the word)
+	};
+	bool any_cells = false;
+	if (CELLS) {
+		const int64_t lay0 = static_cast<int64_t>(slot) * (P.zc + 1) * 4;  // this strip's (layer, band) bounds
+		for (int i = threadIdx.x; i <= P.zc + 2; i += 2 * kWave) {  // (entry zc + 2: the last bound once more)
+			const int k = i <= P.zc + 1 ? i : P.zc + 1;
+			s_lay[0][i] = L.lay_row[lay0 + 4 * k];
+			s_lay[1][i] = L.lay_blk[lay0 + 4 * k];
+		}
+		const V zero = V{};
+		for (int i = threadIdx.x; i < kRing * PS / VX; i += 2 * kWave) { *reinterpret_cast<V*>(&yb[0] + VX * i) = zero; }
+		if (threadIdx.x == 0) {
+			s_flag[0] = 0;
+			s_flag[1] = 0;
+			// Which wave marches: the hardware hands a workgroup's two waves to neighbouring SIMDs, the same pair for every
+			// other workgroup of the CU -- with fixed roles the four marches of a CU (the instruction-heavy role) would share
+			// two SIMDs and the four cell waves idle on the other two.  Wave 0 looks at where it sits (SIMD id and wave slot
+			// from HW_ID) and takes the march when their parities agree; wave 1 takes the other role, whatever IT would see.
+#ifdef FI_STRIP_ROLES_BY_SIMD
+			const int simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_REG_HW_ID[5:4]
+			const int wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID[3:0]
+			s_role = (simd ^ wslot) & 1;
+#else
+			s_role = 0;
+#endif
+		}
+		__syncthreads();
+		any_cells = row_lo(nsteps + 1) > row_lo(0) || blk_lo(nsteps + 1) > blk_lo(0);
+	}
+	const int role = CELLS ? (wave == 0 ? s_role : 1 - s_role) : 0;  // 0: the march, 1: the cell wave
 
+	if (CELLS && role == 1) {
+		// ================================ the cell wave ================================================================
+		if (!any_cells) { return; }
+#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 32)  // timing builds: no cell wave at all
+		return;
+#endif
+		// the 8 corner values of x of the cell with strip-relative origin (tcx, tcy) on local planes lz, lz + 1: four pairs.  A
+		// cell on the lattice's far faces (the one-point rows of nearest-neighbour constraints, field_interpolation.cpp:82-107)
+		// or at extended origin -1 has corners OUTSIDE the lattice under zero coefficients: every address is clamped into the
+		// lattice (a clamped value only has to be finite)
+		// LOADS only (raw pairs, clamped addresses, straight-line code): the selection of the pair's elements happens where the
+		// values are used (corners_fix) -- a select right behind the load is a use, and the wave would wait for the load it has
+		// just issued and, in order, for every older one
+		auto corners_issue = [&](uint32_t pos, int lz, T* raw) {
+#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 512)  // timing builds: no corner loads
+			for (int q = 0; q < 8; ++q) { raw[q] = T(lane + q + lz); }
+			return;
+#endif
+			const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>((pos >> 16) & 0xFFu) - 1;
+			const int cx = x0 + tcx, cy = y0 + tcy;
+			const int bx = cx < 0 ? 0 : (cx > P.nx - 2 ? P.nx - 2 : cx);  // the pair's first column
+#pragma unroll
+			for (int bz = 0; bz < 2; ++bz) {
+				const int pz = lz + bz < 0 ? 0 : (lz + bz > P.nzl - 1 ? P.nzl - 1 : lz + bz);
+				const T* p = x + static_cast<int64_t>(pz) * P.plane;
+#pragma unroll
+				for (int by = 0; by < 2; ++by) {
+					const int ry = cy + by < 0 ? 0 : (cy + by > P.ny - 1 ? P.ny - 1 : cy + by);
+					const PairU v = *reinterpret_cast<const PairU*>(p + (static_cast<uint32_t>(ry) * P.nx + static_cast<uint32_t>(bx)));
+					raw[4 * bz + 2 * by]     = v[0];
+					raw[4 * bz + 2 * by + 1] = v[1];
+				}
+			}
+		};
+		auto corners_fix = [&](uint32_t pos, const T* raw, T* xv) {
+			const int cx = x0 + static_cast<int>(pos & 0xFFu) - 1;
+			const bool left = cx < 0, right = cx > P.nx - 2;  // the pair was read one column to the right / to the left
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				xv[2 * k]     = right ? raw[2 * k + 1] : raw[2 * k];
+				xv[2 * k + 1] = left ? raw[2 * k] : raw[2 * k + 1];
+			}
+		};
+		auto corners = [&](uint32_t pos, int lz, T* xv) {
+			T raw[8];
+			corners_issue(pos, lz, raw);
+			corners_fix(pos, raw, xv);
+		};
+		// add the 8 corner products of a cell of layer l into the ring slots of planes l - 1 (corner z-bit 0) and l (z-bit 1);
+		// every corner has a slot (the ring's halo); the corners beyond the chunk's ends go to a dump area.  Plain LDS read-add-write in four
+		// phases by the corner's (x-bit, y-bit): inside a phase a cell's two corners go to two different planes and the cells
+		// of one instruction are distinct -- no two lanes meet; across phases the LDS instructions of a wave execute in
+		// program order.  Every sum is formed in the same order on every run: bitwise reproducible.  (LDS hardware adds,
+		// ds_add_f64, were measured first: 8 x 64 lane-operations per batch and cell wave go through the CU's atomic unit
+		// one after the other -- 290 us of a 512^3 apply, profiles/r6_ablation.md.  The four round trips of this form are
+		// latency of the cell wave alone, which runs ahead of the march.)
+		auto put8 = [&](uint32_t pos, const T* out, int l, bool on) {
+			const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>((pos >> 16) & 0xFFu) - 1;
+#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 2)  // timing builds: no adds
+			ydump[lane & 7] = out[0] + out[1] + out[2] + out[3] + out[4] + out[5] + out[6] + out[7];
+			return;
+#endif
+			// the slots of the cell's lower and upper corners (corner y-bit and x-bit are immediate offsets from them); a lane
+			// that is off -- the second row of a pair, merged into its neighbour -- and the corners beyond the chunk's ends go
+			// to the dump area (any number of lanes may meet there)
+#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 256)  // timing builds: the adds at lane-linear addresses (no bank conflicts)
+			T* const at = &yb[0] + PW + 2 + 2 * lane + 0 * (tcx + tcy);
+#else
+			T* const at = &yb[0] + (tcy + 1) * PW + (tcx + 2);
+#endif
+			T* const lo = (on && l > 0) ? at + ((l + kRing - 1) % kRing) * PS : &ydump[0];
+			T* const hi = (on && l < nsteps) ? at + (l % kRing) * PS : &ydump[0];
+#pragma unroll
+			for (int ph = 0; ph < 4; ++ph) {
+				const int bx = ph & 1, by = ph >> 1;
+				asm volatile("" ::: "memory");
+				T* d0 = lo + by * PW + bx;
+				T* d1 = hi + by * PW + bx;
+				const T c0 = *d0, c1 = *d1;
+				*d0 = c0 + out[bx + 2 * by];
+				*d1 = c1 + out[bx + 2 * by + 4];
+			}
+			asm volatile("" ::: "memory");
+		};
+		auto row_finish = [&](uint32_t pos, const T* a, const T* xv, int l) {
+			T t = T(0);
+#pragma unroll
+			for (int q = 0; q < 8; ++q) { t += a[q] * xv[q]; }
+			T out[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { out[i] = a[i] * t; }
+			// the second row of a two-row cell sits in the lane next to the first and goes to the same addresses: the first row's
+			// lane takes its products over a DPP shift and adds both at once (a second row in lane 0 has its partner in the
+			// previous batch of 64: it adds by itself)
+			const bool second = ((pos >> 8) & 0xFFu) != 0u;
+			if (__ballot(second) != 0ull) {
+				const int nxt = __builtin_amdgcn_update_dpp(0, second ? 1 : 0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					const T o = lane_shift<T, false>(T(0), out[i]);
+					if (nxt) { out[i] += o; }
+				}
+			}
+			put8(pos, out, l, !(second && lane > 0));
+		};
+		auto load_row = [&](uint32_t r, uint32_t* pos, T* a) {
+			*pos = L.pos_row[r];
+			const V* ap = reinterpret_cast<const V*>(static_cast<const T*>(L.coef_row) + static_cast<int64_t>(r) * 8);
+#pragma unroll
+			for (int k = 0; k < 8 / VX; ++k) {
+				const V  v  = ap[k];
+				const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+				for (int j = 0; j < VX; ++j) { a[k * VX + j] = pv[j]; }
+			}
+		};
+		struct RowRec {
+			uint32_t pos;
+			T        a[8];
+			bool     ok;
+		};
+		// the first 64 row records of layer l (clamped index: the loads of the pipeline are unconditional)
+		auto fetch_rows = [&](int l, RowRec& rec) {
+			const int      lc = l <= nsteps ? l : nsteps;
+			const uint32_t r0 = row_lo(lc), r1 = row_lo(lc + 1);
+			const uint32_t r  = r0 + lane;
+			rec.ok = l <= nsteps && r < r1;
+			load_row(r < r1 ? r : r0, &rec.pos, rec.a);  // (r0 <= n_row, and the arrays hold n_row + 1 records)
+		};
+		auto fetch_blk_pos = [&](int l, uint32_t* pos, bool* ok) {
+			const int      lc = l <= nsteps ? l : nsteps;
+			const uint32_t b0 = blk_lo(lc), b1 = blk_lo(lc + 1);
+			const uint32_t r  = b0 + lane;
+			*ok  = l <= nsteps && r < b1;
+			*pos = L.pos_blk[r < b1 ? r : b0];
+		};
+		const T* multi = static_cast<const T*>(L.coef_blk);
+		// out = (the cell's block) x for block record r: the packed symmetric block (36 coefficients, all asked for at once) or
+		// the cell's factor rows one after another
+		auto block_apply = [&](uint32_t r, uint32_t pos, const T* xv, int l, const T* first8) {
+			const int nrows = static_cast<int>((pos >> 8) & 0xFFu);
+			T out[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { out[i] = T(0); }
+			const uint32_t ro = r * 64u;
+			auto mul8 = [&](int e0, const T* w, int n) {  // packed coefficients e0 .. e0 + n - 1 (constants once unrolled)
+#pragma unroll
+				for (int e = 0; e < 12; ++e) {
+					if (e < n) {
+						const int i = stri_row(e0 + e), j = stri_col(e0 + e);
+						out[i] += w[e] * xv[j];
+						if (i != j) { out[j] += w[e] * xv[i]; }
+					}
+				}
+			};
+			if (nrows == 0xFF) {
+				// the packed symmetric block, out = B x: 36 coefficients in batches (all at once do not fit beside the pipeline's
+				// register sets); the first 8 may have travelled with the pipeline, their lines' neighbours touched
+				T w[12];
+				if (first8) {
+					mul8(0, first8, 8);
+				} else {
+#pragma unroll
+					for (int v = 0; v < 8 / VX; ++v) { *reinterpret_cast<V*>(&w[v * VX]) = *reinterpret_cast<const V*>(multi + (ro + static_cast<uint32_t>(v * VX))); }
+					mul8(0, w, 8);
+				}
+#pragma unroll
+				for (int v = 0; v < 12 / VX; ++v) { *reinterpret_cast<V*>(&w[v * VX]) = *reinterpret_cast<const V*>(multi + (ro + static_cast<uint32_t>(8 + v * VX))); }
+				mul8(8, w, 12);
+#pragma unroll
+				for (int v = 0; v < 12 / VX; ++v) { *reinterpret_cast<V*>(&w[v * VX]) = *reinterpret_cast<const V*>(multi + (ro + static_cast<uint32_t>(20 + v * VX))); }
+				mul8(20, w, 12);
+#pragma unroll
+				for (int v = 0; v < 4 / VX; ++v) { *reinterpret_cast<V*>(&w[v * VX]) = *reinterpret_cast<const V*>(multi + (ro + static_cast<uint32_t>(32 + v * VX))); }
+				mul8(32, w, 4);
+			} else {
+				const V* ap = reinterpret_cast<const V*>(multi + static_cast<int64_t>(r) * 64);
+				for (int k = 0; k < nrows; ++k) {  // out += a (a . x)
+					T a[8];
+#pragma unroll
+					for (int v = 0; v < 8 / VX; ++v) {
+						const V  w2 = ap[k * (8 / VX) + v];
+						const T* pw = reinterpret_cast<const T*>(&w2);
+#pragma unroll
+						for (int j = 0; j < VX; ++j) { a[v * VX + j] = pw[j]; }
+					}
+					T t = T(0);
+#pragma unroll
+					for (int q = 0; q < 8; ++q) { t += a[q] * xv[q]; }
+#pragma unroll
+					for (int i = 0; i < 8; ++i) { out[i] += a[i] * t; }
+				}
+			}
+			put8(pos, out, l, true);
+		};
+		// Pipeline over LAYERS (the march consumes one per step; the ring lets this wave ADD kRing - 1 layers ahead, and ask
+		// for data as far ahead as it likes).  A record's origin word decides the addresses of its corner values, and a wave
+		// that waits for a load waits for every older one: with one layer between the origins' load and the corners' load the
+		// wave advanced one layer per memory round trip and the march waited for it (profiles/r6_ablation.md).  So: the
+		// origins of the first 64 row records and of the first 64 block records of layer l + 4, then the coefficients and
+		// the corner values of layer l + 2, then layer l is multiplied and added.  Six origin sets and three data sets take
+		// the roles in turn -- the loop body is instantiated six times: a register MOVE of a set in flight would wait for
+		// its loads.  Records beyond the first 64 of a layer (dense layers: the polar caps of an SDF, coarse lattices) are
+		// fetched where they are used.
+		struct Org {
+			uint32_t pos;
+			bool     ok;
+		};
+		struct Dat {
+			T a[8], xv[8];
+			uint32_t touch[2];
+		};
+		Org O0{}, O1{}, O2{}, O3{}, O4{}, O5{};
+		Dat D0{}, D1{}, D2{};
+		// the piped kind's record of this lane in layer l: index (clamped: the pipeline's loads are unconditional) and presence
+		auto piped = [&](int l, uint32_t* r, bool* ok) {
+			const int      lc = l <= nsteps ? l : nsteps;
+			const uint32_t r0 = PACK ? blk_lo(lc) : row_lo(lc), r1 = PACK ? blk_lo(lc + 1) : row_lo(lc + 1);
+			*ok = l <= nsteps && r0 + lane < r1;
+			*r  = r0 + lane < r1 ? r0 + lane : r0;  // (r0 <= the number of records, and the arrays hold one more)
+		};
+		auto fetch_org = [&](int l, Org& o) {
+			uint32_t r;
+			piped(l, &r, &o.ok);
+			o.pos = PACK ? L.pos_blk[r] : L.pos_row[r];
+		};
+		auto fetch_dat = [&](int l, const Org& o, Dat& d) {
+			uint32_t r;
+			bool     ok;
+			piped(l, &r, &ok);
+#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 1024)  // timing builds: every lane reads the layer's first record
+			r = r - lane * 0 - (r - r) ;
+			const T* rec = PACK ? multi + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(r)) * 64 : static_cast<const T*>(L.coef_row) + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(r)) * 8;
+#else
+			const T* rec = PACK ? multi + static_cast<int64_t>(r) * 64 : static_cast<const T*>(L.coef_row) + static_cast<int64_t>(r) * 8;
+#endif
+			const V* ap = reinterpret_cast<const V*>(rec);
+#pragma unroll
+			for (int k = 0; k < 8 / VX; ++k) {
+				const V  v  = ap[k];
+				const T* pv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+				for (int j = 0; j < VX; ++j) { d.a[k * VX + j] = pv[j]; }
+			}
+			if (PACK) {  // the block's other lines on their way to the L2 (288 bytes = the first line and up to two more)
+				d.touch[0] = *reinterpret_cast<const uint32_t*>(rec + 128 / sizeof(T));
+				d.touch[1] = *reinterpret_cast<const uint32_t*>(rec + 256 / sizeof(T));
+			}
+			corners_issue(o.pos, z_begin - 1 + l, d.xv);
+		};
+		auto stage = [&](int l, Org& oNew, const Org& oMid, Dat& dMid, const Org& o, const Dat& d) {
+			const int lz = z_begin - 1 + l;  // local plane of the layer's origins
+			const int lq = l <= nsteps ? l : nsteps + 1;  // (a layer beyond the chunk's last: the empty range at the lists' end)
+			fetch_org(l + 4, oNew);
+			fetch_dat(l + 2, oMid, dMid);
+			// the slot of plane l must have been collected (plane l - kRing): the march is at most kRing - 1 planes behind
+#if !(defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 64))  // timing builds: the cell wave does not wait for the march
+			wait_ge(1, (l <= nsteps ? l : nsteps) - kRing + 1);
+#endif
+			T xvf[8];
+			corners_fix(o.pos, d.xv, xvf);
+			if (!PACK && o.ok) { row_finish(o.pos, d.a, xvf, l); }
+#if !(defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 128))  // timing builds: no records beyond the piped ones
+			{
+				const uint32_t rs = row_lo(lq) + (PACK ? 0u : 64u), re = row_lo(lq + 1);
+				for (uint32_t r = rs + lane; r < re; r += 64) {
+					RowRec rr;
+					load_row(r, &rr.pos, rr.a);
+					T xv[8];
+					corners(rr.pos, lz, xv);
+					row_finish(rr.pos, rr.a, xv, l);
+				}
+			}
+			const uint32_t bs = blk_lo(lq), be = blk_lo(lq + 1);
+			if (PACK && o.ok) {
+				asm volatile("" ::"v"(d.touch[0]), "v"(d.touch[1]));  // (the touches are loads somebody waits for)
+				block_apply(bs + lane, o.pos, xvf, l, d.a);
+			}
+			for (uint32_t r = bs + (PACK ? 64u : 0u) + lane; r < be; r += 64) {
+				const uint32_t pos = L.pos_blk[r];
+				T xv[8];
+				corners(pos, lz, xv);
+				block_apply(r, pos, xv, l, nullptr);
+			}
+#else
+			const uint32_t bs = blk_lo(lq);
+			if (PACK && o.ok) { block_apply(bs + lane, o.pos, xvf, l, d.a); }
+#endif
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the layer's adds have been performed
+			if (l <= nsteps) { __hip_atomic_store(&s_flag[0], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+		};
+		fetch_org(0, O0);
+		fetch_org(1, O1);
+		fetch_org(2, O2);
+		fetch_org(3, O3);
+		fetch_dat(0, O0, D0);
+		fetch_dat(1, O1, D1);
+		// (whole rounds of six: layers beyond the chunk's last find no records and wait for nothing -- a loop body without
+		// exits keeps the compiler's count of the loads in flight exact)
+		for (int l0 = 0; l0 <= nsteps; l0 += 6) {
+			stage(l0, O4, O2, D2, O0, D0);
+			stage(l0 + 1, O5, O3, D0, O1, D1);
+			stage(l0 + 2, O0, O4, D1, O2, D2);
+			stage(l0 + 3, O1, O5, D2, O3, D0);
+			stage(l0 + 4, O2, O0, D0, O4, D1);
+			stage(l0 + 5, O3, O1, D1, O5, D2);
+		}
+		return;
+	}
+
+	// ==================================== the march =========================================================================
 	// ---- masks: rows that do not exist (global coordinates) -----------------------------------------------------------
 	bool m2x[VX + 2], m1x[VX + 1];
 #pragma unroll
@@ -193,177 +563,8 @@ __global__ __launch_bounds__(kWave, CELLS ? FI_STRIP_WPS_CELLS : 1) void k_apply
 		for (int j = 0; j < RY; ++j) { h.hx[j] = *reinterpret_cast<const PairU*>(p + hx_off[j]); }
 	};
 
-	// ---- data cells ---------------------------------------------------------------------------------------------------
-	const int64_t lay0 = static_cast<int64_t>(slot) * (P.zc + 1) * 4;  // this strip's (layer, band) bounds
-	auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
-	auto row_lo = [&](int l) { return uni(s_lay[0][l]); };
-	auto blk_lo = [&](int l) { return uni(s_lay[1][l]); };
-	// the 8 corner values of x of the cell with strip-relative origin (tcx, tcy) on local planes lz, lz + 1: four pairs.  A cell
-	// on the lattice's far faces (the one-point rows of nearest-neighbour constraints, field_interpolation.cpp:82-107) or at
-	// extended origin -1 has corners OUTSIDE the lattice under zero coefficients: every address is clamped into the lattice (a
-	// clamped value only has to be finite)
-	auto corners = [&](int tcx, int tcy, int lz, T* xv) {
-#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 1)  // timing builds: no corner loads
-		for (int q = 0; q < 8; ++q) { xv[q] = T(tcx + q); }
-		return;
-#endif
-		const int cx = x0 + tcx, cy = y0 + tcy;
-		const int bx = cx < 0 ? 0 : (cx > P.nx - 2 ? P.nx - 2 : cx);  // the pair's first column
-		const int dx = cx - bx;                                       // -1 / 0 / +1
-#pragma unroll
-		for (int bz = 0; bz < 2; ++bz) {
-			const int pz = lz + bz < 0 ? 0 : (lz + bz > P.nzl - 1 ? P.nzl - 1 : lz + bz);
-			const T* p = x + static_cast<int64_t>(pz) * P.plane;
-#pragma unroll
-			for (int by = 0; by < 2; ++by) {
-				const int ry = cy + by < 0 ? 0 : (cy + by > P.ny - 1 ? P.ny - 1 : cy + by);
-				const PairU v = *reinterpret_cast<const PairU*>(p + (static_cast<uint32_t>(ry) * P.nx + static_cast<uint32_t>(bx)));
-				xv[4 * bz + 2 * by]     = dx > 0 ? v[1] : v[0];
-				xv[4 * bz + 2 * by + 1] = dx < 0 ? v[0] : v[1];
-			}
-		}
-	};
-	// add the 8 corner products of a cell into the accumulation planes slot_lo (corner z-bit 0) and slot_hi (z-bit 1); corners
-	// outside the strip -- and the lower ones when lo_ok is false -- go to the lane's dump slot (no branches)
-	auto put8 = [&](int tcx, int tcy, const T* out, int slot_lo, int slot_hi, bool lo_ok, bool on = true) {
-		T* const dump = &ydump[lane];
-#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 2)  // timing builds: no scatter
-		*dump = out[0] + out[1] + out[2] + out[3] + out[4] + out[5] + out[6] + out[7];
-		return;
-#endif
-		const bool vx0 = on && tcx >= 0, vx1 = on && tcx + 1 < TX, vy0 = tcy >= 0, vy1 = tcy + 1 < RY;
-		T* const base = &yb[0][0][0] + tcy * TX + tcx;
-		// LDS hardware adds (ds_add_f64, no return): eight instructions and no round trip.  One instruction carries the same
-		// corner of 64 DISTINCT cells -- no two lanes meet -- and the LDS instructions of a wave execute in order, so every sum
-		// is formed in the same order on every run: bitwise reproducible.  (The marching kernel's read-add-write in phases is
-		// the cheaper form THERE, where twelve waves share the LDS pipeline; here it sits idle and the round trips were the
-		// step's longest dependent chain: profiles/r6_ablation.md)
-#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			const int bx = q & 1, by = (q >> 1) & 1, bz = q >> 2;
-			const bool ok = (bx ? vx1 : vx0) && (by ? vy1 : vy0) && (bz ? true : lo_ok);
-			T* d = base + (bz ? slot_hi : slot_lo) * (RY * TX) + by * TX + bx;
-			unsafeAtomicAdd(ok ? d : dump, out[q]);
-		}
-	};
-	auto row_finish = [&](uint32_t pos, const T* a, const T* xv, int slot_lo, int slot_hi, bool lo_ok) {
-		const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
-		T t = T(0);
-#pragma unroll
-		for (int q = 0; q < 8; ++q) { t += a[q] * xv[q]; }
-		T out[8];
-#pragma unroll
-		for (int i = 0; i < 8; ++i) { out[i] = a[i] * t; }
-		// the second row of a two-row cell sits in the lane next to the first and goes to the same addresses: the first row's
-		// lane takes its products over a DPP shift and adds both at once (a second row in lane 0 has its partner in the
-		// previous batch of 64: it adds by itself)
-		const bool second = ((pos >> 8) & 0xFFu) != 0u;
-		if (__ballot(second) != 0ull) {
-			const int nxt = __builtin_amdgcn_update_dpp(0, second ? 1 : 0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-#pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				const T o = lane_shift<T, false>(T(0), out[i]);
-				if (nxt) { out[i] += o; }
-			}
-		}
-		put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok, !(second && lane > 0));
-	};
-	auto row_apply = [&](uint32_t pos, const T* a, int lz, int slot_lo, int slot_hi, bool lo_ok) {
-		T xv[8];
-		corners(static_cast<int>(pos & 0xFFu) - 1, static_cast<int>(pos >> 16) - 1, lz, xv);
-		row_finish(pos, a, xv, slot_lo, slot_hi, lo_ok);
-	};
-	auto load_row = [&](uint32_t r, uint32_t* pos, T* a) {
-		*pos = L.pos_row[r];
-		const V* ap = reinterpret_cast<const V*>(static_cast<const T*>(L.coef_row) + static_cast<int64_t>(r) * 8);
-#pragma unroll
-		for (int k = 0; k < 8 / VX; ++k) {
-			const V  v  = ap[k];
-			const T* pv = reinterpret_cast<const T*>(&v);
-#pragma unroll
-			for (int j = 0; j < VX; ++j) { a[k * VX + j] = pv[j]; }
-		}
-	};
-	struct RowPF {
-		uint32_t pos;
-		T        a[8];
-		bool     ok;
-	};
-	// the first 64 row records of layer l (clamped: loads that cross a step are unconditional)
-	auto prefetch_rows = [&](int l, RowPF& pf) {
-		const int      lc = l <= nsteps ? l : nsteps;
-		const uint32_t r0 = row_lo(lc), r1 = row_lo(lc + 1);
-		const uint32_t r  = r0 + lane;
-		pf.ok = l <= nsteps && r < r1;
-		load_row(r < r1 ? r : r0, &pf.pos, pf.a);  // (r0 <= n_row, and the arrays hold n_row + 1 records)
-	};
-	// all records of layer l (origins on local plane lz) beyond the prefetched 64 rows, and every block record
-	auto layer_rest = [&](int l, int lz, int slot_lo, int slot_hi, bool lo_ok, uint32_t skip) {
-		const uint32_t rs = row_lo(l) + skip, re = row_lo(l + 1);
-		for (uint32_t r = rs + lane; r < re; r += 64) {
-			uint32_t pos;
-			T a[8];
-			load_row(r, &pos, a);
-			row_apply(pos, a, lz, slot_lo, slot_hi, lo_ok);
-		}
-		const T* multi = static_cast<const T*>(L.coef_blk);
-		const uint32_t bs = blk_lo(l), be = blk_lo(l + 1);
-		for (uint32_t r = bs + lane; r < be; r += 64) {
-			const uint32_t pos = L.pos_blk[r];
-			const int tcx = static_cast<int>(pos & 0xFFu) - 1, tcy = static_cast<int>(pos >> 16) - 1;
-			const int nrows = static_cast<int>((pos >> 8) & 0xFFu);
-			T xv[8], out[8];
-			corners(tcx, tcy, lz, xv);
-#pragma unroll
-			for (int i = 0; i < 8; ++i) { out[i] = T(0); }
-			const uint32_t ro = r * 64u;
-			if (nrows == 0xFF) {  // the packed symmetric block, out = B x: batches of 8 coefficients
-#pragma unroll
-				for (int batch = 0; batch < 5; ++batch) {
-					constexpr int NV8 = 8 / VX;
-					V w[NV8];
-#pragma unroll
-					for (int v = 0; v < NV8; ++v) {
-						if (batch * 8 + v * VX < 36) { w[v] = *reinterpret_cast<const V*>(multi + (ro + static_cast<uint32_t>(batch * 8 + v * VX))); }
-					}
-#pragma unroll
-					for (int e = 0; e < 8; ++e) {
-						if (batch * 8 + e < 36) {
-							const int i = stri_row(batch * 8 + e), j = stri_col(batch * 8 + e);  // constants once unrolled
-							const T bv = reinterpret_cast<const T*>(&w[e / VX])[e % VX];
-							out[i] += bv * xv[j];
-							if (i != j) { out[j] += bv * xv[i]; }
-						}
-					}
-				}
-			} else {
-				const V* ap = reinterpret_cast<const V*>(multi + static_cast<int64_t>(r) * 64);
-				for (int k = 0; k < nrows; ++k) {  // the cell's factor rows, one after another: out += a (a . x)
-					T a[8];
-#pragma unroll
-					for (int v = 0; v < 8 / VX; ++v) {
-						const V  w  = ap[k * (8 / VX) + v];
-						const T* pw = reinterpret_cast<const T*>(&w);
-#pragma unroll
-						for (int j = 0; j < VX; ++j) { a[v * VX + j] = pw[j]; }
-					}
-					T t = T(0);
-#pragma unroll
-					for (int q = 0; q < 8; ++q) { t += a[q] * xv[q]; }
-#pragma unroll
-					for (int i = 0; i < 8; ++i) { out[i] += a[i] * t; }
-				}
-			}
-			put8(tcx, tcy, out, slot_lo, slot_hi, lo_ok);
-		}
-	};
-
 	// ---- prologue -----------------------------------------------------------------------------------------------------
 	T U1[RY][VX], U2[RY][VX], D1[RY][VX];  // masked u(z-2), u(z-1); masked d(z-1) = x(z) - x(z-1)
-	// the first 64 row records of a layer are asked for TWO steps before the layer's turn: a record is read once -- an HBM
-	// miss, ~2 us under load -- and a wave has nothing else to wait with (a lead of one step left 0.7 us of every step exposed)
-	RowPF PFr[2];
-	PFr[0].ok = PFr[1].ok = false;
 	{
 		V a[RY], b[RY];
 		load_own(z_begin - 2, a);
@@ -389,20 +590,6 @@ __global__ __launch_bounds__(kWave, CELLS ? FI_STRIP_WPS_CELLS : 1) void k_apply
 				D1[j][e] = md1 * (pc[e] - pb[e]);
 			}
 		}
-		if (CELLS) {
-			for (int i = lane; i <= P.zc + 1; i += kWave) {
-				s_lay[0][i] = L.lay_row[lay0 + 4 * i];
-				s_lay[1][i] = L.lay_blk[lay0 + 4 * i];
-			}
-			const V zero = V{};
-#pragma unroll
-			for (int q = 0; q < 2 * RY; ++q) { *reinterpret_cast<V*>(&yb[q / RY][q % RY][VX * lane]) = zero; }
-			// layer 0: origins on the plane below the chunk -- its upper corners sit on plane z_begin (slot 0), the lower ones
-			// belong to the chunk below (dump)
-			prefetch_rows(1, PFr[0]);
-			prefetch_rows(2, PFr[1]);
-			layer_rest(0, z_begin - 1, 1, 0, false, 0u);
-		}
 	}
 
 	double dot_acc = 0.0;
@@ -416,17 +603,6 @@ __global__ __launch_bounds__(kWave, CELLS ? FI_STRIP_WPS_CELLS : 1) void k_apply
 			const V* xp1 = X[(u + 1) % kOwn];
 			const V* xp2 = X[(u + 2) % kOwn];
 			Halo& h = H[u % kHal];
-			const int b0 = s & 1, b1 = b0 ^ 1;
-			// layer s + 1: origins on plane z, corners on planes z (slot b0) and z + 1 (slot b1).  The corner values of its first 64
-			// row records (prefetched a step ago) are asked for NOW, ahead of this step's plane prefetch and of the stencil's
-			// arithmetic, and used behind it: an L2 round trip that nothing else of this wave would hide (one wave per SIMD)
-			T xv0[CELLS ? 8 : 1];
-			RowPF& PF = PFr[u % 2];
-			RowPF  pf = PF;  // (this step's records; the set is refilled for the layer two steps on, at once)
-			if (CELLS) {
-				corners(static_cast<int>(pf.pos & 0xFFu) - 1, static_cast<int>(pf.pos >> 16) - 1, z, xv0);
-				prefetch_rows(s + 3, PF);
-			}
 			load_own(z + kOwn - 1, X[(u + kOwn - 1) % kOwn]);
 			const int gzc = z + P.zoff;
 			const T mz  = (HAS2 && gzc >= 0 && gzc + 2 < P.gz) ? T(1) : T(0);
@@ -514,31 +690,30 @@ __global__ __launch_bounds__(kWave, CELLS ? FI_STRIP_WPS_CELLS : 1) void k_apply
 					po[e] = v;
 				}
 			}
-			if (CELLS) {
-#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 8)  // timing builds: the prefetched records are not applied
-				if (false) { row_finish(pf.pos, pf.a, xv0, b0, b1, true); }
-#else
-				if (pf.ok) { row_finish(pf.pos, pf.a, xv0, b0, b1, true); }
+			if (CELLS && any_cells) {
+				// plane s is complete when the cell wave has finished layers s and s + 1; its slot goes back zeroed
+#if !(defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 16))  // timing builds: the march does not wait for the cell wave
+				wait_ge(0, s + 2);
 #endif
-				layer_rest(s + 1, z, b0, b1, true, 64u);
+				T* slotp = &yb[0] + (s % kRing) * PS + PW + 2 + VX * lane;
+#pragma unroll
+				for (int j = 0; j < RY; ++j) {
+					V* sp = reinterpret_cast<V*>(slotp + j * PW);
+					const V  v0 = *sp;
+					const T* p0 = reinterpret_cast<const T*>(&v0);
+					T* po = reinterpret_cast<T*>(&outs[j]);
+#pragma unroll
+					for (int e = 0; e < VX; ++e) { po[e] += p0[e]; }
+					*sp = V{};
+				}
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the zeros are in before the slot is handed back
+				__hip_atomic_store(&s_flag[1], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 #pragma unroll
 			for (int j = 0; j < RY; ++j) {
-				const T* pc = reinterpret_cast<const T*>(&xc[j]);
-				T* po = reinterpret_cast<T*>(&outs[j]);
-#if defined(FI_STRIP_DBG) && (FI_STRIP_DBG & 4)  // timing builds: no gather
-				if (false) {
-#else
-				if (CELLS) {  // the finished sums of plane z (layers s and s + 1 are both in); the slots are zeroed for plane z + 2
-#endif
-					V* s0p = reinterpret_cast<V*>(&yb[b0][j][VX * lane]);
-					const V  v0 = *s0p;
-					const T* p0 = reinterpret_cast<const T*>(&v0);
-#pragma unroll
-					for (int e = 0; e < VX; ++e) { po[e] += p0[e]; }
-					*s0p = V{};
-				}
 				if (lane_ok && row_ok[j]) {
+					const T* pc = reinterpret_cast<const T*>(&xc[j]);
+					const T* po = reinterpret_cast<const T*>(&outs[j]);
 					*reinterpret_cast<V*>(yp + own_off[j]) = outs[j];
 					T dsum = T(0);
 #pragma unroll
@@ -595,7 +770,11 @@ __global__ void k_strip_check(MarchParams P, StripLists L, int64_t n_row, int64_
 // The strip kernel takes the context's apply: see the head of this file for the conditions.
 bool strip_wanted(const fi_ctx* c)
 {
-	if (test_switch("FI_NO_STRIP") || test_switch("FI_NO_MARCH")) { return false; }
+	// NOT the default (round 6's measurements, profiles/r6_ablation.md): without data cells the strips run at 0.60-0.66 of
+	// 8 TB/s where the marching kernel stops at 0.55-0.57, but every data-carrying context of this library pays for the
+	// cell wave's scattered reads of corner values and records through the CU's one vector-memory pipeline -- 0.46-0.55
+	// against the marching kernel's 0.56 (value data) / 0.47 (oriented points) at 512^3.  FI_STRIP=1 takes this path (tests do).
+	if (!test_switch("FI_STRIP") || test_switch("FI_NO_STRIP") || test_switch("FI_NO_MARCH")) { return false; }
 	const Geom& g = c->g;
 	if (g.ndim != 3 || c->dtype != FI_F64 || c->nranks != 1 || g.nown != g.nloc) { return false; }
 	constexpr int VX = VecOf<double>::VX;
@@ -672,15 +851,24 @@ void strip_launch(fi_ctx* c, const T* x, T* y, double* partial)
 	const int  grid = ((P.nwg + 7) / 8) * 8;
 	const bool h1 = c->w.model_1 > 0, h2 = c->w.model_2 > 0;
 	constexpr int RY = strip_rows<T>();
-	auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kWave), 0, c->stream, P, C, L, x, y, partial, done); };
-	auto pick = [&](auto cells) {
+	const int  threads = m.fused ? 2 * kWave : kWave;  // (with data cells: the march and the strip's cell wave)
+	// with data cells: FOUR workgroups per CU -- four marches, as without cells; the cell waves of strips without a record
+	// leave at once, and the freed wave slots would let a fifth to eighth march in (measured slower: 539 against 465 us at
+	// 512^3 without data).  37 KB of LDS per workgroup (27 static + this pad) keep the fifth out.
+	size_t pad = 0;
+	if (m.fused) {
+		if (const char* e = test_switch("FI_STRIP_LDS_PAD")) { pad = static_cast<size_t>(atoi(e)); } else { pad = 10 * 1024; }
+	}
+	auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), pad, c->stream, P, C, L, x, y, partial, done); };
+	auto pick = [&](auto cells, auto pack) {
 		constexpr bool CL = decltype(cells)::value;
+		constexpr bool PK = decltype(pack)::value;
 		if (h1 && h2) {
-			launch(k_apply_strip3d<T, true, true, CL, RY>);
+			launch(k_apply_strip3d<T, true, true, CL, RY, PK>);
 		} else if (h2) {
-			launch(k_apply_strip3d<T, false, true, CL, RY>);
+			launch(k_apply_strip3d<T, false, true, CL, RY, PK>);
 		} else {
-			launch(k_apply_strip3d<T, true, false, CL, RY>);
+			launch(k_apply_strip3d<T, true, false, CL, RY, PK>);
 		}
 	};
 	if (m.fused && test_switch("FI_STRIP_CHECK")) {
@@ -696,7 +884,14 @@ void strip_launch(fi_ctx* c, const T* x, T* y, double* partial)
 		FI_REQUIRE(h[0] + h[1] + h[2] + h[3] == 0, FI_ERR_STATE, "strip lists failed their check");
 		if (!strcmp(test_switch("FI_STRIP_CHECK"), "only")) { return; }
 	}
-	if (m.fused) { pick(std::integral_constant<bool, true>{}); } else { pick(std::integral_constant<bool, false>{}); }
+	using std::integral_constant;
+	if (!m.fused) {
+		pick(integral_constant<bool, false>{}, integral_constant<bool, false>{});
+	} else if (c->cells.pack) {
+		pick(integral_constant<bool, true>{}, integral_constant<bool, true>{});
+	} else {
+		pick(integral_constant<bool, true>{}, integral_constant<bool, false>{});
+	}
 	FI_HIP_TRY(hipGetLastError());
 }
 
