@@ -49,7 +49,8 @@ class FiStats(C.Structure):
                 ("num_levels", C.c_int), ("coarse_iterations", C.c_int),
                 ("prec_ms_avg", C.c_double), ("prec_samples", C.c_int), ("prec_bytes", C.c_double),
                 ("operator_applies", C.c_int), ("halo_exchanges", C.c_int), ("reductions", C.c_int),
-                ("coarse_unconverged", C.c_int)]
+                ("coarse_unconverged", C.c_int), ("field_estimate", C.c_double), ("field_per_residual", C.c_double),
+                ("stop_residual", C.c_double), ("field_rounds", C.c_int)]
 
 
 class FiError(RuntimeError):

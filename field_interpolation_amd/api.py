@@ -297,6 +297,12 @@ class LatticeField:
         check(_capi.lib().fi_set_option(self._h, 5, 1.0 if on else 0.0))
         self._dirty = True
 
+    def set_field_tolerance(self, tol):
+        """FI_OPT_FIELD_TOLERANCE (V-cycle PCG, undivided lattices): stop when the field is within `tol` (relative, maximum
+        norm) of the converged solution by the solver's own measure -- one more V-cycle on the residual, added onto x --
+        instead of at a residual.  0: the residual rule.  stats(): field_estimate, field_per_residual, stop_residual."""
+        check(_capi.lib().fi_set_option(self._h, 12, float(tol)))
+
     def set_polynomial(self, terms, ratio=None):
         """FI_OPT_POLY_TERMS / FI_OPT_POLY_RATIO: CG preconditioned by a Chebyshev polynomial of `terms` terms
         (0: the Jacobi diagonal).  No re-assembly needed."""

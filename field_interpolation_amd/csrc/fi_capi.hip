@@ -756,6 +756,10 @@ int fi_set_option(fi_ctx* c, int option, double value)
 		c->mg_pratio = value;
 		c->assembled = false;
 		break;
+	case FI_OPT_FIELD_TOLERANCE:
+		FI_REQUIRE(value >= 0.0 && value < 1.0, FI_ERR_INVALID, "FI_OPT_FIELD_TOLERANCE must be in [0, 1)");
+		c->field_tol = value;
+		break;
 	default: FI_REQUIRE(false, FI_ERR_INVALID, "unknown option %d", option);
 	}
 	FI_API_END

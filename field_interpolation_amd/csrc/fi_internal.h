@@ -294,6 +294,10 @@ struct CgScalars {  // lives in device memory; kernels read/write it, the host p
 	double tscale;  // mixed precision: the scale the fp32 copy of the current residual was divided by
 	int    iter, done, max_iter, restarts;
 	int    tag, pad_;  // second slot only (single-rank fused CG): the iteration whose first half filled it
+	// FI_OPT_FIELD_TOLERANCE (V-cycle PCG, fi_multigrid.hip): the stop test on the field.  The step kernel leaves
+	// max |x_k - x_(k-1)| = |alpha| max |p| and max |x_k| here (bit patterns of non-negative doubles: atomicMax)
+	double field_tol, field_est, field_kappa;
+	unsigned long long dmax_bits, xmax_bits;
 };
 
 }  // namespace fi
@@ -403,6 +407,7 @@ struct fi_ctx {
 	int        unwatched_expected = 0;
 	hipEvent_t ev_unwatched = nullptr;
 	int        last_cg_iterations = 0;     // of the previous Jacobi-PCG solve of this context (coarser levels: first look at the stop flag)
+	double     field_tol = 0;          // FI_OPT_FIELD_TOLERANCE (0: the residual rule)
 	bool       pred_recalled[2] = {false, false};  // a fresh context has asked the process-wide record of iteration counts once
 	bool       cg_count_recalled = false;  // last_cg_iterations came from that record, not from a solve of this context: the next
 	                                       // solve is scheduled by it but WATCHED (cg_run)

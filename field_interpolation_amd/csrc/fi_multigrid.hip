@@ -186,22 +186,43 @@ __global__ __launch_bounds__(kThreads) void k_power_step(int64_t n, const T* __r
 }
 
 
+// FI_OPT_FIELD_TOLERANCE: a wave's max |x_k - x_(k-1)| and max |x_k| into the scalars (the step kernels, for free in
+// the pass that updates x; k_mg_logic(kMgResid) reads and clears them)
+__device__ inline void field_maxes(CgScalars* sc, double md, double mx)
+{
+	if (!(sc->field_tol > 0.0)) { return; }
+	for (int o = 32; o > 0; o >>= 1) {
+		md = fmax(md, __shfl_down(md, o, 64));
+		mx = fmax(mx, __shfl_down(mx, o, 64));
+	}
+	if ((threadIdx.x & 63) == 0) {
+		atomicMax(&sc->dmax_bits, static_cast<unsigned long long>(__double_as_longlong(md)));
+		atomicMax(&sc->xmax_bits, static_cast<unsigned long long>(__double_as_longlong(mx)));
+	}
+}
+
 // CG with a preconditioner: r -= alpha q, x += alpha p (p is still the direction of this step), partial r.r
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, const CgScalars* __restrict__ sc, const T* __restrict__ p,
+__global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, CgScalars* __restrict__ sc, const T* __restrict__ p,
                                                        const T* __restrict__ q, T* __restrict__ x, T* __restrict__ r,
                                                        double* __restrict__ partial)
 {
 	if (sc->done) { return; }
 	const T alpha = static_cast<T>(sc->alpha);
 	double acc[1] = {0};
+	double mp = 0.0, mx = 0.0;  // FI_OPT_FIELD_TOLERANCE: max |p|, max |x_new|
 	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
 	     i += static_cast<int64_t>(gridDim.x) * kThreads) {
-		x[i] += alpha * p[i];
+		const T pi = p[i];
+		const T xi = x[i] + alpha * pi;
+		x[i] = xi;
+		mp = fmax(mp, fabs(static_cast<double>(pi)));
+		mx = fmax(mx, fabs(static_cast<double>(xi)));
 		const T ri = r[i] - alpha * q[i];
 		r[i] = ri;
 		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
 	}
+	field_maxes(sc, fabs(static_cast<double>(alpha)) * mp, mx);
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
@@ -254,7 +275,7 @@ __device__ inline void stv(U v, U* p)
 // update itself, and the fp64 copy of z = V(r) is never formed -- r.z and the new direction read the fp32 result.
 // Per step 3 fp64 lattice passes less than k_mg_step + k_to_twin + k_from_twin + k_dot + k_mg_direction.
 template <bool NT>
-__global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgScalars* __restrict__ sc,
+__global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, CgScalars* __restrict__ sc,
                                                              const double* __restrict__ p, const double* __restrict__ q,
                                                              double* __restrict__ x, double* __restrict__ r,
                                                              float* __restrict__ r32, double* __restrict__ partial)
@@ -267,14 +288,19 @@ __global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgS
 	// workgroups touch 2 048 places of every stream at once; 256^3: the same 150 us)
 	const int64_t piece = ((n + gridDim.x - 1) / gridDim.x + kThreads - 1) / kThreads * kThreads;
 	const int64_t i0 = static_cast<int64_t>(blockIdx.x) * piece, i1 = i0 + piece < n ? i0 + piece : n;
+	double mp = 0.0, mx = 0.0;  // FI_OPT_FIELD_TOLERANCE: max |p|, max |x_new|
 	for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
-		const double xi = ldv<NT>(x + i) + alpha * ldv<NT>(p + i);
+		const double pi = ldv<NT>(p + i);
+		const double xi = ldv<NT>(x + i) + alpha * pi;
 		stv<NT>(xi, x + i);
+		mp = fmax(mp, fabs(pi));
+		mx = fmax(mx, fabs(xi));
 		const double ri = ldv<NT>(r + i) - alpha * ldv<NT>(q + i);
 		stv<NT>(ri, r + i);
 		stv<NT>(static_cast<float>(ri * inv), r32 + i);
 		acc[0] += ri * ri;
 	}
+	field_maxes(sc, fabs(alpha) * mp, mx);
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
@@ -1148,13 +1174,19 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		const int64_t dflt = 2 * static_cast<int64_t>(c0->g.gn[0]) * c0->g.gn[1] * c0->g.gn[2];
 		max_iterations = dflt > std::numeric_limits<int>::max() ? std::numeric_limits<int>::max() : static_cast<int>(dflt);
 	}
-	const double tolerance = tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon());
+	// FI_OPT_FIELD_TOLERANCE (an undivided lattice): the solve stops by the field (k_mg_logic, kMgResid); the residual rule
+	// stays as the floor of what the precision's recurrence can still tell apart
+	const bool by_field = c0->field_tol > 0 && R.size() == 1 && c0->nranks == 1;
+	const double tolerance = by_field ? (sizeof(T) == 8 ? 1e-13 : 2e-7)
+	                                  : (tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon()));
 	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
 	const hipEvent_t e0 = timer.e0, e1 = timer.e1;
 	FI_HIP_TRY(hipEventRecord(e0, st));
 	CgScalars init{};
-	init.tol2     = tolerance * tolerance;
-	init.max_iter = max_iterations;
+	init.tol2      = tolerance * tolerance;
+	init.max_iter  = max_iterations;
+	init.field_tol = by_field ? c0->field_tol : 0.0;
+	init.field_est = -1.0;
 	reset_scalars(R, init);
 	CgScalars* sc0 = c0->scal.as<CgScalars>();
 	auto nbv      = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
@@ -1297,7 +1329,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	if (const char* env = getenv("FI_SOLVE_TIMEOUT_S")) { limit_s = atof(env); }
 	const auto wall0 = std::chrono::steady_clock::now();
 	bool timed_out = false;
-	int restarts_left = c0->verify_residual ? 3 : 0;
+	int restarts_left = (c0->verify_residual && !by_field) ? 3 : 0;  // (by the field: the recurrence of an fp64 CG is the residual)
 	int widenings_left = 2;
 	// One look at the stop flag per iteration, right behind the residual update: the V-cycle of an iteration that has just
 	// converged is not launched.
@@ -1421,10 +1453,14 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		c->last_mg_iterations = timed_out || h.done == 2 ? 0 : h.iter;  // (the same on every rank: the scalars are sums over all)
 		c->last_mg_tol        = tolerance;
 		if (R.size() == 1 && c0->predictable_start && !timed_out && h.done != 2) { remember_iterations(c, 1, tolerance, h.iter); }
-		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && !c0->verify_residual))) ? 1 : 0;
+		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && (!c0->verify_residual || by_field)))) ? 1 : 0;
 		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
 		c->stats.restarts     = h.restarts;
 		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;
+		c->stats.field_estimate     = by_field ? h.field_est : -1.0;
+		c->stats.field_per_residual = by_field ? h.field_kappa : 0.0;
+		c->stats.stop_residual      = c->stats.rel_residual;
+		c->stats.field_rounds       = by_field ? 1 : 0;
 		if (h.done == 4) { FI_HIP_TRY(hipMemsetAsync(c->x.p, 0, sizeof(T) * c->g.nloc, c->stream)); }
 	}
 	FI_REQUIRE(h.done != 2, FI_ERR_BREAKDOWN, "CG breakdown: non-finite or non-positive curvature (p.AtA p = %g)", h.pq);

@@ -385,6 +385,7 @@ __device__ inline double twin_scale(const CgScalars* sc) { return sc->tscale > 0
 
 // scalar steps of the preconditioned recurrence (single block, thread 0)
 enum MgPhase { kMgInitRz = 10, kMgAlpha = 11, kMgResid = 12, kMgBeta = 13, kMgInitRr = 14 };
+constexpr double kFieldMargin = 2.0;  // FI_OPT_FIELD_TOLERANCE: see k_mg_logic(kMgResid)
 __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const double* __restrict__ partial, int count,
                                                         int phase, int twin_sum = 0)
 {
@@ -432,18 +433,40 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 		sc->alpha = sc->rz / s;
 		if (!(s > 0.0) || !isfinite(s)) { sc->done = 2; }
 		break;
-	case kMgResid:
+	case kMgResid: {
 		sc->tscale = mixed_scale(sc);  // of the norm k_mg_step_mixed scaled its fp32 residual by
+		const double prev = sc->rr;
 		sc->rr = s;
 		sc->iter += 1;
+		bool field_met = false;
+		if (sc->field_tol > 0.0) {
+			// FI_OPT_FIELD_TOLERANCE: two consecutive iterates x_(k-1), x_k and their residuals.  If the error shrinks like
+			// the residual, e_k = rho e_(k-1) with rho = ||r_k|| / ||r_(k-1)||, then x_k - x_(k-1) = e_(k-1) - e_k gives
+			// ||e_k|| = ||x_k - x_(k-1)|| rho / (1 - rho): the change of the field per unit of residual dropped, times the
+			// residual that is left -- with a margin (kFieldMargin) for the smooth modes, which converge last
+			const double dmax = __longlong_as_double(static_cast<long long>(sc->dmax_bits));
+			const double xmax = __longlong_as_double(static_cast<long long>(sc->xmax_bits));
+			sc->dmax_bits = 0ull;
+			sc->xmax_bits = 0ull;
+			sc->field_est = -1.0;
+			if (sc->bb > 0.0 && xmax > 0.0 && prev > 0.0 && isfinite(s)) {
+				const double ra = sqrt(prev / sc->bb), rb = sqrt(s / sc->bb);
+				if (ra > 1.25 * rb) {
+					sc->field_kappa = dmax / xmax / (ra - rb);
+					sc->field_est   = kFieldMargin * sc->field_kappa * rb;
+					field_met = sc->field_est <= sc->field_tol;
+				}
+			}
+		}
 		if (!isfinite(s)) {
 			sc->done = 2;
-		} else if (!(s > sc->tol2)) {
+		} else if (field_met || !(s > sc->tol2)) {
 			sc->done = 1;
 		} else if (sc->iter >= sc->max_iter) {
 			sc->done = 3;
 		}
 		break;
+	}
 	case kMgBeta:
 		sc->beta = s / sc->rz;
 		sc->rz   = s;

@@ -640,3 +640,30 @@ def test_wide_stencils_are_bitwise_reproducible(oracle, fi, monkeypatch, dtype, 
         g = rng.normal(size=int(np.prod(sizes))).astype(np.float32)
         t1, t2 = fg.tile_pass(g, 8), fg.tile_pass(g, 8)
         np.testing.assert_array_equal(t1, t2)
+
+
+@pytest.mark.parametrize("sizes,npts,kw", [([128, 20, 70], 400, dict()), ([132, 20, 70], 400, dict(model_2=0.0, model_1=0.8)),
+                                           ([256, 30, 40], 3000, dict(model_0=0.3, model_1=0.6, model_2=1.7)),
+                                           ([256, 32, 40], 3000, dict())])
+def test_strip_kernel_equals_the_oracle(oracle, fi, monkeypatch, sizes, npts, kw):
+    """fi_strip.hip (round 6, FI_STRIP=1: not the default -- profiles/r6_ablation.md): the fp64 apply of an undivided 3-D lattice
+    as wave-private strips, one wave marching a 128 x 4 strip with DPP x neighbours and its cell wave adding the data rows
+    through an LDS ring.  The same operator as the oracle's explicit AtA (value rows, pairs, factor rows and packed blocks,
+    partial tiles, cells on the lattice's faces), chunk seams included, and the same bits run after run."""
+    monkeypatch.setenv("FI_STRIP", "1")
+    monkeypatch.setenv("FI_STRIP_CHECK", "1")
+    rng = np.random.default_rng(sum(sizes))
+    pos, nrm, pw, val = random_points(rng, sizes, npts, margin=0.7)
+    x = rng.normal(size=int(np.prod(sizes)))
+    ref = None
+    for zc in (None, "7", "16"):
+        if zc:
+            monkeypatch.setenv("FI_STRIP_ZC", zc)
+        fo, fg = build_pair(oracle, fi, sizes, fi.Weights(**kw), pos, nrm, pw, val, dtype="f64")
+        y = fg.apply_AtA(x)
+        if ref is None:
+            AtA, _, _ = fo.normal_equations()
+            ref = AtA @ x
+        assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+        np.testing.assert_array_equal(y, fg.apply_AtA(x))
+    monkeypatch.delenv("FI_STRIP_ZC")
