@@ -13,9 +13,25 @@
 
 #include <fi_hip.h>
 
+#include "recipe.hpp"
+
 namespace field_interpolation {
 
 namespace {
+
+// the note beside the rows (recipe.hpp): a copy of the old note plus one segment (the note is shared by copies of eq)
+void note_segment(LatticeField* field, detail::Segment&& seg)
+{
+	auto next = std::make_shared<detail::Recipe>();
+	if (field->eq.recipe && field->eq.recipe->sizes == field->sizes) { *next = *field->eq.recipe; }
+	next->sizes = field->sizes;
+	seg.row1  = field->eq.rhs.size();
+	seg.trip1 = field->eq.triplets.size();
+	if (seg.trip1 == seg.trip0) { return; }  // nothing appended
+	seg.checksum = detail::sample_checksum(field->eq.triplets, seg.trip0, seg.trip1);
+	next->segments.push_back(std::move(seg));
+	field->eq.recipe = std::move(next);
+}
 
 [[noreturn]] void fatal(const char* what)
 {
@@ -160,6 +176,15 @@ void add_field_constraints(LatticeField* field, const Weights& w)
 	long n = 1;
 	for (int s : field->sizes) { n *= s; }
 	LinearEquation* eq = &field->eq;
+	detail::Segment seg;
+	seg.kind    = detail::Segment::kModel;
+	seg.row0    = eq->rhs.size();
+	seg.trip0   = eq->triplets.size();
+	seg.weights = w;
+	struct Note {
+		LatticeField* f; detail::Segment* s;
+		~Note() { note_segment(f, std::move(*s)); }
+	} note{field, &seg};
 	for (int index = 0; index < n; ++index) {
 		int coord[MAX_DIM] = {0, 0, 0};
 		for (int d = 0, rest = index; d < D; ++d) {
@@ -201,6 +226,24 @@ void add_points(LatticeField* field, float value_weight, ValueKernel value_kerne
                 const float* point_weights)
 {
 	const int D = field->num_dim();
+	detail::Segment seg;
+	seg.kind  = detail::Segment::kPoints;
+	seg.row0  = field->eq.rhs.size();
+	seg.trip0 = field->eq.triplets.size();
+	seg.value_weight    = value_weight;
+	seg.value_kernel    = value_kernel;
+	seg.gradient_weight = gradient_weight;
+	seg.gradient_kernel = gradient_kernel;
+	seg.num_points      = num_points;
+	if (num_points > 0 && D >= 1 && D <= MAX_DIM) {
+		seg.positions.assign(positions, positions + static_cast<size_t>(num_points) * D);
+		if (normals) { seg.normals.assign(normals, normals + static_cast<size_t>(num_points) * D); }
+		if (point_weights) { seg.point_weights.assign(point_weights, point_weights + num_points); }
+	}
+	struct Note {
+		LatticeField* f; detail::Segment* s;
+		~Note() { note_segment(f, std::move(*s)); }
+	} note{field, &seg};
 	for (int i = 0; i < num_points; ++i) {
 		const float  w   = point_weights ? point_weights[i] : 1.0f;
 		const float* pos = positions + static_cast<size_t>(i) * D;

@@ -9,9 +9,12 @@
 
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <ostream>
 
 #include <fi_hip.h>
+
+#include "recipe.hpp"
 
 namespace field_interpolation {
 
@@ -132,12 +135,117 @@ struct RowsOnGpu {
 	{
 		if (owned && ctx) { fi_ctx_destroy(ctx); }
 	}
-	RowsOnGpu(const LinearEquation& eq, int num_columns, int dtype, const std::vector<int>* lattice = nullptr)
-	    : RowsOnGpu(eq.triplets, eq.rhs, num_columns, dtype, lattice)
+	// The rows' note (recipe.hpp) still holds: the noted rows matrix-free on their lattice -- fi_set_model for the model rows
+	// (never uploaded: config 3's 100 M triplets stay on the host), fi_add_points for the data rows from the noted copies of
+	// the point arrays -- and only the rows nobody vouches for as triplets.  false: nothing was set up (the caller's edits
+	// broke a checksum, two sets of model weights, a triplet appended to a noted row, a lattice of another shape, more than
+	// three dimensions): the generic path below takes all rows, as before round 6.
+	bool from_recipe(const LinearEquation& eq, int num_columns, int dtype, const std::vector<int>* lattice)
 	{
+		const detail::Recipe* r = eq.recipe.get();
+		if (!r || r->segments.empty() || std::getenv("FI_DROPIN_NO_RECIPE")) { return false; }
+		if (lattice && !lattice->empty() && *lattice != r->sizes) { return false; }
+		if (r->sizes.empty() || r->sizes.size() > 3) { return false; }
+		long long n = 1;
+		for (int s : r->sizes) { n *= s; }
+		if (n != num_columns) { return false; }
+		const detail::Segment* model = nullptr;
+		size_t row_end = 0, trip_end = 0;
+		for (const detail::Segment& s : r->segments) {
+			if (s.row0 < row_end || s.trip0 < trip_end || s.row1 < s.row0 || s.trip1 < s.trip0 || s.row1 > eq.rhs.size() ||
+			    s.trip1 > eq.triplets.size()) {
+				return false;
+			}
+			row_end  = s.row1;
+			trip_end = s.trip1;
+			if (detail::sample_checksum(eq.triplets, s.trip0, s.trip1) != s.checksum) { return false; }
+			if (s.kind == detail::Segment::kModel) {
+				if (model) { return false; }
+				model = &s;
+			}
+		}
+		// the rows between the noted ranges, renumbered from 0 in their order
+		std::vector<Triplet> extra;
+		std::vector<float>   extra_rhs;
+		{
+			size_t t = 0, row = 0, shift = 0;  // shift: noted rows in front of the current gap
+			auto gap = [&](size_t t_end, size_t row_endx) -> bool {
+				for (; t < t_end; ++t) {
+					const Triplet& q = eq.triplets[t];
+					if (q.row < 0 || static_cast<size_t>(q.row) < row || static_cast<size_t>(q.row) >= row_endx) { return false; }
+					extra.emplace_back(static_cast<int>(static_cast<size_t>(q.row) - shift), q.col, q.value);
+				}
+				for (; row < row_endx; ++row) { extra_rhs.push_back(eq.rhs[row]); }
+				return true;
+			};
+			for (const detail::Segment& s : r->segments) {
+				if (!gap(s.trip0, s.row0)) { return false; }
+				t = s.trip1;
+				row = s.row1;
+				shift += s.row1 - s.row0;
+			}
+			if (!gap(eq.triplets.size(), eq.rhs.size())) { return false; }
+		}
+		if (CtxCache::cacheable(r->sizes)) {
+			ctx = cache().get(r->sizes, dtype);
+		} else if (fi_ctx_create(&ctx, static_cast<int>(r->sizes.size()), r->sizes.data(), dtype) == FI_OK) {
+			owned = true;
+		} else {
+			warn("fi_ctx_create");
+			ctx = nullptr;
+		}
+		if (!ctx) { return false; }
+		fi_weights w = {1, 1, 0, 0, 0, 0, 0, 0, FI_VALUE_LINEAR_INTERPOLATION, FI_GRADIENT_CELL_EDGES};
+		if (model) {
+			const Weights& m = model->weights;
+			w = fi_weights{m.data_pos, m.data_gradient, m.model_0, m.model_1, m.model_2, m.model_3, m.model_4, m.gradient_smoothness,
+			               static_cast<int>(m.value_kernel), static_cast<int>(m.gradient_kernel)};
+		}
+		bool ok = fi_clear_points(ctx) == FI_OK && fi_set_model(ctx, &w) == FI_OK;
+		for (const detail::Segment& s : r->segments) {
+			if (!ok || s.kind != detail::Segment::kPoints || s.num_points <= 0) { continue; }
+			ok = fi_add_points(ctx, s.num_points, s.positions.data(), s.normals.empty() ? nullptr : s.normals.data(),
+			                   s.point_weights.empty() ? nullptr : s.point_weights.data(), nullptr, s.value_weight,
+			                   static_cast<int>(s.value_kernel), s.gradient_weight, static_cast<int>(s.gradient_kernel), FI_HOST) == FI_OK;
+		}
+		if (ok && !extra_rhs.empty()) {
+			ok = fi_add_rows_coo(ctx, static_cast<long>(extra_rhs.size()), static_cast<long>(extra.size()),
+			                     reinterpret_cast<const fi_triplet*>(extra.data()), extra_rhs.data(), FI_HOST) == FI_OK;
+		}
+		ok = ok && fi_assemble(ctx) == FI_OK;
+		if (!ok) {  // (a state the lattice path does not take: the generic path answers)
+			if (owned) { fi_ctx_destroy(ctx); } else { cache().drop(ctx); }
+			owned = false;
+			ctx   = nullptr;
+			return false;
+		}
+		matrix_free = true;
+		return true;
+	}
+	bool matrix_free = false;  // the noted rows were applied on their lattice (from_recipe)
+
+	RowsOnGpu(const LinearEquation& eq, int num_columns, int dtype, const std::vector<int>* lattice = nullptr)
+	{
+		if (num_columns >= 1 && from_recipe(eq, num_columns, dtype, lattice)) {
+			last_matrix_free() = true;
+			return;
+		}
+		last_matrix_free() = false;
+		upload(eq.triplets, eq.rhs, num_columns, dtype, lattice);
 	}
 	RowsOnGpu(const std::vector<Triplet>& triplets, const std::vector<float>& rhs, int num_columns, int dtype,
 	          const std::vector<int>* lattice = nullptr)
+	{
+		last_matrix_free() = false;
+		upload(triplets, rhs, num_columns, dtype, lattice);
+	}
+	static bool& last_matrix_free()
+	{
+		static thread_local bool flag = false;
+		return flag;
+	}
+	void upload(const std::vector<Triplet>& triplets, const std::vector<float>& rhs, int num_columns, int dtype,
+	            const std::vector<int>* lattice)
 	{
 		struct { const std::vector<Triplet>& triplets; const std::vector<float>& rhs; } eq{triplets, rhs};
 		if (num_columns < 1) { return; }
@@ -177,9 +285,9 @@ int cg_budget(int bicgstab_iterations)
 }
 
 std::vector<float> iterate(const LinearEquation& eq, const std::vector<float>* guess, int num_columns, int dtype,
-                           int max_iterations, float tolerance)
+                           int max_iterations, float tolerance, const std::vector<int>* lattice = nullptr)
 {
-	RowsOnGpu gpu(eq, num_columns, dtype);
+	RowsOnGpu gpu(eq, num_columns, dtype, lattice);
 	if (!gpu.ctx) { return {}; }
 	std::vector<float> out(static_cast<size_t>(num_columns));
 	int   iterations = 0;
@@ -276,7 +384,10 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 	}
 	if (!options.tile) {
 		if (!options.cg) { return guess; }
-		return iterate(eq, &guess, static_cast<int>(n), FI_F32, cg_budget(options.max_iterations), options.error_tolerance);
+		// (the caller's lattice shapes the context of generic rows too: a context's extent per axis is limited to 2^20, and a
+		// 1024^2 system as ONE axis of 2^20 unknowns would be refused)
+		return iterate(eq, &guess, static_cast<int>(n), FI_F32, cg_budget(options.max_iterations), options.error_tolerance,
+		               sizes.size() <= 3 ? &sizes : nullptr);
 	}
 	// tile_solver_square (sparse_linear.cpp:246-390, 415-425) on the device: fi_tile_pass solves every tile_size^D
 	// tile of the lattice with its couplings to the other tiles taken from the guess, then the iteration starts
@@ -304,6 +415,9 @@ std::vector<float> solve_tiled_with_guess(const LinearEquation& eq, const std::v
 	}
 	return out;
 }
+
+// (gpu_field.hpp) whether this thread's last solver call applied the rows' note matrix-free on its lattice
+bool last_solve_was_matrix_free() { return RowsOnGpu::last_matrix_free(); }
 
 // Frees the device contexts this thread's stateless calls have cached (gpu_field.hpp).
 void clear_context_cache()

@@ -76,4 +76,10 @@ std::unique_ptr<GpuLatticeField> gpu_sdf_from_points(const std::vector<int>& siz
 // and the device memory the library keeps of destroyed contexts (fi_memory_pool).
 void clear_context_cache();
 
+// Whether this thread's last stateless solver call (solve_sparse_linear_with_guess, solve_tiled_with_guess, ...) found the
+// note add_field_constraints / add_points leave beside the rows (LinearEquation::recipe) still valid and applied those rows
+// matrix-free on their lattice -- the path of the reference's own call sequence, sdf_from_points followed by
+// solve_tiled_with_guess(field.eq, ...) (src/sdf_field.cpp:251-304) -- instead of uploading every triplet.
+bool last_solve_was_matrix_free();
+
 } // namespace field_interpolation

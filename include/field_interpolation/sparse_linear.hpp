@@ -9,9 +9,12 @@
 
 #include <initializer_list>
 #include <iosfwd>
+#include <memory>
 #include <vector>
 
 namespace field_interpolation {
+
+namespace detail { struct Recipe; }  // (how the rows were made: libfield_interpolation's note to itself, see below)
 
 // ---- the system in coordinate form ------------------------------------------------------------------------
 
@@ -27,6 +30,11 @@ struct LinearEquation  // A x = rhs; entries sharing (row, col) add up
 {
 	std::vector<Triplet> triplets;
 	std::vector<float> rhs;
+	// Not in the original: add_field_constraints / add_points of this library note beside the rows what they appended
+	// (model weights, the point arrays).  A solver that finds the noted rows unchanged applies them matrix-free on the
+	// lattice instead of uploading them as triplets; rows the note does not cover go up as before.  Callers never touch it
+	// (brace-initialisation, copies and moves of the two members above work as in the original).
+	std::shared_ptr<const detail::Recipe> recipe;
 };
 
 struct LinearEquationPair  // one term of a row: value * x[column]

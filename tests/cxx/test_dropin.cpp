@@ -217,8 +217,17 @@ int main()
 		const std::vector<float> zero(n128, 0.0f);
 		// budget: solve_sparse_linear_with_guess(eq, guess, k, 0) runs 2k CG steps (one operator application each, like
 		// the 2 per BiCGSTAB step of the reference): the same iterate as 2k steps through the C ABI
+		// (on the GENERIC rows, like the C ABI context below: an unconverged iterate after exactly 100 steps is compared bit-closely,
+		// and the rows' note -- section 6 -- would apply them matrix-free, in another order of fp32 sums)
+		setenv("FI_DROPIN_NO_RECIPE", "1", 1);
 		auto x50 = fi::solve_sparse_linear_with_guess(f128.eq, zero, 50, 0.0f);
+		unsetenv("FI_DROPIN_NO_RECIPE");
 		require(x50.size() == n128, "bipolar pattern: solve_sparse_linear_with_guess(eq, guess, 50, 0) returns an iterate");
+		{
+			auto x50mf = fi::solve_sparse_linear_with_guess(f128.eq, zero, 50, 0.0f);   // the same budget, matrix-free
+			require(x50mf.size() == n128 && fi::last_solve_was_matrix_free() && max_rel(x50mf, x50) <= 2e-2f,
+			        "budget rule on the matrix-free path: the same 100 CG steps up to fp32 rounding");
+		}
 		{
 			fi_ctx* ctx = nullptr;
 			const int shape[1] = {static_cast<int>(n128)};
@@ -266,6 +275,89 @@ int main()
 			std::printf("latency 128^2 (%zu rows, %zu triplets), warm-started, context cached: solve_sparse_linear_with_guess(eq, last, 100, 0) "
 			            "%.2f ms/call; jacobi_iterations(eq, last, 100, 0.5) %.2f ms/call\n", f128.eq.rhs.size(), f128.eq.triplets.size(), ms_cg, ms_jac);
 			require(last.size() == n128 && ms_cg < 200.0 && ms_jac < 200.0, "per-frame calls stay interactive");
+		}
+	}
+	// ---- 6. the reference application's own call sequence, unchanged (src/sdf_field.cpp:251-304): sdf_from_points, then
+	//         solve_tiled_with_guess(field.eq, guess, field.sizes, options).  The rows carry the note of how they were made
+	//         (LinearEquation::recipe): the solver applies them matrix-free on the lattice and uploads only what the note does
+	//         not cover (here: border rows appended with add_equation, sdf_field.cpp:218-246) -- and falls back to the generic
+	//         rows when the caller has edited noted rows.
+	{
+		auto circle = [](int side, int count, std::vector<float>* pos, std::vector<float>* nrm) {
+			for (int i = 0; i < count; ++i) {
+				const float a = 6.2831853f * i / count, c = 0.5f * (side - 1), r = 0.3f * (side - 1);
+				pos->push_back(c + r * std::cos(a) + 0.3f * std::sin(17.0f * i));
+				pos->push_back(c + r * std::sin(a) + 0.3f * std::cos(13.0f * i));
+				nrm->push_back(std::cos(a));
+				nrm->push_back(std::sin(a));
+			}
+		};
+		auto with_border = [](fi::LatticeField* f) {  // a few rows the note does not cover
+			const int sx = f->sizes[0], sy = f->sizes[1];
+			for (int x = 0; x < sx; x += 7) {
+				fi::add_equation(&f->eq, fi::Weight{0.05f}, fi::Rhs{0.3f * sx}, {{x, 1.0f}});
+				fi::add_equation(&f->eq, fi::Weight{0.05f}, fi::Rhs{0.3f * sx}, {{(sy - 1) * sx + x, 1.0f}});
+			}
+		};
+		// (a) a small lattice: both paths to the fp32 floor, the same solution
+		{
+			std::vector<float> pos, nrm;
+			circle(96, 600, &pos, &nrm);
+			fi::LatticeField f = fi::sdf_from_points({96, 80}, fi::Weights{}, 600, pos.data(), nrm.data(), nullptr);
+			with_border(&f);
+			fi::SolveOptions o;
+			o.error_tolerance = 1e-7f;
+			o.max_iterations = 20000;
+			const std::vector<float> zero(96 * 80, 0.0f);
+			auto a = fi::solve_tiled_with_guess(f.eq, zero, f.sizes, o);
+			require(a.size() == zero.size() && fi::last_solve_was_matrix_free(), "recipe: the unchanged call sequence runs matrix-free");
+			setenv("FI_DROPIN_NO_RECIPE", "1", 1);
+			auto b = fi::solve_tiled_with_guess(f.eq, zero, f.sizes, o);
+			unsetenv("FI_DROPIN_NO_RECIPE");
+			require(b.size() == zero.size() && !fi::last_solve_was_matrix_free(), "recipe: FI_DROPIN_NO_RECIPE takes the generic rows");
+			std::printf("   matrix-free vs generic rows at 96 x 80: max relative difference %.2e\n", max_rel(a, b));
+			require(max_rel(a, b) <= 5e-4f, "recipe: matrix-free == generic rows (fp32 CG to 1e-7)");
+			auto c = fi::solve_sparse_linear_with_guess(f.eq, zero, 20000, 1e-7f);
+			require(c.size() == zero.size() && fi::last_solve_was_matrix_free() && max_rel(a, c) <= 5e-4f,
+			        "recipe: solve_sparse_linear_with_guess takes the lattice from the note");
+			// a caller that edits a noted row in place: the checksum fails, the generic path answers
+			fi::LatticeField g = f;
+			g.eq.triplets.front().value *= 1.5f;
+			auto d = fi::solve_tiled_with_guess(g.eq, zero, g.sizes, o);
+			require(d.size() == zero.size() && !fi::last_solve_was_matrix_free(), "recipe: edited rows fall back to the generic path");
+			// a copy of the field keeps the note; rows appended to an EXISTING noted row cannot be expressed: generic
+			fi::LatticeField h = f;
+			h.eq.triplets.emplace_back(0, 5, 0.25f);
+			auto e = fi::solve_tiled_with_guess(h.eq, zero, h.sizes, o);
+			require(e.size() == zero.size() && !fi::last_solve_was_matrix_free(), "recipe: a triplet added to a noted row falls back");
+		}
+		// (b) BASELINE config 3's shape at 1024^2, 20 000 oriented points: what the note saves
+		{
+			std::vector<float> pos, nrm;
+			circle(1024, 20000, &pos, &nrm);
+			const auto t0 = std::chrono::steady_clock::now();
+			fi::LatticeField f = fi::sdf_from_points({1024, 1024}, fi::Weights{}, 20000, pos.data(), nrm.data(), nullptr);
+			with_border(&f);
+			const auto t1 = std::chrono::steady_clock::now();
+			fi::SolveOptions o;   // the reference's defaults: cg, tolerance 1e-3
+			const std::vector<float> zero(1024 * 1024, 0.0f);
+			auto warm = fi::solve_tiled_with_guess(f.eq, zero, f.sizes, o);
+			const auto t2 = std::chrono::steady_clock::now();
+			auto a = fi::solve_tiled_with_guess(f.eq, zero, f.sizes, o);
+			const auto t3 = std::chrono::steady_clock::now();
+			require(a.size() == zero.size() && fi::last_solve_was_matrix_free(), "recipe: 1024^2 runs matrix-free");
+			setenv("FI_DROPIN_NO_RECIPE", "1", 1);
+			auto b = fi::solve_tiled_with_guess(f.eq, zero, f.sizes, o);
+			const auto t4 = std::chrono::steady_clock::now();
+			unsetenv("FI_DROPIN_NO_RECIPE");
+			require(b.size() == zero.size() && !fi::last_solve_was_matrix_free(), "recipe: 1024^2 generic rows");
+			auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+				return std::chrono::duration<double, std::milli>(y - x).count();
+			};
+			std::printf("   1024^2, %zu rows / %zu triplets: host row building %.0f ms; solve_tiled_with_guess matrix-free %.1f ms "
+			            "(first call %.1f), generic rows %.1f ms; max relative difference %.2e\n", f.eq.rhs.size(), f.eq.triplets.size(),
+			            ms(t0, t1), ms(t2, t3), ms(t1, t2), ms(t3, t4), max_rel(a, b));
+			require(max_rel(a, b) <= 5e-2f, "recipe: the two paths agree at the reference's default tolerance (1e-3 residual)");
 		}
 	}
 	fi::clear_context_cache();   // (and a call after it still works: the cache refills)
