@@ -52,6 +52,7 @@ struct HostComm {
 struct Comm {
 	ncclComm_t comm = nullptr;
 	HostComm*  host = nullptr;
+	long       n_allreduce = 0;  // all-reduces issued through this communicator (scalars and vectors): fi_stats.reductions
 };
 
 const char* rccl_error_string(ncclResult_t r);
@@ -255,9 +256,12 @@ void comm_destroy(Comm* cm)
 	delete cm;
 }
 
+long comm_allreduces(const fi_ctx* c) { return c->comm ? c->comm->n_allreduce : 0; }
+
 void allreduce_sum(fi_ctx* c, double* dev, int count)
 {
 	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+	++c->comm->n_allreduce;
 #ifdef FI_TEST_TRANSPORT
 	if (c->comm->host) {
 		host_allreduce(c, dev, count);
@@ -271,6 +275,7 @@ void allreduce_sum(fi_ctx* c, double* dev, int count)
 void allreduce_sum_vec(fi_ctx* c, void* dev, int64_t count, bool f64)
 {
 	FI_REQUIRE(c->comm && (c->comm->comm || c->comm->host), FI_ERR_STATE, "slab context without fi_comm_init");
+	++c->comm->n_allreduce;
 #ifdef FI_TEST_TRANSPORT
 	if (c->comm->host) {
 		host_allreduce_vec(c, dev, count, f64);

@@ -569,6 +569,7 @@ void add_points_device(fi_ctx* c, long n, const float* p, const float* g, const 
 // fi_comm.cpp
 void comm_destroy(Comm* cm);
 void allreduce_sum(fi_ctx* c, double* dev, int count);
+long comm_allreduces(const fi_ctx* c);  // all-reduces this context's communicator has issued so far (0 without one)
 void allreduce_sum_vec(fi_ctx* c, void* dev, int64_t count, bool f64);  // a whole vector, in place
 
 }  // namespace fi

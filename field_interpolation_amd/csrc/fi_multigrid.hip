@@ -1290,6 +1290,15 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		for (fi_ctx* l = top[0]; l; l = l->coarse) { l->n_halo_exchanges = 0; }
 		c0->n_halo_exchanges = 0;
 	}
+	// (slabs: the all-reduces of the solve -- dot products of this level, of the start's and the cycles' coarser levels, the
+	// replicated tail's vector sums; every level of a context shares one communicator)
+	auto reduces_now = [&]() {
+		long n = comm_allreduces(c0);
+		if (mixed) { n += comm_allreduces(Tw[0]) ; }
+		return n;
+	};
+	const bool same_comm = mixed && Tw[0]->comm == c0->comm;
+	const long reduces0 = reduces_now();
 	int  steps = 0;
 	bool first_restart = true;
 	auto restart = [&]() -> int {
@@ -1450,6 +1459,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		}
 		c->stats.solve_ms     = ms;
 		c->stats.iterations   = h.iter;
+		c->stats.reductions   = static_cast<int>((reduces_now() - reduces0) / (same_comm ? 2 : 1));
 		c->last_mg_iterations = timed_out || h.done == 2 ? 0 : h.iter;  // (the same on every rank: the scalars are sums over all)
 		c->last_mg_tol        = tolerance;
 		if (R.size() == 1 && c0->predictable_start && !timed_out && h.done != 2) { remember_iterations(c, 1, tolerance, h.iter); }
