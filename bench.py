@@ -721,6 +721,25 @@ def main():
                 "roofline_apply": roof("k_apply_march3d<float>: AtA apply with fused data cells", fst["spmv_bytes"],
                                        fst["spmv_ms_avg"], fst["spmv_samples"], (None, None))}
             del ff, f_out
+    if world == 1 and args.config == 4 and wl.get("by_field") and not args.no_accuracy and not args.side:
+        # Beside the rule: the residual rounds 4-5 had calibrated against the oracle for exactly this workload (3e-7: five
+        # iterations, field 2.9e-6 off) -- what the headline cost before round 6 made the stop rule the same for every
+        # workload.  Same steps, same data sets, the field rule switched off.
+        field.set_field_tolerance(0.0)
+        for _ in range(len(step.data)):
+            step(tol=3e-7)
+        torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        for _ in range(args.steps):
+            _, r_it, r_rel = step(tol=3e-7)
+        torch.cuda.synchronize()
+        r_ms = 1e3 * (time.perf_counter() - t0r) / args.steps
+        line["calibrated_residual_r5"] = {
+            "ms_per_step": r_ms, "value": n_global / (r_ms * 1e-3), "unit": "lattice points/s", "rel_residual_rule": 3e-7, "iterations": r_it,
+            "rel_residual": r_rel,
+            "note": "the stop rule of rounds 4-5 for THIS workload only (a residual calibrated against the oracle's solution of it); "
+                    "not the line's value: the rule above is the same for every configuration and knows no workload"}
+        field.set_field_tolerance(wl["field_tol"])
     if world == 1 and not args.no_host_io:
         # The boundary hands over HOST buffers (field_interpolation.hpp:153-173: `const float positions[]`, the solution a
         # std::vector<float>; the C ABI takes either kind).  The same step with its host traffic inside the timed region:

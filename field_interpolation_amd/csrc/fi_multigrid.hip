@@ -186,26 +186,65 @@ __global__ __launch_bounds__(kThreads) void k_power_step(int64_t n, const T* __r
 }
 
 
-// FI_OPT_FIELD_TOLERANCE: a wave's max |x_k - x_(k-1)| and max |x_k| into the scalars (the step kernels, for free in
-// the pass that updates x; k_mg_logic(kMgResid) reads and clears them)
-__device__ inline void field_maxes(CgScalars* sc, double md, double mx)
+// FI_OPT_FIELD_TOLERANCE: a workgroup's max |x_k - x_(k-1)| and max |x_k| (the step kernels, for free in the pass that
+// updates x) into the partial array behind the r.r partials -- [grid] + [grid] values; k_field_max reduces them into the
+// scalars in front of k_mg_logic(kMgResid).  (First form: an atomicMax per wave on the two words -- 32 k atomics on one
+// cache line per launch serialise at ~10 ns each: k_mg_step_mixed 144 -> 253 us.)
+__device__ inline void field_maxes(double* __restrict__ field_part, double md, double mx)
 {
-	if (!(sc->field_tol > 0.0)) { return; }
+	if (!field_part) { return; }
+	__shared__ double s_md[kThreads / 64], s_mx[kThreads / 64];
 	for (int o = 32; o > 0; o >>= 1) {
 		md = fmax(md, __shfl_down(md, o, 64));
 		mx = fmax(mx, __shfl_down(mx, o, 64));
 	}
 	if ((threadIdx.x & 63) == 0) {
-		atomicMax(&sc->dmax_bits, static_cast<unsigned long long>(__double_as_longlong(md)));
-		atomicMax(&sc->xmax_bits, static_cast<unsigned long long>(__double_as_longlong(mx)));
+		s_md[threadIdx.x >> 6] = md;
+		s_mx[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < kThreads / 64; ++w) {
+			md = fmax(md, s_md[w]);
+			mx = fmax(mx, s_mx[w]);
+		}
+		field_part[blockIdx.x]             = md;
+		field_part[gridDim.x + blockIdx.x] = mx;
+	}
+}
+__global__ __launch_bounds__(kThreads) void k_field_max(CgScalars* sc, const double* __restrict__ field_part, int count)
+{
+	if (sc->done) { return; }
+	double md = 0.0, mx = 0.0;
+	for (int i = threadIdx.x; i < count; i += kThreads) {
+		md = fmax(md, field_part[i]);
+		mx = fmax(mx, field_part[count + i]);
+	}
+	__shared__ double s_md[kThreads / 64], s_mx[kThreads / 64];
+	for (int o = 32; o > 0; o >>= 1) {
+		md = fmax(md, __shfl_down(md, o, 64));
+		mx = fmax(mx, __shfl_down(mx, o, 64));
+	}
+	if ((threadIdx.x & 63) == 0) {
+		s_md[threadIdx.x >> 6] = md;
+		s_mx[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < kThreads / 64; ++w) {
+			md = fmax(md, s_md[w]);
+			mx = fmax(mx, s_mx[w]);
+		}
+		sc->dmax_bits = static_cast<unsigned long long>(__double_as_longlong(md));
+		sc->xmax_bits = static_cast<unsigned long long>(__double_as_longlong(mx));
 	}
 }
 
 // CG with a preconditioner: r -= alpha q, x += alpha p (p is still the direction of this step), partial r.r
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, CgScalars* __restrict__ sc, const T* __restrict__ p,
+__global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, const CgScalars* __restrict__ sc, const T* __restrict__ p,
                                                        const T* __restrict__ q, T* __restrict__ x, T* __restrict__ r,
-                                                       double* __restrict__ partial)
+                                                       double* __restrict__ partial, double* __restrict__ field_part)
 {
 	if (sc->done) { return; }
 	const T alpha = static_cast<T>(sc->alpha);
@@ -222,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, CgScalars* __re
 		r[i] = ri;
 		acc[0] += static_cast<double>(ri) * static_cast<double>(ri);
 	}
-	field_maxes(sc, fabs(static_cast<double>(alpha)) * mp, mx);
+	field_maxes(field_part, fabs(static_cast<double>(alpha)) * mp, mx);
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
@@ -275,10 +314,11 @@ __device__ inline void stv(U v, U* p)
 // update itself, and the fp64 copy of z = V(r) is never formed -- r.z and the new direction read the fp32 result.
 // Per step 3 fp64 lattice passes less than k_mg_step + k_to_twin + k_from_twin + k_dot + k_mg_direction.
 template <bool NT>
-__global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, CgScalars* __restrict__ sc,
+__global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, const CgScalars* __restrict__ sc,
                                                              const double* __restrict__ p, const double* __restrict__ q,
                                                              double* __restrict__ x, double* __restrict__ r,
-                                                             float* __restrict__ r32, double* __restrict__ partial)
+                                                             float* __restrict__ r32, double* __restrict__ partial,
+                                                             double* __restrict__ field_part)
 {
 	if (sc->done) { return; }
 	const double alpha = sc->alpha;
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_step_mixed(int64_t n, CgScalars
 		stv<NT>(static_cast<float>(ri * inv), r32 + i);
 		acc[0] += ri * ri;
 	}
-	field_maxes(sc, fabs(alpha) * mp, mx);
+	field_maxes(field_part, fabs(alpha) * mp, mx);
 	double out[1];
 	block_sum<1>(acc, out);
 	if (threadIdx.x == 0) { partial[blockIdx.x] = out[0]; }
@@ -1191,6 +1231,8 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	CgScalars* sc0 = c0->scal.as<CgScalars>();
 	auto nbv      = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
 	auto nb_apply = [](fi_ctx* c) { return apply_num_partials(c); };
+	// (the step kernels' workgroup maxima: behind the r.r partials -- the array holds 4 x max_blocks doubles)
+	auto field_part = [&](fi_ctx* c) -> double* { return by_field ? c->partial.as<double>() + static_cast<size_t>(c->max_blocks) : nullptr; };
 	const Vec X = &fi_ctx::x, Rv = &fi_ctx::r, P = &fi_ctx::p, Q = &fi_ctx::q, Z = &fi_ctx::mg_x, B = &fi_ctx::atb;
 	while (static_cast<int>(c0->ev.size()) < 2 * kMaxSamples) {
 		hipEvent_t e;
@@ -1395,7 +1437,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 					fi_ctx* c = R[i];
 					hipLaunchKernelGGL(c->g.nown >= kStreamMin ? k_mg_step_mixed<true> : k_mg_step_mixed<false>, dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
 					                   vown<double>(c, P), vown<double>(c, Q), vown<double>(c, X), vown<double>(c, Rv),
-					                   vown<float>(Tw[i], &fi_ctx::r), c->partial.as<double>());
+					                   vown<float>(Tw[i], &fi_ctx::r), c->partial.as<double>(), field_part(c));
 				}
 				stepped = true;
 			}
@@ -1403,9 +1445,10 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		if (!stepped) {
 			for (fi_ctx* c : R) {
 				hipLaunchKernelGGL((k_mg_step<T>), dim3(nbv(c)), dim3(kThreads), 0, c->stream, c->g.nown, c->scal.as<CgScalars>(),
-				                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>());
+				                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>(), field_part(c));
 			}
 		}
+		if (by_field) { hipLaunchKernelGGL(k_field_max, dim3(1), dim3(kThreads), 0, st, sc0, field_part(c0), nbv(c0)); }
 		mg_reduce(R, nbv, kMgResid);
 		++steps;
 		done = steps < predicted ? 0 : read_flag();

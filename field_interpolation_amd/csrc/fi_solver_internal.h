@@ -444,10 +444,8 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 			// the residual, e_k = rho e_(k-1) with rho = ||r_k|| / ||r_(k-1)||, then x_k - x_(k-1) = e_(k-1) - e_k gives
 			// ||e_k|| = ||x_k - x_(k-1)|| rho / (1 - rho): the change of the field per unit of residual dropped, times the
 			// residual that is left -- with a margin (kFieldMargin) for the smooth modes, which converge last
-			const double dmax = __longlong_as_double(static_cast<long long>(sc->dmax_bits));
+			const double dmax = __longlong_as_double(static_cast<long long>(sc->dmax_bits));  // (k_field_max, just before)
 			const double xmax = __longlong_as_double(static_cast<long long>(sc->xmax_bits));
-			sc->dmax_bits = 0ull;
-			sc->xmax_bits = 0ull;
 			sc->field_est = -1.0;
 			if (sc->bb > 0.0 && xmax > 0.0 && prev > 0.0 && isfinite(s)) {
 				const double ra = sqrt(prev / sc->bb), rb = sqrt(s / sc->bb);
