@@ -526,8 +526,9 @@ def main():
                                  % wl["field_tol"]) if wl.get("by_field") else "relative residual <= %g" % wl["tol"],
                    "field_estimate": st["field_estimate"] if wl.get("by_field") else None,
                    "field_per_residual": st["field_per_residual"] if wl.get("by_field") else None,
-                   "arithmetic": ("fp64: x, r, p, the operator apply, every dot product and the stop test; fp32: the V-cycle "
-                                  "preconditioner" if wl["mixed"] else wl["dtype"]),
+                   "arithmetic": ("fp64: x, r, p, the operator apply, p . A p, r . r and the stop test; fp32: the V-cycle preconditioner, "
+                                  "and r . z = t^2 (b . x of the fp32 cycle, summed four products at a time in float, then in double) "
+                                  "from the cycle's last launch (FI_NO_TWIN_DOT: a pass in fp64 instead)" if wl["mixed"] else wl["dtype"]),
                    "operator_applies": acc["applies"] // max(args.steps, 1),
                    "true_rel_residual": true_rel, "assemble_ms": asm_ms,
                    "solve_ms": acc["solve_ms"] / args.steps, "occupied_cells": st["num_cells"],

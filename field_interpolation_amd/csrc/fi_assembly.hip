@@ -1437,6 +1437,9 @@ void* pinned(fi_ctx* c, int slot, size_t bytes)
 {
 	if (c->pin_bytes[slot] < bytes) {
 		if (c->pin[slot]) {
+			// (the block may still be the source or target of a copy on the context's stream: drained before another context
+			// can take it from the pool -- growth is rare, a few times in a context's life)
+			(void)hipStreamSynchronize(c->stream);
 			pinned_give(c->pin[slot], c->pin_bytes[slot]);
 			c->pin[slot] = nullptr;
 			c->pin_bytes[slot] = 0;

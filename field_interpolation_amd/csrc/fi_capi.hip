@@ -192,9 +192,14 @@ int fi_ctx_destroy(fi_ctx* c)
 		(void)hipEventDestroy(c->ev_halo);
 	}
 	if (c->comm && c->owns_comm) { fi::comm_destroy(c->comm); }
-	if (c->scal_host) { fi::pinned_give(c->scal_host, c->scal_host_cap); }
+	// pinned blocks go back to the pool only when nothing can still be copying into or out of them (the stop-flag copies of an
+	// unwatched level, point staging): a context whose streams did not drain frees them instead -- hipHostFree waits
+	if (c->scal_host) {
+		if (drained) { fi::pinned_give(c->scal_host, c->scal_host_cap); } else { (void)hipHostFree(c->scal_host); }
+	}
 	for (int s = 0; s < 3; ++s) {
-		if (c->pin[s]) { fi::pinned_give(c->pin[s], c->pin_bytes[s]); }
+		if (!c->pin[s]) { continue; }
+		if (drained) { fi::pinned_give(c->pin[s], c->pin_bytes[s]); } else { (void)hipHostFree(c->pin[s]); }
 	}
 	if (c->ev_unwatched) { (void)hipEventDestroy(c->ev_unwatched); }
 	if (c->ev_asm0) {

@@ -123,7 +123,10 @@ struct DevBuf {
 			}
 		}
 		if (used != nbytes) {
-			if (alloc_stream) {
+			// (asynchronously on the stream the caller named -- fi_assemble and fi_solve_cg name the context's stream, on which the
+			// buffer's first reader runs; FI_SYNC_ALLOC_FILL=1 forces the synchronous fill, so that two runs can be compared bit for
+			// bit when a buffer's first use on ANOTHER stream is suspected -- ADVICE r5)
+			if (alloc_stream && !test_switch("FI_SYNC_ALLOC_FILL")) {
 				FI_HIP_TRY(hipMemsetAsync(static_cast<char*>(p) + nbytes, 0, 64, alloc_stream));
 			} else {
 				FI_HIP_TRY(hipMemset(static_cast<char*>(p) + nbytes, 0, 64));

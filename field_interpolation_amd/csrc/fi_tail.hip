@@ -10,6 +10,9 @@
 // global coordinates -- the same boundary rows as the tiled kernels -- and the data rows (cell blocks of fi_assembly.hip) as
 // 3^D diagonals (`dia`, global memory): out-of-lattice corners of a cell carry zero coefficients, so the diagonals need no
 // masks.  Reference role: the small exact solves of tile_solver_square (sparse_linear.cpp:246-390).
+#include <map>
+#include <mutex>
+
 #include "fi_tail.h"
 
 namespace fi {
@@ -428,17 +431,23 @@ TailLevel tail_level_of(const fi_ctx* c)
 
 void tail_run(fi_ctx* top, const void* prog, int nlev, int nops, int lds_floats, const float* b, float* x)
 {
-	static bool lds_allowed[2] = {false, false};  // the dynamic LDS limit of k_tail<2> / k_tail<3> has been raised
+	// the dynamic LDS limit of k_tail<2> / k_tail<3> has been raised -- per DEVICE (the attribute belongs to the function on
+	// a device: a process that drives a second GPU must raise it there too) and under a lock
+	static std::mutex          lds_mutex;
+	static std::map<int, bool> lds_allowed[2];
 	const int D = top->g.ndim;
 	const size_t lds_bytes = sizeof(float) * static_cast<size_t>(lds_floats);
 	FI_REQUIRE(lds_bytes <= 160u * 1024u, FI_ERR_STATE, "the small-level engine's vectors (%zu bytes) do not fit the LDS", lds_bytes);
-	if (!lds_allowed[D - 2]) {
-		if (D == 2) {
-			FI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		} else {
-			FI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	{
+		std::lock_guard<std::mutex> lock(lds_mutex);
+		if (!lds_allowed[D - 2][top->device]) {
+			if (D == 2) {
+				FI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+			} else {
+				FI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+			}
+			lds_allowed[D - 2][top->device] = true;
 		}
-		lds_allowed[D - 2] = true;
 	}
 	const TailLevel* levels = static_cast<const TailLevel*>(prog);
 	const TailOp*    ops    = reinterpret_cast<const TailOp*>(levels + kTailMaxLevels);

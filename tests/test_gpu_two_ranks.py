@@ -149,19 +149,20 @@ def test_release_library_has_no_host_transport():
 
 
 @pytest.mark.parametrize("config,extra", [(4, ["--side", "96"]), (5, ["--side", "96", "--levels", "3"])])
-def test_bench_five_ranks_on_one_gpu(config, extra):
+def test_bench_four_ranks_on_one_gpu(config, extra):
     """Pre-flight of the run nobody has been able to make yet (no 8-GPU node in five rounds): bench.py's
-    orchestration with FIVE ranks -- the most one GPU box admits beside the test runner (six processes per GPU) -- on the two
-    3-D configurations, strong scaling, slabs of 19-20 planes, the deepest levels replicated.  Asserts what a first contact with 8 GPUs must not trip over: every
+    orchestration with FOUR ranks -- the GPU count BASELINE states config 4 on, and the most one GPU box admits beside a test
+    runner that has used the GPU itself (six processes per GPU; five ranks ran from a fresh runner: profiles/r6_preflight_5ranks.txt)
+    -- on the two 3-D configurations, strong scaling, slabs of 24 planes, the deepest levels replicated.  Asserts what a first contact with 8 GPUs must not trip over: every
     rank reports, the collectives per iteration are finite and the same on every run, the solve converges to the slab rule's
     residual.  (The transport is the host-staged test transport: RCCL refuses several ranks on one device.)"""
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "1", "--warmup", "1", "--cpu-side", "0", "--config", str(config),
-                   "--no-accuracy", "--no-cold"] + extra, nproc=5, timeout=900)
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--cpu-side", "0", "--config", str(config),
+                   "--no-accuracy", "--no-cold"] + extra, nproc=4, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 5 and line["config"]["parallelism"] == "slab5" and line["scaling"] == "strong"
-    assert line["config"]["rccl_ranks"] == 5 and len(line["config"]["ranks_seen_by_rccl"]) == 5
-    assert sorted(r_[1] for r_ in line["config"]["ranks_seen_by_rccl"]) == list(range(5))
+    assert line["n_gpus"] == 4 and line["config"]["parallelism"] == "slab4" and line["scaling"] == "strong"
+    assert line["config"]["rccl_ranks"] == 4 and len(line["config"]["ranks_seen_by_rccl"]) == 4
+    assert sorted(r_[1] for r_ in line["config"]["ranks_seen_by_rccl"]) == list(range(4))
     assert "V-cycle PCG" in line["config"]["solver"] and line["config"]["iterations"] > 0
     assert 0 < line["config"]["halo_exchanges_per_iteration"] < 200 and 0 < line["config"]["allreduces_per_iteration"] < 400
     assert line["config"]["true_rel_residual"] <= 1.5 * line["config"]["rel_residual"] + 1e-12
