@@ -76,21 +76,21 @@ __global__ __launch_bounds__(256) void k_naive(Dim d, T w2sq, const T* __restric
 // ---- the strip kernel ----------------------------------------------------------------------------------------------
 // RY rows per lane, OWN = ring of own planes (3 live + OWN - 3 steps of lead), HAL = sets of halo registers (lead HAL steps)
 template <typename T, int RY, int OWN, int HAL, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_strip(Dim d, int zc, T w2sq, const T* __restrict__ x, T* __restrict__ y)
+__global__ __launch_bounds__(256, WPS) void k_strip(Dim d, int zc, T w2sq, const T* __restrict__ x, T* __restrict__ y, int wpb)
 {
 	using V = typename Vec<T>::V;
 	constexpr int VX = Vec<T>::VX;
 	constexpr int TX = 64 * VX;
 	constexpr int U  = (OWN % HAL == 0) ? OWN : OWN * HAL;  // instantiations of the step: every ring index a constant
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int tiles_x = d.nx / TX, tiles_y = d.ny / (4 * RY);
+	const int tiles_x = d.nx / TX, tiles_y = d.ny / (wpb * RY);
 	// XCD-aware order as in the product kernel: blocks b, b + 8, ... (one XCD) take neighbouring tiles
 	const int nwg  = tiles_x * tiles_y * ((d.nz + zc - 1) / zc);
 	const int per  = (nwg + 7) / 8;
 	const int slot = (blockIdx.x % 8) * per + blockIdx.x / 8;
 	if (slot >= nwg) { return; }
 	const int txy = slot % (tiles_x * tiles_y), chunk = slot / (tiles_x * tiles_y);
-	const int x0 = (txy % tiles_x) * TX, y0 = (txy / tiles_x) * (4 * RY) + wave * RY;
+	const int x0 = (txy % tiles_x) * TX, y0 = (txy / tiles_x) * (wpb * RY) + wave * RY;
 	const int gx = x0 + VX * lane;
 	const int z_begin = chunk * zc, z_end = (z_begin + zc < d.nz) ? z_begin + zc : d.nz;
 
@@ -314,13 +314,18 @@ static void run(int side, int reps)
 	time("copy (grid 256*16)", [&] { hipLaunchKernelGGL(k_copy<T>, dim3(4096), dim3(256), 0, 0, x, y, n * sizeof(T) / 16); }, false);
 	time("naive", [&] { hipLaunchKernelGGL(k_naive<T>, dim3((n + 255) / 256), dim3(256), 0, 0, d, w2sq, x, y); }, true);
 	constexpr int VX = Vec<T>::VX;
-	auto strip = [&](const char* name, auto kern, int ry, int zc) {
-		if (side % (64 * VX) || side % (4 * ry)) { return; }
-		const int nwg = (side / (64 * VX)) * (side / (4 * ry)) * ((side + zc - 1) / zc);
+	auto strip = [&](const char* name, auto kern, int ry, int zc, int wpb = 4) {
+		if (side % (64 * VX) || side % (wpb * ry)) { return; }
+		const int nwg = (side / (64 * VX)) * (side / (wpb * ry)) * ((side + zc - 1) / zc);
 		char buf[96];
-		snprintf(buf, sizeof(buf), "%s zc=%d (%d wgs)", name, zc, nwg);
-		time(buf, [&] { hipLaunchKernelGGL(kern, dim3(((nwg + 7) / 8) * 8), dim3(256), 0, 0, d, zc, w2sq, x, y); }, true);
+		snprintf(buf, sizeof(buf), "%s wpb=%d zc=%d (%d wgs)", name, wpb, zc, nwg);
+		time(buf, [&] { hipLaunchKernelGGL(kern, dim3(((nwg + 7) / 8) * 8), dim3(64 * wpb), 0, 0, d, zc, w2sq, x, y, wpb); }, true);
 	};
+	for (int zc : {8, 16, 32}) {  // one-wave workgroups: the granularity a 256^3 fp32 level needs (a strip is a whole row)
+		strip("strip RY4 OWN4 HAL2 wps1", k_strip<T, 4, 4, 2, 1>, 4, zc, 1);
+		strip("strip RY8 OWN4 HAL2 wps1", k_strip<T, 8, 4, 2, 1>, 8, zc, 1);
+		strip("strip RY2 OWN4 HAL2 wps1", k_strip<T, 2, 4, 2, 1>, 2, zc, 1);
+	}
 	for (int zc : {32, 64, 128}) {
 		strip("strip RY8 OWN4 HAL2 wps1", k_strip<T, 8, 4, 2, 1>, 8, zc);
 		strip("strip RY8 OWN4 HAL1 wps1", k_strip<T, 8, 4, 1, 1>, 8, zc);
