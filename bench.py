@@ -61,21 +61,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_ROUND = "r5"       # profiles/<round>_traffic_<kernel>_c4.json: the PMC passes of the shipped kernels
+# profiles/<round>_traffic_<kernel>_c4_<dtype>.json: the PMC passes of the shipped kernels.  The apply: round 6's passes.  The
+# Chebyshev chain: round 5's launch-by-launch table -- those launches are unchanged since, and round 6's file of the same
+# name is the mean over ALL launches of the two kernel names (residuals and power-method steps included), not the chain's.
+TRAFFIC_ROUNDS = {"apply": ("r6", "r5"), "cheb": ("r5",)}   # (tried in turn: round 6 measured the fp64 workload only)
 
 
 def measured_traffic(kind, config, side, points, dtype):
     """HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
     x2 read correction; tools/pmc_traffic.py).  Counters cannot be read from inside this process, so the figure is the
-    committed measurement of exactly this workload (profiles/r2_traffic_*.json); any other workload reports null."""
+    committed measurement of exactly this workload (TRAFFIC_ROUNDS) with the file it came from; any other workload reports null."""
     if (config, side, points) != (4, 256, 1_000_000):
         return None
-    path = os.path.join(ROOT, "profiles", "%s_traffic_%s_c4_%s.json" % (TRAFFIC_ROUND, kind, dtype))
-    try:
-        with open(path) as f:
-            return json.load(f)["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for rnd in TRAFFIC_ROUNDS.get(kind, ("r5",)):
+        name = "profiles/%s_traffic_%s_c4_%s.json" % (rnd, kind, dtype)
+        try:
+            with open(os.path.join(ROOT, name)) as f:
+                return json.load(f)["traffic_bytes"], name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def host_cores():
@@ -466,8 +471,7 @@ def main():
     def tr(kind):
         """(bytes per launch, where they come from): the committed PMC measurement of exactly this workload, or null."""
         t = measured_traffic(kind, args.config, wl["sizes"][0], wl["points"], wl["dtype"]) if world == 1 else None
-        return (t, ("profiles/%s_traffic_%s_c4_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not "
-                    "read in this run)" % (TRAFFIC_ROUND, kind, wl["dtype"])) if t is not None else None)
+        return (t[0], "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not read in this run)" % t[1]) if t else (None, None)
 
     mg_run = wl["multigrid"] and st["num_levels"] > 1
     apply_name = ("k_apply_march3d<%s>: AtA apply, matrix-free stencil + fused data cells (finest level%s)" % (

@@ -457,6 +457,7 @@ int fi_assemble(fi_ctx* c)
 		FI_HIP_TRY(hipEventCreate(&c->ev_asm1));
 	}
 	const hipEvent_t e0 = c->ev_asm0, e1 = c->ev_asm1;
+	fi::chain_mark(nullptr);
 	FI_HIP_TRY(hipEventRecord(e0, c->stream));
 	// Ghost planes along the decomposed axis.  reach: the widest model stencil, at least the cell reach (1) -- the width of
 	// an exchange.  halo (planes stored): the reach, or the polynomial preconditioner's DEEP exchange: 2 (d - 1) planes of
@@ -595,10 +596,14 @@ int fi_assemble(fi_ctx* c)
 		c->defer_scaling_exchange = true;  // slabs: the one exchange of the assembly comes after the ranks have agreed (below)
 		try {
 			fi::AllocStream alloc_on(c->stream);  // (this chain's buffers are first used on the solver stream: fi_internal.h)
+			fi::chain_mark("threads started");
 			fi::assemble(c);
+			fi::chain_mark("finest: rows assembled");
 			fi::generic_assemble(c);
 			fi::stencil_prepare(c);
+			fi::chain_mark("finest: stencil prepared");
 			fi::operator_prepare(c);
+			fi::chain_mark("finest: operator prepared");
 		} catch (const fi::Fail& f) {
 			main_code = f.code;
 		} catch (...) {  // never leave the helper unjoined
@@ -613,6 +618,7 @@ int fi_assemble(fi_ctx* c)
 				fi::AllocStream alloc_on(c->stream);
 				c->twin->defer_scaling_exchange = true;
 				fi::twin_assemble_lumped(c);
+				fi::chain_mark("finest: lumped replica");
 			} catch (const fi::Fail& f) {
 				main_code = f.code;
 			} catch (...) {
@@ -638,6 +644,7 @@ int fi_assemble(fi_ctx* c)
 				helper_msg  = helper2_msg;
 			}
 		}
+		fi::chain_mark("helpers joined");
 		fi_ctx* const first_built = mixed64 ? c->twin : c->coarse;  // the replica, then its levels / the levels
 		for (fi_ctx* l = first_built; l; l = l->coarse) { l->stream = c->stream; }
 		const bool mine_ok = main_code == FI_OK && helper_code == FI_OK;
@@ -658,6 +665,26 @@ int fi_assemble(fi_ctx* c)
 			}
 			fi::set_error("fi_assemble: another rank failed while assembling its slab");
 			throw fi::Fail{FI_ERR_COMM};
+		}
+		if (fi::test_switch("FI_ASM_CHAIN_TIMES")) {  // (diagnostic: where each chain of the assembly ends, from the start event)
+			hipEvent_t a = nullptr, b = nullptr, d = nullptr;
+			FI_HIP_TRY(hipEventCreate(&a));
+			FI_HIP_TRY(hipEventCreate(&b));
+			FI_HIP_TRY(hipEventCreate(&d));
+			FI_HIP_TRY(hipEventRecord(a, c->stream));
+			FI_HIP_TRY(hipEventRecord(b, c->level_stream));
+			if (mixed64) { FI_HIP_TRY(hipEventRecord(d, c->level_stream2)); }
+			FI_HIP_TRY(hipEventSynchronize(a));
+			FI_HIP_TRY(hipEventSynchronize(b));
+			if (mixed64) { FI_HIP_TRY(hipEventSynchronize(d)); }
+			float ta = 0, tb = 0, td = 0;
+			(void)hipEventElapsedTime(&ta, e0, a);
+			(void)hipEventElapsedTime(&tb, e0, b);
+			if (mixed64) { (void)hipEventElapsedTime(&td, e0, d); }
+			std::fprintf(stderr, "fi_assemble chains: solver stream %.3f ms, level stream %.3f ms, second level stream %.3f ms\n", ta, tb, td);
+			(void)hipEventDestroy(a);
+			(void)hipEventDestroy(b);
+			(void)hipEventDestroy(d);
 		}
 		FI_HIP_TRY(hipEventRecord(c->ev_level, c->level_stream));
 		FI_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_level, 0));
@@ -689,6 +716,7 @@ int fi_assemble(fi_ctx* c)
 		fi::build_twin(c);
 	}
 	FI_HIP_TRY(hipEventRecord(e1, c->stream));
+	fi::chain_mark("fi_assemble returns");
 	c->asm_time_pending   = true;
 	c->stats.assemble_ms  = 0.0;
 	c->stats.num_levels   = 1;

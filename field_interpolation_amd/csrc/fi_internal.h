@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,24 @@ inline const char* tuning_switch(const char* name) { return getenv(name); }
 #else
 inline const char* tuning_switch(const char*) { return nullptr; }
 #endif
+
+// FI_ASM_CHAIN_TIMES (diagnostic): host time of the assembly's stages, per thread, since fi_assemble began -- the
+// assembly of a config-4 step is bound by its threads' launch and round-trip times, not by the GPU (profiles/r6_ablation.md)
+inline std::chrono::steady_clock::time_point& chain_origin()
+{
+	static std::chrono::steady_clock::time_point t0;
+	return t0;
+}
+inline void chain_mark(const char* what, int level = -1)
+{
+	if (!test_switch("FI_ASM_CHAIN_TIMES")) { return; }
+	if (!what) {
+		chain_origin() = std::chrono::steady_clock::now();
+		return;
+	}
+	const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - chain_origin()).count();
+	std::fprintf(stderr, "fi_assemble host %8.1f us  %s%s%d\n", us, what, level >= 0 ? " level " : " ", level);
+}
 
 // ---- error plumbing: nothing throws or aborts across the C ABI ------------------------------------
 void set_error(const char* fmt, ...);

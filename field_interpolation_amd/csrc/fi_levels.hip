@@ -188,6 +188,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		AllocStream alloc_on(co->stream);  // (the level's chain runs on co->stream: its buffers' slack is zeroed there)
 		const int   l  = co->level;
 		const float ps = 1.0f / static_cast<float>(1 << l), ns = static_cast<float>(1 << l);
+		chain_mark("begins:", l);
 		for (auto* b : src->batches) {
 			const float* nrm = b->has_nrm ? b->nrm.as<float>() : nullptr;
 			const float* pw  = b->has_pw ? b->pw.as<float>() : nullptr;
@@ -199,9 +200,12 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 				generic_add_gradient_linear(co, b->n, b->pos.as<float>(), nrm, pw, b->gw * ps, ps, ns);
 			}
 		}
+		chain_mark("rows emitted:", l);
 		assemble(co);
+		chain_mark("rows assembled:", l);
 		generic_assemble(co);
 		stencil_prepare(co);
+		chain_mark("stencil prepared:", l);
 		// the polynomial smoother's scaling (and whether the data pin a small level) with the level's assembly, on its chain's
 		// stream, instead of at the head of the first solve (undivided levels: over slabs the ghost planes' diagonal comes later)
 		operator_prepare(co, co->dtype == FI_F32 && co->g.ndim == 3 && co->mg_smoother == 1 && co->value_rows_only && !co->any_trip &&
@@ -210,7 +214,9 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		co->dia_valid = false;
 		// the data rows as 3^D diagonals: the small-level engine's view of them, and what the full operator's direct launches
 		// on levels of up to 2^19 points read (fi_stencil.hip, k_full_direct3)
+		chain_mark("operator prepared:", l);
 		if (tail_level_supported(co) || stencil_full_direct_wanted(co)) { tail_build_operator(co); }
+		chain_mark("done:", l);
 		co->assembled = true;
 		co->vectors_ready = co->vectors_ready && co->max_blocks >= apply_num_partials(co);
 		co->stats.num_unknowns = co->g.nown;
@@ -229,14 +235,24 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		std::vector<Worker*> workers;  // (persistent threads: fi_workers.h)
 		std::vector<int>         codes(built.size(), FI_OK);
 		std::vector<std::string> msgs(built.size());
+		// chain_of[i]: the level whose stream and thread level i runs on -- every level its own chain, or (FI_LEVEL_CHAINS=n)
+		// n chains, the first level alone on `build_stream` and the deeper ones dealt over the other n - 1.  HIP spreads a
+		// process's streams over four hardware queues and two chains on one queue take turns launch by launch (round 6's
+		// trace: the 128^3 and 64^3 chains of config 4), but fewer, longer chains lose more to their host round trips than
+		// they win: config 4's assembly 1.33 ms with 4 chains, 1.32 with 3, 1.55 with 2, 1.49 with all levels on one.
+		int max_chains = static_cast<int>(built.size());
+		if (const char* v = test_switch("FI_LEVEL_CHAINS")) { max_chains = std::atoi(v); }
+		max_chains = max_chains < 2 ? 2 : max_chains;
+		std::vector<size_t> chain_of(built.size(), 0);
 		for (size_t i = 1; i < built.size(); ++i) {
-			fi_ctx* co = built[i];
-			if (!co->build_stream) {
-				co->build_stream = stream_take();
-				FI_HIP_TRY(hipEventCreateWithFlags(&co->ev_build, hipEventDisableTiming));
+			chain_of[i] = 1 + (i - 1) % static_cast<size_t>(max_chains - 1);
+			fi_ctx* head = built[chain_of[i]];
+			if (!head->build_stream) {
+				head->build_stream = stream_take();
+				FI_HIP_TRY(hipEventCreateWithFlags(&head->ev_build, hipEventDisableTiming));
 			}
-			FI_HIP_TRY(hipStreamWaitEvent(co->build_stream, go, 0));
-			co->stream = co->build_stream;
+			if (chain_of[i] == i) { FI_HIP_TRY(hipStreamWaitEvent(head->build_stream, go, 0)); }
+			built[i]->stream = head->build_stream;
 		}
 		auto guarded = [&](size_t i) {
 			try {
@@ -250,34 +266,43 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 				msgs[i]  = "unexpected exception while assembling a coarser level";
 			}
 		};
+		auto run_chain = [&](size_t head) {  // the levels of one chain, finest first
+			for (size_t i = head; i < built.size(); ++i) {
+				if (chain_of[i] == head) { guarded(i); }
+			}
+		};
+		std::vector<size_t> heads;
 		for (size_t i = 1; i < built.size(); ++i) {
+			if (chain_of[i] == i) { heads.push_back(i); }
+		}
+		for (size_t head : heads) {
 			Worker* w = nullptr;
 			try {
 				w = worker_pool().acquire();
-				w->run([&guarded, i]() { guarded(i); });
-			} catch (...) {  // no thread to be had: this one on the caller's thread, behind the first level
+				w->run([&run_chain, head]() { run_chain(head); });
+			} catch (...) {  // no thread to be had: this chain on the caller's thread, behind the first level
 				w = nullptr;
 			}
 			workers.push_back(w);
 		}
 		guarded(0);
-		for (size_t i = 1; i < built.size(); ++i) {
-			Worker* w = workers[i - 1];
+		for (size_t k = 0; k < heads.size(); ++k) {
+			Worker* w = workers[k];
 			if (w) {
 				w->wait();
 				worker_pool().release(w);
 			} else {
-				guarded(i);
+				run_chain(heads[k]);
 			}
 		}
 		// the caller orders `build_stream` against the solver stream: the other chains end in it
-		for (size_t i = 1; i < built.size(); ++i) {
-			(void)hipEventRecord(built[i]->ev_build, built[i]->build_stream);
-			(void)hipStreamWaitEvent(build_stream, built[i]->ev_build, 0);
+		for (size_t head : heads) {
+			(void)hipEventRecord(built[head]->ev_build, built[head]->build_stream);
+			(void)hipStreamWaitEvent(build_stream, built[head]->ev_build, 0);
 		}
 		for (size_t i = 0; i < built.size(); ++i) {
 			if (codes[i] != FI_OK) {
-				for (size_t k = 1; k < built.size(); ++k) { (void)hipStreamSynchronize(built[k]->build_stream); }
+				for (size_t head : heads) { (void)hipStreamSynchronize(built[head]->build_stream); }
 				set_error("%s", msgs[i].c_str());
 				throw Fail{codes[i]};
 			}

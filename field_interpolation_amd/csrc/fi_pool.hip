@@ -84,6 +84,23 @@ hipStream_t stream_take()
 			return st;
 		}
 	}
+	// FI_DUMMY_STREAMS=k (diagnostic): k streams created, used once and kept, in front of the first one the library makes --
+	// shifts which of the library's streams share a hardware queue (profiles/r6_ablation.md: the assembly's chains)
+	static bool shifted = false;
+	if (!shifted) {
+		shifted = true;
+		if (const char* v = test_switch("FI_DUMMY_STREAMS")) {
+			for (int i = 0; i < std::atoi(v); ++i) {
+				hipStream_t d = nullptr;
+				FI_HIP_TRY(hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
+				void* p = nullptr;
+				FI_HIP_TRY(hipMalloc(&p, 256));
+				FI_HIP_TRY(hipMemsetAsync(p, 0, 256, d));
+				FI_HIP_TRY(hipStreamSynchronize(d));
+				(void)hipFree(p);
+			}
+		}
+	}
 	hipStream_t st = nullptr;
 	FI_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 	return st;
