@@ -525,7 +525,8 @@ def main():
                                  "every step re-solves on changed points and values" % (len(step.data), ", ".join(str(d["seed"]) for d in step.data))
                                  if len(step.data) > 1 else "one data set (seed %d), re-solved every step" % step.data[0]["seed"]),
                    "levels": st["num_levels"], "coarse_iterations": st["coarse_iterations"], "solver": solver,
-                   "stop_rule": ("by the field: the change between consecutive iterates per unit of residual dropped, times the residual left, "
+                   "stop_rule": ("by the field: the last step ||x_k - x_(k-1)||_inf times sigma / (1 - sigma), sigma the slowest mean decay of the "
+                                 "residual norm over the recent windows and the whole solve, "
                                  "x 2, <= %g x max |x| (FI_OPT_FIELD_TOLERANCE, include/fi_hip.h) -- every configuration alike"
                                  % wl["field_tol"]) if wl.get("by_field") else "relative residual <= %g" % wl["tol"],
                    "field_estimate": st["field_estimate"] if wl.get("by_field") else None,

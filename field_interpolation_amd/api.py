@@ -299,8 +299,9 @@ class LatticeField:
 
     def set_field_tolerance(self, tol):
         """FI_OPT_FIELD_TOLERANCE (V-cycle PCG, undivided lattices): stop when the field is within `tol` (relative, maximum
-        norm) of the converged solution by the solver's own measure -- one more V-cycle on the residual, added onto x --
-        instead of at a residual.  0: the residual rule.  stats(): field_estimate, field_per_residual, stop_residual."""
+        norm) of the converged solution by the solver's own measure -- the last step times sigma / (1 - sigma), sigma the
+        slowest mean decay of the residual norm over the recent windows and the whole solve, doubled (include/fi_hip.h) --
+        instead of at a residual; the `tol` of solve_cg is then ignored.  0: the residual rule.  stats(): field_estimate, field_per_residual, stop_residual."""
         check(_capi.lib().fi_set_option(self._h, 12, float(tol)))
 
     def set_polynomial(self, terms, ratio=None):

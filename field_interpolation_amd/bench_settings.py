@@ -11,9 +11,11 @@ within 1e-5 of the CPU reference's double solve, sparse_linear.cpp:154-184).  ka
 varies by three orders of magnitude with the lattice, the data and the weights (field error per unit of residual: 2-3 for
 config 2, 70-140 for config 4, 400-800 for the oriented points of configs 3 and 5).  Round 6: ONE rule for every configuration
 and no constant that depends on the workload -- the solver stops by the field (FI_OPT_FIELD_TOLERANCE, include/fi_hip.h: the
-change between consecutive iterates per unit of residual dropped, times the residual left, with a margin of two), checked here
+last step times sigma / (1 - sigma), sigma the slowest mean decay of the residual norm over the recent windows and the whole
+solve, with a margin of two), checked here
 against the oracle's fp64 solutions wherever it has one (tests/test_gpu_fullsize_golden.py: three seeds of config 4 at 256^3,
-config 2 at full size, config 3's shape at 1024^2, config 5's at 128^3; tools/r6_field_rule.py, profiles/r6_field_rule.txt).
+config 2 at full size, config 3's shape at 1024^2, config 5's at 128^3; tools/r6_field_rule.py, profiles/r6_field_rule.txt)
+and on random problems against the solve to the fp64 floor (tests/stress_field_rule.py).
 Rounds 4-5 stopped config 4's own 256^3 / 1 M point workload at a residual calibrated against the oracle for exactly that
 workload (3e-7, five iterations); the rule takes six to seven there -- the price of not knowing the answer in advance.
 Over slabs (one process per GPU) the field rule is not wired up: those runs stop at `slab_residual` below."""

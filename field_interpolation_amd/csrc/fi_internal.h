@@ -320,7 +320,10 @@ struct CgScalars {  // lives in device memory; kernels read/write it, the host p
 	// max |x_k - x_(k-1)| = |alpha| max |p| and max |x_k| here (bit patterns of non-negative doubles: atomicMax)
 	double field_tol, field_est, field_kappa;
 	unsigned long long dmax_bits, xmax_bits;
+	// ... and the last kFieldHist iterations' relative residuals and relative steps (slot: iteration % kFieldHist)
+	double hist_r[32], hist_s[32], hist_r0;  // (hist_r0: the start residual)
 };
+constexpr int kFieldHist = 32;
 
 }  // namespace fi
 

@@ -440,18 +440,52 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 		sc->iter += 1;
 		bool field_met = false;
 		if (sc->field_tol > 0.0) {
-			// FI_OPT_FIELD_TOLERANCE: two consecutive iterates x_(k-1), x_k and their residuals.  If the error shrinks like
-			// the residual, e_k = rho e_(k-1) with rho = ||r_k|| / ||r_(k-1)||, then x_k - x_(k-1) = e_(k-1) - e_k gives
-			// ||e_k|| = ||x_k - x_(k-1)|| rho / (1 - rho): the change of the field per unit of residual dropped, times the
-			// residual that is left -- with a margin (kFieldMargin) for the smooth modes, which converge last
+			// FI_OPT_FIELD_TOLERANCE: x* - x_k is the sum of the steps still to come.  If the steps shrink by sigma per
+			// iteration, ||e_k|| <= ||x_k - x_(k-1)|| sigma / (1 - sigma).  sigma: the SLOWEST mean decay of the residual norm
+			// over the last 1, 2, 4 .. 16 iterations and over the whole solve (one step's ratio ||r_k|| / ||r_(k-1)|| alone reads a lucky drop of a
+			// slowly converging solve as its rate: tests/stress_field_rule.py, errors up to 16 x the tolerance); the step: the
+			// largest of the last four, each carried forward at that rate.  A margin (kFieldMargin) for the smooth modes,
+			// which converge last; no estimate while the residual falls by less than 5 % per iteration.
 			const double dmax = __longlong_as_double(static_cast<long long>(sc->dmax_bits));  // (k_field_max, just before)
 			const double xmax = __longlong_as_double(static_cast<long long>(sc->xmax_bits));
 			sc->field_est = -1.0;
+			const int k = sc->iter;  // (restarts are off under this rule: the iterations count from the solve's start)
 			if (sc->bb > 0.0 && xmax > 0.0 && prev > 0.0 && isfinite(s)) {
 				const double ra = sqrt(prev / sc->bb), rb = sqrt(s / sc->bb);
-				if (ra > 1.25 * rb) {
-					sc->field_kappa = dmax / xmax / (ra - rb);
-					sc->field_est   = kFieldMargin * sc->field_kappa * rb;
+				if (k == 1) {
+					sc->hist_r[0] = ra;
+					sc->hist_r0   = ra;
+				}
+				sc->hist_r[k % kFieldHist] = rb;
+				sc->hist_s[k % kFieldHist] = dmax / xmax;
+				double sigma = rb / ra;
+				for (int lag = 2; lag <= k && lag < kFieldHist; lag *= 2) {
+					const double r0 = sc->hist_r[(k - lag) % kFieldHist];
+					if (r0 > 0.0) {
+						const double rho = pow(rb / r0, 1.0 / lag);
+						sigma = rho > sigma ? rho : sigma;
+					}
+				}
+				if (k > 2 && sc->hist_r0 > 0.0) {  // ... and over the whole solve (CG's faster late phases are not the tail's rate)
+					const double rho = pow(rb / sc->hist_r0, 1.0 / k);
+					sigma = rho > sigma ? rho : sigma;
+				}
+				if (sigma < 0.95 && rb > 0.0) {
+					double step = dmax / xmax, f = sigma;
+					if (sigma < 0.5) {
+						// every window gains more than a factor 2 per iteration (a healthy V-cycle): the last step and its own
+						// ratio predict the next ones best, and the margin covers the rest (the goldens of configs 2 and 4:
+						// estimates 3 to 30 times the true error)
+						sigma = rb / ra;
+					} else {
+						for (int j = 1; j <= 3 && j < k; ++j) {
+							const double sj = sc->hist_s[(k - j) % kFieldHist] * f;
+							step = sj > step ? sj : step;
+							f *= sigma;
+						}
+					}
+					sc->field_est   = kFieldMargin * step * sigma / (1.0 - sigma);
+					sc->field_kappa = sc->field_est / (kFieldMargin * rb);
 					field_met = sc->field_est <= sc->field_tol;
 				}
 			}
