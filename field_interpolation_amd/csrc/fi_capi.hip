@@ -666,7 +666,7 @@ int fi_assemble(fi_ctx* c)
 			fi::set_error("fi_assemble: another rank failed while assembling its slab");
 			throw fi::Fail{FI_ERR_COMM};
 		}
-		if (fi::test_switch("FI_ASM_CHAIN_TIMES")) {  // (diagnostic: where each chain of the assembly ends, from the start event)
+		if (fi::tuning_switch("FI_ASM_CHAIN_TIMES")) {  // (diagnostic: where each chain of the assembly ends, from the start event)
 			hipEvent_t a = nullptr, b = nullptr, d = nullptr;
 			FI_HIP_TRY(hipEventCreate(&a));
 			FI_HIP_TRY(hipEventCreate(&b));

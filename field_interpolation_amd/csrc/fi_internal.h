@@ -37,7 +37,7 @@ inline std::chrono::steady_clock::time_point& chain_origin()
 }
 inline void chain_mark(const char* what, int level = -1)
 {
-	if (!test_switch("FI_ASM_CHAIN_TIMES")) { return; }
+	if (!tuning_switch("FI_ASM_CHAIN_TIMES")) { return; }
 	if (!what) {
 		chain_origin() = std::chrono::steady_clock::now();
 		return;

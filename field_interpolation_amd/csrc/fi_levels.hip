@@ -241,7 +241,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		// trace: the 128^3 and 64^3 chains of config 4), but fewer, longer chains lose more to their host round trips than
 		// they win: config 4's assembly 1.33 ms with 4 chains, 1.32 with 3, 1.55 with 2, 1.49 with all levels on one.
 		int max_chains = static_cast<int>(built.size());
-		if (const char* v = test_switch("FI_LEVEL_CHAINS")) { max_chains = std::atoi(v); }
+		if (const char* v = tuning_switch("FI_LEVEL_CHAINS")) { max_chains = std::atoi(v); }
 		max_chains = max_chains < 2 ? 2 : max_chains;
 		std::vector<size_t> chain_of(built.size(), 0);
 		for (size_t i = 1; i < built.size(); ++i) {

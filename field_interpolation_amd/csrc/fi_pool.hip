@@ -89,7 +89,7 @@ hipStream_t stream_take()
 	static bool shifted = false;
 	if (!shifted) {
 		shifted = true;
-		if (const char* v = test_switch("FI_DUMMY_STREAMS")) {
+		if (const char* v = tuning_switch("FI_DUMMY_STREAMS")) {
 			for (int i = 0; i < std::atoi(v); ++i) {
 				hipStream_t d = nullptr;
 				FI_HIP_TRY(hipStreamCreateWithFlags(&d, hipStreamNonBlocking));
