@@ -74,3 +74,21 @@ def test_tile2d_kernel_budget():
     for name, r in rep.items():
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, name
         assert r["VGPRs"] <= 128 and r["LDS Size [bytes/block]"] <= 40 * 1024, name
+
+
+def test_strip_kernel_budget():
+    """fi_strip.hip (FI_STRIP=1, not the default): a wave per 128 x 4 strip with the z ring in registers -- one wave per SIMD by
+    design (the plain variants of one model term fit three), no scratch in the variants with one model term (config 4 / 5);
+    the two-role variants keep 27.5 KB of LDS, four workgroups per CU with the launch's 10 KB pad."""
+    rep = _variants(_report("fi_strip.usage.txt"), "k_apply_strip3d")
+    assert len(rep) == 9          # {model_1, model_2, both} x {plain, cells, cells + packed blocks}
+    for name, r in rep.items():
+        both = "strip3dIdLb1ELb1E" in name
+        cells = r["LDS Size [bytes/block]"] > 0
+        assert r["AGPRs"] == 0 and r["VGPRs"] <= 256 and r["Occupancy [waves/SIMD]"] >= 2, name
+        if both and cells:   # 13 + 13 taps and the cell pipeline: 12 registers of the prologue spill (52 bytes per lane)
+            assert r["VGPRs Spill"] <= 12 and r["ScratchSize [bytes/lane]"] <= 52, name
+        else:
+            assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, name
+        if cells:
+            assert (r["LDS Size [bytes/block]"] + 10 * 1024) * 4 <= 160 * 1024, name
