@@ -11,8 +11,8 @@ Workloads (--config, named in config.workload; SURVEY.md 8(d) recipes, field_int
     V-cycle (a 1e-5 RESIDUAL leaves the field 2e-3 off: kappa ~ side^4).  STOP RULE (round 6, every configuration alike, no
     constant that depends on the workload): by the FIELD -- FI_OPT_FIELD_TOLERANCE = 1e-5, the solver's own estimate from
     consecutive iterates (include/fi_hip.h); `solution_rel_err` is measured against the ORACLE's fp64 solution of the same
-    inputs (tests/golden/config4_256*_oracle_f64.npz).  Over slabs (--gpus N > 1) the rule is not wired up: those runs stop
-    at bench_settings.slab_residual.
+    inputs (tests/golden/config4_256*_oracle_f64.npz).  Over slabs (--gpus N > 1) the same rule: every slab's two maxima
+    travel with the r . r sum of the iteration's all-reduce (no collective of their own).
     --fast: the fp32 mode of rounds 1-3 as the line's value (coarse-to-fine start + CG preconditioned by a Chebyshev
     polynomial to residual 1e-5, field error 2e-3); the default run reports it in the `fast` sub-object.
   5: 3-D 512^3 SDF from 5 M oriented points, tol 1e-6: fp64 CG with the V-cycle preconditioner in fp32 (mixed)
@@ -213,9 +213,10 @@ def workload(args, world):
         # the solver that meets the north-star's FIELD tolerance: fp64 CG + fp32 V-cycle.  The residual that buys a field
         # within 1e-5 tightens with the lattice (field error per unit of residual: 60 at 256^3, 190 at 512^3)
         dt = args.dtype or "f64"
-        # The stop rule (field_interpolation_amd/bench_settings.py): by the FIELD on one GPU -- the solver's estimate, the
-        # same rule for every configuration and size; at a residual over slabs or when --tol names one
-        by_field = world == 1 and not args.tol
+        # The stop rule (field_interpolation_amd/bench_settings.py): by the FIELD -- the solver's estimate, the same rule for
+        # every configuration, size and number of slabs (up to 16: the slabs' maxima travel with the r.r sum); at a residual
+        # when --tol names one
+        by_field = world <= bs.FIELD_RULE_MAX_SLABS and not args.tol
         tol = args.tol or (st["tol"] if by_field else bs.slab_residual(4, sizes))
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=tol, dtype=dt, by_field=by_field,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
@@ -228,7 +229,7 @@ def workload(args, world):
             raise SystemExit("config 5 is a fixed lattice: use --scaling strong")
         sizes, w, pos, nrm = synth.config5(side=side, num_points=npts, seed=4)
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
-                    by_field=world == 1 and not args.tol,
+                    by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
                     multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, field_tol=bs.FIELD_TOLERANCE, more=[], seed=4,
                     text="config5: 3D %d^3 SDF from %d oriented points (sdf_from_points, default Weights)" % (side, npts))
@@ -239,7 +240,7 @@ def workload(args, world):
             raise SystemExit("config 3 is a fixed lattice: use --scaling strong")
         sizes, w, pos, nrm = synth.config3(side=side, points_per_shape=pps, seed=2)
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
-                    by_field=world == 1 and not args.tol,
+                    by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
                     multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, field_tol=bs.FIELD_TOLERANCE, more=[], seed=2,
                     text="config3: 2D %dx%d SDF from %d oriented points (triangle + inverted circle)" % (side, side, 2 * pps))
@@ -250,7 +251,7 @@ def workload(args, world):
             raise SystemExit("config 2 is a fixed lattice: use --scaling strong")
         sizes, w, pos, val = synth.config2(side=side, num_points=npts, seed=1)
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
-                    by_field=world == 1 and not args.tol,
+                    by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
                     multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, field_tol=bs.FIELD_TOLERANCE, more=[], seed=1,
                     text="config2: 2D %dx%d lattice, %d noisy value constraints, model_2=10" % (side, side, npts))

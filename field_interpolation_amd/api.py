@@ -298,7 +298,7 @@ class LatticeField:
         self._dirty = True
 
     def set_field_tolerance(self, tol):
-        """FI_OPT_FIELD_TOLERANCE (V-cycle PCG, undivided lattices): stop when the field is within `tol` (relative, maximum
+        """FI_OPT_FIELD_TOLERANCE (V-cycle PCG; undivided lattices and up to 16 slabs): stop when the field is within `tol` (relative, maximum
         norm) of the converged solution by the solver's own measure -- the last step times sigma / (1 - sigma), sigma the
         slowest mean decay of the residual norm over the recent windows and the whole solve, doubled (include/fi_hip.h) --
         instead of at a residual; the `tol` of solve_cg is then ignored.  0: the residual rule.  stats(): field_estimate, field_per_residual, stop_residual."""
@@ -438,6 +438,10 @@ class LatticeGroup:
     def set_mixed_precision(self, on=True):
         for m in self.members:
             m.set_mixed_precision(on)
+
+    def set_field_tolerance(self, tol):
+        for m in self.members:
+            m.set_field_tolerance(tol)
 
     def set_polynomial(self, terms, ratio=None):
         for m in self.members:

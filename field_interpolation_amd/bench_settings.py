@@ -18,14 +18,16 @@ config 2 at full size, config 3's shape at 1024^2, config 5's at 128^3; tools/r6
 and on random problems against the solve to the fp64 floor (tests/stress_field_rule.py).
 Rounds 4-5 stopped config 4's own 256^3 / 1 M point workload at a residual calibrated against the oracle for exactly that
 workload (3e-7, five iterations); the rule takes six to seven there -- the price of not knowing the answer in advance.
-Over slabs (one process per GPU) the field rule is not wired up: those runs stop at `slab_residual` below."""
+Over slabs (one process per GPU, up to FIELD_RULE_MAX_SLABS) the same rule: every slab's maxima travel with the r . r sum of
+the iteration's all-reduce; `slab_residual` below is what a run over more slabs (or one given --tol) stops at."""
 
 CONFIG4_SEEDS = (3, 11, 12)      # synth.config4 seeds with an oracle golden at 256^3 (3: the metric's own workload)
 FIELD_TOLERANCE = 1e-5           # BASELINE.json north_star
+FIELD_RULE_MAX_SLABS = 16        # fi_internal.h kFieldRanks
 
 
 def slab_residual(config, sizes):
-    """Residual at which a run over slabs (--gpus N > 1: the field rule needs an undivided lattice) stops: BASELINE's for
+    """Residual at which a run over more than FIELD_RULE_MAX_SLABS slabs stops: BASELINE's for
     configs 2 / 3 / 5, for config 4 the conservative rule of round 3 (1e-7, tightened with the lattice beyond 256^3)."""
     if config == 4:
         return 1e-7 * min(1.0, (256.0 / max(sizes)) ** 1.75)

@@ -264,7 +264,11 @@ void allreduce_sum(fi_ctx* c, double* dev, int count)
 	++c->comm->n_allreduce;
 #ifdef FI_TEST_TRANSPORT
 	if (c->comm->host) {
-		host_allreduce(c, dev, count);
+		if (count <= 8) {
+			host_allreduce(c, dev, count);
+		} else {  // (the field rule's sums + maxima of up to 16 slabs: the vector form)
+			host_allreduce_vec(c, dev, count, true);
+		}
 		return;
 	}
 #endif

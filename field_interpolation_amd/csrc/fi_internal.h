@@ -313,9 +313,14 @@ struct Comm;  // RCCL state (fi_comm.cpp)
 struct CgScalars {  // lives in device memory; kernels read/write it, the host polls it
 	double rz, rz_new, pq, rr, bb, tol2, alpha, beta, true_rr;
 	double sums[4];
+	// FI_OPT_FIELD_TOLERANCE over slabs: every slab's two maxima travel with the r.r sum -- slab s writes entries 2 s and
+	// 2 s + 1, zeros elsewhere, and the SUM over the slabs (the all-reduce the iteration makes anyway, over sums[0 .. 3] and
+	// these) hands every rank all of them; the stop test takes their maximum.  Directly behind sums[]: one contiguous run.
+	double rank_max[2 * 16];
 	double tscale;  // mixed precision: the scale the fp32 copy of the current residual was divided by
 	int    iter, done, max_iter, restarts;
-	int    tag, pad_;  // second slot only (single-rank fused CG): the iteration whose first half filled it
+	int    tag, field_ranks;  // tag: second slot only (single-rank fused CG): the iteration whose first half filled it;
+	                          // field_ranks: slabs whose maxima rank_max[] holds (0: an undivided lattice, dmax_bits / xmax_bits)
 	// FI_OPT_FIELD_TOLERANCE (V-cycle PCG, fi_multigrid.hip): the stop test on the field.  The step kernel leaves
 	// max |x_k - x_(k-1)| = |alpha| max |p| and max |x_k| here (bit patterns of non-negative doubles: atomicMax)
 	double field_tol, field_est, field_kappa;
@@ -324,6 +329,7 @@ struct CgScalars {  // lives in device memory; kernels read/write it, the host p
 	double hist_r[32], hist_s[32], hist_r0;  // (hist_r0: the start residual)
 };
 constexpr int kFieldHist = 32;
+constexpr int kFieldRanks = 16;  // slabs the field rule runs over (CgScalars::rank_max)
 
 }  // namespace fi
 

@@ -240,6 +240,49 @@ __global__ __launch_bounds__(kThreads) void k_field_max(CgScalars* sc, const dou
 	}
 }
 
+// The same over slabs: the slab's maxima into its two entries of CgScalars::rank_max, zeros in everybody else's (and in the
+// sums the all-reduce carries along unused) -- summed over the slabs with the r.r partial sums in ONE collective.
+__global__ __launch_bounds__(kThreads) void k_field_max_slot(CgScalars* sc, const double* __restrict__ field_part, int count, int slot,
+                                                              int nslots)
+{
+	if (sc->done) { return; }
+	double md = 0.0, mx = 0.0;
+	for (int i = threadIdx.x; i < count; i += kThreads) {
+		md = fmax(md, field_part[i]);
+		mx = fmax(mx, field_part[count + i]);
+	}
+	__shared__ double s_md[kThreads / 64], s_mx[kThreads / 64];
+	for (int o = 32; o > 0; o >>= 1) {
+		md = fmax(md, __shfl_down(md, o, 64));
+		mx = fmax(mx, __shfl_down(mx, o, 64));
+	}
+	if ((threadIdx.x & 63) == 0) {
+		s_md[threadIdx.x >> 6] = md;
+		s_mx[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < kThreads / 64; ++w) {
+			md = fmax(md, s_md[w]);
+			mx = fmax(mx, s_mx[w]);
+		}
+		for (int i = 0; i < 2 * nslots; ++i) { sc->rank_max[i] = 0.0; }
+		sc->rank_max[2 * slot]     = md;
+		sc->rank_max[2 * slot + 1] = mx;
+		sc->sums[1] = sc->sums[2] = sc->sums[3] = 0.0;
+	}
+}
+// loop-back group: the members' maxima summed entry by entry like k_group_sum sums sums[] (every entry has one non-zero term)
+__global__ void k_group_sum_field(CgScalars* const* sc, int nranks)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
+	for (int v = 0; v < 2 * nranks; ++v) {
+		double s = 0;
+		for (int r = 0; r < nranks; ++r) { s += sc[r]->rank_max[v]; }
+		for (int r = 0; r < nranks; ++r) { sc[r]->rank_max[v] = s; }
+	}
+}
+
 // CG with a preconditioner: r -= alpha q, x += alpha p (p is still the direction of this step), partial r.r
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_mg_step(int64_t n, const CgScalars* __restrict__ sc, const T* __restrict__ p,
@@ -1216,7 +1259,10 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	}
 	// FI_OPT_FIELD_TOLERANCE (an undivided lattice): the solve stops by the field (k_mg_logic, kMgResid); the residual rule
 	// stays as the floor of what the precision's recurrence can still tell apart
-	const bool by_field = c0->field_tol > 0 && R.size() == 1 && c0->nranks == 1;
+	// Over slabs (a loop-back group's members or one slab per process, at most kFieldRanks of them) every slab's maxima
+	// travel with the r.r sum (CgScalars::rank_max): no collective of their own, and every rank decides on the same numbers.
+	const int  field_slabs = R.size() > 1 ? static_cast<int>(R.size()) : (c0->nranks > 1 ? c0->nranks : 0);
+	const bool by_field = c0->field_tol > 0 && field_slabs <= kFieldRanks && !replicated_copies(R);
 	const double tolerance = by_field ? (sizeof(T) == 8 ? 1e-13 : 2e-7)
 	                                  : (tol > 0 ? static_cast<double>(tol) : static_cast<double>(std::numeric_limits<float>::epsilon()));
 	EventPair timer;  // (destroyed on every way out: a coarse level's breakdown, a timeout)
@@ -1227,6 +1273,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	init.max_iter  = max_iterations;
 	init.field_tol = by_field ? c0->field_tol : 0.0;
 	init.field_est = -1.0;
+	init.field_ranks = by_field ? field_slabs : 0;
 	reset_scalars(R, init);
 	CgScalars* sc0 = c0->scal.as<CgScalars>();
 	auto nbv      = [](fi_ctx* c) { return stream_blocks(c->g.nown); };
@@ -1448,8 +1495,31 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 				                   vown<T>(c, P), vown<T>(c, Q), vown<T>(c, X), vown<T>(c, Rv), c->partial.as<double>(), field_part(c));
 			}
 		}
-		if (by_field) { hipLaunchKernelGGL(k_field_max, dim3(1), dim3(kThreads), 0, st, sc0, field_part(c0), nbv(c0)); }
-		mg_reduce(R, nbv, kMgResid);
+		if (by_field && field_slabs == 0) {
+			hipLaunchKernelGGL(k_field_max, dim3(1), dim3(kThreads), 0, st, sc0, field_part(c0), nbv(c0));
+			mg_reduce(R, nbv, kMgResid);
+		} else if (by_field) {
+			// mg_reduce with the maxima on board: local sums and maxima, ONE sum over the slabs of sums[0 .. 3] + rank_max[], the logic
+			for (size_t i = 0; i < R.size(); ++i) {
+				fi_ctx* c = R[i];
+				hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(), c->partial.as<double>(), 1, nbv(c),
+				                   nbv(c), 1);
+				hipLaunchKernelGGL(k_field_max_slot, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(), field_part(c), nbv(c),
+				                   R.size() > 1 ? static_cast<int>(i) : c->rank, field_slabs);
+			}
+			if (R.size() > 1) {
+				hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(1), 0, st, c0->group_scal.as<CgScalars*>(), static_cast<int>(R.size()), 1, 0);
+				hipLaunchKernelGGL(k_group_sum_field, dim3(1), dim3(1), 0, st, c0->group_scal.as<CgScalars*>(), static_cast<int>(R.size()));
+			} else {
+				allreduce_sum(c0, sc0->sums, 4 + 2 * field_slabs);
+			}
+			for (fi_ctx* c : R) {
+				hipLaunchKernelGGL(k_mg_logic, dim3(1), dim3(kThreads), 0, c->stream, c->scal.as<CgScalars>(), static_cast<const double*>(nullptr), 0,
+				                   kMgResid);
+			}
+		} else {
+			mg_reduce(R, nbv, kMgResid);
+		}
 		++steps;
 		done = steps < predicted ? 0 : read_flag();
 		if (done) { continue; }

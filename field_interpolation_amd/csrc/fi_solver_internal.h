@@ -446,8 +446,16 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 			// slowly converging solve as its rate: tests/stress_field_rule.py, errors up to 16 x the tolerance); the step: the
 			// largest of the last four, each carried forward at that rate.  A margin (kFieldMargin) for the smooth modes,
 			// which converge last; no estimate while the residual falls by less than 5 % per iteration.
-			const double dmax = __longlong_as_double(static_cast<long long>(sc->dmax_bits));  // (k_field_max, just before)
-			const double xmax = __longlong_as_double(static_cast<long long>(sc->xmax_bits));
+			double dmax = __longlong_as_double(static_cast<long long>(sc->dmax_bits));  // (k_field_max, just before)
+			double xmax = __longlong_as_double(static_cast<long long>(sc->xmax_bits));
+			if (sc->field_ranks > 0) {  // over slabs: every slab's pair, summed into place with r.r (k_field_max_slot)
+				dmax = 0.0;
+				xmax = 0.0;
+				for (int r = 0; r < sc->field_ranks; ++r) {
+					dmax = fmax(dmax, sc->rank_max[2 * r]);
+					xmax = fmax(xmax, sc->rank_max[2 * r + 1]);
+				}
+			}
 			sc->field_est = -1.0;
 			const int k = sc->iter;  // (restarts are off under this rule: the iterations count from the solve's start)
 			if (sc->bb > 0.0 && xmax > 0.0 && prev > 0.0 && isfinite(s)) {

@@ -262,7 +262,8 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * cheaper. */
 #define FI_OPT_MG_TERMS 10
 #define FI_OPT_MG_RATIO 11
-/* FI_OPT_FIELD_TOLERANCE (default 0 = off; V-cycle PCG on an undivided lattice): stop by the FIELD, not by the residual --
+/* FI_OPT_FIELD_TOLERANCE (default 0 = off; V-cycle PCG; over slabs up to 16 of them -- their maxima travel with the r . r
+ * sum of the iteration's all-reduce, every rank decides on the same numbers): stop by the FIELD, not by the residual --
  * the north-star's accuracy "values within 1e-5 of the CPU reference's double solve" (sparse_linear.cpp:154-184) is a statement
  * about x, and what a residual buys in x varies with the lattice, the data and the weights by three orders of magnitude
  * (kappa ~ side^4).  x* - x_k is the sum of the steps still to come; every iteration the solver holds the last step's size,
