@@ -327,6 +327,7 @@ struct CgScalars {  // lives in device memory; kernels read/write it, the host p
 	unsigned long long dmax_bits, xmax_bits;
 	// ... and the last kFieldHist iterations' relative residuals and relative steps (slot: iteration % kFieldHist)
 	double hist_r[32], hist_s[32], hist_r0;  // (hist_r0: the start residual)
+	double hist_t[32];  // ... and the steps' squared A-norms, alpha_k r_k . z_k (||x* - x_k||_A^2 is the sum of those still to come)
 };
 constexpr int kFieldHist = 32;
 constexpr int kFieldRanks = 16;  // slabs the field rule runs over (CgScalars::rank_max)

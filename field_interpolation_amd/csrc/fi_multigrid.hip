@@ -1522,6 +1522,12 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		}
 		++steps;
 		done = steps < predicted ? 0 : read_flag();
+		if (by_field && tuning_switch("FI_FIELD_TRACE")) {  // (timing builds: the rule's history, iteration by iteration -- tools/scratch/r6_field_trace.py)
+			if (steps < predicted) { (void)read_flag(); }
+			const CgScalars& h = *c0->scal_host;
+			std::fprintf(stderr, "field trace %d r %.6e s %.6e t2 %.6e est %.6e done %d\n", h.iter, h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0,
+			             h.hist_s[h.iter % kFieldHist], h.hist_t[h.iter % kFieldHist], h.field_est, h.done);
+		}
 		if (done) { continue; }
 		if (mixed) { Tw[0]->bx_dot_done = false; }
 		precondition<T>(R, Tw, Rv, Z, stepped);

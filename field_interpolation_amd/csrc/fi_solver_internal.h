@@ -386,6 +386,8 @@ __device__ inline double twin_scale(const CgScalars* sc) { return sc->tscale > 0
 // scalar steps of the preconditioned recurrence (single block, thread 0)
 enum MgPhase { kMgInitRz = 10, kMgAlpha = 11, kMgResid = 12, kMgBeta = 13, kMgInitRr = 14 };
 constexpr double kFieldMargin = 2.0;  // FI_OPT_FIELD_TOLERANCE: see k_mg_logic(kMgResid)
+constexpr int    kFieldCarry  = 8;    // ... steps carried forward at the rate (CG on an ill-conditioned system converges in stairs: a lull of
+                                      // three to seven iterations with tiny steps and a falling residual, the error unchanged, then the next stair)
 __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const double* __restrict__ partial, int count,
                                                         int phase, int twin_sum = 0)
 {
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 			// iteration, ||e_k|| <= ||x_k - x_(k-1)|| sigma / (1 - sigma).  sigma: the SLOWEST mean decay of the residual norm
 			// over the last 1, 2, 4 .. 16 iterations and over the whole solve (one step's ratio ||r_k|| / ||r_(k-1)|| alone reads a lucky drop of a
 			// slowly converging solve as its rate: tests/stress_field_rule.py, errors up to 16 x the tolerance); the step: the
-			// largest of the last four, each carried forward at that rate.  A margin (kFieldMargin) for the smooth modes,
+			// largest of the last 1 + kFieldCarry, each carried forward at that rate.  A margin (kFieldMargin) for the smooth modes,
 			// which converge last; no estimate while the residual falls by less than 5 % per iteration.
 			double dmax = __longlong_as_double(static_cast<long long>(sc->dmax_bits));  // (k_field_max, just before)
 			double xmax = __longlong_as_double(static_cast<long long>(sc->xmax_bits));
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 				}
 				sc->hist_r[k % kFieldHist] = rb;
 				sc->hist_s[k % kFieldHist] = dmax / xmax;
+				sc->hist_t[k % kFieldHist] = sc->alpha * sc->rz;  // (rz: still this step's, kMgBeta replaces it)
 				double sigma = rb / ra;
 				for (int lag = 2; lag <= k && lag < kFieldHist; lag *= 2) {
 					const double r0 = sc->hist_r[(k - lag) % kFieldHist];
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 						// estimates 3 to 30 times the true error)
 						sigma = rb / ra;
 					} else {
-						for (int j = 1; j <= 3 && j < k; ++j) {
+						for (int j = 1; j <= kFieldCarry && j < k; ++j) {
 							const double sj = sc->hist_s[(k - j) % kFieldHist] * f;
 							step = sj > step ? sj : step;
 							f *= sigma;

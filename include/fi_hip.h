@@ -270,15 +270,16 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * ||x_k - x_(k-1)||_inf = |alpha| ||p||_inf (a by-product of the pass that updates x), and the history of the residual norms.
  * If the steps shrink by sigma per iteration, ||e_k||_inf <= ||x_k - x_(k-1)||_inf sigma / (1 - sigma).  sigma is the SLOWEST
  * mean decay of the residual norm over the last 1, 2, 4, 8, 16 iterations and over the whole solve, the step the largest of
- * the last four carried forward at that rate (a slowly converging solve has lucky single drops; its late, faster phases
- * are not the tail's rate); where every one of those windows gains more than a factor 2 per iteration -- a healthy V-cycle
- * -- the last step and its own ratio ||r_k|| / ||r_(k-1)|| are used.  The solve ends when twice that (a margin for the
- * smooth modes, which converge last) is within the tolerance times ||x_k||_inf; no estimate is formed while the residual
- * falls by less than 5 % per iteration (the residual floor then ends the solve).  The `tol` of fi_solve_cg is ignored (the
- * precision's floor stands in); no constant depends on the workload.  An estimate, not a bound: over 200 random 3-D
- * problems (tests/stress_field_rule.py: value data and oriented points, 1 to 3 levels, 6 to 650 iterations) the true error
- * exceeded the tolerance in 6 cases, by at most 3.4 x; the goldens of configs 2 to 5 end 2 to 100 x below it.  fi_stats:
- * field_estimate, field_per_residual. */
+ * the last nine carried forward at that rate (a slowly converging solve has lucky single drops; its late, faster phases
+ * are not the tail's rate; and CG on an ill-conditioned system converges in stairs -- a lull of several iterations with tiny
+ * steps and a falling residual while the error stands still, then the next stair); where every one of those windows gains
+ * more than a factor 2 per iteration -- a healthy V-cycle -- the last step and its own ratio ||r_k|| / ||r_(k-1)|| are used.
+ * The solve ends when twice that (a margin for the smooth modes, which converge last) is within the tolerance times
+ * ||x_k||_inf; no estimate is formed while the residual falls by less than 5 % per iteration (the residual floor then ends
+ * the solve).  The `tol` of fi_solve_cg is ignored (the precision's floor stands in); no constant depends on the workload.
+ * An estimate, not a bound: over 200 random 3-D and 150 random 2-D problems (tests/stress_field_rule.py: value data and
+ * oriented points, 1 to 5 levels, 6 to 650 iterations) the true error exceeded the tolerance in 3 and 9 cases, by at most
+ * 1.7 x and 2.4 x; the goldens of configs 2 to 5 end 8 to 100 x below it.  fi_stats: field_estimate, field_per_residual. */
 #define FI_OPT_FIELD_TOLERANCE 12
 int fi_set_option(fi_ctx* ctx, int option, double value);
 

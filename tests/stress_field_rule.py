@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised sweep of the field stop rule (FI_OPT_FIELD_TOLERANCE; run on the GPU box): 3-D lattices of random shape, value
+"""Randomised sweep of the field stop rule (FI_OPT_FIELD_TOLERANCE; run on the GPU box): 3-D (seeds from 80000 on: 2-D) lattices of random shape, value
 data or oriented points, random weights, levels and tolerance; the field the rule stops at against the same context's
 solve to the fp64 floor.  The rule is an estimate (twice the extrapolated difference of consecutive iterates): a case
 FAILS when the true error exceeds 2 x the tolerance, and the sweep prints the distribution of error / tolerance.
@@ -22,6 +22,8 @@ def one_case(seed):
     rng = np.random.default_rng(seed)
     big = rng.random() < 0.25
     sizes = [int(rng.integers(40, 161 if big else 73)) for _ in range(3)]
+    if seed >= 80000:   # (seeds from 80000 on: 2-D lattices, the shapes of configs 2 and 3)
+        sizes = [int(rng.integers(96, 1025 if big else 385)) for _ in range(2)]
     sizes[0] = max(8, (sizes[0] // 4) * 4)
     kw = dict(model_2=float(rng.uniform(0.2, 1.0)))
     if rng.random() < 0.4:
@@ -36,7 +38,7 @@ def one_case(seed):
     pos, nrm = sphere_points(rng, sizes, npts, noise=float(rng.uniform(0.1, 1.0)))
     val = None if sdf else rng.normal(size=npts).astype(np.float32)
     mixed = rng.random() < 0.7
-    levels = int(rng.integers(1, 4))
+    levels = int(rng.integers(1, 4)) if len(sizes) == 3 else int(rng.integers(1, 6))
     tol = float(rng.choice([1e-4, 1e-5, 1e-6]))
     desc = "seed %d: sizes %s pts %d sdf %d gk %d %s levels %d tol %.0e %s" % (
         seed, sizes, npts, sdf, gk, "mixed" if mixed else "fp64 V-cycle", levels, tol, {k: round(v, 3) for k, v in kw.items()})
