@@ -169,7 +169,7 @@ def test_mixed_precision_over_slabs(fi):
 @pytest.mark.parametrize("sdf,mixed,sizes,nranks", [(False, True, [48, 40, 64], 4), (True, True, [32, 32, 64], 2), (False, False, [40, 36, 72], 3)])
 def test_field_rule_over_slabs(fi, sdf, mixed, sizes, nranks):
     """FI_OPT_FIELD_TOLERANCE over slabs: every slab's two maxima travel with the r . r sum (CgScalars::rank_max), every member
-    decides on the same numbers -- the same iteration count (give or take one: the V-cycle over slabs differs in rounding)
+    decides on the same numbers -- the same iteration count (give or take two: the V-cycle over slabs differs in rounding)
     and an estimate of the undivided solve's size, the field within the tolerance of the solve to the fp64 floor."""
     rng = np.random.default_rng(31 + nranks)
     pos, nrm = sphere_points(rng, sizes, 900, noise=0.3)
@@ -197,7 +197,7 @@ def test_field_rule_over_slabs(fi, sdf, mixed, sizes, nranks):
         assert st["converged"] == 1 and 0 < st["field_estimate"] <= tol and st["field_rounds"] == 1, st
         got.append((it, st["field_estimate"], rel_inf(f.solution_f64(), ref)))
     (it1, est1, err1), (itg, estg, errg) = got
-    assert abs(itg - it1) <= 1, got
+    assert abs(itg - it1) <= max(2, it1 // 10), got   # (the estimate hovers near the tolerance for a few iterations of a long solve)
     assert errg <= 2 * tol and err1 <= 2 * tol, got
     # (the estimates agree to a few per cent while the two residual histories do -- the first two cases; a solve of 53
     # iterations whose V-cycle over slabs rounds differently ends on a different step size)
