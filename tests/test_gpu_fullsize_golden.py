@@ -229,3 +229,27 @@ def test_the_field_rule_on_random_problems(fi, capsys):
         worst = max(worst, ratio)
     with capsys.disabled():
         print("\n[the field rule on 16 random problems] largest true error / tolerance %.2f" % worst)
+
+
+def test_config4_over_eight_slabs_against_the_oracle(fi, capsys):
+    """The lattice of `bench.py --gpus 8` (256^3 cut into eight slabs of 32 planes; the loop-back group: the RCCL path's
+    kernels, geometry, ownership rules and reductions in one process) with bench.py's settings and stop rule -- over slabs the
+    slabs' maxima ride on the r . r sum -- against the oracle's fp64 solution: within the north-star's 1e-5, in the
+    undivided solve's iterations give or take one."""
+    from field_interpolation_amd import bench_settings as bs
+    from field_interpolation_amd import synth
+    g = np.load(os.path.join(GOLDEN, "config4_256_oracle_f64.npz"))
+    sizes, w, pos, val = synth.config4(seed=3)
+    grp = fi.LatticeGroup(sizes, 8, dtype="f64")
+    grp.add_field_constraints(w)
+    bs.configure(grp, bs.SETTINGS[4]["levels"], bs.SETTINGS[4]["coarse_tol"], by_field=True)
+    grp.add_points(w.data_pos, w.value_kernel, 0.0, w.gradient_kernel, pos, None, None, values=val)
+    grp.assemble()
+    x, it, rel = grp.solve_cg(None, 0, bs.SETTINGS[4]["tol"])
+    st = grp.stats()
+    err = _against_sample(grp.solution_f64(), g)
+    with capsys.disabled():
+        print("\n[config 4 at 256^3 over eight slabs, against the oracle] %d iterations, stopped by the field at residual %.2e "
+              "(estimate %.2e), field error %.2e" % (it, st["stop_residual"], st["field_estimate"], err))
+    assert st["converged"] == 1 and 0 < st["field_estimate"] <= FIELD_TOL and 6 <= it <= 8
+    assert err <= FIELD_TOL
