@@ -675,7 +675,10 @@ bool poly_smoother_ok(const RankSet& R)
 	for (const fi_ctx* c : R) {
 		// 3-D levels only: the 2-D tile kernel applies its cells in the same single launch, so the Chebyshev smoother in
 		// the full operator costs no more per step there and is the better smoother (config 3: 13 iterations against 38)
-		if (c->mg_smoother != 1 || !c->value_rows_only || !c->march.valid || !stencil_full_epi_available(c) || c->generic.ntrip != 0 || c->any_trip) {
+		// (FI_POLY_SMOOTHER_ANY_DATA, timing builds: the experiment of profiles/r6_ablation.md section 9 -- oriented points on
+		// this smoother)
+		const bool rows_ok = c->value_rows_only || tuning_switch("FI_POLY_SMOOTHER_ANY_DATA");
+		if (c->mg_smoother != 1 || !rows_ok || !c->march.valid || !stencil_full_epi_available(c) || c->generic.ntrip != 0 || c->any_trip) {
 			return false;
 		}
 	}
