@@ -28,7 +28,7 @@ void note_segment(LatticeField* field, detail::Segment&& seg)
 	seg.row1  = field->eq.rhs.size();
 	seg.trip1 = field->eq.triplets.size();
 	if (seg.trip1 == seg.trip0) { return; }  // nothing appended
-	seg.checksum = detail::sample_checksum(field->eq.triplets, seg.trip0, seg.trip1);
+	seg.checksum = detail::sample_checksum(field->eq.triplets, seg.trip0, seg.trip1, field->eq.rhs, seg.row0, seg.row1);
 	next->segments.push_back(std::move(seg));
 	field->eq.recipe = std::move(next);
 }

@@ -158,7 +158,7 @@ struct RowsOnGpu {
 			}
 			row_end  = s.row1;
 			trip_end = s.trip1;
-			if (detail::sample_checksum(eq.triplets, s.trip0, s.trip1) != s.checksum) { return false; }
+			if (detail::sample_checksum(eq.triplets, s.trip0, s.trip1, eq.rhs, s.row0, s.row1) != s.checksum) { return false; }
 			if (s.kind == detail::Segment::kModel) {
 				if (model) { return false; }
 				model = &s;

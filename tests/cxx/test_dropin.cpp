@@ -325,6 +325,12 @@ int main()
 			g.eq.triplets.front().value *= 1.5f;
 			auto d = fi::solve_tiled_with_guess(g.eq, zero, g.sizes, o);
 			require(d.size() == zero.size() && !fi::last_solve_was_matrix_free(), "recipe: edited rows fall back to the generic path");
+			// ... or a noted row's right-hand side (the data rows' targets: the note would re-make them from the points)
+			fi::LatticeField g2 = f;
+			const size_t border_rows = 2 * ((96 + 6) / 7);  // (with_border's rows come last and are nobody's: the row in front of them)
+			g2.eq.rhs[g2.eq.rhs.size() - border_rows - 1] += 0.5f;
+			auto d2 = fi::solve_tiled_with_guess(g2.eq, zero, g2.sizes, o);
+			require(d2.size() == zero.size() && !fi::last_solve_was_matrix_free(), "recipe: an edited right-hand side falls back to the generic path");
 			// a copy of the field keeps the note; rows appended to an EXISTING noted row cannot be expressed: generic
 			fi::LatticeField h = f;
 			h.eq.triplets.emplace_back(0, 5, 0.25f);
