@@ -1585,7 +1585,11 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		c->last_mg_iterations = timed_out || h.done == 2 ? 0 : h.iter;  // (the same on every rank: the scalars are sums over all)
 		c->last_mg_tol        = tolerance;
 		if (R.size() == 1 && c0->predictable_start && !timed_out && h.done != 2) { remember_iterations(c, 1, tolerance, h.iter); }
-		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && (!c0->verify_residual || by_field)))) ? 1 : 0;
+		// by the field: met when the estimate says so -- or, in fp64, when the recurrence has reached the precision's floor (the
+		// field is then as converged as the arithmetic allows).  An fp32 solve that ends at ITS floor (2e-7) with the estimate
+		// above the tolerance has not delivered what was asked for: converged = 0, fi_stats::field_estimate says how far off.
+		const bool field_ok = by_field && h.done == 1 && ((h.field_est >= 0.0 && h.field_est <= h.field_tol) || sizeof(T) == 8);
+		c->stats.converged    = (!timed_out && (h.done == 4 || h.done == 5 || (h.done == 1 && (by_field ? field_ok : !c0->verify_residual)))) ? 1 : 0;
 		c->stats.rel_residual = h.bb > 0 ? std::sqrt(h.rr / h.bb) : 0.0;
 		c->stats.restarts     = h.restarts;
 		c->stats.verified_residual = (h.restarts > 0 && h.bb > 0) ? std::sqrt(h.true_rr / h.bb) : -1.0;

@@ -84,7 +84,9 @@ typedef struct fi_stats {
 	long   num_cells;          /* distinct lattice cells holding data */
 	long   num_generic_rows;   /* rows held in generic (COO) form */
 	int    iterations;         /* CG iterations of the last solve */
-	int    converged;          /* 1: ||r|| <= tol*||Atb|| reached; 0: stopped by max_iterations */
+	int    converged;          /* 1: ||r|| <= tol*||Atb|| reached; 0: stopped by max_iterations.  Under FI_OPT_FIELD_TOLERANCE: 1 when the
+	                              field estimate is within the tolerance (or an fp64 recurrence has reached its floor: as converged as
+	                              the arithmetic allows); 0 also for an fp32 solve that ends at ITS floor with the estimate above it */
 	double rel_residual;       /* recurrence ||r||/||Atb|| at exit */
 	double assemble_ms;        /* GPU time of the last fi_assemble */
 	double solve_ms;           /* GPU time of the last solve */
@@ -276,10 +278,13 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * more than a factor 2 per iteration -- a healthy V-cycle -- the last step and its own ratio ||r_k|| / ||r_(k-1)|| are used.
  * The solve ends when twice that (a margin for the smooth modes, which converge last) is within the tolerance times
  * ||x_k||_inf; no estimate is formed while the residual falls by less than 5 % per iteration (the residual floor then ends
- * the solve).  The `tol` of fi_solve_cg is ignored (the precision's floor stands in); no constant depends on the workload.
- * An estimate, not a bound: over 200 random 3-D and 150 random 2-D problems (tests/stress_field_rule.py: value data and
- * oriented points, 1 to 5 levels, 6 to 650 iterations) the true error exceeded the tolerance in 3 and 9 cases, by at most
- * 1.7 x and 2.4 x; the goldens of configs 2 to 5 end 8 to 100 x below it.  fi_stats: field_estimate, field_per_residual. */
+ * the solve) and no stop before the third iteration (CG's first steps remove the rough part of the error: small steps, a
+ * falling residual, the smooth part not yet moved).  The `tol` of fi_solve_cg is ignored (the precision's floor stands in:
+ * 1e-13 in fp64, 2e-7 in fp32 -- an fp32 solve that ends there with the estimate above the tolerance reports converged = 0);
+ * no constant depends on the workload.  An estimate, not a bound: over 200 random 3-D, 150 random 2-D and 100 random fp32
+ * problems (tests/stress_field_rule.py: value data and oriented points, 1 to 5 levels, 6 to 650 iterations) the true error
+ * exceeded the tolerance in 3, 9 and 0 cases, by at most 1.7 x and 2.4 x; the goldens of configs 2 to 5 end 8 to 100 x
+ * below it.  fi_stats: field_estimate, field_per_residual. */
 #define FI_OPT_FIELD_TOLERANCE 12
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
