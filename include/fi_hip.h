@@ -283,7 +283,7 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * 1e-13 in fp64, 2e-7 in fp32 -- an fp32 solve that ends there with the estimate above the tolerance reports converged = 0);
  * no constant depends on the workload.  An estimate, not a bound: over 200 random 3-D, 150 random 2-D and 100 random fp32
  * problems (tests/stress_field_rule.py: value data and oriented points, 1 to 5 levels, 6 to 650 iterations) the true error
- * exceeded the tolerance in 3, 9 and 0 cases, by at most 1.7 x and 2.4 x; the goldens of configs 2 to 5 end 8 to 100 x
+ * exceeded the tolerance in 4, 11 and 1 cases (warm starts included), by at most 1.7 x, 2.4 x and 1.1 x; the goldens of configs 2 to 5 end 8 to 100 x
  * below it.  fi_stats: field_estimate, field_per_residual. */
 #define FI_OPT_FIELD_TOLERANCE 12
 int fi_set_option(fi_ctx* ctx, int option, double value);
