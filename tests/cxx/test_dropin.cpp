@@ -366,6 +366,63 @@ int main()
 			require(max_rel(a, b) <= 5e-2f, "recipe: the two paths agree at the reference's default tolerance (1e-3 residual)");
 		}
 	}
+	// (c) the note in other orders and dimensions: a 3-D lattice whose rows were made by hand in the order points, rows of the
+	//     caller's own, model rows, more points (value rows with another kernel) -- and a 1-D lattice; both paths, the same field
+	{
+		auto both_paths = [&](const fi::LatticeField& f, const char* what, float tol_between) {
+			fi::SolveOptions o;
+			o.error_tolerance = 1e-7f;
+			o.max_iterations = 20000;
+			size_t n = 1;
+			for (int s : f.sizes) { n *= static_cast<size_t>(s); }
+			const std::vector<float> zero(n, 0.0f);
+			auto a = fi::solve_tiled_with_guess(f.eq, zero, f.sizes, o);
+			const bool mf = fi::last_solve_was_matrix_free();
+			setenv("FI_DROPIN_NO_RECIPE", "1", 1);
+			auto b = fi::solve_tiled_with_guess(f.eq, zero, f.sizes, o);
+			unsetenv("FI_DROPIN_NO_RECIPE");
+			char msg[160];
+			std::snprintf(msg, sizeof msg, "recipe: %s runs matrix-free and equals the generic rows", what);
+			require(a.size() == n && b.size() == n && mf && !fi::last_solve_was_matrix_free() && max_rel(a, b) <= tol_between, msg);
+		};
+		{
+			const int S[3] = {24, 20, 28};
+			std::vector<float> pos, nrm, pos2;
+			for (int i = 0; i < 300; ++i) {
+				const float a = 6.2831853f * i / 300, b = 3.1415927f * (0.15f + 0.7f * ((i * 37) % 300) / 300.0f);
+				const float d[3] = {std::sin(b) * std::cos(a), std::sin(b) * std::sin(a), std::cos(b)};
+				for (int k = 0; k < 3; ++k) {
+					pos.push_back(0.5f * (S[k] - 1) + 0.3f * (S[k] - 1) * d[k]);
+					nrm.push_back(d[k]);
+				}
+			}
+			for (int i = 0; i < 40; ++i) {
+				for (int k = 0; k < 3; ++k) { pos2.push_back(1.5f + std::fmod(7.31f * i + 2.17f * k, static_cast<float>(S[k]) - 3.0f)); }
+			}
+			fi::LatticeField f{{S[0], S[1], S[2]}};
+			fi::Weights w;
+			fi::add_points(&f, w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, 300, pos.data(), nrm.data(), nullptr);
+			fi::add_equation(&f.eq, fi::Weight{0.2f}, fi::Rhs{3.0f}, {{0, 1.0f}});                       // nobody's rows, in between
+			fi::add_equation(&f.eq, fi::Weight{0.2f}, fi::Rhs{-2.0f}, {{S[0] * S[1] * S[2] - 1, 1.0f}, {5, 0.5f}});
+			fi::add_field_constraints(&f, w);
+			fi::add_points(&f, 0.7f, fi::ValueKernel::kLinearInterpolation, 0.0f, w.gradient_kernel, 40, pos2.data(), nullptr, nullptr);
+			both_paths(f, "a 3-D lattice (points, own rows, model, more points)", 2e-3f);
+		}
+		{
+			fi::LatticeField f{{300}};
+			fi::Weights w;
+			w.model_1 = 0.1f;
+			fi::add_field_constraints(&f, w);
+			std::vector<float> pos, nrm;
+			for (int i = 0; i < 25; ++i) {
+				pos.push_back(3.3f + 11.7f * i);
+				nrm.push_back(i % 2 ? 1.0f : -1.0f);
+			}
+			fi::add_points(&f, w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, 25, pos.data(), nrm.data(), nullptr);
+			fi::add_equation(&f.eq, fi::Weight{1.0f}, fi::Rhs{4.0f}, {{150, 1.0f}});
+			both_paths(f, "a 1-D lattice", 2e-3f);
+		}
+	}
 	fi::clear_context_cache();   // (and a call after it still works: the cache refills)
 	{
 		fi::LinearEquation eq;
