@@ -450,8 +450,22 @@ __global__ __launch_bounds__(kThreads) void k_sum_to_slot2(CgScalars* sc, const 
 	if (threadIdx.x == 0) { sc->sums[2] = out[0]; }
 }
 
-int mg_degree() { const char* e = tuning_switch("FI_MG_DEGREE"); return e && atoi(e) > 0 ? atoi(e) : 4; }  // config 3 / 5: degree 2 -> 4 halves the solve time
-double mg_ratio() { const char* e = tuning_switch("FI_MG_RATIO"); return e && atof(e) > 1 ? atof(e) : 10.0; }
+// The Chebyshev smoother in the full operator (every level that does not run the polynomial smoother: 2-D lattices, oriented
+// points, fp64 levels): degree and interval [lambda / ratio, 1.1 lambda].  Round 2: degree 2 -> 4 halved the solve time of
+// configs 3 / 5.  Round 6, swept under the field stop rule (tools/r6_sweep_sdf_smoother.sh, profiles/r6_sweep_smoother.txt):
+// a wider interval pays -- rediscretised coarse levels correct an SDF's intermediate modes poorly, the smoother has to reach
+// further down -- config 5 (4, 10) 588 ms / 56 iterations, (5, 40) 508 / 40, (6, 40) 513 / 36, (5, 80) 838 / 68 (past 40 the
+// damping at the upper end gives out); config 3 (4, 10) 52.8 ms / 34, (4, 40) 49.1 / 29, (5, 40) 52.7 / 28; config 2 5.1 -> 4.8.
+int mg_degree(const fi_ctx* c)
+{
+	const char* e = tuning_switch("FI_MG_DEGREE");
+	return e && atoi(e) > 0 ? atoi(e) : (c->g.ndim == 3 ? 5 : 4);
+}
+double mg_ratio(const fi_ctx* c)
+{
+	const char* e = tuning_switch("FI_MG_RATIO");
+	return e && atof(e) > 1 ? atof(e) : (c->g.ndim == 3 ? 40.0 : 10.0);
+}
 
 template <typename T>
 void mg_alloc(fi_ctx* c)
@@ -899,8 +913,8 @@ struct TailProgram {
 		RankSet one{c};
 		const bool last = l + 1 == static_cast<int>(chain.size());
 		const bool poly = poly_smoother_ok<float>(one);
-		const int    deg = mg_degree();
-		const double ratio = mg_ratio();
+		const int    deg = mg_degree(c);
+		const double ratio = mg_ratio(c);
 		if (c->lumped) { ok = false; return; }
 		if (last) {
 			if (poly && c->dinv16s_valid && c->data_pinned && !test_switch("FI_MG_COARSEST_CHEB")) {
@@ -990,8 +1004,8 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		return;
 	}
 	if (tail_vcycle<T>(R, b, x)) { return; }  // the small-level engine: this level and all below it in one launch
-	const int deg = mg_degree();
-	const double ratio = mg_ratio();
+	const int deg = mg_degree(R[0]);
+	const double ratio = mg_ratio(R[0]);
 	if (tuning_switch("FI_MG_POLY")) {  // experiment: the polynomial alone as the preconditioner, no coarse correction
 		cheb_smooth<T>(R, b, x, deg, ratio, true);
 		return;

@@ -389,6 +389,7 @@ constexpr double kFieldMargin = 2.0;  // FI_OPT_FIELD_TOLERANCE: see k_mg_logic(
 constexpr int    kFieldMinIter = 3;   // ... no stop before the third iteration: CG's first steps remove the rough part of the error,
                                       // the residual falls and the steps are small while the smooth part has not moved yet (an fp32 2-D
                                       // case of tests/stress_field_rule.py stopped after ONE iteration, 83 % off)
+constexpr double kFieldFast   = 0.3;  // ... every window gains more than this factor per iteration: the last step and its own ratio are used
 constexpr int    kFieldCarry  = 8;    // ... steps carried forward at the rate (CG on an ill-conditioned system converges in stairs: a lull of
                                       // three to seven iterations with tiny steps and a falling residual, the error unchanged, then the next stair)
 __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const double* __restrict__ partial, int count,
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 				}
 				if (sigma < 0.95 && rb > 0.0) {
 					double step = dmax / xmax, f = sigma;
-					if (sigma < 0.5) {
+					if (sigma < kFieldFast) {
 						// every window gains more than a factor 2 per iteration (a healthy V-cycle): the last step and its own
 						// ratio predict the next ones best, and the margin covers the rest (the goldens of configs 2 and 4:
 						// estimates 3 to 30 times the true error)

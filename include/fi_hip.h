@@ -275,7 +275,7 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * the last nine carried forward at that rate (a slowly converging solve has lucky single drops; its late, faster phases
  * are not the tail's rate; and CG on an ill-conditioned system converges in stairs -- a lull of several iterations with tiny
  * steps and a falling residual while the error stands still, then the next stair); where every one of those windows gains
- * more than a factor 2 per iteration -- a healthy V-cycle -- the last step and its own ratio ||r_k|| / ||r_(k-1)|| are used.
+ * more than a factor 3 per iteration -- a healthy V-cycle -- the last step and its own ratio ||r_k|| / ||r_(k-1)|| are used.
  * The solve ends when twice that (a margin for the smooth modes, which converge last) is within the tolerance times
  * ||x_k||_inf; no estimate is formed while the residual falls by less than 5 % per iteration (the residual floor then ends
  * the solve) and no stop before the third iteration (CG's first steps remove the rough part of the error: small steps, a
@@ -283,7 +283,7 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * 1e-13 in fp64, 2e-7 in fp32 -- an fp32 solve that ends there with the estimate above the tolerance reports converged = 0);
  * no constant depends on the workload.  An estimate, not a bound: over 200 random 3-D, 150 random 2-D and 100 random fp32
  * problems (tests/stress_field_rule.py: value data and oriented points, 1 to 5 levels, 6 to 650 iterations) the true error
- * exceeded the tolerance in 4, 11 and 1 cases (warm starts included), by at most 1.7 x, 2.4 x and 1.1 x; the goldens of configs 2 to 5 end 8 to 100 x
+ * exceeded the tolerance in 3, 7 and 1 cases (warm starts included), by at most 1.5 x, 2.4 x and 1.1 x; the goldens of configs 2 to 5 end 8 to 100 x
  * below it.  fi_stats: field_estimate, field_per_residual. */
 #define FI_OPT_FIELD_TOLERANCE 12
 int fi_set_option(fi_ctx* ctx, int option, double value);

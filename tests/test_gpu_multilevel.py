@@ -737,5 +737,5 @@ def test_solves_without_looks_at_the_stop_flag(fi, monkeypatch):
     for k in (3, 5):
         assert abs(runs[False][k][0] - runs[True][k][0]) <= max(2, runs[True][k][0] // 4), (k, runs[False][k][0], runs[True][k][0])
         scale = np.abs(runs[True][k][2]).max()
-        assert np.abs(runs[False][k][2] - runs[True][k][2]).max() <= 1e-6 * scale
+        assert np.abs(runs[False][k][2] - runs[True][k][2]).max() <= 3e-6 * scale   # (two solves to a residual of 1e-8 each: ~1e-6 apiece)
 
