@@ -993,6 +993,45 @@ bool tail_vcycle(RankSet& R, Vec b, Vec x)
 	return true;
 }
 
+template <typename T>
+void vcycle(RankSet& R, Vec b, Vec x);
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_add_scaled(int64_t n, const T* __restrict__ d, T* __restrict__ x, T w)
+{
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		x[i] += w * d[i];
+	}
+}
+
+// The coarse correction of a level: mg_x = V(mg_b) on the coarser level Rc -- and, in timing builds with FI_MG_GAMMA=2 (the
+// experiment of profiles/r6_ablation.md section 11: a W-cycle), once more on what that left: mg_x += omega V(mg_b - A mg_x), through
+// the level's CG vectors r and p (idle inside a cycle); FI_MG_GAMMA_FROM: the first level visited twice; FI_MG_OMEGA: the damping.
+// Levels the small-level engine runs in one launch keep their V-cycle.  NOT shipped: it cuts the iterations of oriented-point
+// problems by a third to two thirds where it works and is INDEFINITE on config 5's hierarchy (the rediscretised coarse levels
+// overcorrect some modes more than threefold -- harmless under CG, fatal once a level iterates on its own correction).
+template <typename T>
+void coarse_correction(RankSet& Rc)
+{
+	vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
+	const char* g = tuning_switch("FI_MG_GAMMA");
+	const char* from = tuning_switch("FI_MG_GAMMA_FROM");  // the first level (1 = the one below the finest) that is visited twice
+	if (!(g && atoi(g) == 2) || !Rc[0]->coarse || !smooth_fused_ok(Rc) || replicated_copies(Rc)) { return; }
+	if (from && Rc[0]->level < atoi(from)) { return; }
+	for (fi_ctx* c : Rc) {
+		if (c->lumped || c->tail_ok) { return; }
+	}
+	for (fi_ctx* c : Rc) { ensure_vectors(c); }
+	halo_exchange(Rc, &fi_ctx::mg_x);
+	for (fi_ctx* c : Rc) { stencil_full_step(c, c->mg_x.p, nullptr, c->mg_b.p, true, c->r.p, 0.0, 0.0, 0.0); }  // r = mg_b - A mg_x
+	vcycle<T>(Rc, &fi_ctx::r, &fi_ctx::p);
+	const char* om = tuning_switch("FI_MG_OMEGA");  // damping of the second visit's correction (1: the plain W-cycle)
+	const T omega = om ? static_cast<T>(atof(om)) : T(1);
+	for (fi_ctx* c : Rc) {
+		hipLaunchKernelGGL((k_add_scaled<T>), dim3(stream_blocks(c->g.nown)), dim3(kThreads), 0, c->stream, c->g.nown, vown<T>(c, &fi_ctx::p),
+		                   vown<T>(c, &fi_ctx::mg_x), omega);
+	}
+}
+
 // x = V(b) on the level of R.  Over slabs every level is a slab decomposition of its own (coarse plane k lives
 // with fine plane 2k): restriction reads one ghost plane of the fine residual, interpolation one of the coarse
 // correction.
@@ -1074,7 +1113,7 @@ void vcycle(RankSet& R, Vec b, Vec x)
 			                   R[i]->g.n[2]);
 		}
 		if (junction) { sum_over_ranks<T>(R, Rc, &fi_ctx::mg_b); }
-		vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
+		coarse_correction<T>(Rc);
 		halo_exchange(Rc, &fi_ctx::mg_x);
 		for (size_t i = 0; i < R.size(); ++i) {
 			const LevelPair L = level_pair(R[i], Rc[i]);
@@ -1102,7 +1141,7 @@ void vcycle(RankSet& R, Vec b, Vec x)
 		                   R[i]->g.n[2]);
 	}
 	if (junction) { sum_over_ranks<T>(R, Rc, &fi_ctx::mg_b); }
-	vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
+	coarse_correction<T>(Rc);
 	halo_exchange(Rc, &fi_ctx::mg_x);
 	for (size_t i = 0; i < R.size(); ++i) {
 		const LevelPair L = level_pair(R[i], Rc[i]);
