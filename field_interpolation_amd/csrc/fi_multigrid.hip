@@ -461,6 +461,18 @@ int mg_degree(const fi_ctx* c)
 	const char* e = tuning_switch("FI_MG_DEGREE");
 	return e && atoi(e) > 0 ? atoi(e) : (c->g.ndim == 3 ? 5 : 4);
 }
+// the coarsest level's solve: a longer polynomial over a wider band (FI_MG_COARSEST_STEPS / FI_MG_COARSEST_RATIO: timing builds)
+int mg_coarsest_steps(const fi_ctx* c)
+{
+	const char* e = tuning_switch("FI_MG_COARSEST_STEPS");
+	return e && atoi(e) > 1 ? atoi(e) : 4 * mg_degree(c) + 4;
+}
+double mg_ratio(const fi_ctx* c);
+double mg_coarsest_ratio(const fi_ctx* c)
+{
+	const char* e = tuning_switch("FI_MG_COARSEST_RATIO");
+	return e && atof(e) > 1 ? atof(e) : 10.0 * mg_ratio(c);
+}
 double mg_ratio(const fi_ctx* c)
 {
 	const char* e = tuning_switch("FI_MG_RATIO");
@@ -922,7 +934,7 @@ struct TailProgram {
 				residual(l);
 				poly_ops(l, Rr, -1, X);
 			} else {
-				cheb_ops(l, 4 * deg + 4, 10.0 * ratio, true);
+				cheb_ops(l, mg_coarsest_steps(c), mg_coarsest_ratio(c), true);
 			}
 			return;
 		}
@@ -1084,7 +1096,7 @@ void vcycle(RankSet& R, Vec b, Vec x)
 			post_smooth();
 			return;
 		}
-		cheb_smooth<T>(R, b, x, 4 * deg + 4, 10.0 * ratio, true);
+		cheb_smooth<T>(R, b, x, mg_coarsest_steps(R[0]), mg_coarsest_ratio(R[0]), true);
 		return;
 	}
 	RankSet Rc = coarse_of(R);
