@@ -1029,6 +1029,9 @@ void coarse_correction(RankSet& Rc)
 	const char* from = tuning_switch("FI_MG_GAMMA_FROM");  // the first level (1 = the one below the finest) that is visited twice
 	if (!(g && atoi(g) == 2) || !Rc[0]->coarse || !smooth_fused_ok(Rc) || replicated_copies(Rc)) { return; }
 	if (from && Rc[0]->level < atoi(from)) { return; }
+	if (const char* to = tuning_switch("FI_MG_GAMMA_TO")) {  // ... and the last one
+		if (Rc[0]->level > atoi(to)) { return; }
+	}
 	for (fi_ctx* c : Rc) {
 		if (c->lumped || c->tail_ok) { return; }
 	}
