@@ -1611,6 +1611,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	FI_HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	FI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	if (tuning_switch("FI_MG_LOOP_DBG")) { std::fprintf(stderr, "cg_run_mg: %d host steps, predicted %d, device iterations %d\n", steps, predicted, c0->scal_host->iter); }
 	const CgScalars h = *c0->scal_host;
 	int used = samples < h.iter ? samples : h.iter;
 	double sum_ms = 0;
