@@ -148,6 +148,14 @@ def test_error_conventions(fi):
         fi.LatticeField([4, 4, 4, 4])      # MAX_DIM = 3 (hpp:44)
     with pytest.raises(ValueError):
         fi.sdf_from_points([4, 4], fi.Weights(), None)      # CHECK_NOTNULL_F(positions), cpp:382
+    # options: out-of-range values are refused, the context keeps what it had
+    for bad in (-1e-5, 1.0, 2.0):
+        with pytest.raises(FiError):
+            f.set_field_tolerance(bad)
+    f.set_field_tolerance(0.0)
+    f.set_field_tolerance(1e-5)
+    with pytest.raises(FiError):
+        f.set_mixed_precision(True)       # an FI_F32 context
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
