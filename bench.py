@@ -221,7 +221,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=tol, dtype=dt, by_field=by_field,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
                     multigrid=True, mixed=dt == "f64", poly=0, points=npts, text=text, field_tol=bs.FIELD_TOLERANCE, more=more,
-                    seed=seeds[0])
+                    seed=seeds[0], kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle)
     if cfg == 5:
         side = args.side or 512
         npts = args.points or int(round(5_000_000 * (side / 512.0) ** 2))
@@ -231,7 +231,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, field_tol=bs.FIELD_TOLERANCE, more=[], seed=4,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, field_tol=bs.FIELD_TOLERANCE, more=[], seed=4,
                     text="config5: 3D %d^3 SDF from %d oriented points (sdf_from_points, default Weights)" % (side, npts))
     if cfg == 3:
         side = args.side or 4096
@@ -242,7 +242,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, field_tol=bs.FIELD_TOLERANCE, more=[], seed=2,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, field_tol=bs.FIELD_TOLERANCE, more=[], seed=2,
                     text="config3: 2D %dx%d SDF from %d oriented points (triangle + inverted circle)" % (side, side, 2 * pps))
     if cfg == 2:
         side = args.side or 1024
@@ -253,7 +253,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, field_tol=bs.FIELD_TOLERANCE, more=[], seed=1,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, field_tol=bs.FIELD_TOLERANCE, more=[], seed=1,
                     text="config2: 2D %dx%d lattice, %d noisy value constraints, model_2=10" % (side, side, npts))
     raise SystemExit("--config must be 2, 3, 4 or 5 (config 1 is the CPU-runnable 1-D case: tests/)")
 
@@ -279,6 +279,7 @@ def main():
                     help="config 4: the fp32 / residual-1e-5 mode of rounds 1-3 as the line's value (field error 2e-3: outside "
                          "the north-star's tolerance); the default is the solver that meets it")
     ap.add_argument("--levels", type=int, default=None, help="coarser levels (config 4: coarse-to-fine start; 0: none)")
+    ap.add_argument("--kcycle", type=int, default=None, help="FI_OPT_MG_KCYCLE: coarse levels corrected by two flexible-CG steps (default: the configuration's setting)")
     ap.add_argument("--coarse-tol", type=float, default=0.0)
     ap.add_argument("--multigrid", action="store_true", help="config 4: V-cycle preconditioned CG")
     ap.add_argument("--poly", type=int, default=4, help="terms of the Chebyshev polynomial preconditioner (0: Jacobi-PCG)")
@@ -344,6 +345,8 @@ def main():
         if cfg.get("by_field"):
             from field_interpolation_amd import bench_settings as bs
             field.set_field_tolerance(bs.FIELD_TOLERANCE)
+        if cfg.get("kcycle", 0) > 0 and cfg["multigrid"] and cfg["levels"] > 0:
+            field.set_kcycle(cfg["kcycle"])
 
     def build(slabs):
         """slabs: ONE lattice, a slab per rank, halo planes and dot products over RCCL.  not slabs (--allow-replicas, only
@@ -674,7 +677,7 @@ def main():
             fs.add_field_constraints(w_s)
             side_ratio = max(wl["sizes"]) // max(sz)
             lv = max(1, wl["levels"] - int(round(np.log2(max(side_ratio, 1)))))     # the same coarsest lattice
-            bs.configure(fs, lv, wl["coarse_tol"], by_field=wl.get("by_field", False))
+            bs.configure(fs, lv, wl["coarse_tol"], by_field=wl.get("by_field", False), kcycle=wl.get("kcycle", 0))
             fs.add_points(w_s.data_pos, w_s.value_kernel, w_s.data_gradient if nrm_s is not None else 0.0, w_s.gradient_kernel,
                           pos_s, nrm_s, None, values=val_s)
             fs.assemble()

@@ -304,6 +304,11 @@ class LatticeField:
         instead of at a residual; the `tol` of solve_cg is then ignored.  0: the residual rule.  stats(): field_estimate, field_per_residual, stop_residual."""
         check(_capi.lib().fi_set_option(self._h, 12, float(tol)))
 
+    def set_kcycle(self, levels):
+        """FI_OPT_MG_KCYCLE: the first `levels` coarse levels corrected by two flexible-CG steps each (a K-cycle); 0: the V-cycle."""
+        check(_capi.lib().fi_set_option(self._h, 13, float(levels)))
+        self._dirty = True
+
     def set_polynomial(self, terms, ratio=None):
         """FI_OPT_POLY_TERMS / FI_OPT_POLY_RATIO: CG preconditioned by a Chebyshev polynomial of `terms` terms
         (0: the Jacobi diagonal).  No re-assembly needed."""

@@ -37,25 +37,29 @@ def slab_residual(config, sizes):
 #            coarser levels, tolerance of the start's levels, BASELINE's residual
 SETTINGS = {
     4: dict(levels=3, coarse_tol=3e-4, tol=1e-5),
-    5: dict(levels=6, coarse_tol=1e-2, tol=1e-6),
+    # (kcycle, round 6: FI_OPT_MG_KCYCLE on the first four coarse levels -- 44 -> 17 iterations, 568 -> 371 ms; 1 / 2 / 3 levels: 525 / 413 / 386)
+    5: dict(levels=6, coarse_tol=1e-2, tol=1e-6, kcycle=4),
     # (hierarchy depth and the levels' tolerance: tools/r4_sweep_c23.sh, tools/r5_sweep_levels.sh -- the levels of a
     # coarse-to-fine start are worth a loose solve only: config 3 with 7 levels to 1e-4 57.6 ms per step, 8 levels to 1e-1 28.4)
     # (round 6, under the field rule: 9 levels -- the coarsest 8^2 -- 45 ms and 26 iterations against 52 / 34 with 8; 7 levels: 129 / 93)
-    3: dict(levels=9, coarse_tol=1e-1, tol=1e-5),
+    # (kcycle 2: 26 -> 11 iterations, 45.5 -> 40.1 ms; 1: 43.6, 3: 41.8, 4: 59 -- the small levels' launches)
+    3: dict(levels=9, coarse_tol=1e-1, tol=1e-5, kcycle=2),
     # (round 5, profiles/r5_sweep_levels.txt: 3 levels -- the coarsest 128^2 -- 4.0 ms per step and 8 iterations, 4 levels 4.8 / 9, 2 levels 9.9 / 25)
     2: dict(levels=3, coarse_tol=1e-1, tol=1e-5),
 }
 
 
-def configure(field, levels, coarse_tol, multigrid=True, mixed=True, by_field=False):
+def configure(field, levels, coarse_tol, multigrid=True, mixed=True, by_field=False, kcycle=0):
     """The headline solver on a LatticeField whose model weights are set.  by_field: stop by the field (the bench's rule on one
-    GPU: FIELD_TOLERANCE), otherwise at the residual passed to solve_cg."""
+    GPU: FIELD_TOLERANCE), otherwise at the residual passed to solve_cg.  kcycle: FI_OPT_MG_KCYCLE (SETTINGS[config].get("kcycle", 0))."""
     if levels > 0:
         field.set_levels(levels, coarse_tol)
         if multigrid:
             field.set_multigrid(True)
             if mixed:
                 field.set_mixed_precision(True)
+            if kcycle > 0 and hasattr(field, "set_kcycle"):
+                field.set_kcycle(kcycle)
     if by_field:
         field.set_field_tolerance(FIELD_TOLERANCE)
 
@@ -65,5 +69,5 @@ def headline_field(fi, config, sizes, weights, by_field=False, **kw):
     s = SETTINGS[config]
     f = fi.LatticeField(sizes, dtype="f64", **kw)
     f.add_field_constraints(weights)
-    configure(f, s["levels"], s["coarse_tol"], by_field=by_field)
+    configure(f, s["levels"], s["coarse_tol"], by_field=by_field, kcycle=s.get("kcycle", 0))
     return f

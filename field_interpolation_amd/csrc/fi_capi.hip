@@ -789,6 +789,11 @@ int fi_set_option(fi_ctx* c, int option, double value)
 		c->mg_pratio = value;
 		c->assembled = false;
 		break;
+	case FI_OPT_MG_KCYCLE:
+		FI_REQUIRE(value >= 0 && value <= 16, FI_ERR_INVALID, "FI_OPT_MG_KCYCLE must be 0..16");
+		c->mg_kcycle = static_cast<int>(value);
+		c->assembled = false;  // the levels take the setting when they are built
+		break;
 	case FI_OPT_FIELD_TOLERANCE:
 		FI_REQUIRE(value >= 0.0 && value < 1.0, FI_ERR_INVALID, "FI_OPT_FIELD_TOLERANCE must be in [0, 1)");
 		c->field_tol = value;

@@ -408,6 +408,8 @@ struct fi_ctx {
 	double     mg_safe = 4.0;
 	int        mg_terms = 5;      // the polynomial smoother: terms and interval ratio (FI_OPT_MG_TERMS / FI_OPT_MG_RATIO)
 	double     mg_pratio = 30.0;
+	int        mg_kcycle = 0;      // FI_OPT_MG_KCYCLE: coarse levels (from the first one down) whose correction is two flexible-CG steps
+	fi::DevBuf kc;                 // ... and their coefficients (KcScalars, fi_multigrid.hip)
 	int        mg_smoother = 1;   // 1: the polynomial in A_model + f diag(A_data) where the marching kernel runs it; 0: Chebyshev in A
 	// Data facts that decide which kernels AND WHICH COLLECTIVES a solve runs -- triplet rows anywhere (any_trip), gradient
 	// rows anywhere (value_rows_only is its negation) -- are agreed over the ranks at the start of fi_assemble (one

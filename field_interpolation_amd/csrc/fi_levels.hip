@@ -159,6 +159,7 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		co->mg_safe     = c->mg_safe;
 		co->mg_terms    = c->mg_terms;
 		co->mg_pratio   = c->mg_pratio;
+		co->mg_kcycle   = c->mg_kcycle;
 		co->value_rows_only = src->value_rows_only;  // (agreed over the ranks: fi_assemble)
 		co->any_trip        = src->any_trip;
 		co->stream = build_stream ? build_stream : c->stream;
@@ -439,6 +440,7 @@ fi_ctx* twin_prepare(fi_ctx* c)
 	t->mg_safe         = c->mg_safe;
 	t->mg_terms        = c->mg_terms;
 	t->mg_pratio       = c->mg_pratio;
+	t->mg_kcycle       = c->mg_kcycle;
 	t->min_slab        = c->min_slab;
 	t->poly_terms      = c->poly_terms;   // (the coarse-to-fine start on the replica solves its levels with them)
 	t->poly_ratio      = c->poly_ratio;

@@ -1015,6 +1015,106 @@ __global__ __launch_bounds__(kThreads) void k_add_scaled(int64_t n, const T* __r
 	}
 }
 
+// ---- K-cycle (FI_OPT_MG_KCYCLE) ----------------------------------------------------------------------------------------
+// The correction of a coarse level by two steps of flexible CG on ITS system A e = b, each preconditioned by the level's own
+// cycle K(.):  c1 = K(b), then c2 = K(b - s1 A c1), and e = the combination of c1 and c2 that minimises the energy norm of the
+// error over their span.  Everything is written with RESIDUALS w = rhs - A c (the launch a cycle makes anyway, ChebEpi mode
+// 3) instead of products: v1 = A c1 = b - w1, v2 = A c2 = r1 - w2.  Five vectors of the level beside the cycle's own:
+// c1 = mg_x, w1 = r, r1 = x, c2 = p, w2 = q (the level's CG vectors: idle inside a cycle).
+struct KcScalars {
+	double a1, rho1;      // c1 . b, c1 . A c1
+	double s1;            // a1 / rho1
+	double coef1, coef2;  // e = coef1 c1 + coef2 c2
+};
+// step 1: partials of c1 . b and c1 . w1 -> s1;  step 2: of c2 . b, c2 . w1, c2 . r1, c2 . w2 -> coef1, coef2
+__global__ __launch_bounds__(kThreads) void k_kc_coef(KcScalars* kc, const double* __restrict__ partial, int stride, int count, int step)
+{
+	double acc[4] = {0, 0, 0, 0};
+	const int nv = step == 1 ? 2 : 4;
+	for (int v = 0; v < nv; ++v) {
+		for (int i = threadIdx.x; i < count; i += kThreads) { acc[v] += partial[static_cast<size_t>(v) * stride + i]; }
+	}
+	double out[4];
+	block_sum<4>(acc, out);
+	if (threadIdx.x != 0) { return; }
+	if (step == 1) {
+		kc->a1   = out[0];
+		kc->rho1 = out[0] - out[1];  // c1 . (b - w1)
+		const bool ok = kc->rho1 > 0.0 && isfinite(kc->rho1) && isfinite(kc->a1);
+		kc->s1    = ok ? kc->a1 / kc->rho1 : 1.0;  // (a cycle that is not positive on b: its plain result, like a V-cycle)
+		kc->coef1 = kc->s1;
+		kc->coef2 = 0.0;
+		return;
+	}
+	// r1 = b - s1 v1 = (1 - s1) b + s1 w1
+	const double s1 = kc->s1, rho1 = kc->rho1;
+	const double gam  = out[0] - out[1];   // c2 . v1
+	const double beta = out[2] - out[3];   // c2 . v2 = c2 . (r1 - w2)
+	const double a2   = out[2];            // c2 . r1
+	const double rho2 = beta - (rho1 > 0.0 ? gam * gam / rho1 : 0.0);
+	if (rho1 > 0.0 && rho2 > 1e-30 * fabs(beta) && isfinite(rho2) && isfinite(a2) && isfinite(gam)) {
+		kc->coef1 = s1 - gam * a2 / (rho1 * rho2);
+		kc->coef2 = a2 / rho2;
+	} else {  // the second direction adds nothing (or the numbers are not usable): the first step stands
+		kc->coef1 = s1;
+		kc->coef2 = 0.0;
+	}
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_kc_r1(int64_t n, const KcScalars* __restrict__ kc, const T* __restrict__ b, const T* __restrict__ w1,
+                                                     T* __restrict__ r1)
+{
+	const T s1 = static_cast<T>(kc->s1);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		r1[i] = (T(1) - s1) * b[i] + s1 * w1[i];
+	}
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_kc_combine(int64_t n, const KcScalars* __restrict__ kc, T* __restrict__ c1, const T* __restrict__ c2)
+{
+	const T a = static_cast<T>(kc->coef1), b = static_cast<T>(kc->coef2);
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		c1[i] = a * c1[i] + b * c2[i];
+	}
+}
+bool kcycle_level(const RankSet& Rc)
+{
+	const fi_ctx* c = Rc[0];
+	return Rc.size() == 1 && c->nranks == 1 && c->mg_kcycle > 0 && c->level >= 1 && c->level <= c->mg_kcycle && c->coarse != nullptr && !c->lumped &&
+	       !c->tail_ok && !c->replicated && smooth_fused_ok(Rc) && !test_switch("FI_NO_KCYCLE");
+}
+template <typename T>
+void kcycle_correction(RankSet& Rc)
+{
+	fi_ctx* c = Rc[0];
+	ensure_vectors(c);
+	c->kc.alloc(sizeof(KcScalars));
+	KcScalars* kc = c->kc.as<KcScalars>();
+	const int64_t n = c->g.nown;
+	const int nb = stream_blocks(n);
+	const int stride = c->max_blocks;
+	double* part = c->partial.as<double>();
+	auto dot = [&](Vec a, Vec b, int region) {
+		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, vown<T>(c, a), vown<T>(c, b), part + static_cast<size_t>(region) * stride);
+	};
+	const Vec B = &fi_ctx::mg_b, C1 = &fi_ctx::mg_x, W1 = &fi_ctx::r, R1 = &fi_ctx::x, C2 = &fi_ctx::p, W2 = &fi_ctx::q;
+	vcycle<T>(Rc, B, C1);
+	stencil_full_step(c, (c->*C1).p, nullptr, (c->*B).p, true, (c->*W1).p, 0.0, 0.0, 0.0);   // w1 = b - A c1
+	dot(C1, B, 0);
+	dot(C1, W1, 1);
+	hipLaunchKernelGGL(k_kc_coef, dim3(1), dim3(kThreads), 0, c->stream, kc, part, stride, nb, 1);
+	hipLaunchKernelGGL((k_kc_r1<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, kc, vown<T>(c, B), vown<T>(c, W1), vown<T>(c, R1));
+	vcycle<T>(Rc, R1, C2);
+	stencil_full_step(c, (c->*C2).p, nullptr, (c->*R1).p, true, (c->*W2).p, 0.0, 0.0, 0.0);  // w2 = r1 - A c2
+	dot(C2, B, 0);
+	dot(C2, W1, 1);
+	dot(C2, R1, 2);
+	dot(C2, W2, 3);
+	hipLaunchKernelGGL(k_kc_coef, dim3(1), dim3(kThreads), 0, c->stream, kc, part, stride, nb, 2);
+	hipLaunchKernelGGL((k_kc_combine<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, kc, vown<T>(c, C1), vown<T>(c, C2));
+	FI_HIP_TRY(hipGetLastError());
+}
+
 // The coarse correction of a level: mg_x = V(mg_b) on the coarser level Rc -- and, in timing builds with FI_MG_GAMMA=2 (the
 // experiment of profiles/r6_ablation.md section 11: a W-cycle), once more on what that left: mg_x += omega V(mg_b - A mg_x), through
 // the level's CG vectors r and p (idle inside a cycle); FI_MG_GAMMA_FROM: the first level visited twice; FI_MG_OMEGA: the damping.
@@ -1024,6 +1124,10 @@ __global__ __launch_bounds__(kThreads) void k_add_scaled(int64_t n, const T* __r
 template <typename T>
 void coarse_correction(RankSet& Rc)
 {
+	if (kcycle_level(Rc)) {
+		kcycle_correction<T>(Rc);
+		return;
+	}
 	vcycle<T>(Rc, &fi_ctx::mg_b, &fi_ctx::mg_x);
 	const char* g = tuning_switch("FI_MG_GAMMA");
 	const char* from = tuning_switch("FI_MG_GAMMA_FROM");  // the first level (1 = the one below the finest) that is visited twice
@@ -1359,6 +1463,9 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	}
 	int samples = 0;
 	const bool mixed = !Tw.empty();
+	// FI_OPT_MG_KCYCLE: the cycle then depends on its argument and CG takes the flexible beta (one undivided context)
+	const bool flexible = (mixed ? Tw[0] : c0)->mg_kcycle > 0 && (mixed ? Tw[0] : c0)->coarse != nullptr && R.size() == 1 && c0->nranks == 1 &&
+	                      !test_switch("FI_NO_KCYCLE");
 	fi_ctx* const prec_ctx = mixed ? Tw[0] : c0;  // the context whose finest-level smoother chains are timed (vcycle)
 	if (prec_ctx->level == 0 && !(mixed ? replicated_copies(Tw) : replicated_copies(R))) {
 		while (static_cast<int>(prec_ctx->ev_prec.size()) < 2 * kPolySamples) {
@@ -1604,6 +1711,19 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 		precondition<T>(R, Tw, Rv, Z, stepped);
 		dot_rz();
 		reduce_rz(kMgBeta);
+		if (flexible) {  // z_(k+1) . q_k for the flexible beta (q: still A p_k)
+			if constexpr (std::is_same<T, double>::value) {
+				if (mixed) {
+					hipLaunchKernelGGL(c0->g.nown >= kStreamMin ? k_dot_mixed<true> : k_dot_mixed<false>, dim3(nbv(c0)), dim3(kThreads), 0, st, c0->g.nown, sc0,
+					                   vown<double>(c0, Q), vown<float>(Tw[0], &fi_ctx::mg_x), c0->partial.as<double>());
+				} else {
+					dot(Q, Z);
+				}
+			} else {
+				dot(Q, Z);
+			}
+			mg_reduce(R, nbv, kMgFlex);
+		}
 		direction(0);
 		FI_HIP_TRY(hipGetLastError());
 	}

@@ -384,7 +384,7 @@ __device__ inline double twin_scale(const CgScalars* sc) { return sc->tscale > 0
 
 
 // scalar steps of the preconditioned recurrence (single block, thread 0)
-enum MgPhase { kMgInitRz = 10, kMgAlpha = 11, kMgResid = 12, kMgBeta = 13, kMgInitRr = 14 };
+enum MgPhase { kMgInitRz = 10, kMgAlpha = 11, kMgResid = 12, kMgBeta = 13, kMgInitRr = 14, kMgFlex = 15 };
 constexpr double kFieldMargin = 2.0;  // FI_OPT_FIELD_TOLERANCE: see k_mg_logic(kMgResid)
 constexpr int    kFieldMinIter = 3;   // ... no stop before the third iteration: CG's first steps remove the rough part of the error,
                                       // the residual falls and the steps are small while the smooth part has not moved yet (an fp32 2-D
@@ -519,6 +519,14 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 		sc->rz   = s;
 		if (!(s > 0.0) || !isfinite(s)) { sc->done = 2; }  // (an indefinite or diverging V-cycle: see cg_run_mg)
 		break;
+	case kMgFlex: {
+		// A preconditioner that depends on its argument (FI_OPT_MG_KCYCLE): the flexible beta, z_(k+1) . (r_(k+1) - r_k) / (z_k . r_k)
+		// = -alpha z_(k+1) . q_k / rz_old (s: z_(k+1) . q_k).  kMgBeta has run: beta = rz_new / rz_old, rz = rz_new.
+		const double rz_old = sc->beta > 0.0 ? sc->rz / sc->beta : 0.0;
+		const double flex = rz_old > 0.0 ? -sc->alpha * s / rz_old : sc->beta;
+		if (isfinite(flex)) { sc->beta = flex > 0.0 ? flex : 0.0; }  // (a negative one: restart the directions from z)
+		break;
+	}
 	}
 }
 

@@ -286,6 +286,14 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * exceeded the tolerance in 3, 7 and 1 cases (warm starts included), by at most 1.5 x, 2.4 x and 1.1 x; the goldens of configs 2 to 5 end 8 to 100 x
  * below it.  fi_stats: field_estimate, field_per_residual. */
 #define FI_OPT_FIELD_TOLERANCE 12
+/* FI_OPT_MG_KCYCLE (default 0 = off; V-cycle PCG on an undivided lattice, fp32 levels): a K-cycle -- the correction of the
+ * first `value` coarse levels is not one application of the coarser level's cycle but TWO steps of flexible CG on that
+ * level's system, each preconditioned by the level's cycle (Notay & Vassilevski: the lengths of the two corrections come from
+ * a line search in the energy norm, so a level whose own cycle overcorrects -- the re-discretised coarse levels of
+ * oriented-point data do, profiles/r6_ablation.md section 11 -- cannot make the preconditioner indefinite the way a W-cycle
+ * does).  The preconditioner then depends on its argument: the outer CG takes the flexible beta, -alpha z_(k+1) . A p_k /
+ * (z_k . r_k), one more dot product per iteration.  Set before fi_assemble. */
+#define FI_OPT_MG_KCYCLE 13
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */

@@ -55,7 +55,7 @@ def test_config3_4096x4096_sdf_from_oriented_points(fi):
     sizes, w, pos, nrm = synth.config3()
     from field_interpolation_amd import bench_settings as bs
     f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
-    bs.configure(f, bs.SETTINGS[3]["levels"], bs.SETTINGS[3]["coarse_tol"])   # bench.py --config 3's settings
+    bs.configure(f, bs.SETTINGS[3]["levels"], bs.SETTINGS[3]["coarse_tol"], kcycle=bs.SETTINGS[3].get("kcycle", 0))   # bench.py --config 3's settings
     f.assemble()
     assert f.stats()["num_data_rows"] == 3 * 200000
     x, it, rel = f.solve_cg(None, 3000, 1e-5)
@@ -132,21 +132,21 @@ def test_config4_slabs_equal_undivided_at_128cubed(fi):
 
 
 def test_config5_512cubed_sdf_tol_1e6(fi):
-    """3D 512^3 SDF from 5M oriented points, CG to 1e-6 with bench.py --config 5's settings (fp64 CG, fp32 V-cycle over 6
+    """3D 512^3 SDF from 5M oriented points, CG to 1e-6 with bench.py --config 5's settings (fp64 CG, fp32 K-cycle over 6
     coarser levels): verified residual, the bench's iteration count, and the meaning of the result -- a signed distance
     near the sphere."""
     from field_interpolation_amd import synth
     sizes, w, pos, nrm = synth.config5()
     from field_interpolation_amd import bench_settings as bs
     f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
-    bs.configure(f, bs.SETTINGS[5]["levels"], bs.SETTINGS[5]["coarse_tol"])   # bench.py --config 5: fp64 CG, fp32 V-cycle, 6 levels to 1e-2
+    bs.configure(f, bs.SETTINGS[5]["levels"], bs.SETTINGS[5]["coarse_tol"], kcycle=bs.SETTINGS[5].get("kcycle", 0))   # bench.py --config 5: fp64 CG, fp32 K-cycle, 6 levels to 1e-2
     f.assemble()
     st = f.stats()
     assert st["num_data_rows"] == 4 * 5000000 and st["num_levels"] == 7
     x, it, rel = f.solve_cg(None, 1000, 1e-6)
     st = f.stats()
     assert st["converged"] == 1 and st["verified_residual"] <= 1e-6
-    assert abs(it - 20) <= 3, it                     # (round 5's smoother, degree 4 over [l / 10, l]: 24; round 6's, 5 over [l / 40, l]: 20)
+    assert abs(it - 9) <= 3, it                      # (round 5's V-cycle, smoother of degree 4 over [l / 10, l]: 24; round 6's, 5 over [l / 40, l]: 20; the K-cycle on four levels: 9)
     field = x.reshape(512, 512, 512)
     c, R = 255.5, 0.3 * 511
     # "only accurate near field = 0" (field_interpolation.hpp:165): a signed distance close to the surface,

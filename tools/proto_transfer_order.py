@@ -122,6 +122,15 @@ def vcycle(L, l, b):
     x = cheb(lev["A"], lev["dinv"], lev["lam"], b, None, 4, 10.0)
     r = b - lev["A"] @ x
     bc = lev["P"].T @ r
+    if MODE == "K" and l + 1 < len(L) - 1:      # two FCG steps on the coarser level, each preconditioned by ITS cycle
+        Ac = L[l + 1]["A"]
+        c1 = vcycle(L, l + 1, bc); v1 = Ac @ c1; rho1 = c1 @ v1; a1 = c1 @ bc
+        r1 = bc - (a1 / rho1) * v1
+        c2 = vcycle(L, l + 1, r1); v2 = Ac @ c2; gam = c2 @ v1; beta = c2 @ v2; a2 = c2 @ r1
+        rho2 = beta - gam * gam / rho1
+        ec = (a1 / rho1 - gam * a2 / (rho1 * rho2)) * c1 + (a2 / rho2) * c2
+        x = x + lev["P"] @ ec
+        return cheb(lev["A"], lev["dinv"], lev["lam"], b, x, 4, 10.0)
     ec = vcycle(L, l + 1, bc)
     if MODE == "W" and l + 1 < len(L) - 1:      # the coarser level once more on what the first visit left
         ec = ec + vcycle(L, l + 1, bc - L[l + 1]["A"] @ ec)
@@ -136,11 +145,13 @@ def pcg(L, tol=1e-8, maxit=400):
         q = A @ p; al = rz / (p @ q); x += al * p; r -= al * q
         if np.sqrt(r @ r) <= tol * bb:
             return it
-        z = vcycle(L, 0, r); rz2 = r @ z; p = z + (rz2 / rz) * p; rz = rz2
+        z = vcycle(L, 0, r); rz2 = r @ z
+        beta = -al * (z @ q) / rz if MODE == "K" else rz2 / rz     # flexible (Polak-Ribiere): z . (r_new - r_old) / (z_old . r_old) = -alpha z . q / rz_old
+        p = z + beta * p; rz = rz2
     return maxit
 
 
-for MODE in ("rediscretised", "W", "galerkin", "stiffer", "damped"):
+for MODE in ("rediscretised", "W", "K"):
     for cubic in (False, True):
         L = build(cubic)
         print("side %d, %d levels, %d oriented points, coarse levels %s, %s interpolation (R = P^T): %d iterations" % (
