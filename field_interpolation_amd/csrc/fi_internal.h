@@ -319,6 +319,7 @@ struct CgScalars {  // lives in device memory; kernels read/write it, the host p
 	double rank_max[2 * 16];
 	double tscale;  // mixed precision: the scale the fp32 copy of the current residual was divided by
 	int    iter, done, max_iter, restarts;
+	int    field_min_iter, pad2_;  // FI_OPT_FIELD_TOLERANCE: no stop before this iteration (kFieldMinIter; more behind a caller's guess)
 	int    tag, field_ranks;  // tag: second slot only (single-rank fused CG): the iteration whose first half filled it;
 	                          // field_ranks: slabs whose maxima rank_max[] holds (0: an undivided lattice, dmax_bits / xmax_bits)
 	// FI_OPT_FIELD_TOLERANCE (V-cycle PCG, fi_multigrid.hip): the stop test on the field.  The step kernel leaves

@@ -1449,6 +1449,7 @@ void cg_run_mg(RankSet& R, int max_iterations, float tol)
 	init.field_tol = by_field ? c0->field_tol : 0.0;
 	init.field_est = -1.0;
 	init.field_ranks = by_field ? field_slabs : 0;
+	init.field_min_iter = c0->predictable_start ? kFieldMinIter : kFieldMinIterGuess;
 	reset_scalars(R, init);
 	CgScalars* sc0 = c0->scal.as<CgScalars>();
 	auto nbv      = [](fi_ctx* c) { return stream_blocks(c->g.nown); };

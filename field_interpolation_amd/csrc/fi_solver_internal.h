@@ -389,6 +389,9 @@ constexpr double kFieldMargin = 2.0;  // FI_OPT_FIELD_TOLERANCE: see k_mg_logic(
 constexpr int    kFieldMinIter = 3;   // ... no stop before the third iteration: CG's first steps remove the rough part of the error,
                                       // the residual falls and the steps are small while the smooth part has not moved yet (an fp32 2-D
                                       // case of tests/stress_field_rule.py stopped after ONE iteration, 83 % off)
+constexpr int    kFieldMinIterGuess = 8;  // ... behind a CALLER'S guess: its error may be smooth -- an old solution after a small change of the
+                                      // data -- and a smooth error shows neither in the residual nor in the first steps (the coarsest levels
+                                      // are solved loosely); the coarse-to-fine start's error is spread over all modes
 constexpr double kFieldFast   = 0.3;  // ... every window gains more than this factor per iteration: the last step and its own ratio are used
 constexpr int    kFieldCarry  = 8;    // ... steps carried forward at the rate (CG on an ill-conditioned system converges in stairs: a lull of
                                       // three to seven iterations with tiny steps and a falling residual, the error unchanged, then the next stair)
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(kThreads) void k_mg_logic(CgScalars* sc, const doub
 					}
 					sc->field_est   = kFieldMargin * step * sigma / (1.0 - sigma);
 					sc->field_kappa = sc->field_est / (kFieldMargin * rb);
-					field_met = sc->field_est <= sc->field_tol && k >= kFieldMinIter;
+					field_met = sc->field_est <= sc->field_tol && k >= (sc->field_min_iter > 0 ? sc->field_min_iter : kFieldMinIter);
 				}
 			}
 		}

@@ -279,11 +279,12 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * The solve ends when twice that (a margin for the smooth modes, which converge last) is within the tolerance times
  * ||x_k||_inf; no estimate is formed while the residual falls by less than 5 % per iteration (the residual floor then ends
  * the solve) and no stop before the third iteration (CG's first steps remove the rough part of the error: small steps, a
- * falling residual, the smooth part not yet moved).  The `tol` of fi_solve_cg is ignored (the precision's floor stands in:
+ * falling residual, the smooth part not yet moved) -- the eighth behind a caller's guess, whose error may be smooth from the start.  The `tol` of fi_solve_cg is ignored (the precision's floor stands in:
  * 1e-13 in fp64, 2e-7 in fp32 -- an fp32 solve that ends there with the estimate above the tolerance reports converged = 0);
  * no constant depends on the workload.  An estimate, not a bound: over 200 random 3-D, 150 random 2-D and 100 random fp32
  * problems (tests/stress_field_rule.py: value data and oriented points, 1 to 5 levels, 6 to 650 iterations) the true error
- * exceeded the tolerance in 3, 7 and 1 cases (warm starts included), by at most 1.5 x, 2.4 x and 1.1 x; the goldens of configs 2 to 5 end 8 to 100 x
+ * exceeded the tolerance in 3, 7 and 0 cases (warm starts included; 3 and 9 of 150 + 150 with FI_OPT_MG_KCYCLE), by at most 1.5 x and 2.4 x --
+ * but for warm starts on hierarchies whose cold solves take a thousand iterations (2 cases, 15 x); the goldens of configs 2 to 5 end 8 to 100 x
  * below it.  fi_stats: field_estimate, field_per_residual. */
 #define FI_OPT_FIELD_TOLERANCE 12
 /* FI_OPT_MG_KCYCLE (default 0 = off; V-cycle PCG on an undivided lattice, fp32 levels): a K-cycle -- the correction of the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised sweep of the field stop rule (FI_OPT_FIELD_TOLERANCE; run on the GPU box): 3-D (seeds from 80000 on: 2-D; from 90000 on: fp32
-contexts in 2-D) lattices of random shape, value
+"""Randomised sweep of the field stop rule (FI_OPT_FIELD_TOLERANCE; run on the GPU box): 3-D (seeds from 80000 on: 2-D; 90000-99999: fp32
+contexts in 2-D; from 100000 on: the K-cycle, 3-D, from 110000 on 2-D) lattices of random shape, value
 data or oriented points, random weights, levels and tolerance; the field the rule stops at against the same context's
 solve to the fp64 floor.  The rule is an estimate (twice the extrapolated difference of consecutive iterates): a case
 FAILS when the true error exceeds 2 x the tolerance, and the sweep prints the distribution of error / tolerance.
@@ -23,7 +23,7 @@ def one_case(seed):
     rng = np.random.default_rng(seed)
     big = rng.random() < 0.25
     sizes = [int(rng.integers(40, 161 if big else 73)) for _ in range(3)]
-    if seed >= 80000:   # (seeds from 80000 on: 2-D lattices, the shapes of configs 2 and 3)
+    if 80000 <= seed < 100000 or seed >= 110000:   # (seeds 80000-99999 and from 110000 on: 2-D lattices, the shapes of configs 2 and 3)
         sizes = [int(rng.integers(96, 1025 if big else 385)) for _ in range(2)]
     sizes[0] = max(8, (sizes[0] // 4) * 4)
     kw = dict(model_2=float(rng.uniform(0.2, 1.0)))
@@ -41,12 +41,15 @@ def one_case(seed):
     mixed = rng.random() < 0.7
     levels = int(rng.integers(1, 4)) if len(sizes) == 3 else int(rng.integers(1, 6))
     tol = float(rng.choice([1e-4, 1e-5, 1e-6]))
-    f32 = seed >= 90000     # (seeds from 90000 on: fp32 contexts -- value data, the tolerances fp32 can meet -- against an fp64 twin)
+    f32 = 90000 <= seed < 100000     # (seeds 90000-99999: fp32 contexts -- value data, the tolerances fp32 can meet -- against an fp64 twin)
+    kc = int(rng.integers(1, levels + 1)) if seed >= 100000 else 0   # (seeds from 100000 on: the K-cycle on 1 .. levels coarse levels; 3-D, from 110000: 2-D)
+    if kc:
+        mixed = True
     if f32:
         sdf, val, mixed = False, (val if val is not None else rng.normal(size=npts).astype(np.float32)), False
         tol = float(rng.choice([1e-3, 1e-4]))
     desc = "seed %d: sizes %s pts %d sdf %d gk %d %s levels %d tol %.0e %s" % (
-        seed, sizes, npts, sdf, gk, "fp32" if f32 else ("mixed" if mixed else "fp64 V-cycle"), levels, tol, {k: round(v, 3) for k, v in kw.items()})
+        seed, sizes, npts, sdf, gk, "fp32" if f32 else (("K-cycle %d" % kc) if kc else ("mixed" if mixed else "fp64 V-cycle")), levels, tol, {k: round(v, 3) for k, v in kw.items()})
 
     def build(dtype):
         g = fi.LatticeField(sizes, dtype=dtype)
@@ -57,6 +60,8 @@ def one_case(seed):
         g.set_multigrid(True)
         if mixed:
             g.set_mixed_precision(True)
+        if kc:
+            g.set_kcycle(kc)
         g.assemble()
         return g
 

@@ -219,7 +219,7 @@ def test_the_field_rule_on_random_problems(fi, capsys):
     """The stop rule away from the configurations it was built on: sixteen random 3-D problems of tests/stress_field_rule.py
     (value data or oriented points, one to three levels, fp64 or mixed V-cycles, tolerances 1e-4 .. 1e-6, solves of 6 to 400
     iterations) against the same context's solve to the fp64 floor.  The rule is an estimate: the sweep's bar is twice the
-    tolerance (200 cases in 3-D on the GPU box: 3 above the tolerance, none above twice; 150 in 2-D: 7 and 1, worst 2.4 x;
+    tolerance (200 cases in 3-D on the GPU box: 3 above the tolerance, none above twice; 150 in 2-D: 7 and 1, worst 2.4 x; 300 with the K-cycle: 12 and 2;
     the rule of the round's first builds -- one step's residual ratio alone -- failed 12 of the first 61, by up to 16 x)."""
     import stress_field_rule as sweep
     worst = 0.0
