@@ -221,7 +221,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=tol, dtype=dt, by_field=by_field,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
                     multigrid=True, mixed=dt == "f64", poly=0, points=npts, text=text, field_tol=bs.FIELD_TOLERANCE, more=more,
-                    seed=seeds[0], kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle)
+                    seed=seeds[0], kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"))
     if cfg == 5:
         side = args.side or 512
         npts = args.points or int(round(5_000_000 * (side / 512.0) ** 2))
@@ -231,7 +231,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, field_tol=bs.FIELD_TOLERANCE, more=[], seed=4,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=4,
                     text="config5: 3D %d^3 SDF from %d oriented points (sdf_from_points, default Weights)" % (side, npts))
     if cfg == 3:
         side = args.side or 4096
@@ -242,7 +242,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, field_tol=bs.FIELD_TOLERANCE, more=[], seed=2,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=2,
                     text="config3: 2D %dx%d SDF from %d oriented points (triangle + inverted circle)" % (side, side, 2 * pps))
     if cfg == 2:
         side = args.side or 1024
@@ -253,7 +253,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, field_tol=bs.FIELD_TOLERANCE, more=[], seed=1,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=1,
                     text="config2: 2D %dx%d lattice, %d noisy value constraints, model_2=10" % (side, side, npts))
     raise SystemExit("--config must be 2, 3, 4 or 5 (config 1 is the CPU-runnable 1-D case: tests/)")
 
@@ -347,6 +347,8 @@ def main():
             field.set_field_tolerance(bs.FIELD_TOLERANCE)
         if cfg.get("kcycle", 0) > 0 and cfg["multigrid"] and cfg["levels"] > 0:
             field.set_kcycle(cfg["kcycle"])
+            if cfg.get("cheb"):
+                field.set_cheb_smoother(*cfg["cheb"])
 
     def build(slabs):
         """slabs: ONE lattice, a slab per rank, halo planes and dot products over RCCL.  not slabs (--allow-replicas, only
@@ -677,7 +679,7 @@ def main():
             fs.add_field_constraints(w_s)
             side_ratio = max(wl["sizes"]) // max(sz)
             lv = max(1, wl["levels"] - int(round(np.log2(max(side_ratio, 1)))))     # the same coarsest lattice
-            bs.configure(fs, lv, wl["coarse_tol"], by_field=wl.get("by_field", False), kcycle=wl.get("kcycle", 0))
+            bs.configure(fs, lv, wl["coarse_tol"], by_field=wl.get("by_field", False), kcycle=wl.get("kcycle", 0), cheb=wl.get("cheb"))
             fs.add_points(w_s.data_pos, w_s.value_kernel, w_s.data_gradient if nrm_s is not None else 0.0, w_s.gradient_kernel,
                           pos_s, nrm_s, None, values=val_s)
             fs.assemble()

@@ -304,6 +304,12 @@ class LatticeField:
         instead of at a residual; the `tol` of solve_cg is then ignored.  0: the residual rule.  stats(): field_estimate, field_per_residual, stop_residual."""
         check(_capi.lib().fi_set_option(self._h, 12, float(tol)))
 
+    def set_cheb_smoother(self, degree=0, ratio=0.0):
+        """FI_OPT_MG_CHEB_DEGREE / FI_OPT_MG_CHEB_RATIO: the full-operator Chebyshev smoother's degree and interval; 0: by the dimension."""
+        check(_capi.lib().fi_set_option(self._h, 14, float(degree)))
+        check(_capi.lib().fi_set_option(self._h, 15, float(ratio)))
+        self._dirty = True
+
     def set_kcycle(self, levels):
         """FI_OPT_MG_KCYCLE: the first `levels` coarse levels corrected by two flexible-CG steps each (a K-cycle); 0: the V-cycle."""
         check(_capi.lib().fi_set_option(self._h, 13, float(levels)))

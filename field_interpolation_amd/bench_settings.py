@@ -38,7 +38,8 @@ def slab_residual(config, sizes):
 SETTINGS = {
     4: dict(levels=3, coarse_tol=3e-4, tol=1e-5),
     # (kcycle, round 6: FI_OPT_MG_KCYCLE on the first four coarse levels -- 44 -> 17 iterations, 568 -> 371 ms; 1 / 2 / 3 levels: 525 / 413 / 386)
-    5: dict(levels=6, coarse_tol=1e-2, tol=1e-6, kcycle=4),
+    # (cheb: the full-operator smoother under the K-cycle -- (4, 10) 228-259 ms / 12-14 iterations, the 3-D default (5, 40) 347-371 / 16-17)
+    5: dict(levels=6, coarse_tol=1e-2, tol=1e-6, kcycle=4, cheb=(4, 10.0)),
     # (hierarchy depth and the levels' tolerance: tools/r4_sweep_c23.sh, tools/r5_sweep_levels.sh -- the levels of a
     # coarse-to-fine start are worth a loose solve only: config 3 with 7 levels to 1e-4 57.6 ms per step, 8 levels to 1e-1 28.4)
     # (round 6, under the field rule: 9 levels -- the coarsest 8^2 -- 45 ms and 26 iterations against 52 / 34 with 8; 7 levels: 129 / 93)
@@ -49,7 +50,7 @@ SETTINGS = {
 }
 
 
-def configure(field, levels, coarse_tol, multigrid=True, mixed=True, by_field=False, kcycle=0):
+def configure(field, levels, coarse_tol, multigrid=True, mixed=True, by_field=False, kcycle=0, cheb=None):
     """The headline solver on a LatticeField whose model weights are set.  by_field: stop by the field (the bench's rule on one
     GPU: FIELD_TOLERANCE), otherwise at the residual passed to solve_cg.  kcycle: FI_OPT_MG_KCYCLE (SETTINGS[config].get("kcycle", 0))."""
     if levels > 0:
@@ -60,6 +61,8 @@ def configure(field, levels, coarse_tol, multigrid=True, mixed=True, by_field=Fa
                 field.set_mixed_precision(True)
             if kcycle > 0 and hasattr(field, "set_kcycle"):
                 field.set_kcycle(kcycle)
+                if cheb and hasattr(field, "set_cheb_smoother"):   # (the K-cycle's companion setting: with the V-cycle the defaults stand)
+                    field.set_cheb_smoother(*cheb)
     if by_field:
         field.set_field_tolerance(FIELD_TOLERANCE)
 
@@ -69,5 +72,5 @@ def headline_field(fi, config, sizes, weights, by_field=False, **kw):
     s = SETTINGS[config]
     f = fi.LatticeField(sizes, dtype="f64", **kw)
     f.add_field_constraints(weights)
-    configure(f, s["levels"], s["coarse_tol"], by_field=by_field, kcycle=s.get("kcycle", 0))
+    configure(f, s["levels"], s["coarse_tol"], by_field=by_field, kcycle=s.get("kcycle", 0), cheb=s.get("cheb"))
     return f

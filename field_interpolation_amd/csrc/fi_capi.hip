@@ -789,6 +789,16 @@ int fi_set_option(fi_ctx* c, int option, double value)
 		c->mg_pratio = value;
 		c->assembled = false;
 		break;
+	case FI_OPT_MG_CHEB_DEGREE:
+		FI_REQUIRE(value == 0 || (value >= 2 && value <= 16), FI_ERR_INVALID, "FI_OPT_MG_CHEB_DEGREE must be 0 or 2..16");
+		c->mg_cheb_degree = static_cast<int>(value);
+		c->assembled = false;
+		break;
+	case FI_OPT_MG_CHEB_RATIO:
+		FI_REQUIRE(value == 0 || (value > 1.0 && value <= 1000.0), FI_ERR_INVALID, "FI_OPT_MG_CHEB_RATIO must be 0 or in (1, 1000]");
+		c->mg_cheb_ratio = value;
+		c->assembled = false;
+		break;
 	case FI_OPT_MG_KCYCLE:
 		FI_REQUIRE(value >= 0 && value <= 16, FI_ERR_INVALID, "FI_OPT_MG_KCYCLE must be 0..16");
 		c->mg_kcycle = static_cast<int>(value);

@@ -409,6 +409,8 @@ struct fi_ctx {
 	double     mg_safe = 4.0;
 	int        mg_terms = 5;      // the polynomial smoother: terms and interval ratio (FI_OPT_MG_TERMS / FI_OPT_MG_RATIO)
 	double     mg_pratio = 30.0;
+	int        mg_cheb_degree = 0;  // FI_OPT_MG_CHEB_DEGREE / _RATIO: the full-operator Chebyshev smoother (0: by the lattice's dimension)
+	double     mg_cheb_ratio = 0.0;
 	int        mg_kcycle = 0;      // FI_OPT_MG_KCYCLE: coarse levels (from the first one down) whose correction is two flexible-CG steps
 	fi::DevBuf kc;                 // ... and their coefficients (KcScalars, fi_multigrid.hip)
 	int        mg_smoother = 1;   // 1: the polynomial in A_model + f diag(A_data) where the marching kernel runs it; 0: Chebyshev in A

@@ -160,6 +160,8 @@ void build_levels(fi_ctx* c, fi_ctx* src, hipStream_t build_stream)  // src: the
 		co->mg_terms    = c->mg_terms;
 		co->mg_pratio   = c->mg_pratio;
 		co->mg_kcycle   = c->mg_kcycle;
+		co->mg_cheb_degree = c->mg_cheb_degree;
+		co->mg_cheb_ratio  = c->mg_cheb_ratio;
 		co->value_rows_only = src->value_rows_only;  // (agreed over the ranks: fi_assemble)
 		co->any_trip        = src->any_trip;
 		co->stream = build_stream ? build_stream : c->stream;
@@ -441,6 +443,8 @@ fi_ctx* twin_prepare(fi_ctx* c)
 	t->mg_terms        = c->mg_terms;
 	t->mg_pratio       = c->mg_pratio;
 	t->mg_kcycle       = c->mg_kcycle;
+	t->mg_cheb_degree  = c->mg_cheb_degree;
+	t->mg_cheb_ratio   = c->mg_cheb_ratio;
 	t->min_slab        = c->min_slab;
 	t->poly_terms      = c->poly_terms;   // (the coarse-to-fine start on the replica solves its levels with them)
 	t->poly_ratio      = c->poly_ratio;

@@ -456,10 +456,14 @@ __global__ __launch_bounds__(kThreads) void k_sum_to_slot2(CgScalars* sc, const 
 // a wider interval pays -- rediscretised coarse levels correct an SDF's intermediate modes poorly, the smoother has to reach
 // further down -- config 5 (4, 10) 588 ms / 56 iterations, (5, 40) 508 / 40, (6, 40) 513 / 36, (5, 80) 838 / 68 (past 40 the
 // damping at the upper end gives out); config 3 (4, 10) 52.8 ms / 34, (4, 40) 49.1 / 29, (5, 40) 52.7 / 28; config 2 5.1 -> 4.8.
+// Under the K-cycle (FI_OPT_MG_KCYCLE) the coarse correction is strong and the smoother need not reach down: config 5 with four
+// K-levels (4, 10) 259 ms / 14 iterations, (5, 40) 347 / 16, (3, 20) 256 / 16, (6, 20) 252 / 10 -- but NOT on a shallow hierarchy (96 x 80 x 64
+// with two levels: 123 iterations against the V-cycle's 96 with (5, 40)): FI_OPT_MG_CHEB_DEGREE / _RATIO, set by bench_settings for config 5.
 int mg_degree(const fi_ctx* c)
 {
 	const char* e = tuning_switch("FI_MG_DEGREE");
-	return e && atoi(e) > 0 ? atoi(e) : (c->g.ndim == 3 ? 5 : 4);
+	if (e && atoi(e) > 0) { return atoi(e); }
+	return c->mg_cheb_degree > 0 ? c->mg_cheb_degree : (c->g.ndim == 3 ? 5 : 4);
 }
 // the coarsest level's solve: a longer polynomial over a wider band (FI_MG_COARSEST_STEPS / FI_MG_COARSEST_RATIO: timing builds)
 int mg_coarsest_steps(const fi_ctx* c)
@@ -476,7 +480,8 @@ double mg_coarsest_ratio(const fi_ctx* c)
 double mg_ratio(const fi_ctx* c)
 {
 	const char* e = tuning_switch("FI_MG_RATIO");
-	return e && atof(e) > 1 ? atof(e) : (c->g.ndim == 3 ? 40.0 : 10.0);
+	if (e && atof(e) > 1) { return atof(e); }
+	return c->mg_cheb_ratio > 1.0 ? c->mg_cheb_ratio : (c->g.ndim == 3 ? 40.0 : 10.0);
 }
 
 template <typename T>

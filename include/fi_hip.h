@@ -295,6 +295,13 @@ int fi_solve_cg(fi_ctx* ctx, const float* guess, int max_iterations, float tol, 
  * does).  The preconditioner then depends on its argument: the outer CG takes the flexible beta, -alpha z_(k+1) . A p_k /
  * (z_k . r_k), one more dot product per iteration.  Set before fi_assemble. */
 #define FI_OPT_MG_KCYCLE 13
+/* FI_OPT_MG_CHEB_DEGREE (0 or 2..16) and FI_OPT_MG_CHEB_RATIO (0 or (1, 1000]): degree and interval [lambda / ratio, 1.1 lambda] of
+ * the Chebyshev smoother in the full operator (2-D lattices, oriented points, fp64 levels).  0 (default): by the lattice's
+ * dimension -- 4 over [lambda / 10] in 2-D, 5 over [lambda / 40] in 3-D (swept under the field rule with the V-cycle).  With
+ * the K-cycle on a deep hierarchy the coarse correction is strong and the smoother need not reach down: config 5 runs (4, 10)
+ * (profiles/r6_ablation.md section 12).  Set before fi_assemble. */
+#define FI_OPT_MG_CHEB_DEGREE 14
+#define FI_OPT_MG_CHEB_RATIO 15
 int fi_set_option(fi_ctx* ctx, int option, double value);
 
 /* Replaces jacobi_iterations (sparse_linear.cpp:214-241): x <- x + w*(Atb - AtA x)/diag, true Jacobi. */

@@ -55,7 +55,7 @@ def test_config3_4096x4096_sdf_from_oriented_points(fi):
     sizes, w, pos, nrm = synth.config3()
     from field_interpolation_amd import bench_settings as bs
     f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
-    bs.configure(f, bs.SETTINGS[3]["levels"], bs.SETTINGS[3]["coarse_tol"], kcycle=bs.SETTINGS[3].get("kcycle", 0))   # bench.py --config 3's settings
+    bs.configure(f, bs.SETTINGS[3]["levels"], bs.SETTINGS[3]["coarse_tol"], kcycle=bs.SETTINGS[3].get("kcycle", 0), cheb=bs.SETTINGS[3].get("cheb"))   # bench.py --config 3's settings
     f.assemble()
     assert f.stats()["num_data_rows"] == 3 * 200000
     x, it, rel = f.solve_cg(None, 3000, 1e-5)
@@ -139,7 +139,7 @@ def test_config5_512cubed_sdf_tol_1e6(fi):
     sizes, w, pos, nrm = synth.config5()
     from field_interpolation_amd import bench_settings as bs
     f = fi.sdf_from_points(sizes, w, pos, nrm, dtype="f64")
-    bs.configure(f, bs.SETTINGS[5]["levels"], bs.SETTINGS[5]["coarse_tol"], kcycle=bs.SETTINGS[5].get("kcycle", 0))   # bench.py --config 5: fp64 CG, fp32 K-cycle, 6 levels to 1e-2
+    bs.configure(f, bs.SETTINGS[5]["levels"], bs.SETTINGS[5]["coarse_tol"], kcycle=bs.SETTINGS[5].get("kcycle", 0), cheb=bs.SETTINGS[5].get("cheb"))   # bench.py --config 5: fp64 CG, fp32 K-cycle, 6 levels to 1e-2
     f.assemble()
     st = f.stats()
     assert st["num_data_rows"] == 4 * 5000000 and st["num_levels"] == 7

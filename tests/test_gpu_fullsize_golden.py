@@ -161,7 +161,7 @@ def test_config3_shape_against_the_oracles_exact_solve(fi, capsys):
     assert sizes == [int(s) for s in g["sizes"]]
     f = fi.LatticeField(sizes, dtype="f64")
     f.add_field_constraints(w)
-    bs.configure(f, bs.SETTINGS[3]["levels"] - 2, bs.SETTINGS[3]["coarse_tol"], kcycle=bs.SETTINGS[3].get("kcycle", 0))     # 4096 -> 1024: two levels less, the same coarsest lattice
+    bs.configure(f, bs.SETTINGS[3]["levels"] - 2, bs.SETTINGS[3]["coarse_tol"], kcycle=bs.SETTINGS[3].get("kcycle", 0), cheb=bs.SETTINGS[3].get("cheb"))     # 4096 -> 1024: two levels less, the same coarsest lattice
     f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
     f.assemble()
     rows = []
@@ -193,14 +193,14 @@ def test_the_field_rule_on_the_other_configurations(fi, capsys):
     sizes, w, pos, nrm = synth.config3(side=1024, points_per_shape=int(g["num_points"]) // 2, seed=2)
     f = fi.LatticeField(sizes, dtype="f64")
     f.add_field_constraints(w)
-    bs.configure(f, bs.SETTINGS[3]["levels"] - 2, bs.SETTINGS[3]["coarse_tol"], by_field=True, kcycle=bs.SETTINGS[3].get("kcycle", 0))
+    bs.configure(f, bs.SETTINGS[3]["levels"] - 2, bs.SETTINGS[3]["coarse_tol"], by_field=True, kcycle=bs.SETTINGS[3].get("kcycle", 0), cheb=bs.SETTINGS[3].get("cheb"))
     f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
     rows.append(("config 3's shape at 1024^2", f, g, bs.SETTINGS[3]["tol"]))
     g = np.load(os.path.join(GOLDEN, "config5_128_oracle_f64.npz"))
     sizes, w, pos, nrm = synth.config5(side=128, num_points=int(g["num_points"]), seed=int(g["seed"]))
     f = fi.LatticeField(sizes, dtype="f64")
     f.add_field_constraints(w)
-    bs.configure(f, bs.SETTINGS[5]["levels"] - 2, bs.SETTINGS[5]["coarse_tol"], by_field=True, kcycle=bs.SETTINGS[5].get("kcycle", 0))
+    bs.configure(f, bs.SETTINGS[5]["levels"] - 2, bs.SETTINGS[5]["coarse_tol"], by_field=True, kcycle=bs.SETTINGS[5].get("kcycle", 0), cheb=bs.SETTINGS[5].get("cheb"))
     f.add_points(w.data_pos, w.value_kernel, w.data_gradient, w.gradient_kernel, pos, nrm, None)
     rows.append(("config 5's shape at 128^3", f, g, bs.SETTINGS[5]["tol"]))
     for name, f, g, tol in rows:

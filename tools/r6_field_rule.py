@@ -60,7 +60,7 @@ g = np.load(os.path.join(G, "config3_1024_oracle_f64.npz"))
 sizes, w3, pos3, nrm3 = synth.config3(side=1024, points_per_shape=int(g["num_points"]) // 2, seed=2)
 f = fi.LatticeField(sizes, dtype="f64")
 f.add_field_constraints(w3)
-bs.configure(f, max(1, bs.SETTINGS[3]["levels"] - 2), bs.SETTINGS[3]["coarse_tol"], kcycle=bs.SETTINGS[3].get("kcycle", 0))
+bs.configure(f, max(1, bs.SETTINGS[3]["levels"] - 2), bs.SETTINGS[3]["coarse_tol"], kcycle=bs.SETTINGS[3].get("kcycle", 0), cheb=bs.SETTINGS[3].get("cheb"))
 f.set_field_tolerance(tol)
 run("config 3 shape 1024^2", f, [lambda ff: ff.add_points(w3.data_pos, w3.value_kernel, w3.data_gradient, w3.gradient_kernel, pos3, nrm3, None)], [g], 1e-5)
 del f
@@ -69,6 +69,6 @@ g = np.load(os.path.join(G, "config5_128_oracle_f64.npz"))
 sizes, w5, pos5, nrm5 = synth.config5(side=128, num_points=int(g["num_points"]), seed=4)
 f = fi.LatticeField(sizes, dtype="f64")
 f.add_field_constraints(w5)
-bs.configure(f, max(1, bs.SETTINGS[5]["levels"] - 2), bs.SETTINGS[5]["coarse_tol"], kcycle=bs.SETTINGS[5].get("kcycle", 0))
+bs.configure(f, max(1, bs.SETTINGS[5]["levels"] - 2), bs.SETTINGS[5]["coarse_tol"], kcycle=bs.SETTINGS[5].get("kcycle", 0), cheb=bs.SETTINGS[5].get("cheb"))
 f.set_field_tolerance(tol)
 run("config 5 shape 128^3", f, [lambda ff: ff.add_points(w5.data_pos, w5.value_kernel, w5.data_gradient, w5.gradient_kernel, pos5, nrm5, None)], [g], 1e-6)
