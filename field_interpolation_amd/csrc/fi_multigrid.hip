@@ -1108,6 +1108,12 @@ void kcycle_correction(RankSet& Rc)
 	dot(C1, B, 0);
 	dot(C1, W1, 1);
 	hipLaunchKernelGGL(k_kc_coef, dim3(1), dim3(kThreads), 0, c->stream, kc, part, stride, nb, 1);
+	if (const char* e = tuning_switch("FI_KC_STEPS")) {  // (timing builds: ONE step -- the cycle's result scaled by its line search)
+		if (atoi(e) == 1) {
+			hipLaunchKernelGGL((k_kc_combine<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, kc, vown<T>(c, C1), vown<T>(c, C1));
+			return;
+		}
+	}
 	hipLaunchKernelGGL((k_kc_r1<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, kc, vown<T>(c, B), vown<T>(c, W1), vown<T>(c, R1));
 	vcycle<T>(Rc, R1, C2);
 	stencil_full_step(c, (c->*C2).p, nullptr, (c->*R1).p, true, (c->*W2).p, 0.0, 0.0, 0.0);  // w2 = r1 - A c2
