@@ -221,7 +221,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=tol, dtype=dt, by_field=by_field,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
                     multigrid=True, mixed=dt == "f64", poly=0, points=npts, text=text, field_tol=bs.FIELD_TOLERANCE, more=more,
-                    seed=seeds[0], kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"))
+                    seed=seeds[0], kcycle=(st.get("kcycle", 0) if args.kcycle is None else args.kcycle) if world == 1 else 0, cheb=st.get("cheb"))
     if cfg == 5:
         side = args.side or 512
         npts = args.points or int(round(5_000_000 * (side / 512.0) ** 2))
@@ -231,7 +231,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=4,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=(st.get("kcycle", 0) if args.kcycle is None else args.kcycle) if world == 1 else 0, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=4,
                     text="config5: 3D %d^3 SDF from %d oriented points (sdf_from_points, default Weights)" % (side, npts))
     if cfg == 3:
         side = args.side or 4096
@@ -242,7 +242,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=nrm, val=None, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=2,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=2 * pps, kcycle=(st.get("kcycle", 0) if args.kcycle is None else args.kcycle) if world == 1 else 0, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=2,
                     text="config3: 2D %dx%d SDF from %d oriented points (triangle + inverted circle)" % (side, side, 2 * pps))
     if cfg == 2:
         side = args.side or 1024
@@ -253,7 +253,7 @@ def workload(args, world):
         return dict(sizes=sizes, w=w, pos=pos, nrm=None, val=val, tol=args.tol or st["tol"], dtype=args.dtype or "f64",
                     by_field=world <= bs.FIELD_RULE_MAX_SLABS and not args.tol,
                     levels=st["levels"] if args.levels is None else args.levels, coarse_tol=args.coarse_tol or st["coarse_tol"],
-                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=st.get("kcycle", 0) if args.kcycle is None else args.kcycle, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=1,
+                    multigrid=True, mixed=(args.dtype or "f64") == "f64", poly=0, points=npts, kcycle=(st.get("kcycle", 0) if args.kcycle is None else args.kcycle) if world == 1 else 0, cheb=st.get("cheb"), field_tol=bs.FIELD_TOLERANCE, more=[], seed=1,
                     text="config2: 2D %dx%d lattice, %d noisy value constraints, model_2=10" % (side, side, npts))
     raise SystemExit("--config must be 2, 3, 4 or 5 (config 1 is the CPU-runnable 1-D case: tests/)")
 
@@ -279,7 +279,8 @@ def main():
                     help="config 4: the fp32 / residual-1e-5 mode of rounds 1-3 as the line's value (field error 2e-3: outside "
                          "the north-star's tolerance); the default is the solver that meets it")
     ap.add_argument("--levels", type=int, default=None, help="coarser levels (config 4: coarse-to-fine start; 0: none)")
-    ap.add_argument("--kcycle", type=int, default=None, help="FI_OPT_MG_KCYCLE: coarse levels corrected by two flexible-CG steps (default: the configuration's setting)")
+    ap.add_argument("--kcycle", type=int, default=None, help="FI_OPT_MG_KCYCLE: coarse levels corrected by two flexible-CG steps (default: the configuration's setting; "
+                    "one GPU only -- over slabs every coarse dot product would be an all-reduce, those runs keep the V-cycle and its smoother)")
     ap.add_argument("--coarse-tol", type=float, default=0.0)
     ap.add_argument("--multigrid", action="store_true", help="config 4: V-cycle preconditioned CG")
     ap.add_argument("--poly", type=int, default=4, help="terms of the Chebyshev polynomial preconditioner (0: Jacobi-PCG)")
