@@ -37,6 +37,16 @@ void GpuLatticeField::set_levels(int levels, bool multigrid, bool mixed_precisio
 	dirty_ = true;
 }
 
+bool GpuLatticeField::set_option(int option, double value)
+{
+	if (fi_set_option(ctx_, option, value) != FI_OK) {
+		warn("set_option");
+		return false;
+	}
+	dirty_ = true;
+	return true;
+}
+
 size_t GpuLatticeField::num_unknowns() const
 {
 	size_t n = 1;

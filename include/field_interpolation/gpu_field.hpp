@@ -31,6 +31,10 @@ public:
 	// multigrid: V-cycle preconditioned CG over the levels (needed by SDF problems from oriented points).
 	// mixed_precision (double_precision fields): CG in fp64, the V-cycle on an fp32 replica.
 	void set_levels(int levels, bool multigrid = false, bool mixed_precision = false);
+	// Any solver option of the C ABI by number (include/fi_hip.h FI_OPT_*: e.g. FI_OPT_FIELD_TOLERANCE = 12 stops by the field,
+	// FI_OPT_MG_KCYCLE = 13 corrects that many coarse levels by two flexible-CG steps each -- a third of the iterations on SDF
+	// problems).  false: the library refused the value.
+	bool set_option(int option, double value);
 
 	void add_field_constraints(const Weights& weights);
 	bool add_value_constraint(const float pos[], float value, float weight);

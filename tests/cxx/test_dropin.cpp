@@ -197,6 +197,19 @@ int main()
 		auto leveled = deep.solve(0, 1e-7f);
 		require(leveled.size() == n && deep.last_error() <= 1e-7f && max_rel(leveled, exact) <= 1e-4f,
 		        "set_levels(2, multigrid, mixed): V-cycle CG with an fp32 replica");
+		// ... and the K-cycle through set_option (FI_OPT_MG_KCYCLE): the same field in no more iterations; a bad value is refused
+		{
+			const int it_v = deep.last_iterations();
+			fi::GpuLatticeField kdeep(sizes, true);
+			kdeep.set_levels(2, true, true);
+			require(kdeep.set_option(FI_OPT_MG_KCYCLE, 1) && !kdeep.set_option(FI_OPT_MG_KCYCLE, -3), "set_option: accepted and refused values");
+			kdeep.add_field_constraints(weights);
+			kdeep.add_points(weights.data_pos, weights.value_kernel, weights.data_gradient, weights.gradient_kernel, 160,
+			                 positions.data(), normals.data(), nullptr);
+			auto kfield = kdeep.solve(0, 1e-7f);
+			require(kfield.size() == n && kdeep.last_error() <= 1e-7f && max_rel(kfield, exact) <= 1e-4f && kdeep.last_iterations() <= it_v,
+			        "set_option(FI_OPT_MG_KCYCLE): K-cycle CG reaches the same field");
+		}
 		auto big = fi::upscale_field(exact.data(), sizes, {47, 39});
 		require(big.size() == 47u * 39u && std::fabs(big[0] - exact[0]) < 1e-6f && std::fabs(big.back() - exact.back()) < 1e-6f,
 		        "upscale_field keeps the corners");
