@@ -1065,6 +1065,30 @@ __global__ __launch_bounds__(kThreads) void k_kc_coef(KcScalars* kc, const doubl
 		kc->coef2 = 0.0;
 	}
 }
+// the dot products of one step in ONE pass over the vectors: a . b0, a . b1 (step 1), ... a . b3 (step 2) -> partial[v * stride + block]
+template <typename T, int NV>
+__global__ __launch_bounds__(kThreads) void k_kc_dots(int64_t n, const T* __restrict__ a, const T* __restrict__ b0, const T* __restrict__ b1,
+                                                       const T* __restrict__ b2, const T* __restrict__ b3, double* __restrict__ partial, int stride)
+{
+	double acc[NV];
+#pragma unroll
+	for (int v = 0; v < NV; ++v) { acc[v] = 0.0; }
+	for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
+		const double av = static_cast<double>(a[i]);
+		acc[0] += av * static_cast<double>(b0[i]);
+		acc[1] += av * static_cast<double>(b1[i]);
+		if (NV > 2) {
+			acc[2] += av * static_cast<double>(b2[i]);
+			acc[3] += av * static_cast<double>(b3[i]);
+		}
+	}
+	double out[NV];
+	block_sum<NV>(acc, out);
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int v = 0; v < NV; ++v) { partial[static_cast<size_t>(v) * stride + blockIdx.x] = out[v]; }
+	}
+}
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_kc_r1(int64_t n, const KcScalars* __restrict__ kc, const T* __restrict__ b, const T* __restrict__ w1,
                                                      T* __restrict__ r1)
@@ -1099,14 +1123,11 @@ void kcycle_correction(RankSet& Rc)
 	const int nb = stream_blocks(n);
 	const int stride = c->max_blocks;
 	double* part = c->partial.as<double>();
-	auto dot = [&](Vec a, Vec b, int region) {
-		hipLaunchKernelGGL((k_dot<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, vown<T>(c, a), vown<T>(c, b), part + static_cast<size_t>(region) * stride);
-	};
 	const Vec B = &fi_ctx::mg_b, C1 = &fi_ctx::mg_x, W1 = &fi_ctx::r, R1 = &fi_ctx::x, C2 = &fi_ctx::p, W2 = &fi_ctx::q;
 	vcycle<T>(Rc, B, C1);
 	stencil_full_step(c, (c->*C1).p, nullptr, (c->*B).p, true, (c->*W1).p, 0.0, 0.0, 0.0);   // w1 = b - A c1
-	dot(C1, B, 0);
-	dot(C1, W1, 1);
+	hipLaunchKernelGGL((k_kc_dots<T, 2>), dim3(nb), dim3(kThreads), 0, c->stream, n, vown<T>(c, C1), vown<T>(c, B), vown<T>(c, W1),
+	                   static_cast<const T*>(nullptr), static_cast<const T*>(nullptr), part, stride);
 	hipLaunchKernelGGL(k_kc_coef, dim3(1), dim3(kThreads), 0, c->stream, kc, part, stride, nb, 1);
 	if (const char* e = tuning_switch("FI_KC_STEPS")) {  // (timing builds: ONE step -- the cycle's result scaled by its line search)
 		if (atoi(e) == 1) {
@@ -1117,10 +1138,8 @@ void kcycle_correction(RankSet& Rc)
 	hipLaunchKernelGGL((k_kc_r1<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, kc, vown<T>(c, B), vown<T>(c, W1), vown<T>(c, R1));
 	vcycle<T>(Rc, R1, C2);
 	stencil_full_step(c, (c->*C2).p, nullptr, (c->*R1).p, true, (c->*W2).p, 0.0, 0.0, 0.0);  // w2 = r1 - A c2
-	dot(C2, B, 0);
-	dot(C2, W1, 1);
-	dot(C2, R1, 2);
-	dot(C2, W2, 3);
+	hipLaunchKernelGGL((k_kc_dots<T, 4>), dim3(nb), dim3(kThreads), 0, c->stream, n, vown<T>(c, C2), vown<T>(c, B), vown<T>(c, W1), vown<T>(c, R1),
+	                   vown<T>(c, W2), part, stride);
 	hipLaunchKernelGGL(k_kc_coef, dim3(1), dim3(kThreads), 0, c->stream, kc, part, stride, nb, 2);
 	hipLaunchKernelGGL((k_kc_combine<T>), dim3(nb), dim3(kThreads), 0, c->stream, n, kc, vown<T>(c, C1), vown<T>(c, C2));
 	FI_HIP_TRY(hipGetLastError());
